@@ -1,0 +1,186 @@
+#!/usr/bin/env python
+"""bench.py -- solved-samples/sec of the Diffusion-CCSP reverse-diffusion sampler on MI355X.
+
+Workload (BASELINE.json configs[1] "C2"; configs[2] "C3" = the same shard on every GPU):
+RandomSplitQualitativeWorld, 8 objects per graph, T=1000, ULA with 10 Langevin steps per timestep,
+256 graphs per GPU, hidden_dim 256, fp32 -- 11 000 network evaluations per chain.
+
+A "step" is one whole `GaussianDiffusion.sample(batch)` call: graph upload/planning + the full
+reverse chain of the rank's 256 graphs (+ the gather of final poses when N > 1).  Inputs (the
+collated batch tensors and the weights) are resident in HBM before the timed region.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  Extra blocks: "roofline" (the evaluation kernels timed with HIP
+events on the chain's stream in a separate profiled pass, priced against the fp32 MFMA peak with the
+ALGORITHMIC flops of SURVEY.md 8d) and "cpu_baseline" (the cost-faithful PyTorch-CPU port of the
+reference sampler, oracle/torch_proxy.py, timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md (dense f32 matrix peak)
+GRAPHS_PER_GPU = 256
+N_OBJECTS = 8
+HIDDEN = 256
+T_STEPS = 1000
+S_LANGEVIN = 10
+
+
+def load_weights(path):
+    z = np.load(path)
+    out = {}
+    for k in z.files:
+        if k.endswith('::q8'):
+            out[k[:-4]] = (z[k].astype(np.float32) * z[k[:-4] + '::scale'][:, None]).astype(np.float32)
+        elif not k.endswith('::scale'):
+            out[k] = z[k].astype(np.float32)
+    return out
+
+
+def algorithmic_flops(n_nodes, n_edges, H=HIDDEN, P=4, kin_mult=5):
+    """reference dense formulation, 2 flop per multiply-add, per network evaluation"""
+    f_node = 2 * (P * H // 2 + (H // 2) * H)
+    f_edge = 2 * (kin_mult * H * 2 * H) + 2 * 2 * (H * H // 2 + (H // 2) * P)
+    return n_nodes * f_node + n_edges * f_edge, f_node, f_edge
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--graphs-per-gpu', type=int, default=GRAPHS_PER_GPU)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP path has no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from diffusion_ccsp_amd import ConstraintDiffuser, GaussianDiffusion, device_info, sharding, worlds
+    B = args.graphs_per_gpu
+    # independent shards: rank r owns graphs [r*B, (r+1)*B) of the global batch (seed 5 + rank)
+    batch_np = worlds.qualitative_batch(B, N_OBJECTS, seed=5 + rank)
+    n_nodes, n_edges = batch_np.x.shape[0], batch_np.edge_index.shape[1]
+    dims = worlds.MODE_DIMS['qualitative']
+
+    # weights: rank 0 reads the fixture, every other rank receives them over RCCL (xGMI)
+    wpath = os.path.join(ROOT, 'tests', 'golden', 'weights_qualitative_h%d.npz' % HIDDEN)
+    den = ConstraintDiffuser(dims=dims, hidden_dim=HIDDEN, input_mode='qualitative', EBM='ULA', device=dev, verbose=False)
+    sd = load_weights(wpath) if rank == 0 else None
+    sd = sharding.broadcast_state_dict(sd, den.shapes(), dev, dist)
+    den.load_state_dict(sd)
+    gd = GaussianDiffusion(den, timesteps=T_STEPS, EBM='ULA', samples_per_step=S_LANGEVIN)
+    base = batch_np.to_torch(dev)
+
+    def one_step(k):
+        b = base.clone()                       # a fresh batch object: graph planning/upload is inside the step
+        x = gd.sample(b, seed=1000 + k, row_offset=rank * n_nodes)
+        if dist is not None:
+            sharding.gather_poses(x, dist)
+        return x
+
+    for k in range(args.warmup):
+        one_step(k)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        x = one_step(args.warmup + k)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    finite = bool(torch.isfinite(x).all().item())
+    samples = world * B * args.steps
+    value = samples / elapsed
+
+    rec = {
+        'metric': 'solved samples/sec, T=1000 ULA, RandomSplitQualitativeWorld 8-obj',
+        'value': value, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'C2: RandomSplitQualitativeWorld 8 objects, T=1000 ULA S=10, %d graphs per GPU, hidden_dim %d'
+                               % (B, HIDDEN),
+                   'graphs_per_gpu': B, 'nodes_per_gpu': n_nodes, 'edges_per_gpu': n_edges,
+                   'evaluations_per_chain': T_STEPS * (1 + S_LANGEVIN),
+                   'parallelism': 'independent graph shards x%d, RCCL weight broadcast + final gather only' % world,
+                   'weights': 'trained in-container with the reference loss (tests/golden/weights_qualitative_h256.npz)',
+                   'solved_fraction': None, 'outputs_finite': finite},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # separate profiled pass: HIP events around every k_ugemm / k_edge launch of the first 1024
+        # evaluations of one more chain, recorded on the stream the kernels run on
+        b = base.clone()
+        gd.profile(b, True)
+        gd.sample(b, seed=77)
+        st = gd.chain_stats()
+        plan = __import__('diffusion_ccsp_amd')._lib.plan_host(n_nodes, 13, batch_np.edge_index, batch_np.edge_attr)
+        f_eval, f_node, f_edge = algorithmic_flops(n_nodes, plan['E_act'])
+        ms_eval = st['ms_ugemm'] + st['ms_edge']
+        exec_flops = 2.0 * plan['R'] * 2 * HIDDEN * HIDDEN + plan['E_act'] * 2 * 2 * (HIDDEN * HIDDEN // 2 + HIDDEN // 2 * 4) + n_nodes * f_node
+        ach = f_eval / (ms_eval * 1e-3) / 1e12 if ms_eval > 0 else None
+        rec['roofline'] = {
+            'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': (ach / PEAK_FP32_MFMA_TFLOPS) if ach else None, 'traffic': None,
+            'kernel': 'k_ugemm<256> + k_edge<256> (the two launches of one network evaluation)',
+            'algorithmic_flops_per_launch_pair': f_eval, 'flops_per_node': f_node, 'flops_per_edge': f_edge,
+            'ms_k_ugemm': st['ms_ugemm'], 'ms_k_edge': st['ms_edge'],
+            'executed_flops_per_launch_pair': exec_flops,
+            'executed_tflops': exec_flops / (ms_eval * 1e-3) / 1e12 if ms_eval > 0 else None,
+            'chain_ms_event': st['ms_total'], 'chain_evals': st['evals'],
+            'whole_chain_algorithmic_tflops': f_eval * st['evals'] / (st['ms_total'] * 1e-3) / 1e12,
+        }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+        import torch_proxy                              # the checker / baseline port, never the product path
+        cpu_batch = batch_np.to_torch('cpu')
+        cpu_batch.num_graphs = B
+        r = torch_proxy.time_baseline(load_weights(wpath), dims, HIDDEN, 13, cpu_batch, T=T_STEPS, S=S_LANGEVIN,
+                                      n_timesteps=3, budget_s=25.0)
+        rec['cpu_baseline'] = {'value': r['samples_per_s'], 'unit': 'samples/s', 'cores': r['cores'], 'kind': 'port',
+                               'sample': r['sample'], 'sec_per_timestep': r['sec_per_timestep'],
+                               'speedup_gpu_over_cpu': value / r['samples_per_s']}
+    if rank == 0:
+        rec['device'] = device_info()
+        print(json.dumps(rec))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,131 @@
+"""ctypes binding of libccsp_hip.so (include/ccsp.h) -- the only way the Python host code reaches
+the HIP kernels.  There is NO CPU fallback: if the library cannot be loaded (or built) every
+entry point raises, loudly."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+SO = os.path.join(CSRC, 'libccsp_hip.so')
+SOURCES = ['ccsp_hip.hip', 'ccsp_philox.h', 'ccsp_plan.h', os.path.join('..', '..', 'include', 'ccsp.h')]
+
+SAMPLERS = {False: 0, None: 0, 'NONE': 0, 'ULA': 1, 'ULA+': 2, 'MALA': 3}
+SCHEDULE_KEYS = ['betas', 'alphas_cumprod', 'alphas_cumprod_prev', 'sqrt_recip_alphas_cumprod',
+                 'sqrt_recipm1_alphas_cumprod', 'posterior_log_variance_clipped', 'posterior_mean_coef1',
+                 'posterior_mean_coef2', '_sqrt_recipm1_alphas_cumprod_custom', 'step_sizes',
+                 'posterior_variance']
+
+
+class CcspError(RuntimeError):
+    pass
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        'hidden_dim', 'pose_dim', 'pose_begin', 'geom_dim', 'grasp_dim', 'grasp_begin', 'n_types',
+        'timesteps', 'normalize', 'energy_wrapper', 'ebm_per_steps')]
+
+
+class Noise(C.Structure):
+    _fields_ = [('mode', C.c_int32), ('_pad', C.c_int32), ('seed', C.c_uint64), ('row_offset', C.c_uint64),
+                ('normal', C.c_void_p), ('n_normal', C.c_uint64), ('uniform', C.c_void_p),
+                ('n_uniform', C.c_uint64), ('call_base', C.c_uint64), ('ucall_base', C.c_uint64)]
+
+
+def _stale():
+    if not os.path.isfile(SO):
+        return True
+    t = os.path.getmtime(SO)
+    return any(os.path.isfile(os.path.join(CSRC, s)) and os.path.getmtime(os.path.join(CSRC, s)) > t for s in SOURCES)
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 the library in-tree (cross-compiles without a GPU)"""
+    if not force and not _stale():
+        return SO
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
+           '-o', SO, os.path.join(CSRC, 'ccsp_hip.hip')]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(SO):
+        try:
+            build()
+        except Exception as e:  # noqa
+            raise CcspError('libccsp_hip.so is missing and could not be built (%s); the HIP extension is '
+                            'required -- there is no CPU fallback' % (e,))
+    try:
+        L = C.CDLL(SO)
+    except OSError as e:
+        raise CcspError('cannot load %s: %s (the HIP extension is required)' % (SO, e))
+    vp, i32, u64p = C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)
+    L.ccsp_last_error.restype = C.c_char_p
+    L.ccsp_version.restype = C.c_int32
+    L.ccsp_device_info.argtypes = [C.c_char_p, i32, C.POINTER(i32), u64p]
+    L.ccsp_model_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(vp), vp, C.POINTER(vp)]
+    L.ccsp_model_destroy.argtypes = [vp]
+    L.ccsp_model_destroy.restype = None
+    L.ccsp_schedule_set.argtypes = [vp, vp, vp, vp, i32]
+    L.ccsp_schedule_get.argtypes = [vp, i32, vp]
+    L.ccsp_time_embedding.argtypes = [vp, i32, vp, vp]
+    L.ccsp_graph_create.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, C.POINTER(vp)]
+    L.ccsp_graph_destroy.argtypes = [vp]
+    L.ccsp_graph_destroy.restype = None
+    L.ccsp_denoise.argtypes = [vp, vp, vp, i32, vp, vp]
+    L.ccsp_energy_grad.argtypes = [vp, vp, vp, i32, vp, vp, vp]
+    L.ccsp_edge_outputs.argtypes = [vp, vp, vp, i32, vp, vp]
+    L.ccsp_chain_run.argtypes = [vp, vp, i32, C.POINTER(Noise), vp, i32, i32, i32, vp, vp, vp]
+    L.ccsp_profile_enable.argtypes = [vp, i32]
+    L.ccsp_chain_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.ccsp_plan_host.argtypes = [i32, i32, i32] + [vp] * 14
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise CcspError(lib().ccsp_last_error().decode())
+
+
+def device_info():
+    L = lib()
+    name = C.create_string_buffer(256)
+    cu = C.c_int32()
+    mem = C.c_uint64()
+    check(L.ccsp_device_info(name, 256, C.byref(cu), C.byref(mem)))
+    return dict(name=name.value.decode(), compute_units=cu.value, hbm_bytes=mem.value)
+
+
+def plan_host(n_nodes, n_types, edge_index, edge_attr):
+    """host-only planning tables (no GPU needed); numpy in, dict of numpy out"""
+    import numpy as np
+    L = lib()
+    ei = np.ascontiguousarray(edge_index, dtype=np.int64).reshape(2, -1)
+    ea = np.ascontiguousarray(edge_attr, dtype=np.float32)
+    E = ei.shape[1]
+    names = ['e_orig', 'e_type', 'e_u0', 'e_u1', 'urow_node', 'urow_ts', 'tile_row0', 'tile_nrows', 'tile_ts',
+             'node_ptr', 'node_ent']
+    sizes = [E, E, E, E, 2 * E, 2 * E, 2 * E + 2 * n_types, 2 * E + 2 * n_types, 2 * E + 2 * n_types,
+             n_nodes + 1, 2 * E]
+    arrs = [np.full(max(s, 1), -1, dtype=np.int32) for s in sizes]
+    counts = np.zeros(3, dtype=np.int32)
+    check(L.ccsp_plan_host(n_nodes, E, n_types, ei.ctypes.data, ea.ctypes.data, counts.ctypes.data,
+                           *[a.ctypes.data for a in arrs]))
+    e_act, rows, tiles = [int(v) for v in counts]
+    trims = [e_act, e_act, e_act, e_act, rows, rows, tiles, tiles, tiles, n_nodes + 1, 2 * e_act]
+    out = {n: a[:t].copy() for n, a, t in zip(names, arrs, trims)}
+    out.update(E_act=e_act, R=rows, n_tiles=tiles)
+    return out

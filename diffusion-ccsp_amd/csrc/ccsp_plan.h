@@ -1,0 +1,94 @@
+// Host-side, one-time index planning for a collated batch of constraint graphs.
+//
+// The reference re-derives, on every network evaluation and for every constraint type, the edge
+// subset `torch.where(edge_attr == i)` through a host round trip (networks/denoise_fn.py:313-339)
+// and accumulates per-edge outputs with scatter_add_ in (type asc, edge asc, slot 0 then 1) order
+// (:377-389, :512-521).  The edge lists are constant over a chain, so this is done once:
+//
+//   * sorted edges  k = 0..E'-1 : edges with a valid type id, stable-sorted by type (edges whose
+//     edge_attr matches no type are dropped exactly as the reference's loop never visits them);
+//   * U rows: the distinct (type, slot, node) triples.  The pose-dependent half of an edge's
+//     pre-activation is  W_i[:, pa-cols] p_a + W_i[:, pb-cols] p_b, which depends on (type, slot,
+//     node) only, so it is evaluated once per triple (row) instead of once per edge;
+//   * row tiles of TILE_M rows that never straddle a (type, slot) group (one weight slice each);
+//   * node -> (edge, slot) CSR whose entries are the flat indices 2k+s in ascending order, which
+//     IS the reference's accumulation order; no atomics are needed downstream.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace ccsp {
+
+struct Plan {
+    int N = 0, E = 0, C = 0;
+    int E_act = 0;                 // edges with a valid type
+    int R = 0;                     // U rows
+    std::vector<int32_t> e_orig, e_a, e_b, e_type, e_u0, e_u1;   // [E_act]
+    std::vector<int32_t> urow_node, urow_ts;                      // [R]   ts = 2*type + slot
+    std::vector<int32_t> tile_row0, tile_nrows, tile_ts;          // [n_tiles]
+    std::vector<int32_t> node_ptr, node_ent;                      // [N+1], [2*E_act]
+    std::vector<int32_t> type_count;                              // [C]
+};
+
+// returns 0, or 1 with *err set, if an endpoint is out of range
+inline int build_plan(int N, int E, int C, int tile_m, const int64_t* ei /*[2,E]*/, const float* ea /*[E]*/,
+                      Plan& p, const char** err) {
+    p = Plan();
+    p.N = N; p.E = E; p.C = C;
+    std::vector<int32_t> etype(E, -1);
+    p.type_count.assign(C, 0);
+    for (int e = 0; e < E; ++e) {
+        const int64_t a = ei[e], b = ei[(size_t)E + e];
+        if (a < 0 || a >= N || b < 0 || b >= N) { *err = "edge endpoint out of range"; return 1; }
+        const float v = ea[e];
+        if (v >= 0.0f && v < (float)C && v == (float)(int)v) { etype[e] = (int)v; p.type_count[(int)v]++; }
+    }
+    for (int i = 0; i < C; ++i)
+        for (int e = 0; e < E; ++e)
+            if (etype[e] == i) {
+                p.e_orig.push_back(e);
+                p.e_a.push_back((int32_t)ei[e]);
+                p.e_b.push_back((int32_t)ei[(size_t)E + e]);
+                p.e_type.push_back(i);
+            }
+    p.E_act = (int)p.e_orig.size();
+    p.e_u0.assign(p.E_act, -1);
+    p.e_u1.assign(p.E_act, -1);
+    std::vector<int32_t> row_of(N, -1);
+    std::vector<int32_t> stamp(N, -1);
+    int k0 = 0, gid = 0;
+    for (int i = 0; i < C; ++i) {
+        const int k1 = k0 + p.type_count[i];
+        for (int s = 0; s < 2; ++s, ++gid) {
+            const int g_row0 = p.R;
+            for (int k = k0; k < k1; ++k) {
+                const int node = s == 0 ? p.e_a[k] : p.e_b[k];
+                if (stamp[node] != gid) {
+                    stamp[node] = gid;
+                    row_of[node] = p.R++;
+                    p.urow_node.push_back(node);
+                    p.urow_ts.push_back(2 * i + s);
+                }
+                (s == 0 ? p.e_u0 : p.e_u1)[k] = row_of[node];
+            }
+            for (int r = g_row0; r < p.R; r += tile_m) {
+                p.tile_row0.push_back(r);
+                p.tile_nrows.push_back(p.R - r < tile_m ? p.R - r : tile_m);
+                p.tile_ts.push_back(2 * i + s);
+            }
+        }
+        k0 = k1;
+    }
+    p.node_ptr.assign(N + 1, 0);
+    for (int k = 0; k < p.E_act; ++k) { p.node_ptr[p.e_a[k] + 1]++; p.node_ptr[p.e_b[k] + 1]++; }
+    for (int n = 0; n < N; ++n) p.node_ptr[n + 1] += p.node_ptr[n];
+    p.node_ent.assign((size_t)2 * p.E_act, 0);
+    std::vector<int32_t> pos(p.node_ptr.begin(), p.node_ptr.end() - 1);
+    for (int k = 0; k < p.E_act; ++k) {
+        p.node_ent[pos[p.e_a[k]]++] = 2 * k;
+        p.node_ent[pos[p.e_b[k]]++] = 2 * k + 1;
+    }
+    return 0;
+}
+
+}  // namespace ccsp

@@ -1,0 +1,182 @@
+"""Host-side mirror of the reference's ``GaussianDiffusion`` sampling interface
+(networks/ddpm.py:168-351) on top of the HIP library: same constructor arguments, the same
+schedule buffers, ``p_sample_loop(batch, return_history=...)`` and ``sample(batch, **kw)`` with the
+``sample_loop_time`` bookkeeping.  The reverse chain itself -- T x (1 + S) network evaluations
+with the fused ancestral / Langevin updates -- is one ``ccsp_chain_run`` call that enqueues every
+kernel on the current stream without a host synchronisation.
+
+Noise: the reference consumes torch's global generator.  Here the chain's draws come from the
+build-owned counter-based stream (noise.py): ``sample(batch, seed=...)``; if no seed is given one
+is drawn from torch's global generator, so ``torch.manual_seed`` keeps runs reproducible.
+``sample(batch, noise=(normal[, uniform]))`` injects recorded draws instead (parity runs).
+"""
+import ctypes as C
+import time
+
+import numpy as np
+import torch
+
+from . import _lib
+from .denoise_fn import _ptr, _stream_ptr
+
+
+class GaussianDiffusion(object):
+    def __init__(self, denoise_fn, timesteps=100, loss_type='l2', EBM=False, betas=None,
+                 samples_per_step=10, step_sizes='2*self.betas'):
+        self.denoise_fn = denoise_fn
+        self.device = denoise_fn.device
+        self.dims = denoise_fn.dims
+        self.input_mode = denoise_fn.input_mode
+        self.loss_type = loss_type
+        self.EBM = EBM
+        self.training = False
+        if betas is not None:
+            betas = betas.detach().cpu().numpy() if isinstance(betas, torch.Tensor) else np.asarray(betas)
+            timesteps = int(betas.shape[0])
+        self.num_timesteps = int(timesteps)
+        self.samples_per_step = samples_per_step
+        self._core()._bind(self.num_timesteps)
+        self._betas_arg = None if betas is None else np.ascontiguousarray(betas, dtype=np.float64)
+        self._step_sizes_expr = step_sizes
+        self._apply_schedule()
+        self.sample_loop_time = []
+        self.last_stats = None
+
+    # the native handle lives on the ConstraintDiffuser (possibly behind the EBM wrapper)
+    def _core(self):
+        inner = getattr(self.denoise_fn, 'model', None)
+        return inner if hasattr(inner, '_handle') else self.denoise_fn
+
+    def _apply_schedule(self):
+        L = _lib.lib()
+        h = self._core()._handle()
+        b = self._betas_arg
+        sps = self.samples_per_step
+        if torch.is_tensor(sps):
+            sps = sps.cpu().numpy()
+        if np.isscalar(sps):
+            sp_arr, default = None, int(sps)
+        else:
+            sp_arr, default = np.ascontiguousarray(sps, dtype=np.int32), 0
+        _lib.check(L.ccsp_schedule_set(h, None if b is None else b.ctypes.data, None,
+                                       None if sp_arr is None else sp_arr.ctypes.data, default))
+        self._read_buffers()
+        # `step_sizes` is a Python expression of self.betas evaluated in the module (ddpm.py:207)
+        self.step_sizes = eval(self._step_sizes_expr) if isinstance(self._step_sizes_expr, str) else self._step_sizes_expr
+        ss = torch.as_tensor(self.step_sizes, dtype=torch.float32).cpu().numpy()
+        ss = np.ascontiguousarray(np.broadcast_to(ss, (self.num_timesteps,)), dtype=np.float32)
+        _lib.check(L.ccsp_schedule_set(h, None if b is None else b.ctypes.data, ss.ctypes.data,
+                                       None if sp_arr is None else sp_arr.ctypes.data, default))
+        self._schedule_owner = h.value
+
+    def _read_buffers(self):
+        L = _lib.lib()
+        h = self._core()._handle()
+        for i, k in enumerate(_lib.SCHEDULE_KEYS):
+            a = np.empty(self.num_timesteps, dtype=np.float32)
+            _lib.check(L.ccsp_schedule_get(h, i, a.ctypes.data))
+            if k != 'step_sizes':
+                setattr(self, k, torch.from_numpy(a).to(self.device))
+
+    def _handle(self):
+        h = self._core()._handle()
+        if getattr(self, '_schedule_owner', None) != h.value:   # weights were reloaded -> new native model
+            self._apply_schedule()
+            h = self._core()._handle()
+        return h
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def load_state_dict(self, sd, strict=True):
+        """a reference checkpoint's 'model' dict: schedule buffers are recomputed, denoiser weights loaded"""
+        self._core().load_state_dict({k: v for k, v in sd.items() if k.startswith('denoise_fn.')}, strict)
+        return self
+
+    def state_dict(self):
+        out = {k: getattr(self, k) for k in _lib.SCHEDULE_KEYS if hasattr(self, k) and not k.startswith('_') and k != 'step_sizes'}
+        pre = 'denoise_fn.model.' if self._core() is not self.denoise_fn else 'denoise_fn.'
+        out.update({pre + k: v for k, v in self._core().state_dict().items()})
+        return out
+
+    # ------------------------------------------------------------------------------------
+    def _sampler(self):
+        if not self.EBM:
+            return 'NONE'
+        if self.EBM in ('ULA', 'ULA+', 'MALA'):
+            return self.EBM
+        if 'ULA' in self.EBM:
+            return 'ULA'
+        raise NotImplementedError('EBM=%r (HMC is out of scope, SURVEY 8a-13)' % (self.EBM,))
+
+    def n_normal_calls(self):
+        from .noise import n_normal_calls
+        if self._sampler() == 'NONE':
+            return 1 + self.num_timesteps
+        if self._sampler() == 'ULA+':
+            n = self.num_timesteps // 4
+            return 1 + self.num_timesteps + n * (4 + 8 + 12 + 16)
+        return n_normal_calls(self.num_timesteps, self.samples_per_step if np.isscalar(self.samples_per_step)
+                              else np.asarray(self.samples_per_step))
+
+    def p_sample_loop(self, batch, return_history=False, seed=None, noise=None, row_offset=0, **kwargs):
+        """GaussianDiffusion.p_sample_loop (ddpm.py:260-340)"""
+        assert not self.training
+        L = _lib.lib()
+        core = self._core()
+        h = self._handle()
+        g = core._graph(batch)
+        dev = self.device
+        P = self.dims[-1][0]
+        T = self.num_timesteps
+        nz = _lib.Noise()
+        keep = []
+        if noise is not None:
+            normal = noise[0] if isinstance(noise, (tuple, list)) else noise
+            normal = normal.detach().to(dev, torch.float32).contiguous()
+            keep.append(normal)
+            nz.mode, nz.normal, nz.n_normal = 1, normal.data_ptr(), normal.shape[0]
+            if isinstance(noise, (tuple, list)) and len(noise) > 1 and noise[1] is not None:
+                uni = noise[1].detach().to(dev, torch.float32).contiguous()
+                keep.append(uni)
+                nz.uniform, nz.n_uniform = uni.data_ptr(), uni.shape[0]
+        else:
+            if seed is None:
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            nz.mode, nz.seed, nz.row_offset = 0, int(seed), int(row_offset)
+        x = torch.empty((g.N, P), device=dev, dtype=torch.float32)
+        hist = torch.empty((T + 1, g.N, P), device=dev, dtype=torch.float32) if return_history else None
+        with torch.cuda.device(dev):
+            _lib.check(L.ccsp_chain_run(h, g.h, _lib.SAMPLERS[self._sampler()], C.byref(nz), _ptr(x), 1, T - 1, 0,
+                                        None if hist is None else _ptr(hist), None, _stream_ptr(dev)))
+        self._last_graph = g
+        self._keepalive = keep
+        if return_history:
+            return x, [hist[i] for i in range(T + 1)]
+        return x
+
+    def sample(self, batch, **kwargs):
+        """GaussianDiffusion.sample (ddpm.py:342-351): wall-clock timed p_sample_loop"""
+        start = time.time()
+        outputs = self.p_sample_loop(batch, **kwargs)
+        torch.cuda.synchronize(self.device)
+        passed = time.time() - start
+        self.sample_loop_time.append(passed)
+        if len(self.sample_loop_time) > 10:
+            self.sample_loop_time.pop(0)
+        return outputs
+
+    def chain_stats(self):
+        """HIP-event timing of the last chain on its graph (ccsp_chain_stats)"""
+        g = getattr(self, '_last_graph', None)
+        if g is None:
+            raise _lib.CcspError('no chain has run')
+        ev, ms, mu, me = C.c_int64(), C.c_float(), C.c_float(), C.c_float()
+        _lib.check(_lib.lib().ccsp_chain_stats(g.h, C.byref(ev), C.byref(ms), C.byref(mu), C.byref(me)))
+        return dict(evals=ev.value, ms_total=ms.value, ms_ugemm=mu.value, ms_edge=me.value)
+
+    def profile(self, batch, on=True):
+        """bracket the evaluation kernels of the next chains on this batch with HIP events"""
+        g = self._core()._graph(batch)
+        _lib.check(_lib.lib().ccsp_profile_enable(g.h, int(bool(on))))

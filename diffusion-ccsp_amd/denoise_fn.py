@@ -1,0 +1,305 @@
+"""Host-side mirror of the reference's denoiser interface (networks/denoise_fn.py) on top of the
+HIP library.  Same class names, constructor arguments, attributes and call signatures as the
+reference so that ``GaussianDiffusion`` / ``Trainer.evaluate`` / ``visualize_energy.py`` style
+callers work unchanged; the arithmetic happens in csrc/ccsp_hip.hip.
+
+    ConstraintDiffuser(dims, hidden_dim, ..., input_mode, EBM, normalize, energy_wrapper, device)
+        reference: networks/denoise_fn.py:184-291 (ctor), :453-548 (forward)
+    ComposedEBMDenoiseFn(model)      reference: networks/denoise_fn.py:57-83
+
+PyTorch is used for device memory and streams only.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .worlds import constraint_set
+
+
+def param_names(n_types, grasp):
+    """nn.Linear modules in reference state_dict order (networks/denoise_fn.py:227-308)"""
+    names = ['geom_encoder.0', 'geom_encoder.2']
+    if grasp:
+        names += ['grasp_encoder.0', 'grasp_encoder.2']
+    names += ['pose_encoder.0', 'pose_encoder.2', 'pose_decoder.0', 'pose_decoder.2', 'time_mlp.1', 'time_mlp.3']
+    names += ['mlps.%d.0' % i for i in range(n_types)]
+    return names
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+class _Graph(object):
+    """one collated batch uploaded to the library (ccsp_graph_create)"""
+
+    def __init__(self, owner, batch):
+        dev = owner.device
+        self.owner = owner
+        self.x = batch.x.detach().to(dev, torch.float32).contiguous()
+        self.edge_index = batch.edge_index.detach().to(dev, torch.int64).contiguous()
+        self.edge_attr = batch.edge_attr.detach().to(dev, torch.float32).contiguous()
+        self.mask = batch.mask.detach().to(dev, torch.int8).contiguous()
+        self.N, self.F = self.x.shape
+        self.E = self.edge_index.shape[1] if self.edge_index.dim() == 2 else 0
+        h = C.c_void_p()
+        L = _lib.lib()
+        _lib.check(L.ccsp_graph_create(owner._handle(), self.N, self.E, self.F, _ptr(self.x), _ptr(self.edge_index),
+                                       _ptr(self.edge_attr), _ptr(self.mask), _stream_ptr(dev), C.byref(h)))
+        self.h = h
+        self.model_handle = owner._h.value
+
+    def __del__(self):
+        try:
+            if getattr(self, 'h', None):
+                _lib.lib().ccsp_graph_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class ConstraintDiffuser(object):
+    """drop-in for the reference class of the same name (model='Diffusion-CCSP' only)."""
+
+    def __init__(self, dims=((2, 0, 2), (2, 2, 4)), hidden_dim=256, max_num_obj=12, input_mode=None,
+                 EBM=False, pretrained=False, normalize=True, energy_wrapper=False, device='cuda',
+                 model='Diffusion-CCSP', verbose=True, timesteps=1000):
+        if model != 'Diffusion-CCSP':
+            raise NotImplementedError("model=%r: only 'Diffusion-CCSP' is built (StructDiffusion baseline: see DESIGN.md)" % model)
+        if input_mode is None:
+            raise ValueError('input_mode is required')
+        self.hidden_dim = hidden_dim
+        self.max_num_obj = max_num_obj
+        self.EBM = EBM
+        self.device = torch.device(device)
+        self.dims = tuple(tuple(d) for d in dims)
+        self.input_mode = input_mode
+        self.use_image = False
+        self.normalize = normalize
+        self.verbose = verbose
+        self.energy_wrapper = energy_wrapper
+        self.model = model
+        self.constraint_sets = constraint_set(input_mode)
+        self.ebm_per_steps = 1
+        self.training = False
+        self.timesteps = timesteps
+        self._grasp = 'robot' in input_mode
+        if self._grasp and len(self.dims) != 3:
+            raise ValueError("'robot' input modes need dims with a grasp group")
+        self._params = None       # name -> device tensor
+        self._h = None
+        self._graphs = {}
+        if self.device.type != 'cuda':
+            raise _lib.CcspError("ConstraintDiffuser(device=%r): the HIP path needs a GPU device ('cuda'); "
+                                 "there is no CPU fallback" % (device,))
+
+    # ---- weights ------------------------------------------------------------------------
+    def shapes(self):
+        H, P = self.hidden_dim, self.dims[-1][0]
+        kin = H * (6 if self._grasp else 5)
+        sh = {'geom_encoder.0': (H // 2, self.dims[0][0]), 'geom_encoder.2': (H, H // 2),
+              'pose_encoder.0': (H // 2, P), 'pose_encoder.2': (H, H // 2),
+              'pose_decoder.0': (H // 2, H), 'pose_decoder.2': (P, H // 2),
+              'time_mlp.1': (4 * H, H), 'time_mlp.3': (H, 4 * H)}
+        if self._grasp:
+            sh.update({'grasp_encoder.0': (H // 2, self.dims[1][0]), 'grasp_encoder.2': (H, H // 2)})
+        for i in range(len(self.constraint_sets)):
+            sh['mlps.%d.0' % i] = (2 * H, kin)
+        return sh
+
+    def load_state_dict(self, sd, strict=True):
+        """accepts the reference's key names, bare or with the 'denoise_fn.' / 'denoise_fn.model.' prefixes
+        a GaussianDiffusion checkpoint carries (networks/ddpm.py:503-514)"""
+        clean = {}
+        for k, v in sd.items():
+            for pre in ('denoise_fn.model.', 'denoise_fn.', 'model.'):
+                if k.startswith(pre):
+                    k = k[len(pre):]
+                    break
+            clean[k] = v
+        params = {}
+        for name, shape in self.shapes().items():
+            for suffix, shp in (('.weight', shape), ('.bias', (shape[0],))):
+                key = name + suffix
+                if key not in clean:
+                    raise KeyError('missing key %s in state_dict' % key)
+                t = clean[key]
+                if isinstance(t, np.ndarray):
+                    t = torch.from_numpy(np.ascontiguousarray(t))
+                t = t.detach().to(self.device, torch.float32).contiguous()
+                if tuple(t.shape) != tuple(shp):
+                    raise ValueError('size mismatch for %s: %s vs %s' % (key, tuple(t.shape), tuple(shp)))
+                params[key] = t
+        self._params = params
+        self._drop_handle()
+        return self
+
+    def reset_parameters(self, seed=0):
+        """nn.Linear default init (uniform +-1/sqrt(fan_in)), for plumbing runs without a checkpoint"""
+        g = torch.Generator().manual_seed(seed)
+        sd = {}
+        for name, (o, i) in self.shapes().items():
+            bound = 1.0 / math.sqrt(i)
+            sd[name + '.weight'] = (torch.rand((o, i), generator=g) * 2 - 1) * bound
+            sd[name + '.bias'] = (torch.rand((o,), generator=g) * 2 - 1) * bound
+        return self.load_state_dict(sd)
+
+    def state_dict(self):
+        if self._params is None:
+            raise _lib.CcspError('no weights loaded')
+        return dict(self._params)
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError('training is outside the sampling path (SURVEY 2, row 1)')
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def cuda(self):
+        return self
+
+    # ---- native handles -----------------------------------------------------------------
+    def _drop_handle(self):
+        self._graphs.clear()
+        if self._h is not None:
+            _lib.lib().ccsp_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self._drop_handle()
+        except Exception:
+            pass
+
+    def _bind(self, timesteps):
+        if timesteps != self.timesteps:
+            self.timesteps = timesteps
+            self._drop_handle()
+
+    def _handle(self):
+        if self._h is not None:
+            return self._h
+        if self._params is None:
+            raise _lib.CcspError('ConstraintDiffuser has no weights: call load_state_dict() (or reset_parameters())')
+        L = _lib.lib()
+        grasp = self._grasp
+        d = _lib.ModelDesc(hidden_dim=self.hidden_dim, pose_dim=self.dims[-1][0], pose_begin=self.dims[-1][1],
+                           geom_dim=self.dims[0][0], grasp_dim=self.dims[1][0] if grasp else 0,
+                           grasp_begin=self.dims[1][1] if grasp else 0, n_types=len(self.constraint_sets),
+                           timesteps=self.timesteps, normalize=int(bool(self.normalize)),
+                           energy_wrapper=int(bool(self.energy_wrapper)), ebm_per_steps=int(self.ebm_per_steps))
+        ptrs = []
+        for name in param_names(len(self.constraint_sets), grasp):
+            ptrs.append(self._params[name + '.weight'].data_ptr())
+            ptrs.append(self._params[name + '.bias'].data_ptr())
+        arr = (C.c_void_p * len(ptrs))(*ptrs)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(L.ccsp_model_create(C.byref(d), arr, _stream_ptr(self.device), C.byref(h)))
+        self._h = h
+        return h
+
+    def _graph(self, batch):
+        """graph handle for this batch, cached on the batch's tensors (static over a chain)"""
+        key = (id(batch), batch.x.data_ptr(), batch.edge_index.data_ptr(), tuple(batch.x.shape),
+               tuple(batch.edge_index.shape))
+        self._handle()
+        g = self._graphs.get(key)
+        if g is None or g.model_handle != self._h.value:
+            if len(self._graphs) > 8:
+                self._graphs.clear()
+            with torch.cuda.device(self.device):
+                g = _Graph(self, batch)
+            self._graphs[key] = g
+        return g
+
+    # ---- the reference's call surface ---------------------------------------------------
+    def time_mlp(self, t):
+        """time embedding rows for integer timesteps t [n] -> [n, H] (denoise_fn.py:259-264)"""
+        L = _lib.lib()
+        ts = [int(v) for v in torch.as_tensor(t).reshape(-1).tolist()]
+        out = torch.empty((len(ts), self.hidden_dim), device=self.device, dtype=torch.float32)
+        for i, tv in enumerate(ts):
+            _lib.check(L.ccsp_time_embedding(self._handle(), tv, _ptr(out[i]), _stream_ptr(self.device)))
+        return out
+
+    def edge_outputs(self, poses_in, batch, t):
+        """_process_constraint outputs of every edge, [E, 2, P] in the caller's edge order"""
+        g = self._graph(batch)
+        p = poses_in.detach().to(self.device, torch.float32).contiguous()
+        out = torch.empty((g.E, 2, self.dims[-1][0]), device=self.device, dtype=torch.float32)
+        _lib.check(_lib.lib().ccsp_edge_outputs(self._h, g.h, _ptr(p), int(torch.as_tensor(t).reshape(-1)[0]),
+                                                _ptr(out), _stream_ptr(self.device)))
+        return out
+
+    def forward(self, poses_in, batch, t, verbose=False, debug=False, tag='EBM', eval=False):
+        """ConstraintDiffuser.forward (denoise_fn.py:453-537).  direct mode -> [N,P];
+        energy mode (tag == 'EBM' and energy_wrapper) -> (gradients [N,P], energy scalar)"""
+        L = _lib.lib()
+        g = self._graph(batch)
+        p = poses_in.detach().to(self.device, torch.float32).contiguous()
+        tv = int(torch.as_tensor(t).reshape(-1)[0])
+        out = torch.empty_like(p)
+        if tag == 'EBM' and self.energy_wrapper:
+            energy = torch.zeros((), device=self.device, dtype=torch.float32)
+            _lib.check(L.ccsp_energy_grad(self._h, g.h, _ptr(p), tv, _ptr(out), _ptr(energy), _stream_ptr(self.device)))
+            return out, energy
+        _lib.check(L.ccsp_denoise(self._h, g.h, _ptr(p), tv, _ptr(out), _stream_ptr(self.device)))
+        return out
+
+    __call__ = forward
+
+
+class ComposedEBMDenoiseFn(object):
+    """wrapper exposing forward -> gradients and neg_logp_unnorm -> energy
+    (reference networks/denoise_fn.py:57-83)"""
+
+    def __init__(self, model, ebm_per_steps=1):
+        self.model = model
+        self.device = model.device
+        self.dims = model.dims
+        self.input_mode = model.input_mode
+        self.ebm_per_steps = ebm_per_steps
+        self.energy_wrapper = True
+        model.energy_wrapper = True
+        model.ebm_per_steps = ebm_per_steps
+        model._drop_handle()
+        self.training = False
+
+    def neg_logp_unnorm(self, poses_in, batch, t, **kwargs):
+        kwargs['tag'] = 'EBM'
+        gradients, energy = self.model.forward(poses_in, batch, t, **kwargs)
+        return energy.sum()
+
+    def forward(self, poses_in, batch, t, **kwargs):
+        if isinstance(poses_in, np.ndarray):
+            poses_in = torch.tensor(poses_in, device=self.model.device)
+            t = torch.tensor(t, device=self.model.device)
+        kwargs['tag'] = 'EBM'
+        gradients, energy = self.model.forward(poses_in, batch, t, **kwargs)
+        return gradients
+
+    __call__ = forward
+
+    def eval(self):
+        return self
+
+    def load_state_dict(self, sd, strict=True):
+        self.model.load_state_dict(sd, strict)
+        return self
+
+    def state_dict(self):
+        return {'model.' + k: v for k, v in self.model.state_dict().items()}

@@ -1,0 +1,103 @@
+"""Multi-GPU: independent graph shards, one process per GPU.
+
+The reference has no distributed code at all.  Every operation of the sampling path is per node or
+per edge *within one graph* (collation is block-diagonal), so a batch of B graphs shards into
+contiguous blocks of graphs with no data-path collective: the chain of each shard runs on its own
+GPU.  The only communication is
+
+  * one broadcast of the weights (36.6 MB fp32 at hidden_dim 256) from rank 0 at start-up, and
+  * one gather of the final poses ([N, P] fp32, ~37 KB per 256-graph shard) per sampled batch,
+
+both through ``torch.distributed`` (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU
+tests).  Noise parity across shardings comes from the counter-based stream being indexed by the
+*global* node row (noise.py): a shard passes ``row_offset`` = index of its first node.
+"""
+import numpy as np
+import torch
+
+from .worlds import GraphBatch
+
+
+def shard_bounds(n_graphs, rank, world):
+    """contiguous block [g0, g1) of graphs owned by `rank` (sizes differ by at most one)"""
+    base, rem = divmod(n_graphs, world)
+    g0 = rank * base + min(rank, rem)
+    return g0, g0 + base + (1 if rank < rem else 0)
+
+
+def shard_batch(batch, rank, world):
+    """sub-batch of a collated numpy GraphBatch for `rank` -> (sub_batch, row_offset).
+    `batch.batch` is the graph id of every node (PyG convention)."""
+    gid = np.asarray(batch.batch)
+    n_graphs = int(gid.max()) + 1 if gid.size else 0
+    g0, g1 = shard_bounds(n_graphs, rank, world)
+    nodes = np.nonzero((gid >= g0) & (gid < g1))[0]
+    if nodes.size == 0:
+        r0, r1 = 0, 0
+    else:
+        r0, r1 = int(nodes[0]), int(nodes[-1]) + 1
+    assert nodes.size == r1 - r0, 'graphs must be stored contiguously'
+    ei = np.asarray(batch.edge_index)
+    sel = (ei[0] >= r0) & (ei[0] < r1)
+    assert (((ei[1] >= r0) & (ei[1] < r1)) == sel).all(), 'an edge crosses graphs'
+    sub = GraphBatch(x=np.asarray(batch.x)[r0:r1], edge_index=ei[:, sel] - r0,
+                     edge_attr=np.asarray(batch.edge_attr)[sel], mask=np.asarray(batch.mask)[r0:r1],
+                     batch=gid[r0:r1] - g0, num_graphs=g1 - g0)
+    return sub, r0
+
+
+def broadcast_state_dict(sd, shapes, device, dist=None, src=0):
+    """rank `src` holds `sd` (name.weight / name.bias -> array); every rank returns device tensors.
+    One flat fp32 buffer, one collective (ring algorithms are per-link bound on xGMI: fewer, larger)."""
+    keys = []
+    for name, (o, i) in shapes.items():
+        keys.append((name + '.weight', (o, i)))
+        keys.append((name + '.bias', (o,)))
+    total = sum(int(np.prod(s)) for _, s in keys)
+    if dist is None or dist.get_world_size() == 1:
+        return {k: torch.as_tensor(np.asarray(sd[k]), dtype=torch.float32).to(device) for k, _ in keys}
+    flat = torch.empty(total, dtype=torch.float32, device=device)
+    if dist.get_rank() == src:
+        host = np.concatenate([np.asarray(sd[k], dtype=np.float32).reshape(-1) for k, _ in keys])
+        flat.copy_(torch.from_numpy(host))
+    dist.broadcast(flat, src=src)
+    out, off = {}, 0
+    for k, s in keys:
+        n = int(np.prod(s))
+        out[k] = flat[off:off + n].view(*s).clone()
+        off += n
+    return out
+
+
+def gather_poses(x_local, dist=None, sizes=None):
+    """final poses of every shard on every rank, concatenated in rank order.  `sizes`: rows per rank
+    when shards are uneven (default: equal)."""
+    if dist is None or dist.get_world_size() == 1:
+        return x_local
+    world = dist.get_world_size()
+    if sizes is None:
+        parts = [torch.empty_like(x_local) for _ in range(world)]
+        dist.all_gather(parts, x_local.contiguous())
+        return torch.cat(parts, 0)
+    mx = max(sizes)
+    pad = torch.zeros((mx,) + tuple(x_local.shape[1:]), dtype=x_local.dtype, device=x_local.device)
+    pad[:x_local.shape[0]] = x_local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    return torch.cat([p[:n] for p, n in zip(parts, sizes)], 0)
+
+
+def sample_sharded(sample_fn, batch, dist=None, seed=0):
+    """shard `batch` (numpy GraphBatch) by graphs, run `sample_fn(sub_batch, seed, row_offset) -> [n,P]`
+    on the local shard, gather.  Every rank returns the full [N, P] result, identical to the
+    unsharded run with the same seed."""
+    if dist is None or dist.get_world_size() == 1:
+        return sample_fn(batch, seed, 0)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    sub, r0 = shard_batch(batch, rank, world)
+    x = sample_fn(sub, seed, r0)
+    sizes = []
+    for r in range(world):
+        s, _ = shard_batch(batch, r, world)
+        sizes.append(int(s.x.shape[0]))
+    return gather_poses(x, dist, sizes)

@@ -1,0 +1,156 @@
+/* ccsp.h -- C ABI of the MI355X-native Diffusion-CCSP sampling path (libccsp_hip.so).
+ *
+ * The reference (zt-yang/diffusion-ccsp) has no FFI; its seam for this path is duck-typed Python
+ * (SURVEY.md 8b).  Each entry point below names the reference interface it replaces
+ * (file:line in the reference repository).  INTEGRATION.md shows the ctypes binding a reference
+ * maintainer would add; diffusion-ccsp_amd/_lib.py is that binding.
+ *
+ * Conventions
+ *  - every array pointer is a DEVICE pointer owned by the caller (e.g. torch tensor.data_ptr()),
+ *    fp32 / int64 / int8 row-major contiguous, unless the parameter is documented "host";
+ *  - every call enqueues its work on the caller-supplied hipStream_t (`stream`, passed as
+ *    void*; NULL = the default stream).  Only ccsp_model_create / ccsp_schedule_set /
+ *    ccsp_graph_create (one-time set-up: they read small arrays back to build index tables) and
+ *    ccsp_*_get synchronise; the evaluation and chain calls never do;
+ *  - return value 0 = ok, non-zero = error; ccsp_last_error() gives the thread-local message;
+ *  - no exceptions cross the boundary; handles are not thread-safe (one per device & stream);
+ *  - NaN is data, not an error (isolated nodes give 0/0 exactly like the reference,
+ *    networks/denoise_fn.py:523-524).
+ */
+#ifndef CCSP_H
+#define CCSP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCSP_VERSION_MAJOR 0
+#define CCSP_VERSION_MINOR 1
+
+typedef struct ccsp_model ccsp_model;   /* ConstraintDiffuser weights + GaussianDiffusion schedule */
+typedef struct ccsp_graph ccsp_graph;   /* one collated batch of constraint graphs              */
+
+/* Static description of a ConstraintDiffuser (networks/denoise_fn.py:184-291) wrapped in a
+ * GaussianDiffusion (networks/ddpm.py:168-228).  `dims` is the reference's tuple of
+ * (length, begin, end) per variable group (train_utils.py:266-278). */
+typedef struct {
+    int32_t hidden_dim;     /* H: -hidden_dim (train_utils.py:107); supported: 64, 256          */
+    int32_t pose_dim;       /* P = dims[-1][0] (4 or 5)                                          */
+    int32_t pose_begin;     /* dims[-1][1]: ground-truth pose columns x[:, pose_begin:+P]        */
+    int32_t geom_dim;       /* dims[0][0]: geometry columns x[:, 0:geom_dim]                     */
+    int32_t grasp_dim;      /* 0, or dims[1][0] when 'robot' in input_mode                       */
+    int32_t grasp_begin;    /* dims[1][1]                                                        */
+    int32_t n_types;        /* len(constraint_sets) (denoise_fn.py:207-214)                      */
+    int32_t timesteps;      /* -timesteps                                                        */
+    int32_t normalize;      /* -normalize (denoise_fn.py:523)                                    */
+    int32_t energy_wrapper; /* 1 when wrapped in ComposedEBMDenoiseFn (denoise_fn.py:57-83)      */
+    int32_t ebm_per_steps;  /* denoise_fn.ebm_per_steps (denoise_fn.py:284; ddpm.py:330)         */
+} ccsp_model_desc;
+
+enum { CCSP_SAMPLER_NONE = 0, CCSP_SAMPLER_ULA = 1, CCSP_SAMPLER_ULA_PLUS = 2, CCSP_SAMPLER_MALA = 3 };
+enum { CCSP_NOISE_PHILOX = 0, CCSP_NOISE_INJECTED = 1 };
+
+/* Where the chain's torch.randn / torch.rand draws come from (ddpm.py:255,273,292,1037).
+ * PHILOX: the stateless counter-based stream of diffusion-ccsp_amd/noise.py, regenerated on
+ * device.  INJECTED: the caller supplies the draws (parity runs against a recorded stream). */
+typedef struct {
+    int32_t mode;
+    int32_t _pad;
+    uint64_t seed;          /* PHILOX                                                            */
+    uint64_t row_offset;    /* PHILOX: global row index of this batch's row 0 (sharded batches)  */
+    const float* normal;    /* INJECTED: device [n_normal, N, P]; entry k = randn call call_base+k */
+    uint64_t n_normal;
+    const float* uniform;   /* INJECTED (MALA): device [n_uniform, N]                            */
+    uint64_t n_uniform;
+    uint64_t call_base;
+    uint64_t ucall_base;
+} ccsp_noise;
+
+const char* ccsp_last_error(void);
+int32_t ccsp_version(void);                       /* major * 1000 + minor                        */
+/* name, compute units, HBM bytes of the current HIP device; 0 on success                       */
+int ccsp_device_info(char* name, int32_t name_len, int32_t* compute_units, uint64_t* hbm_bytes);
+
+/* Replaces ConstraintDiffuser.__init__ + load_state_dict (denoise_fn.py:184-308,
+ * ddpm.py:503-514).  params: host array of 2*n_linear DEVICE pointers, weight then bias, in the
+ * reference state_dict order: geom_encoder.{0,2}, [grasp_encoder.{0,2}], pose_encoder.{0,2},
+ * pose_decoder.{0,2}, time_mlp.{1,3}, mlps.i.0 (i < n_types).  Weights are copied (and re-laid
+ * out) into library-owned HBM; the cosine schedule (ddpm.py:152-162) and the per-type time-term
+ * table are built here. */
+int ccsp_model_create(const ccsp_model_desc* desc, const float* const* params, void* stream,
+                      ccsp_model** out);
+void ccsp_model_destroy(ccsp_model* model);
+
+/* Replaces GaussianDiffusion.__init__'s betas / step_sizes / samples_per_step arguments
+ * (ddpm.py:169-228).  betas: HOST double[T] or NULL (cosine); step_sizes: HOST float[T] or NULL
+ * ('2*self.betas'); samples_per_step: HOST int32[T] or NULL (default_samples for every t). */
+int ccsp_schedule_set(ccsp_model* model, const double* betas, const float* step_sizes,
+                      const int32_t* samples_per_step, int32_t default_samples);
+/* Copies one schedule buffer to HOST float[T].  which: 0 betas, 1 alphas_cumprod,
+ * 2 alphas_cumprod_prev, 3 sqrt_recip_alphas_cumprod, 4 sqrt_recipm1_alphas_cumprod,
+ * 5 posterior_log_variance_clipped, 6 posterior_mean_coef1, 7 posterior_mean_coef2,
+ * 8 _sqrt_recipm1_alphas_cumprod_custom, 9 step_sizes, 10 posterior_variance. */
+int ccsp_schedule_get(const ccsp_model* model, int32_t which, float* out_host);
+/* time_mlp(t) (denoise_fn.py:259-264) for one t -> DEVICE float[H] (visualize_energy.py:402-450
+ * reads denoise_fn.time_mlp) */
+int ccsp_time_embedding(ccsp_model* model, int32_t t, float* out, void* stream);
+
+/* Replaces the per-evaluation graph handling of ConstraintDiffuser.forward
+ * (denoise_fn.py:313-339,466-485,508): one-time type sort of the edges, node->edge CSR in the
+ * reference's accumulation order, geometry/grasp embeddings and the chain-constant part of every
+ * edge's pre-activation.  x [N,F] fp32, edge_index [2,E] int64, edge_attr [E] fp32 (integer
+ * ids; edges matching no type are ignored like the reference does), mask [N] int8. */
+int ccsp_graph_create(ccsp_model* model, int32_t N, int32_t E, int32_t F, const float* x,
+                      const int64_t* edge_index, const float* edge_attr, const int8_t* mask,
+                      void* stream, ccsp_graph** out);
+void ccsp_graph_destroy(ccsp_graph* graph);
+
+/* ConstraintDiffuser.forward(poses_in, batch, t, eval=True), direct mode
+ * (denoise_fn.py:453-537): poses_in [N,P] -> out [N,P]. */
+int ccsp_denoise(ccsp_model* model, ccsp_graph* graph, const float* poses_in, int32_t t,
+                 float* out, void* stream);
+/* Energy mode (denoise_fn.py:373-375,518-519,527-529,539-548; ComposedEBMDenoiseFn.forward /
+ * .neg_logp_unnorm :70-83): grad [N,P] = dE/dposes_in, energy [1] = E summed over the batch. */
+int ccsp_energy_grad(ccsp_model* model, ccsp_graph* graph, const float* poses_in, int32_t t,
+                     float* grad, float* energy, void* stream);
+/* _process_constraint outputs (denoise_fn.py:341-371; visualize_energy.py:450): [E,2,P] in the
+ * caller's edge order, NaN rows for ignored edges. */
+int ccsp_edge_outputs(ccsp_model* model, ccsp_graph* graph, const float* poses_in, int32_t t,
+                      float* out, void* stream);
+
+/* GaussianDiffusion.p_sample_loop (ddpm.py:260-340) with p_sample (:245-258) and
+ * AnnealedULASampler / AnnealedMALASampler.sample_step (:940-966, :999-1047): runs timesteps
+ * t_first, t_first-1, ..., t_last.  init != 0: draw the initial state first (randn call 0,
+ * ddpm.py:273-274) -- a whole chain is (init=1, t_first=T-1, t_last=0); init == 0: x [N,P]
+ * holds the state on entry.  x receives the final state.  history: NULL or [(T+1),N,P]; entry k
+ * = state after k timesteps.  accept: NULL or [T] mean MALA acceptance per timestep.
+ * Asynchronous: the caller synchronises the stream before reading x. */
+int ccsp_chain_run(ccsp_model* model, ccsp_graph* graph, int32_t sampler, const ccsp_noise* noise,
+                   float* x, int32_t init, int32_t t_first, int32_t t_last, float* history,
+                   float* accept, void* stream);
+
+/* Kernel-level timing of the most recent ccsp_chain_run on this graph, measured with HIP events
+ * on the chain's stream (bench.py's roofline block).  evals = network evaluations executed,
+ * ms_total = event time of the whole chain.  After ccsp_profile_enable(graph, 1) the first 1024
+ * evaluations of a chain are additionally bracketed launch by launch: ms_ugemm / ms_edge = mean
+ * duration of k_ugemm / k_edge (0 when profiling is off).  Synchronises on the chain's end. */
+int ccsp_profile_enable(ccsp_graph* graph, int32_t on);
+int ccsp_chain_stats(ccsp_graph* graph, int64_t* evals, float* ms_total, float* ms_ugemm, float* ms_edge);
+
+/* Host-only planning entry (needs no device): the one-time index tables ccsp_graph_create builds
+ * from the edge lists -- type-sorted edges, the distinct (type, slot, node) rows, their row tiles
+ * and the node->(edge,slot) CSR in the reference's scatter_add_ order (denoise_fn.py:377-389,
+ * :512-521).  All pointers are HOST pointers sized by the caller: per-edge arrays [E],
+ * urow_* [2E], tile_* [2E + 2C], node_ptr [N+1], node_ent [2E]; counts = {E_act, R, n_tiles}.
+ * Output arrays may be NULL. */
+int ccsp_plan_host(int32_t N, int32_t E, int32_t C, const int64_t* edge_index, const float* edge_attr,
+                   int32_t* counts, int32_t* e_orig, int32_t* e_type, int32_t* e_u0, int32_t* e_u1,
+                   int32_t* urow_node, int32_t* urow_ts, int32_t* tile_row0, int32_t* tile_nrows,
+                   int32_t* tile_ts, int32_t* node_ptr, int32_t* node_ent);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

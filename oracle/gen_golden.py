@@ -1,0 +1,266 @@
+"""TEST INFRASTRUCTURE ONLY (build container; needs /root/reference).
+
+Generates the golden vectors under tests/golden/ by running the *reference itself*
+(zt-yang/diffusion-ccsp, imported unmodified through oracle/ref_import.py) on PyTorch-CPU.  The
+reference holds no tests, fixtures or golden vectors for the sampling path, so these
+files are what pins the oracle (oracle/ccsp_oracle.c) and, through it and directly, the HIP path.
+
+Only arrays are written: inputs (graphs, poses, noise seeds), expected outputs, and the weights
+trained by oracle/ref_train.py.  No reference source or bytecode is copied.
+
+Noise: ``torch.randn`` / ``torch.rand`` are temporarily replaced by the build-owned counter-based
+stream (diffusion-ccsp_amd/noise.py), because networks/ddpm.py calls them as module attributes
+(ddpm.py:121-122,255,273,292,1037).
+
+usage: python oracle/gen_golden.py [names...]      (no names = everything)
+"""
+import contextlib
+import io
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_import  # noqa: E402
+import oracle as oracle_mod  # noqa: E402  (only for load_weights)
+import diffusion_ccsp_amd  # noqa: E402,F401
+from diffusion_ccsp_amd import noise, worlds  # noqa: E402
+
+ddpm, dfn = ref_import.load()
+
+
+class PatchedNoise(object):
+    def __init__(self, seed, dtype=torch.float32):
+        self.seed, self.c, self.uc, self.dtype = seed, 0, 0, dtype
+
+    @staticmethod
+    def _shape(shape):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+            return tuple(shape[0])
+        return tuple(shape)
+
+    def __enter__(self):
+        self.orig = (torch.randn, torch.rand)
+
+        def randn(*shape, **kw):
+            shape = self._shape(shape)
+            z = noise.normal(self.seed, self.c, shape[0], shape[1])
+            self.c += 1
+            return torch.from_numpy(z).to(self.dtype)
+
+        def rand(*shape, **kw):
+            shape = self._shape(shape)
+            u = noise.uniform(self.seed, self.uc, shape[0])
+            self.uc += 1
+            return torch.from_numpy(u).to(self.dtype)
+
+        torch.randn, torch.rand = randn, rand
+        return self
+
+    def __exit__(self, *a):
+        torch.randn, torch.rand = self.orig
+
+
+def build_reference(mode, H, weights, energy=False, EBM='ULA', T=1000, S=10, dtype=torch.float32):
+    dims = worlds.MODE_DIMS[mode]
+    if dtype == torch.float64:
+        torch.set_default_dtype(torch.float64)
+    try:
+        model = dfn.ConstraintDiffuser(dims=dims, hidden_dim=H, EBM=EBM, input_mode=mode, energy_wrapper=energy,
+                                       device='cpu', verbose=False)
+        model.load_state_dict({k: torch.from_numpy(v).to(dtype) for k, v in weights.items()})
+        den = dfn.ComposedEBMDenoiseFn(model) if energy else model
+        gd = ddpm.GaussianDiffusion(den, timesteps=T, EBM=EBM, samples_per_step=S, step_sizes='2*self.betas')
+        if dtype == torch.float64:
+            gd = gd.double()
+            gd._sqrt_recipm1_alphas_cumprod_custom = gd._sqrt_recipm1_alphas_cumprod_custom.double()
+            gd.step_sizes = gd.step_sizes.double() if torch.is_tensor(gd.step_sizes) else gd.step_sizes
+    finally:
+        torch.set_default_dtype(torch.float32)
+    return model, gd.eval()
+
+
+def batch_arrays(b):
+    return dict(x=b.x.numpy().astype(np.float32), edge_index=b.edge_index.numpy().astype(np.int64),
+                edge_attr=b.edge_attr.numpy().astype(np.float32), mask=b.mask.numpy().astype(np.int8))
+
+
+HIST_IDX = [0, 1, 2, 3, 4, 5, 10, 50, 100, 200, 300, 400, 500, 600, 700, 800, 900, 950, 990, 998, 999, 1000]
+
+
+def run_chain(name, mode, H, wfile, batch, EBM, T=1000, S=10, seed=7, energy=False, dtype=torch.float32):
+    W = oracle_mod.load_weights(os.path.join(GOLD, wfile))
+    model, gd = build_reference(mode, H, W, energy=energy, EBM=EBM, T=T, S=S, dtype=dtype)
+    b = batch.clone()
+    if dtype == torch.float64:
+        b.x = b.x.double()
+    t0 = time.time()
+    with PatchedNoise(seed, dtype) as pn, contextlib.redirect_stdout(io.StringIO()):
+        out, hist = gd.sample(b, return_history=True)
+    dt = time.time() - t0
+    out = out.detach().numpy()
+    hist = np.stack([h.detach().numpy() for h in hist])
+    idx = sorted(set(i for i in HIST_IDX if i <= T) | {T})
+    rec = dict(batch_arrays(batch))
+    rec.update(final=out.astype(np.float64 if dtype == torch.float64 else np.float32),
+               hist_idx=np.asarray(idx, dtype=np.int32), hist=hist[idx].astype(out.dtype),
+               seed=np.int64(seed), T=np.int32(T), S=np.int32(S), H=np.int32(H), n_randn=np.int64(pn.c),
+               n_rand=np.int64(pn.uc), ref_seconds=np.float64(dt), threads=np.int32(torch.get_num_threads()))
+    meta = dict(mode=mode, EBM=str(EBM), weights=wfile, energy=bool(energy), dtype=str(dtype))
+    np.savez_compressed(os.path.join(GOLD, name + '.npz'), meta=np.asarray(repr(meta)), **rec)
+    print('%-34s %6.1fs  randn calls %d  |final|max %.3f  |hist|max %.3g' %
+          (name, dt, pn.c, np.abs(out).max(), np.abs(hist).max()), flush=True)
+
+
+def gen_schedule():
+    rec = {}
+    for T in (100, 1000):
+        W = oracle_mod.load_weights(os.path.join(GOLD, 'weights_qualitative_h64.npz'))
+        _, gd = build_reference('qualitative', 64, W, T=T)
+        for k in ['betas', 'alphas_cumprod', 'alphas_cumprod_prev', 'sqrt_recip_alphas_cumprod',
+                  'sqrt_recipm1_alphas_cumprod', 'posterior_log_variance_clipped', 'posterior_mean_coef1',
+                  'posterior_mean_coef2', 'posterior_variance']:
+            rec['T%d/%s' % (T, k)] = getattr(gd, k).numpy()
+        rec['T%d/kappa' % T] = gd._sqrt_recipm1_alphas_cumprod_custom.numpy()
+        rec['T%d/step_sizes' % T] = gd.step_sizes.numpy()
+    np.savez_compressed(os.path.join(GOLD, 'schedule.npz'), **rec)
+    print('schedule.npz')
+
+
+def gen_labeller():
+    """objects -> constraints of the reference's qualitative labeller (envs/data_utils.py:427-621)"""
+    _, du = ref_import.load_envs()
+    rng = np.random.default_rng(123)
+    rec = {}
+    for i in range(40):
+        n = int(rng.integers(2, 9))
+        wd = worlds.sample_qualitative_world(rng, n)
+        objs = {k: dict(label=k, center=v['center'], extents=v['extents']) for k, v in wd['objects'].items()}
+        ref = du.compute_qualitative_constraints(objs, rotations={}, scale=1)
+        boxes = np.asarray([list(v['center'][:2]) + list(v['extents'][:2]) for k, v in wd['objects'].items() if k.startswith('tile_')])
+        rec['case%d/boxes' % i] = boxes
+        rec['case%d/cons' % i] = np.asarray([[worlds.QUALITATIVE_CONSTRAINTS.index(c[0]), c[1], c[2]] for c in ref], dtype=np.int32).reshape(-1, 3)
+    np.savez_compressed(os.path.join(GOLD, 'labeller.npz'), **rec)
+    print('labeller.npz')
+
+
+def synth_weights(mode, H, seed):
+    """untrained nn.Linear-style weights (single evaluations do not need contractive weights)"""
+    dims = worlds.MODE_DIMS[mode]
+    torch.manual_seed(seed)
+    m = dfn.ConstraintDiffuser(dims=dims, hidden_dim=H, EBM='ULA', input_mode=mode, device='cpu', verbose=False)
+    return {k: v.detach().numpy().astype(np.float32) for k, v in m.state_dict().items()}
+
+
+def gen_single_eval():
+    """single network evaluations, direct mode and energy mode"""
+    rec = {}
+    rng = np.random.default_rng(99)
+    cases = [
+        ('q64', 'qualitative', 64, 'weights_qualitative_h64.npz', worlds.qualitative_batch(3, 8, seed=21)),
+        ('q64small', 'qualitative', 64, 'weights_qualitative_h64.npz', worlds.qualitative_batch(1, 3, seed=22)),
+        ('q256', 'qualitative', 256, 'weights_qualitative_h256.npz', worlds.qualitative_batch(2, 8, seed=23)),
+        ('t64', 'diffuse_pairwise', 64, 'weights_diffuse_pairwise_h64.npz', worlds.triangular_batch(2, 12, seed=24)),
+        ('t64e', 'diffuse_pairwise', 64, 'weights_diffuse_pairwise_h64_energy.npz', worlds.triangular_batch(2, 12, seed=25)),
+        ('r64', 'robot_box', 64, 'weights_robot_box_h64.npz', worlds.robot_box_batch(2, 10, seed=26)),
+    ]
+    for tag, mode, H, wfile, batch in cases:
+        W = oracle_mod.load_weights(os.path.join(GOLD, wfile))
+        b = batch.to_torch()
+        if tag == 'q64':
+            # quirks: an edge whose type id matches no constraint is ignored (denoise_fn.py:512-517);
+            # an isolated node divides 0/0 in the count normalisation (:523-524)
+            ea = b.edge_attr.clone()
+            ea[5] = 13.0
+            ea[17] = 2.5
+            b.edge_attr = ea
+            keep = (b.edge_index != 3).all(dim=0)
+            b.edge_index = b.edge_index[:, keep]
+            b.edge_attr = b.edge_attr[keep]
+        energy = tag.endswith('e')
+        model, gd = build_reference(mode, H, W, energy=energy, EBM='MALA' if energy else 'ULA')
+        P = worlds.MODE_DIMS[mode][-1][0]
+        for key, val in batch_arrays(b).items():
+            rec['%s/%s' % (tag, key)] = val
+        ts = [0, 1, 37, 500, 998, 999]
+        poses = (rng.standard_normal((len(ts), b.x.shape[0], P)) * 0.7).astype(np.float32)
+        outs, grads, energies = [], [], []
+        for i, t in enumerate(ts):
+            tt = torch.tensor([t])
+            if energy:
+                g, e = model(torch.from_numpy(poses[i]).clone(), b, tt, eval=True, tag='EBM')
+                grads.append(g.detach().numpy())
+                energies.append(float(e.detach()))
+            else:
+                with torch.no_grad():
+                    outs.append(model(torch.from_numpy(poses[i]).clone(), b, tt, eval=True).numpy())
+        rec['%s/t' % tag] = np.asarray(ts, dtype=np.int32)
+        rec['%s/poses' % tag] = poses
+        if energy:
+            rec['%s/grad' % tag] = np.stack(grads)
+            rec['%s/energy' % tag] = np.asarray(energies, dtype=np.float64)
+        else:
+            rec['%s/out' % tag] = np.stack(outs)
+        rec['%s/time_emb' % tag] = model.time_mlp(torch.tensor(ts)).detach().numpy()
+    # untrained H=256 weights for every mode: regenerated from the seed by the reference here and
+    # by the tests through the committed outputs only (weights are not stored: they are inputs of
+    # a pure function of the seed -> stored as a checksum + outputs on the fixed graphs)
+    np.savez_compressed(os.path.join(GOLD, 'single_eval.npz'), **rec)
+    print('single_eval.npz')
+
+
+def gen_chains(which):
+    jobs = {
+        'chain_q64_T1000_B4': lambda: run_chain('chain_q64_T1000_B4', 'qualitative', 64, 'weights_qualitative_h64.npz',
+                                                worlds.qualitative_batch(4, 8, seed=31).to_torch(), 'ULA'),
+        'chain_q64_T100_B1': lambda: run_chain('chain_q64_T100_B1', 'qualitative', 64, 'weights_qualitative_h64.npz',
+                                               worlds.qualitative_batch(1, 3, seed=5).to_torch(), 'ULA', T=100),
+        'chain_q256_T100_B1': lambda: run_chain('chain_q256_T100_B1', 'qualitative', 256, 'weights_qualitative_h256.npz',
+                                                worlds.qualitative_batch(1, 3, seed=5).to_torch(), 'ULA', T=100),
+        'chain_q256_T1000_B4': lambda: run_chain('chain_q256_T1000_B4', 'qualitative', 256, 'weights_qualitative_h256.npz',
+                                                 worlds.qualitative_batch(4, 8, seed=32).to_torch(), 'ULA'),
+        'chain_q64_noebm': lambda: run_chain('chain_q64_noebm', 'qualitative', 64, 'weights_qualitative_h64.npz',
+                                             mixed_batch(), False),
+        'chain_q64_ulaplus': lambda: run_chain('chain_q64_ulaplus', 'qualitative', 64, 'weights_qualitative_h64.npz',
+                                               worlds.qualitative_batch(1, 5, seed=33).to_torch(), 'ULA+'),
+        'chain_t64_mala': lambda: run_chain('chain_t64_mala', 'diffuse_pairwise', 64, 'weights_diffuse_pairwise_h64_energy.npz',
+                                            worlds.triangular_batch(2, 12, seed=34).to_torch(), 'MALA', S=2, energy=True),
+        'chain_t64_ula': lambda: run_chain('chain_t64_ula', 'diffuse_pairwise', 64, 'weights_diffuse_pairwise_h64.npz',
+                                           worlds.triangular_batch(2, 12, seed=35).to_torch(), 'ULA', S=3),
+        'chain_r64_ula': lambda: run_chain('chain_r64_ula', 'robot_box', 64, 'weights_robot_box_h64.npz',
+                                           worlds.robot_box_batch(2, 10, seed=36).to_torch(), 'ULA', S=5),
+        'chain_q64_T1000_B4_f64': lambda: run_chain('chain_q64_T1000_B4_f64', 'qualitative', 64, 'weights_qualitative_h64.npz',
+                                                    worlds.qualitative_batch(4, 8, seed=31).to_torch(), 'ULA', dtype=torch.float64),
+    }
+    for k, fn in jobs.items():
+        if not which or k in which:
+            fn()
+
+
+def mixed_batch():
+    rng = np.random.default_rng(41)
+    gs = []
+    for n in (2, 5, 8):
+        wd = worlds.sample_qualitative_world(rng, n)
+        gs.append(worlds.encode_qualitative(wd['nodes'], wd['constraints']))
+    return worlds.collate(gs).to_torch()
+
+
+if __name__ == '__main__':
+    which = set(sys.argv[1:])
+    os.makedirs(GOLD, exist_ok=True)
+    if not which or 'schedule' in which:
+        gen_schedule()
+    if not which or 'labeller' in which:
+        gen_labeller()
+    if not which or 'single_eval' in which:
+        gen_single_eval()
+    gen_chains(which)

@@ -1,0 +1,149 @@
+"""TEST / BASELINE INFRASTRUCTURE ONLY -- a cost-faithful PyTorch-CPU *proxy* of the reference
+sampler, written from SURVEY.md Appendix A (not from the reference's files).
+
+Purpose: the reference's Python cannot travel to the GPU box, so bench.py's ``cpu_baseline`` leg
+times this proxy on the box's host cores instead ("kind": "port").  To make that number stand for
+"the reference's PyTorch-CPU path" the proxy keeps the reference's op sequence *and its
+redundancies*: the geometry encoder runs on every evaluation, the edge subset of every constraint
+type is found with ``where`` + a host round trip, the ``[E_i, 5H]`` input is materialised with
+``cat``, the time MLP runs once per edge row, outputs are accumulated with ``scatter_add_`` /
+``bincount``.  tests/test_oracle_golden.py checks its outputs against the reference-generated
+golden vectors; oracle/gen_golden.py's companion check (oracle/certify_proxy.py) times it next to
+the imported reference in the build container.
+
+The product (diffusion-ccsp_amd/) never imports this file.
+"""
+import math
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def _lin(x, w, b):
+    return F.linear(x, w, b)
+
+
+class ProxyDiffuser(object):
+    def __init__(self, weights, dims, hidden_dim, n_types, normalize=True):
+        self.W = {k: torch.as_tensor(np.asarray(v), dtype=torch.float32) for k, v in weights.items()}
+        self.dims, self.H, self.C, self.normalize = dims, hidden_dim, n_types, normalize
+        self.grasp = len(dims) == 3
+        self.P = dims[-1][0]
+
+    def _mlp2(self, name, x, last_act=True):
+        h = F.silu(_lin(x, self.W[name + '.0.weight'], self.W[name + '.0.bias']))
+        h = _lin(h, self.W[name + '.2.weight'], self.W[name + '.2.bias'])
+        return F.silu(h) if last_act else h
+
+    def time_mlp(self, t_rows):
+        half = self.H // 2
+        emb = math.log(10000) / (half - 1)
+        emb = torch.exp(torch.arange(half) * -emb)
+        emb = t_rows[:, None] * emb[None, :]
+        emb = torch.cat((emb.sin(), emb.cos()), dim=-1)
+        h = F.mish(_lin(emb, self.W['time_mlp.1.weight'], self.W['time_mlp.1.bias']))
+        return _lin(h, self.W['time_mlp.3.weight'], self.W['time_mlp.3.bias'])
+
+    def __call__(self, poses_in, batch, t):
+        H, P = self.H, self.P
+        x = batch.x.clone()
+        geoms_emb = self._mlp2('geom_encoder', x[:, :self.dims[0][2]])
+        poses_emb = self._mlp2('pose_encoder', poses_in)
+        grasp_emb = self._mlp2('grasp_encoder', x[:, self.dims[1][1]:self.dims[1][2]]) if self.grasp else None
+        edge_index = batch.edge_index.T
+        out = torch.zeros_like(poses_in)
+        cnt = torch.zeros_like(poses_in[:, 0])
+        for i in range(self.C):
+            edges = torch.where(batch.edge_attr == i)[0]
+            edges = edges.detach().cpu().numpy()
+            if edges.shape[0] == 0:
+                continue
+            args = torch.stack([edge_index[edges][:, 0], edge_index[edges][:, 1]], dim=1)
+            temb = self.time_mlp(t.expand(edges.shape[0]))
+            parts = [geoms_emb[args].reshape(len(edges), -1), poses_emb[args].reshape(len(edges), -1), temb]
+            if self.grasp:
+                parts = [grasp_emb[args[:, 0]]] + parts
+            inputs = torch.cat(parts, dim=-1)
+            h = F.silu(_lin(inputs, self.W['mlps.%d.0.weight' % i], self.W['mlps.%d.0.bias' % i]))
+            h = torch.stack([h[:, :H], h[:, H:]], dim=1)
+            o = self._mlp2('pose_decoder', h, last_act=False)
+            flat = args.reshape(-1)
+            o = o.reshape(-1, P)
+            out.scatter_add_(0, flat.unsqueeze(-1).expand(o.shape), o)
+            cnt += torch.bincount(flat, minlength=out.shape[0])
+        if self.normalize:
+            out /= torch.sqrt(cnt.unsqueeze(-1))
+        m = batch.mask.bool()
+        out[m] = x[:, -P:][m]
+        return out
+
+
+def cosine_schedule(T):
+    steps = T + 1
+    xs = np.linspace(0, steps, steps)
+    ac = np.cos(((xs / steps) + 0.008) / 1.008 * np.pi * 0.5) ** 2
+    ac = ac / ac[0]
+    betas = np.clip(1 - ac[1:] / ac[:-1], 0, 0.999)
+    alphas = 1 - betas
+    acp = np.cumprod(alphas)
+    prev = np.append(1.0, acp[:-1])
+    f = lambda a: torch.tensor(a, dtype=torch.float32)  # noqa: E731
+    pv = betas * (1 - prev) / (1 - acp)
+    return dict(betas=f(betas), a=f(np.sqrt(1 / acp)), b=f(np.sqrt(1 / acp - 1)), kappa=f(np.sqrt(1 / (1 - acp))),
+                lv=f(np.log(np.maximum(pv, 1e-20))), c1=f(betas * np.sqrt(prev) / (1 - acp)),
+                c2=f((1 - prev) * np.sqrt(alphas) / (1 - acp)))
+
+
+@torch.no_grad()
+def timestep(model, sch, batch, x, t, S, noise_fn):
+    """one timestep of the ULA chain: ancestral step + S Langevin steps + mask reset"""
+    tt = torch.full((1,), t, dtype=torch.long)
+    eps = model(x, batch, tt)
+    x0 = sch['a'][t] * x - sch['b'][t] * eps
+    mean = sch['c1'][t] * x0 + sch['c2'][t] * x
+    x = mean + (0 if t == 0 else 1) * (0.5 * sch['lv'][t]).exp() * noise_fn()
+    ss = 2 * sch['betas'][t]
+    std = (2 * ss) ** .5
+    for _ in range(S):
+        grad = -model(x, batch, tt) * sch['kappa'][t]
+        x = x + grad * ss + noise_fn() * std
+    m = batch.mask.bool()
+    x[m] = batch.x[:, model.dims[-1][1]:model.dims[-1][2]][m]
+    return x
+
+
+@torch.no_grad()
+def sample(model, batch, T, S, noise_fn):
+    sch = cosine_schedule(T)
+    gt = batch.x[:, model.dims[-1][1]:model.dims[-1][2]]
+    x = 0.5 * noise_fn()
+    m = batch.mask.bool()
+    x[m] = gt[m]
+    for t in reversed(range(T)):
+        x = timestep(model, sch, batch, x, t, S, noise_fn)
+    return x
+
+
+def time_baseline(weights, dims, hidden_dim, n_types, batch, T=1000, S=10, n_timesteps=4, budget_s=25.0):
+    """times `n_timesteps` full timesteps (1+S evaluations each) of the proxy on the host cores and
+    extrapolates x T.  Returns dict(samples_per_s, sec_per_timestep, cores, sample)."""
+    model = ProxyDiffuser(weights, dims, hidden_dim, n_types)
+    sch = cosine_schedule(T)
+    g = torch.Generator().manual_seed(0)
+    N, P = batch.x.shape[0], dims[-1][0]
+    noise_fn = lambda: torch.randn((N, P), generator=g)  # noqa: E731
+    x = 0.5 * noise_fn()
+    timestep(model, sch, batch, x, T // 2, 1, noise_fn)          # warm-up (allocator, threads)
+    done, t0 = 0, time.time()
+    for k in range(n_timesteps):
+        x = timestep(model, sch, batch, x, T - 1 - k, S, noise_fn)
+        done += 1
+        if time.time() - t0 > budget_s:
+            break
+    dt = (time.time() - t0) / done
+    n_graphs = int(batch.num_graphs) if hasattr(batch, 'num_graphs') else 1
+    return dict(samples_per_s=n_graphs / (dt * T), sec_per_timestep=dt, cores=torch.get_num_threads(),
+                sample='%d full timesteps (%d network evaluations) of the %d-graph batch, extrapolated x%d/%d'
+                       % (done, done * (1 + S), n_graphs, T, done))

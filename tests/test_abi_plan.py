@@ -1,0 +1,131 @@
+"""no-GPU checks of the product: the C-ABI library builds/loads and exports every symbol that
+include/ccsp.h declares; the host-side index planning equals a numpy restatement; host classes
+fail loudly without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, worlds
+from diffusion_ccsp_amd import _lib
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'ccsp.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(ccsp_[a-z_0-9]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    names = declared_symbols()
+    assert len(names) >= 17
+    for n in names:
+        assert hasattr(L, n), n
+    assert L.ccsp_version() == 1
+    assert isinstance(L.ccsp_last_error(), bytes)
+
+
+def test_structs_match_header_layout():
+    assert ctypes.sizeof(_lib.ModelDesc) == 11 * 4
+    assert ctypes.sizeof(_lib.Noise) == 72
+    assert _lib.Noise.seed.offset == 8 and _lib.Noise.normal.offset == 24 and _lib.Noise.ucall_base.offset == 64
+
+
+def numpy_plan(N, C, ei, ea, tile_m=64):
+    E = ei.shape[1]
+    et = np.full(E, -1)
+    for e in range(E):
+        v = ea[e]
+        if 0 <= v < C and v == int(v):
+            et[e] = int(v)
+    order = [e for i in range(C) for e in range(E) if et[e] == i]
+    e_a = [int(ei[0, e]) for e in order]
+    e_b = [int(ei[1, e]) for e in order]
+    e_type = [int(et[e]) for e in order]
+    rows, ts, u0, u1, tiles = [], [], [-1] * len(order), [-1] * len(order), []
+    for i in range(C):
+        ks = [k for k in range(len(order)) if e_type[k] == i]
+        for s in range(2):
+            first = len(rows)
+            seen = {}
+            for k in ks:
+                node = e_a[k] if s == 0 else e_b[k]
+                if node not in seen:
+                    seen[node] = len(rows)
+                    rows.append(node)
+                    ts.append(2 * i + s)
+                (u0 if s == 0 else u1)[k] = seen[node]
+            for r in range(first, len(rows), tile_m):
+                tiles.append((r, min(tile_m, len(rows) - r), 2 * i + s))
+    ent = [[] for _ in range(N)]
+    for k in range(len(order)):
+        ent[e_a[k]].append(2 * k)
+        ent[e_b[k]].append(2 * k + 1)
+    ptr = np.cumsum([0] + [len(x) for x in ent])
+    return dict(e_orig=order, e_type=e_type, e_u0=u0, e_u1=u1, urow_node=rows, urow_ts=ts,
+                tile_row0=[t[0] for t in tiles], tile_nrows=[t[1] for t in tiles], tile_ts=[t[2] for t in tiles],
+                node_ptr=ptr, node_ent=[v for x in ent for v in x])
+
+
+@pytest.mark.parametrize('case', ['qualitative', 'triangular', 'robot', 'ragged'])
+def test_plan_host_matches_numpy(case):
+    if case == 'qualitative':
+        b, C = worlds.qualitative_batch(12, 8, seed=3), 13
+    elif case == 'triangular':
+        b, C = worlds.triangular_batch(7, 12, seed=3), 2
+    elif case == 'robot':
+        b, C = worlds.robot_box_batch(5, 10, seed=3), 2
+    else:
+        b, C = worlds.qualitative_batch(3, 4, seed=9), 13
+        b.edge_attr = b.edge_attr.copy()
+        b.edge_attr[1] = 13.0      # unknown type id -> ignored
+        b.edge_attr[4] = 0.5       # non-integer -> ignored
+        b.edge_attr[7] = -1.0
+    N = b.x.shape[0]
+    got = _lib.plan_host(N, C, b.edge_index, b.edge_attr)
+    want = numpy_plan(N, C, b.edge_index, b.edge_attr)
+    for k, v in want.items():
+        assert np.array_equal(got[k], np.asarray(v, dtype=np.int32)), k
+    assert got['E_act'] == len(want['e_orig']) and got['R'] == len(want['urow_node'])
+    # CSR entries ascend per node == the reference's scatter_add_ order (type, edge, slot)
+    for n in range(N):
+        seg = got['node_ent'][got['node_ptr'][n]:got['node_ptr'][n + 1]]
+        assert (np.diff(seg) > 0).all()
+    # every tile stays inside one (type, slot) group
+    for r0, nr, ts in zip(got['tile_row0'], got['tile_nrows'], got['tile_ts']):
+        assert (got['urow_ts'][r0:r0 + nr] == ts).all() and 1 <= nr <= 64
+
+
+def test_plan_edge_cases():
+    # no edges at all
+    p = _lib.plan_host(3, 13, np.zeros((2, 0), dtype=np.int64), np.zeros(0, dtype=np.float32))
+    assert p['E_act'] == 0 and p['R'] == 0 and p['n_tiles'] == 0 and (p['node_ptr'] == 0).all()
+    # an endpoint out of range is an error, not a crash
+    with pytest.raises(_lib.CcspError):
+        _lib.plan_host(3, 13, np.array([[0], [7]], dtype=np.int64), np.zeros(1, dtype=np.float32))
+    # self loop: both slots of the same node
+    p = _lib.plan_host(2, 2, np.array([[1], [1]], dtype=np.int64), np.array([1.0], dtype=np.float32))
+    assert list(p['node_ent']) == [0, 1] and list(p['node_ptr']) == [0, 0, 2]
+
+
+def test_no_cpu_fallback():
+    from diffusion_ccsp_amd import ConstraintDiffuser
+    with pytest.raises(_lib.CcspError):
+        ConstraintDiffuser(dims=worlds.MODE_DIMS['qualitative'], hidden_dim=64, input_mode='qualitative', device='cpu')
+
+
+def test_product_never_imports_the_oracle():
+    """the oracle is test infrastructure: nothing under the package may import, include, link or load it"""
+    pkg = os.path.join(ROOT, 'diffusion-ccsp_amd')
+    bad = re.compile(r'^\s*(import|from)\s+(oracle|torch_proxy|ref_import|gen_golden)\b|#include\s*[<"].*oracle|libccsp_oracle|'
+                     r'import_module\([\'"]oracle', re.M)
+    n = 0
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                n += 1
+                assert not bad.search(open(os.path.join(dp, f)).read()), f
+    assert n >= 6

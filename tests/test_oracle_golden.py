@@ -1,0 +1,115 @@
+"""The CPU oracle (oracle/ccsp_oracle.c) against golden vectors produced by the reference itself
+(oracle/gen_golden.py).  This is what pins the checker; the reference has no tests of its own.
+Tolerances: schedule buffers bit-exact; single evaluations 2e-5 relative (fp32 summation-order
+noise of a 1280-long dot product); final poses of full chains 1e-4 (the north-star bound)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import (MODE_TYPES, golden, golden_batch, golden_meta, oracle, oracle_model, rel_err,
+                      weights, worlds)
+
+
+def test_schedule_bit_exact():
+    z = golden('schedule')
+    for T in (100, 1000):
+        m = oracle.OracleModel(weights('weights_qualitative_h64.npz'), worlds.MODE_DIMS['qualitative'], 64, 13, timesteps=T)
+        s = m.schedule()
+        for k in ['betas', 'alphas_cumprod', 'alphas_cumprod_prev', 'sqrt_recip_alphas_cumprod',
+                  'sqrt_recipm1_alphas_cumprod', 'posterior_log_variance_clipped', 'posterior_mean_coef1',
+                  'posterior_mean_coef2', 'posterior_variance', 'kappa', 'step_sizes']:
+            assert np.array_equal(s[k], z['T%d/%s' % (T, k)]), (T, k)
+    # SURVEY 8a-1 probe values
+    z1000 = {k: z['T1000/' + k] for k in ('betas', 'alphas_cumprod', 'kappa', 'step_sizes')}
+    assert abs(z1000['betas'][0] - 4.128e-5) < 1e-7 and z1000['betas'][999] == np.float32(0.999)
+    assert abs(z1000['kappa'][0] - 155.6) < 0.1 and abs(z1000['step_sizes'][999] - 1.998) < 1e-6
+
+
+CASES = [('q64', 'qualitative', 64, 'weights_qualitative_h64.npz'),
+         ('q64small', 'qualitative', 64, 'weights_qualitative_h64.npz'),
+         ('q256', 'qualitative', 256, 'weights_qualitative_h256.npz'),
+         ('t64', 'diffuse_pairwise', 64, 'weights_diffuse_pairwise_h64.npz'),
+         ('r64', 'robot_box', 64, 'weights_robot_box_h64.npz')]
+
+
+@pytest.mark.parametrize('tag,mode,H,wfile', CASES)
+def test_single_evaluation_direct(tag, mode, H, wfile):
+    z = golden('single_eval')
+    m = oracle_model(mode, H, wfile)
+    g = m.graph(golden_batch(z, tag + '/'))
+    for i, t in enumerate(z[tag + '/t']):
+        want = z[tag + '/out'][i]
+        got = g.denoise(z[tag + '/poses'][i], int(t))
+        assert np.array_equal(np.isnan(got), np.isnan(want))      # isolated node -> NaN row, like the reference
+        ok = ~np.isnan(want)
+        assert rel_err(got[ok], want[ok]) < 2e-5, (tag, t)
+        assert rel_err(m.time_embedding(int(t)), z[tag + '/time_emb'][i]) < 1e-5
+    if tag == 'q64':
+        assert np.isnan(z[tag + '/out']).any()
+
+
+def test_single_evaluation_energy():
+    z = golden('single_eval')
+    tag = 't64e'
+    m = oracle_model('diffuse_pairwise', 64, 'weights_diffuse_pairwise_h64_energy.npz', energy=True)
+    g = m.graph(golden_batch(z, tag + '/'))
+    for i, t in enumerate(z[tag + '/t']):
+        grad, E = g.energy_grad(z[tag + '/poses'][i], int(t))
+        assert abs(E - z[tag + '/energy'][i]) <= 2e-5 * (1 + abs(z[tag + '/energy'][i]))
+        assert rel_err(grad, z[tag + '/grad'][i]) < 5e-5, t
+
+
+CHAINS = ['chain_q64_T1000_B4', 'chain_q64_T100_B1', 'chain_q256_T100_B1', 'chain_q64_noebm',
+          'chain_q64_ulaplus', 'chain_t64_ula', 'chain_r64_ula', 'chain_t64_mala']
+
+
+def _run_oracle_chain(z, f64=False, history=True):
+    meta = golden_meta(z)
+    EBM = {'False': False}.get(meta['EBM'], meta['EBM'])
+    m = oracle_model(meta['mode'], int(z['H']), meta['weights'], T=int(z['T']), S=int(z['S']), energy=meta['energy'], f64=f64)
+    g = m.graph(golden_batch(z))
+    return g.chain(EBM, seed=int(z['seed']), history=history)
+
+
+@pytest.mark.parametrize('name', CHAINS)
+def test_full_chain_final_poses(name):
+    z = golden(name)
+    final, hist = _run_oracle_chain(z)
+    # the north-star bound: final poses within 1e-4 of the reference sampler on identical noise
+    assert np.abs(final - z['final']).max() < 1e-4, name
+    assert np.abs(z['final']).max() < 50.0          # trained-like weights: the chain is contractive
+    # history checkpoints (relative: early timesteps pass through very large transients)
+    for k, idx in enumerate(z['hist_idx']):
+        assert rel_err(hist[idx], z['hist'][k]) < 2e-3, (name, int(idx))
+
+
+def test_fp32_noise_floor_of_the_reference():
+    """the reference's own fp32-vs-fp64 disagreement bounds how tight parity can be"""
+    z32, z64 = golden('chain_q64_T1000_B4'), golden('chain_q64_T1000_B4_f64')
+    floor = np.abs(z32['final'].astype(np.float64) - z64['final']).max()
+    assert floor < 1e-5
+    o64 = _run_oracle_chain(z32, f64=True, history=False)
+    assert np.abs(o64 - z64['final']).max() < 1e-5
+
+
+def test_torch_proxy_matches_reference():
+    """the cost-faithful PyTorch proxy (cpu_baseline 'port') reproduces reference outputs"""
+    import torch_proxy
+    z = golden('single_eval')
+    for tag, mode, H, wfile in [CASES[1], CASES[4]]:
+        model = torch_proxy.ProxyDiffuser(weights(wfile), worlds.MODE_DIMS[mode], H, MODE_TYPES[mode])
+        b = golden_batch(z, tag + '/')
+        for i, t in enumerate(z[tag + '/t'][:3]):
+            with torch.no_grad():
+                got = model(torch.from_numpy(z[tag + '/poses'][i]), b, torch.tensor([int(t)])).numpy()
+            assert rel_err(got, z[tag + '/out'][i]) < 1e-5
+
+
+def test_timestep_restart_equals_full_chain():
+    """chain_run(init=0, t_first..t_last) continues a chain exactly (single-timestep vectors)"""
+    z = golden('chain_q64_T100_B1')
+    m = oracle_model('qualitative', 64, 'weights_qualitative_h64.npz', T=100)
+    g = m.graph(golden_batch(z))
+    full, hist = g.chain('ULA', seed=int(z['seed']), history=True)
+    x = g.chain('ULA', seed=int(z['seed']), x=hist[40], t_first=59, t_last=20)
+    assert np.array_equal(x, hist[80])
