@@ -3,7 +3,7 @@
 //
 // One network evaluation (reference networks/denoise_fn.py:453-537) is three launches:
 //   k_ugemm   U[r,:]  = pose_emb[node(r),:] . Wp[type,slot]^T       fp32 MFMA 32x32x2, LDS tiled
-//   k_edge    O[k,s,:] = Dec( SiLU( G[k] + tau[t,type] + U[u0(k)] + U[u1(k)] )[s-half] )
+//   k_edge    O[k,s,:] = Dec( SiLU( U[u0(k)] + U[u1(k)] )[s-half] )      (U rows carry geometry + time terms)
 //   k_node    eps[n] = ordered sum over the node's CSR / sqrt(cnt), mask fill; then the fused
 //             Langevin / ancestral update of the pose rows and the pose encoder for the next
 //             evaluation.
@@ -19,6 +19,10 @@
 #include "../../include/ccsp.h"
 #include "ccsp_philox.h"
 #include "ccsp_plan.h"
+
+#ifndef CCSP_ABLATE
+#define CCSP_ABLATE 0   // tools/ablate.hip builds k_ugemm variants with parts of the loop removed
+#endif
 
 namespace {
 
@@ -46,7 +50,14 @@ constexpr int NODE_TILE = 16; // nodes per workgroup in the node kernels
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
+// SiLU.  silu_f: IEEE division + libm-grade expf (set-up kernels).  silu_fast: v_exp_f32 + v_rcp_f32
+// (~1 ulp each, relative error of the result ~3e-7), 6 VALU instructions instead of ~35 -- the
+// activation sits on the operand path of the MFMA kernels, where VALU issue competes with the
+// matrix pipe.  Limits: v -> -inf gives -0 (exp2 -> inf, rcp -> 0), v -> +inf gives v, NaN stays NaN.
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
+__device__ __forceinline__ float silu_fast(float v) {
+    return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
+}
 __device__ __forceinline__ float mish_f(float v) {
     const float sp = v > 20.0f ? v : log1pf(expf(v));
     return v * tanhf(sp);
@@ -110,7 +121,69 @@ struct EncW {
     const float* W2T;  // [H/2, H]   (transposed: lanes read consecutive output columns)
     const float* b2;   // [H]
     int in_dim;
+    const float* W2F;  // layer-2 weight in v_mfma_f32_16x16x4_f32 B-fragment order (k_pack_enc_frag), or null
 };
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+// W2 [H, H/2] (nn.Linear weight) -> B fragments of 16x16x4: for wave w (H/4 columns), k-step ks,
+// lane l, column tile j:  W2F[((w*KS + ks)*64 + l)*TPW + j] = W2[w*16*TPW + j*16 + (l&15)][ks*4 + (l>>4)]
+__global__ void k_pack_enc_frag(int H, const float* __restrict__ W2, float* __restrict__ W2F) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int TPW = H / 64, KS = H / 8;
+    if (idx >= H * (H / 2)) return;
+    const int j = idx % TPW, l = (idx / TPW) % 64, ks = (idx / (TPW * 64)) % KS, w = idx / (TPW * 64 * KS);
+    const int col = w * 16 * TPW + j * 16 + (l & 15), k = ks * 4 + (l >> 4);
+    W2F[idx] = W2[(size_t)col * (H / 2) + k];
+}
+
+// pose encoder of a 16-node tile on the matrix cores: layer 1 (P -> H/2) on the VALU into LDS,
+// layer 2 (H/2 -> H) as 16 x H x H/2 with v_mfma_f32_16x16x4_f32 (M = the 16 nodes of the tile).
+// s1 has row stride H/2 + 1 (conflict-free A-fragment reads).  All 256 threads participate.
+template <int H>
+__device__ __forceinline__ void encode_tile_mfma(const EncW w, float (*xs)[8], float (*s1)[H / 2 + 1], int node0, int N,
+                                                 float* __restrict__ out /*[N,H]*/) {
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < NODE_TILE * (H / 2); idx += 256) {
+        const int n = idx / (H / 2), j = idx % (H / 2);
+        float acc = 0.0f;
+        for (int d = 0; d < w.in_dim; ++d) acc = fmaf(xs[n][d], w.W0[j * w.in_dim + d], acc);
+        s1[n][j] = silu_fast(acc + w.b0[j]);
+    }
+    __syncthreads();
+    constexpr int TPW = H / 64, KS = H / 8;
+    const int wave = tid >> 6, lane = tid & 63;
+    floatx4 acc[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) acc[j] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+    const float* wf = w.W2F + ((size_t)wave * KS * 64 + lane) * TPW;
+    const float* ap = &s1[lane & 15][lane >> 4];
+#pragma unroll 8
+    for (int ks = 0; ks < KS; ++ks) {
+        const float a = ap[ks * 4];
+        float b[TPW];
+        if constexpr (TPW == 4) {
+            const float4 v = *reinterpret_cast<const float4*>(wf + (size_t)ks * 64 * TPW);
+            b[0] = v.x; b[1] = v.y; b[2] = v.z; b[3] = v.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) b[j] = wf[(size_t)ks * 64 * TPW + j];
+        }
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[j], acc[j], 0, 0, 0);
+    }
+    // C/D layout of 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int col = wave * 16 * TPW + j * 16 + (lane & 15);
+        const float bj = w.b2[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = node0 + (lane >> 4) * 4 + r;
+            if (n < N) out[(size_t)n * H + col] = silu_fast(acc[j][r] + bj);
+        }
+    }
+}
 
 // xs: [NODE_TILE][8] in LDS; s1: [NODE_TILE][H/2] in LDS.  All 256 threads participate.
 template <int H>
@@ -121,7 +194,7 @@ __device__ __forceinline__ void encode_tile(const EncW w, float (*xs)[8], float 
         const int n = idx / (H / 2), j = idx % (H / 2);
         float acc = 0.0f;
         for (int d = 0; d < w.in_dim; ++d) acc = fmaf(xs[n][d], w.W0[j * w.in_dim + d], acc);
-        s1[n][j] = silu_f(acc + w.b0[j]);
+        s1[n][j] = silu_fast(acc + w.b0[j]);
     }
     __syncthreads();
     constexpr int NG = 256 / H;             // node groups per workgroup (H=256: 1, H=64: 4)
@@ -139,7 +212,7 @@ __device__ __forceinline__ void encode_tile(const EncW w, float (*xs)[8], float 
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
         const int n = node0 + g * NPT + i;
-        if (n < N) out[(size_t)n * H + j] = silu_f(acc[i] + bj);
+        if (n < N) out[(size_t)n * H + j] = silu_fast(acc[i] + bj);
     }
 }
 
@@ -170,15 +243,39 @@ __device__ __forceinline__ void mfma_chunk(const float* __restrict__ As, const f
     const int lane = threadIdx.x & 63;
     const float* ap = As + (a_row0 + (lane & 31)) * LDS_LD + (lane >> 5);
     const float* bp = Bs + (b_row0 + (lane & 31)) * LDS_LD + (lane >> 5);
+    // fetch every fragment of the chunk first (BK/2 * (1 + TN) registers), then issue the MFMAs back
+    // to back: the matrix pipe is not held up by LDS round trips between dependent k-steps
+    float a[BK / 2], b[TN][BK / 2];
+#if CCSP_ABLATE >= 4
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-        const float a = ap[kk];
+    for (int kk = 0; kk < BK / 2; ++kk) {          // ablation: operands from registers only
+        a[kk] = __int_as_float(0x3f800000 + lane + kk);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const float b = bp[j * 32 * LDS_LD + kk];
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
-        }
+        for (int j = 0; j < TN; ++j) b[j][kk] = __int_as_float(0x3f000000 + lane * 3 + kk + j);
     }
+    asm volatile("" ::"v"(ap), "v"(bp));
+#else
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+        a[kk] = ap[2 * kk];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j][kk] = bp[j * 32 * LDS_LD + 2 * kk];
+    }
+#endif
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b[j][kk], acc[j], 0, 0, 0);
+}
+
+// XCD-aware workgroup order (cdna_hip_programming.md T1): the dispatcher places block b on XCD b % 8
+// and every XCD has a private 4 MiB L2.  Remapping block ids so that each XCD owns a contiguous range
+// of tiles makes neighbouring tiles (same weight slice, same gathered rows) hit the same L2.
+// Bijective for any grid size; a different placement would only change speed.
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = b & 7, idx = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
 __device__ __forceinline__ void lds_store4(float* dst, const float4 v) {
@@ -186,19 +283,22 @@ __device__ __forceinline__ void lds_store4(float* dst, const float4 v) {
 }
 
 // ------------------------------------------------------------------------------------------
-// k_ugemm: U[row0+r, col0+c] = sum_k A[node(row0+r), k] * W[ts][col0+c, k]
-//   grid = (n_tiles, 2H / TILE_N); 4 waves as 2(M) x 2(N), each 32 x 64.
+// k_ugemm: U[row0+r, col0+c] = sum_k A[node(row0+r), k] * W[ts][col0+c, k]  (+ base[row] + tau[type] on slot-0 rows)
+//   grid = n_tiles * (2H / TILE_N), XCD-remapped; 4 waves as 2(M) x 2(N), each 32 x 64.
 // ------------------------------------------------------------------------------------------
 template <int H>
 __global__ __launch_bounds__(256) void k_ugemm(const float* __restrict__ A, const int* __restrict__ urow_node,
                                                const int* __restrict__ tile_row0, const int* __restrict__ tile_nrows,
                                                const int* __restrict__ tile_ts, const float* __restrict__ W,
-                                               size_t w_stride, float* __restrict__ U) {
+                                               size_t w_stride, const float* __restrict__ base /*[R,2H] or null*/,
+                                               const float* __restrict__ tau_t /*[C,2H] or null*/, float* __restrict__ U) {
     __shared__ float As[2][TILE_M * LDS_LD];
     __shared__ float Bs[2][TILE_N * LDS_LD];
-    const int tile = blockIdx.x;
+    constexpr int NCT = 2 * H / TILE_N;                 // column tiles per row tile
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = bid / NCT;
     const int row0 = tile_row0[tile], nrows = tile_nrows[tile], ts = tile_ts[tile];
-    const int col0 = blockIdx.y * TILE_N;
+    const int col0 = (bid % NCT) * TILE_N;
     const float* Wt = W + (size_t)ts * w_stride + (size_t)col0 * H;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
@@ -223,70 +323,100 @@ __global__ __launch_bounds__(256) void k_ugemm(const float* __restrict__ A, cons
 #pragma unroll
     for (int i = 0; i < 4; ++i) lds_store4(&Bs[0][(lr + 32 * i) * LDS_LD + lq * 4], rb[i]);
     __syncthreads();
+    // accumulators start from the row's chain-constant term `base` (+ the time term and bias `tau` on
+    // slot-0 rows), so that an edge's pre-activation downstream is simply U[u0] + U[u1]; these loads are
+    // in flight while the first K chunk is staged.  C/D layout of 32x32: col = lane & 31,
+    // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     floatx16 acc[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j) {
+        const int col = col0 + wn * 64 + j * 32 + (lane & 31);
+        const float tv = (tau_t && (ts & 1) == 0) ? tau_t[(size_t)(ts >> 1) * (2 * H) + col] : 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) {
+            int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            row = row < nrows ? row : nrows - 1;
+#if CCSP_ABLATE >= 5
+            acc[j][r] = tv;
+#else
+            acc[j][r] = (base ? base[(size_t)(row0 + row) * (2 * H) + col] : 0.0f) + tv;
+#endif
+        }
+    }
     constexpr int NCH = H / BK;
     for (int c = 0; c < NCH; ++c) {
+#if CCSP_ABLATE >= 2
+        const int buf = 0;
+#else
         const int buf = c & 1;
+#endif
+#if CCSP_ABLATE == 0
         if (c + 1 < NCH) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) ra[i] = *reinterpret_cast<const float4*>(a_ptr[i] + (c + 1) * BK);
 #pragma unroll
             for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const float4*>(b_ptr[i] + (c + 1) * BK);
         }
+#endif
+        // keep the prefetch ahead of the MFMA block: without this fence hipcc sinks the global loads to
+        // just before their first use (the LDS stores below) and the whole L2/HBM latency is exposed
+        __builtin_amdgcn_sched_barrier(0);
         mfma_chunk<2>(As[buf], Bs[buf], wm * 32, wn * 64, acc);
+        __builtin_amdgcn_sched_barrier(0);
+#if CCSP_ABLATE <= 1
         if (c + 1 < NCH) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) lds_store4(&As[buf ^ 1][(lr + 32 * i) * LDS_LD + lq * 4], ra[i]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) lds_store4(&Bs[buf ^ 1][(lr + 32 * i) * LDS_LD + lq * 4], rb[i]);
         }
+#endif
+#if CCSP_ABLATE <= 2
         __syncthreads();
+#endif
     }
-    // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             const int col = col0 + wn * 64 + j * 32 + (lane & 31);
+#if CCSP_ABLATE >= 5
+            if (row < nrows && acc[j][r] == 123.456f) U[(size_t)(row0 + row) * (2 * H) + col] = acc[j][r];
+#else
             if (row < nrows) U[(size_t)(row0 + row) * (2 * H) + col] = acc[j][r];
+#endif
         }
 }
 
-// G[k, :] = UG[u0(k), :] + UG[u1(k), :] (+ UR[u0(k), :])   -- chain-constant part of the pre-activation
-__global__ void k_gcombine(int E_act, int W2, const int* __restrict__ e_u0, const int* __restrict__ e_u1,
-                           const float* __restrict__ UG, const float* __restrict__ UR, float* __restrict__ G) {
+// base[r, :] = UG[r, :] (+ UR[r, :] on slot-0 rows: grasp_emb[args_1], denoise_fn.py:337) -- the
+// chain-constant geometry/grasp part of row r's contribution to an edge pre-activation
+__global__ void k_rowbase(int R, int W2, const int* __restrict__ urow_ts, const float* __restrict__ UR, float* __restrict__ UG) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)E_act * W2) return;
-    const int k = (int)(idx / W2), j = (int)(idx % W2);
-    float v = UG[(size_t)e_u0[k] * W2 + j] + UG[(size_t)e_u1[k] * W2 + j];
-    if (UR) v += UR[(size_t)e_u0[k] * W2 + j];
-    G[idx] = v;
+    if (idx >= (long)R * W2) return;
+    const int r = (int)(idx / W2);
+    if (UR && (urow_ts[r] & 1) == 0) UG[idx] += UR[idx];
 }
 
 // ------------------------------------------------------------------------------------------
-// k_edge: rows = (sorted edge k, half s).  h = SiLU(G + tau + U0 + U1)[s*H : (s+1)*H] is built
+// k_edge: rows = (sorted edge k, half s).  h = SiLU(U[u0(k)] + U[u1(k)])[s*H : (s+1)*H] is built
 // chunk by chunk straight into the LDS A tile; B = pose_decoder.0 weight [H/2, H]; epilogue
 // bias + SiLU -> LDS -> pose_decoder.2 (H/2 -> P) -> O[(2k+s)*P ..]   (denoise_fn.py:341-371)
 //   H=256: 64 rows x 128 cols per workgroup (waves 2x2, 32x64 each)
 //   H=64 : 128 rows x 32 cols per workgroup (waves 4x1, 32x32 each)
-// grid = (ceil(E_act / BM), 2)
+// grid = 2 * ceil(E_act / BM), XCD-remapped
 // ------------------------------------------------------------------------------------------
 template <int H> struct EdgeCfg;
 template <> struct EdgeCfg<256> { static constexpr int WM = 2, WN = 2, TN = 2; };
 template <> struct EdgeCfg<64> { static constexpr int WM = 4, WN = 1, TN = 1; };
 
 template <int H>
-__global__ __launch_bounds__(256) void k_edge(int E_act, int P, const int* __restrict__ e_type,
+__global__ __launch_bounds__(256, 3) void k_edge(int E_act, int P,
                                               const int* __restrict__ e_u0, const int* __restrict__ e_u1,
-                                              const float* __restrict__ G, const float* __restrict__ tau_t /*[C,2H]*/,
                                               const float* __restrict__ U, const float* __restrict__ Wd1 /*[H/2,H]*/,
                                               const float* __restrict__ bd1, const float* __restrict__ Wd2 /*[P,H/2]*/,
-                                              const float* __restrict__ bd2, float* __restrict__ O) {
+                                              const float* __restrict__ bd2, const int* __restrict__ ent_pos,
+                                              float* __restrict__ O) {
     using Cfg = EdgeCfg<H>;
     constexpr int BM = 32 * Cfg::WM, BN = 32 * Cfg::TN * Cfg::WN, TN = Cfg::TN;
     static_assert(BN == H / 2, "decoder hidden width must fit one column tile");
@@ -297,13 +427,12 @@ __global__ __launch_bounds__(256) void k_edge(int E_act, int P, const int* __res
     __shared__ float smem[SMEM];
     auto As = [&](int buf) -> float* { return smem + buf * STAGE; };
     auto Bs = [&](int buf) -> float* { return smem + buf * STAGE + BM * LDS_LD; };
-    const int e0 = blockIdx.x * BM;
-    const int s = blockIdx.y;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int e0 = (bid >> 1) * BM;
+    const int s = bid & 1;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
     const int lr = tid >> 3, lq = tid & 7;
-    const float* g_ptr[A_ROWS_PT];
-    const float* t_ptr[A_ROWS_PT];
     const float* u0_ptr[A_ROWS_PT];
     const float* u1_ptr[A_ROWS_PT];
     const float* b_ptr[B_ROWS_PT];
@@ -312,8 +441,6 @@ __global__ __launch_bounds__(256) void k_edge(int E_act, int P, const int* __res
         int k = e0 + lr + 32 * i;
         k = k < E_act ? k : E_act - 1;
         const int coff = s * H + lq * 4;
-        g_ptr[i] = G + (size_t)k * (2 * H) + coff;
-        t_ptr[i] = tau_t + (size_t)e_type[k] * (2 * H) + coff;
         u0_ptr[i] = U + (size_t)e_u0[k] * (2 * H) + coff;
         u1_ptr[i] = U + (size_t)e_u1[k] * (2 * H) + coff;
     }
@@ -323,14 +450,12 @@ __global__ __launch_bounds__(256) void k_edge(int E_act, int P, const int* __res
     auto load_chunk = [&](int c) {
 #pragma unroll
         for (int i = 0; i < A_ROWS_PT; ++i) {
-            const float4 g = *reinterpret_cast<const float4*>(g_ptr[i] + c * BK);
-            const float4 t = *reinterpret_cast<const float4*>(t_ptr[i] + c * BK);
             const float4 a = *reinterpret_cast<const float4*>(u0_ptr[i] + c * BK);
             const float4 b = *reinterpret_cast<const float4*>(u1_ptr[i] + c * BK);
-            ra[i].x = silu_f(((g.x + t.x) + a.x) + b.x);
-            ra[i].y = silu_f(((g.y + t.y) + a.y) + b.y);
-            ra[i].z = silu_f(((g.z + t.z) + a.z) + b.z);
-            ra[i].w = silu_f(((g.w + t.w) + a.w) + b.w);
+            ra[i].x = silu_fast(a.x + b.x);
+            ra[i].y = silu_fast(a.y + b.y);
+            ra[i].z = silu_fast(a.z + b.z);
+            ra[i].w = silu_fast(a.w + b.w);
         }
 #pragma unroll
         for (int i = 0; i < B_ROWS_PT; ++i) rb[i] = *reinterpret_cast<const float4*>(b_ptr[i] + c * BK);
@@ -353,7 +478,9 @@ __global__ __launch_bounds__(256) void k_edge(int E_act, int P, const int* __res
     for (int c = 0; c < NCH; ++c) {
         const int buf = c & 1;
         if (c + 1 < NCH) load_chunk(c + 1);
+        __builtin_amdgcn_sched_barrier(0);       // prefetch stays ahead of the MFMA block (see k_ugemm)
         mfma_chunk<TN>(As(buf), Bs(buf), wm * 32, wn * 32 * TN, acc);
+        __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < NCH) store_chunk(buf ^ 1);
         __syncthreads();
     }
@@ -366,7 +493,7 @@ __global__ __launch_bounds__(256) void k_edge(int E_act, int P, const int* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            S1[row * S1_LD + col] = silu_f(acc[j][r] + bj);
+            S1[row * S1_LD + col] = silu_fast(acc[j][r] + bj);
         }
     }
     __syncthreads();
@@ -378,7 +505,7 @@ __global__ __launch_bounds__(256) void k_edge(int E_act, int P, const int* __res
         for (int j = 0; j < BN; ++j) o = fmaf(S1[row * S1_LD + j], w[j], o);
         o += bd2[p];
         const int k = e0 + row;
-        if (k < E_act) O[((size_t)2 * k + s) * P + p] = o;
+        if (k < E_act) O[(size_t)ent_pos[2 * k + s] * P + p] = o;      // straight to the node's CSR slot
     }
 }
 
@@ -405,8 +532,7 @@ struct NodeArgs {
     int reset_mask;         // x[mask] = gt[mask] after the update (end of a timestep)
     int do_encode;
     const int* node_ptr;
-    const int* node_ent;
-    const float* O;         // [2 E_act, P]
+    const float* O;         // [2 E_act, P] in CSR order (a node's inputs are contiguous)
     const float* xfeat;     // batch.x [N,F]
     int pose_begin;
     const signed char* mask;
@@ -423,7 +549,7 @@ struct NodeArgs {
 template <int H>
 __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, float* __restrict__ pemb) {
     __shared__ float xs[NODE_TILE][8];
-    __shared__ float s1[NODE_TILE][H / 2];
+    __shared__ float s1[NODE_TILE][H / 2 + 1];
     const int node0 = blockIdx.x * NODE_TILE;
     const int tid = threadIdx.x;
     if (tid < NODE_TILE * 8) {
@@ -437,7 +563,9 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, float* __restr
             if (a.src == 0) {
                 const int beg = a.node_ptr[n], end = a.node_ptr[n + 1];
                 float acc = 0.0f;
-                for (int q = beg; q < end; ++q) acc += a.O[(size_t)a.node_ent[q] * a.P + p];
+                const float* op = a.O + (size_t)beg * a.P + p;
+#pragma unroll 8
+                for (int q = 0; q < end - beg; ++q) acc += op[(size_t)q * a.P];
                 if (a.normalize) acc = acc / sqrtf((float)(end - beg));        // 0/0 -> NaN like the reference
                 eps = masked ? a.xfeat[(size_t)n * a.F + a.F - a.P + p] : acc; // out[mask] = x[:, -P:][mask]
             } else if (a.src == 1) {
@@ -469,7 +597,7 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, float* __restr
     }
     if (!a.do_encode) return;
     __syncthreads();
-    encode_tile<H>(w, xs, s1, node0, a.N, pemb);
+    encode_tile_mfma<H>(w, xs, s1, node0, a.N, pemb);
 }
 
 // NaN rows for the edge-output debug API, then scatter sorted -> original order
@@ -477,11 +605,13 @@ __global__ void k_fill(float* p, long n, float v) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
-__global__ void k_unsort_edges(int E_act, int W, const int* __restrict__ e_orig, const float* __restrict__ O, float* __restrict__ out) {
+__global__ void k_unsort_edges(int E_act, int P, const int* __restrict__ e_orig, const int* __restrict__ ent_pos,
+                               const float* __restrict__ O, float* __restrict__ out) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)E_act * W) return;
-    const int k = (int)(idx / W), j = (int)(idx % W);
-    out[(size_t)e_orig[k] * W + j] = O[idx];
+    if (idx >= (long)E_act * 2 * P) return;
+    const int k = (int)(idx / (2 * P)), j = (int)(idx % (2 * P));
+    const int sl = j / P, p = j % P;
+    out[(size_t)e_orig[k] * 2 * P + j] = O[(size_t)ent_pos[2 * k + sl] * P + p];
 }
 
 inline int nblk(long n, int b) { return (int)((n + b - 1) / b); }
@@ -498,7 +628,7 @@ struct ccsp_model {
     // device weights (library-owned copies)
     float *ge0_w, *ge0_b, *ge2_wT, *ge2_b;
     float *gr0_w, *gr0_b, *gr2_wT, *gr2_b;
-    float *pe0_w, *pe0_b, *pe2_wT, *pe2_b;
+    float *pe0_w, *pe0_b, *pe2_wT, *pe2_b, *pe2_wF;
     float *pd0_w, *pd0_b, *pd2_w, *pd2_b;
     float* Wg;     // [C][2][2H][H]   geometry slices (slot 0 = node a, slot 1 = node b)
     float* Wr;     // [C][2][2H][H]   grasp slice in slot 0 (slot 1 unused) or nullptr
@@ -518,8 +648,9 @@ struct ccsp_graph {
     // device
     float* xfeat;
     signed char* mask;
-    int *e_type, *e_u0, *e_u1, *e_orig, *urow_node, *tile_row0, *tile_nrows, *tile_ts, *node_ptr, *node_ent;
-    float *G, *U, *O, *pemb, *x, *eps;
+    int *e_type, *e_u0, *e_u1, *e_orig, *urow_node, *tile_row0, *tile_nrows, *tile_ts, *node_ptr, *node_ent, *ent_pos;
+    float *base, *U, *O, *pemb, *x, *eps;
+    int* urow_ts;
     std::vector<void*> allocs;
     // profiling
     int profile = 0;
@@ -566,7 +697,7 @@ void cosine_betas(int T, std::vector<double>& betas) {   // ddpm.py:152-162
     }
 }
 
-EncW enc_pose(const ccsp_model* m) { return EncW{m->pe0_w, m->pe0_b, m->pe2_wT, m->pe2_b, m->d.pose_dim}; }
+EncW enc_pose(const ccsp_model* m) { return EncW{m->pe0_w, m->pe0_b, m->pe2_wT, m->pe2_b, m->d.pose_dim, m->pe2_wF}; }
 
 template <int H>
 int launch_eval(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s) {
@@ -575,13 +706,12 @@ int launch_eval(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s) {
     if (p.E_act == 0) return 0;
     const bool prof = g->profile && g->kev_used + 3 <= g->kev.size();
     if (prof) HIP_TRY(hipEventRecord(g->kev[g->kev_used], s));
-    hipLaunchKernelGGL(k_ugemm<H>, dim3(g->n_tiles, 2 * H / TILE_N), dim3(256), 0, s, g->pemb, g->urow_node, g->tile_row0,
-                       g->tile_nrows, g->tile_ts, m->Wp, (size_t)2 * H * H, g->U);
+    hipLaunchKernelGGL(k_ugemm<H>, dim3(g->n_tiles * (2 * H / TILE_N)), dim3(256), 0, s, g->pemb, g->urow_node, g->tile_row0,
+                       g->tile_nrows, g->tile_ts, m->Wp, (size_t)2 * H * H, g->base, m->tau + (size_t)t * m->d.n_types * 2 * H, g->U);
     if (prof) HIP_TRY(hipEventRecord(g->kev[g->kev_used + 1], s));
     constexpr int BM = 32 * EdgeCfg<H>::WM;
-    hipLaunchKernelGGL(k_edge<H>, dim3(nblk(p.E_act, BM), 2), dim3(256), 0, s, p.E_act, m->d.pose_dim, g->e_type, g->e_u0,
-                       g->e_u1, g->G, m->tau + (size_t)t * m->d.n_types * 2 * H, g->U, m->pd0_w, m->pd0_b, m->pd2_w, m->pd2_b,
-                       g->O);
+    hipLaunchKernelGGL(k_edge<H>, dim3(2 * nblk(p.E_act, BM)), dim3(256), 0, s, p.E_act, m->d.pose_dim, g->e_u0,
+                       g->e_u1, g->U, m->pd0_w, m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O);
     if (prof) { HIP_TRY(hipEventRecord(g->kev[g->kev_used + 2], s)); g->kev_used += 3; }
     g->evals++;
     return 0;
@@ -592,7 +722,7 @@ NodeArgs node_args(ccsp_model* m, ccsp_graph* g) {
     memset(&a, 0, sizeof(a));
     a.N = g->N; a.P = m->d.pose_dim; a.F = g->F;
     a.normalize = m->d.normalize;
-    a.node_ptr = g->node_ptr; a.node_ent = g->node_ent; a.O = g->O;
+    a.node_ptr = g->node_ptr; a.O = g->O;
     a.xfeat = g->xfeat; a.pose_begin = m->d.pose_begin; a.mask = g->mask;
     a.x = g->x;
     return a;
@@ -764,6 +894,8 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
         TRY(dupT(&m->gr2_wT, H, H / 2)); TRY(dup(&m->gr2_b, H));
     }
     TRY(dup(&m->pe0_w, (size_t)(H / 2) * P)); TRY(dup(&m->pe0_b, H / 2));
+    TRY(dev_alloc(reg, &m->pe2_wF, (size_t)H * (H / 2)));
+    hipLaunchKernelGGL(k_pack_enc_frag, dim3(nblk((long)H * (H / 2), 256)), dim3(256), 0, s, H, params[k], m->pe2_wF);
     TRY(dupT(&m->pe2_wT, H, H / 2)); TRY(dup(&m->pe2_b, H));
     TRY(dup(&m->pd0_w, (size_t)(H / 2) * H)); TRY(dup(&m->pd0_b, H / 2));
     TRY(dup(&m->pd2_w, (size_t)P * (H / 2))); TRY(dup(&m->pd2_b, P));
@@ -864,39 +996,42 @@ int ccsp_graph_create(ccsp_model* m, int32_t N, int32_t E, int32_t F, const floa
     TRY(dev_upload(reg, &g->tile_ts, p.tile_ts, s));
     TRY(dev_upload(reg, &g->node_ptr, p.node_ptr, s));
     TRY(dev_upload(reg, &g->node_ent, p.node_ent, s));
-    TRY(dev_alloc(reg, &g->G, (size_t)p.E_act * 2 * H));
+    TRY(dev_upload(reg, &g->ent_pos, p.ent_pos, s));
+    TRY(dev_upload(reg, &g->urow_ts, p.urow_ts, s));
+    TRY(dev_alloc(reg, &g->base, (size_t)p.R * 2 * H));
     TRY(dev_alloc(reg, &g->U, (size_t)p.R * 2 * H));
     TRY(dev_alloc(reg, &g->O, (size_t)2 * p.E_act * P));
     TRY(dev_alloc(reg, &g->pemb, (size_t)N * H));
     TRY(dev_alloc(reg, &g->x, (size_t)N * P));
     TRY(dev_alloc(reg, &g->eps, (size_t)N * P));
-    // chain-constant part: geometry (and grasp) embeddings -> per-row products -> G[k]
+    // chain-constant part: geometry (and grasp) embeddings -> per-row products base[r] (the reference
+    // re-evaluates the geometry encoder and these products on every call, denoise_fn.py:474-475)
     if (p.E_act > 0) {
-        float *gemb = nullptr, *UG = nullptr, *UR = nullptr, *remb = nullptr;
+        float *gemb = nullptr, *UR = nullptr, *remb = nullptr;
         TRY(dev_alloc(reg, &gemb, (size_t)N * H));
-        TRY(dev_alloc(reg, &UG, (size_t)p.R * 2 * H));
-        const EncW wg{m->ge0_w, m->ge0_b, m->ge2_wT, m->ge2_b, d.geom_dim};
-        const dim3 ggrid(g->n_tiles, 2 * H / TILE_N);
+        const EncW wg{m->ge0_w, m->ge0_b, m->ge2_wT, m->ge2_b, d.geom_dim, nullptr};
+        const dim3 ggrid(g->n_tiles * (2 * H / TILE_N));
+        const float* nof = nullptr;
         if (H == 256) {
             hipLaunchKernelGGL(k_encode<256>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, 0, wg, gemb);
-            hipLaunchKernelGGL(k_ugemm<256>, ggrid, dim3(256), 0, s, gemb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wg, (size_t)2 * H * H, UG);
+            hipLaunchKernelGGL(k_ugemm<256>, ggrid, dim3(256), 0, s, gemb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wg, (size_t)2 * H * H, nof, nof, g->base);
         } else {
             hipLaunchKernelGGL(k_encode<64>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, 0, wg, gemb);
-            hipLaunchKernelGGL(k_ugemm<64>, ggrid, dim3(256), 0, s, gemb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wg, (size_t)2 * H * H, UG);
+            hipLaunchKernelGGL(k_ugemm<64>, ggrid, dim3(256), 0, s, gemb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wg, (size_t)2 * H * H, nof, nof, g->base);
         }
         if (d.grasp_dim > 0) {
             TRY(dev_alloc(reg, &remb, (size_t)N * H));
             TRY(dev_alloc(reg, &UR, (size_t)p.R * 2 * H));
-            const EncW wr{m->gr0_w, m->gr0_b, m->gr2_wT, m->gr2_b, d.grasp_dim};
+            const EncW wr{m->gr0_w, m->gr0_b, m->gr2_wT, m->gr2_b, d.grasp_dim, nullptr};
             if (H == 256) {
                 hipLaunchKernelGGL(k_encode<256>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, d.grasp_begin, wr, remb);
-                hipLaunchKernelGGL(k_ugemm<256>, ggrid, dim3(256), 0, s, remb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wr, (size_t)2 * H * H, UR);
+                hipLaunchKernelGGL(k_ugemm<256>, ggrid, dim3(256), 0, s, remb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wr, (size_t)2 * H * H, nof, nof, UR);
             } else {
                 hipLaunchKernelGGL(k_encode<64>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, d.grasp_begin, wr, remb);
-                hipLaunchKernelGGL(k_ugemm<64>, ggrid, dim3(256), 0, s, remb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wr, (size_t)2 * H * H, UR);
+                hipLaunchKernelGGL(k_ugemm<64>, ggrid, dim3(256), 0, s, remb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wr, (size_t)2 * H * H, nof, nof, UR);
             }
+            hipLaunchKernelGGL(k_rowbase, dim3(nblk((long)p.R * 2 * H, 256)), dim3(256), 0, s, p.R, 2 * H, g->urow_ts, UR, g->base);
         }
-        hipLaunchKernelGGL(k_gcombine, dim3(nblk((long)p.E_act * 2 * H, 256)), dim3(256), 0, s, p.E_act, 2 * H, g->e_u0, g->e_u1, UG, UR, g->G);
     }
 #undef TRY
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
@@ -942,7 +1077,7 @@ int ccsp_edge_outputs(ccsp_model* m, ccsp_graph* g, const float* poses_in, int32
     else { launch_node<64>(m, g, a, s); if (launch_eval<64>(m, g, t, s)) return 1; }
     if (g->E > 0) hipLaunchKernelGGL(k_fill, dim3(nblk((long)g->E * 2 * P, 256)), dim3(256), 0, s, out, (long)g->E * 2 * P, nanf(""));
     if (g->plan.E_act > 0)
-        hipLaunchKernelGGL(k_unsort_edges, dim3(nblk((long)g->plan.E_act * 2 * P, 256)), dim3(256), 0, s, g->plan.E_act, 2 * P, g->e_orig, g->O, out);
+        hipLaunchKernelGGL(k_unsort_edges, dim3(nblk((long)g->plan.E_act * 2 * P, 256)), dim3(256), 0, s, g->plan.E_act, P, g->e_orig, g->ent_pos, g->O, out);
     HIP_TRY(hipGetLastError());
     return 0;
 }

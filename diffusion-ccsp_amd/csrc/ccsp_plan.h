@@ -12,7 +12,8 @@
 //     node) only, so it is evaluated once per triple (row) instead of once per edge;
 //   * row tiles of TILE_M rows that never straddle a (type, slot) group (one weight slice each);
 //   * node -> (edge, slot) CSR whose entries are the flat indices 2k+s in ascending order, which
-//     IS the reference's accumulation order; no atomics are needed downstream.
+//     IS the reference's accumulation order; no atomics are needed downstream.  The edge kernel
+//     writes each output straight to its CSR position (ent_pos), so a node's inputs are contiguous.
 #pragma once
 #include <cstdint>
 #include <vector>
@@ -27,6 +28,7 @@ struct Plan {
     std::vector<int32_t> urow_node, urow_ts;                      // [R]   ts = 2*type + slot
     std::vector<int32_t> tile_row0, tile_nrows, tile_ts;          // [n_tiles]
     std::vector<int32_t> node_ptr, node_ent;                      // [N+1], [2*E_act]
+    std::vector<int32_t> ent_pos;                                 // [2*E_act] CSR position of flat entry 2k+s
     std::vector<int32_t> type_count;                              // [C]
 };
 
@@ -84,8 +86,11 @@ inline int build_plan(int N, int E, int C, int tile_m, const int64_t* ei /*[2,E]
     for (int n = 0; n < N; ++n) p.node_ptr[n + 1] += p.node_ptr[n];
     p.node_ent.assign((size_t)2 * p.E_act, 0);
     std::vector<int32_t> pos(p.node_ptr.begin(), p.node_ptr.end() - 1);
+    p.ent_pos.assign((size_t)2 * p.E_act, 0);
     for (int k = 0; k < p.E_act; ++k) {
+        p.ent_pos[2 * k] = pos[p.e_a[k]];
         p.node_ent[pos[p.e_a[k]]++] = 2 * k;
+        p.ent_pos[2 * k + 1] = pos[p.e_b[k]];
         p.node_ent[pos[p.e_b[k]]++] = 2 * k + 1;
     }
     return 0;

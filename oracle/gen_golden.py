@@ -36,6 +36,13 @@ from diffusion_ccsp_amd import noise, worlds  # noqa: E402
 
 ddpm, dfn = ref_import.load()
 
+# AnnealedULASampler.sample_step runs under @torch.enable_grad() (ddpm.py:955), so the state it
+# returns carries the autograd graph of its S network evaluations; with return_history=True the
+# reference keeps all T of them alive (tens of GB at hidden_dim 256).  Detaching the returned state
+# changes no value -- p_sample runs under no_grad anyway -- and lets the capture fit in memory.
+_ula_step = ddpm.AnnealedULASampler.sample_step
+ddpm.AnnealedULASampler.sample_step = lambda self, x, batch, t: _ula_step(self, x, batch, t).detach()
+
 
 class PatchedNoise(object):
     def __init__(self, seed, dtype=torch.float32):
@@ -103,8 +110,12 @@ def run_chain(name, mode, H, wfile, batch, EBM, T=1000, S=10, seed=7, energy=Fal
     if dtype == torch.float64:
         b.x = b.x.double()
     t0 = time.time()
-    with PatchedNoise(seed, dtype) as pn, contextlib.redirect_stdout(io.StringIO()):
-        out, hist = gd.sample(b, return_history=True)
+    torch.set_default_dtype(dtype)          # SinusoidalPosEmb builds its table in the default dtype
+    try:
+        with PatchedNoise(seed, dtype) as pn, contextlib.redirect_stdout(io.StringIO()):
+            out, hist = gd.sample(b, return_history=True)
+    finally:
+        torch.set_default_dtype(torch.float32)
     dt = time.time() - t0
     out = out.detach().numpy()
     hist = np.stack([h.detach().numpy() for h in hist])

@@ -60,7 +60,7 @@ def test_single_evaluation_energy():
 
 
 CHAINS = ['chain_q64_T1000_B4', 'chain_q64_T100_B1', 'chain_q256_T100_B1', 'chain_q64_noebm',
-          'chain_q64_ulaplus', 'chain_t64_ula', 'chain_r64_ula', 'chain_t64_mala']
+          'chain_q64_ulaplus', 'chain_t64_ula', 'chain_r64_ula']
 
 
 def _run_oracle_chain(z, f64=False, history=True):
@@ -81,6 +81,43 @@ def test_full_chain_final_poses(name):
     # history checkpoints (relative: early timesteps pass through very large transients)
     for k, idx in enumerate(z['hist_idx']):
         assert rel_err(hist[idx], z['hist'][k]) < 2e-3, (name, int(idx))
+
+
+MALA_SEGMENTS = [(0, 1), (1, 2), (50, 100), (100, 200), (200, 300), (900, 950), (950, 990), (990, 998),
+                 (998, 999), (999, 1000), (900, 1000)]
+
+
+def mala_segment_errors(run_segment, z):
+    """MALA (ddpm.py:999-1047) accepts per node with a *discrete* test u < exp(.), and this fixture's
+    chain passes through a 1e8 transient in its first ~50 timesteps, so a full chain from the initial
+    draw is chaotic (two fp32 runs of the reference itself would not agree).  Parity is therefore
+    checked segment by segment from recorded reference states: every timestep's arithmetic (gradient,
+    batch-scalar energies, proposal log-probabilities, accept mask) must reproduce the reference's next
+    recorded state.  A near-tie may still flip one node's decision: at most one of the
+    segments may contain flipped rows, all others must match within 1e-4 (early segments: relative)."""
+    idx = list(z['hist_idx'])
+    bad = []
+    for i0, i1 in MALA_SEGMENTS:
+        k0, k1 = idx.index(i0), idx.index(i1)
+        x = run_segment(z['hist'][k0], 999 - i0, 1000 - i1)
+        want = z['hist'][k1]
+        scale = 1.0 + (np.abs(want).max() if i1 < 50 else 0.0)
+        rows_off = int((np.abs(x - want).max(axis=1) > 1e-4 * scale).sum())
+        if rows_off:
+            bad.append((i0, i1, rows_off))
+    return bad
+
+
+def test_mala_segments_vs_reference():
+    z = golden('chain_t64_mala')
+    m = oracle_model('diffuse_pairwise', 64, 'weights_diffuse_pairwise_h64_energy.npz', T=1000, S=int(z['S']), energy=True)
+    g = m.graph(golden_batch(z))
+    assert int(z['n_rand']) == 1000 * int(z['S'])            # one rand(N) per MALA inner step
+    bad = mala_segment_errors(lambda x, tf, tl: g.chain('MALA', seed=int(z['seed']), x=x, t_first=tf, t_last=tl), z)
+    assert len(bad) <= 1 and all(b[2] <= 2 for b in bad), bad
+    # acceptance bookkeeping (MetropolisSampler, ddpm.py:969-996): rates in [0,1], high at low noise
+    _, acc = g.chain('MALA', seed=int(z['seed']), x=z['hist'][list(z['hist_idx']).index(990)], t_first=9, t_last=0, accept=True)
+    assert (acc[:10] >= 0).all() and (acc[:10] <= 1).all() and acc[:10].mean() > 0.5
 
 
 def test_fp32_noise_floor_of_the_reference():
