@@ -1,0 +1,270 @@
+// Energy mode of the denoiser (reference networks/denoise_fn.py:373-375,518-519,527-529,539-548 and
+// ComposedEBMDenoiseFn :57-83): E = sum over (edge, slot) |o - pose|^2 for the whole batch, and the
+// "epsilon" the sampler consumes is dE/dposes.  The reference gets the gradient from autograd; here it
+// is the hand-derived backward of SURVEY.md Appendix A.4, evaluated with the same row factorisation
+// as the forward pass:
+//
+//   k_edge<H, true>   forward decoder; writes -2 d = -2 (o - pose) to the node CSR slots (the direct
+//                     term), the decoder pre-activations q, and a per-workgroup partial of sum d^2
+//   k_edge_bwd        g_h = (Wd2^T 2d  (.) SiLU'(q)) Wd1  per (edge, slot) on the MFMA; epilogue
+//                     g_z = g_h (.) SiLU'(z), z recomputed from the two U rows of the edge
+//   k_rowsum          g_z summed over the edges that share a U row (ordered, no atomics)
+//   k_rowgemm<2H, H>  g_p[row] = g_z[row] . Wp[type, slot]   (the transpose GEMM of k_ugemm)
+//   k_node_energy     per node: direct term (CSR) + pose-encoder backward of sum_rows g_p -> dE/dpose
+//
+// This file is included inside the anonymous namespace of ccsp_hip.hip.
+#pragma once
+
+// sum of n partials in a fixed order -> out[0]   (one workgroup of 256)
+__global__ __launch_bounds__(256) void k_energy_sum(const float* __restrict__ partial, int n, float* __restrict__ out) {
+    __shared__ float red[256];
+    float v = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 256) v += partial[i];
+    const float s = block_sum_256(v, red);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_edge_bwd: rows = (sorted edge k, slot s); K = H/2 (decoder hidden), N = H (one half of the
+// type-MLP output).  A[row, j] = (sum_p go[p] Wd2[p, j]) * SiLU'(q[row, j]) with go = 2 d = -O_csr.
+// B rows = Wd1^T [H, H/2].  Epilogue: GZ[k, s*H + n] = acc * SiLU'(U[u0(k)] + U[u1(k)])[s*H + n].
+// ------------------------------------------------------------------------------------------
+template <int H> struct BwdCfg;
+template <> struct BwdCfg<256> { static constexpr int WM = 2, WN = 2, TN = 2; };   // 64 x 128 tile, 2 column tiles
+template <> struct BwdCfg<64> { static constexpr int WM = 2, WN = 2, TN = 1; };    // 64 x 64 tile, 1 column tile
+
+template <int H>
+__global__ __launch_bounds__(256) void k_edge_bwd(int E_act, int P, const int* __restrict__ e_u0,
+                                                  const int* __restrict__ e_u1, const int* __restrict__ ent_pos,
+                                                  const float* __restrict__ U, const float* __restrict__ Ocsr,
+                                                  const float* __restrict__ Q /*[2E,H/2]*/,
+                                                  const float* __restrict__ Wd1T /*[H,H/2]*/,
+                                                  const float* __restrict__ Wd2 /*[P,H/2]*/, float* __restrict__ GZ) {
+    using Cfg = BwdCfg<H>;
+    constexpr int BM = 32 * Cfg::WM, BN = 32 * Cfg::TN * Cfg::WN, TN = Cfg::TN, KD = H / 2;
+    constexpr int NCT = H / BN;
+    constexpr int A_ROWS_PT = BM / 32, B_ROWS_PT = BN / 32;
+    constexpr int STAGE = (BM + BN) * LDS_LD;
+    __shared__ float smem[2 * STAGE];
+    auto As = [&](int buf) -> float* { return smem + buf * STAGE; };
+    auto Bs = [&](int buf) -> float* { return smem + buf * STAGE + BM * LDS_LD; };
+    const int bid = blockIdx.x;
+    const int ct = bid % NCT, s = (bid / NCT) & 1, e0 = (bid / (2 * NCT)) * BM;
+    const int n0 = ct * BN;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+    const int lr = tid >> 3, lq = tid & 7;
+    float go[A_ROWS_PT][8];
+    const float* q_ptr[A_ROWS_PT];
+    const float* b_ptr[B_ROWS_PT];
+#pragma unroll
+    for (int i = 0; i < A_ROWS_PT; ++i) {
+        int k = e0 + lr + 32 * i;
+        k = k < E_act ? k : E_act - 1;
+        const size_t row = (size_t)2 * k + s;
+        const float* o = Ocsr + (size_t)ent_pos[row] * P;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) go[i][p] = p < P ? -o[p] : 0.0f;       // 2 d = -(-2 d)
+        q_ptr[i] = Q + row * KD + lq * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < B_ROWS_PT; ++i) b_ptr[i] = Wd1T + (size_t)(n0 + lr + 32 * i) * KD + lq * 4;
+    float4 ra[A_ROWS_PT], rb[B_ROWS_PT];
+    auto load_chunk = [&](int c) {
+        float4 w2[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+            w2[p] = p < P ? *reinterpret_cast<const float4*>(Wd2 + (size_t)p * KD + c * BK + lq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < A_ROWS_PT; ++i) {
+            const float4 q = *reinterpret_cast<const float4*>(q_ptr[i] + c * BK);
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                g.x = fmaf(go[i][p], w2[p].x, g.x); g.y = fmaf(go[i][p], w2[p].y, g.y);
+                g.z = fmaf(go[i][p], w2[p].z, g.z); g.w = fmaf(go[i][p], w2[p].w, g.w);
+            }
+            ra[i].x = g.x * silu_grad_fast(q.x); ra[i].y = g.y * silu_grad_fast(q.y);
+            ra[i].z = g.z * silu_grad_fast(q.z); ra[i].w = g.w * silu_grad_fast(q.w);
+        }
+#pragma unroll
+        for (int i = 0; i < B_ROWS_PT; ++i) rb[i] = *reinterpret_cast<const float4*>(b_ptr[i] + c * BK);
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_ROWS_PT; ++i) lds_store4(As(buf) + (lr + 32 * i) * LDS_LD + lq * 4, ra[i]);
+#pragma unroll
+        for (int i = 0; i < B_ROWS_PT; ++i) lds_store4(Bs(buf) + (lr + 32 * i) * LDS_LD + lq * 4, rb[i]);
+    };
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    floatx16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    constexpr int NCH = KD / BK;
+    for (int c = 0; c < NCH; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < NCH) load_chunk(c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_chunk<TN>(As(buf), Bs(buf), wm * 32, wn * 32 * TN, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < NCH) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int k = e0 + row;
+        if (k >= E_act) continue;
+        const float* u0 = U + (size_t)e_u0[k] * (2 * H) + s * H;
+        const float* u1 = U + (size_t)e_u1[k] * (2 * H) + s * H;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * 32 * TN + j * 32 + (lane & 31);
+            const float z = u0[n] + u1[n];
+            GZ[(size_t)k * (2 * H) + s * H + n] = acc[j][r] * silu_grad_fast(z);
+        }
+    }
+}
+
+// GZR[r, :] = sum over the sorted edges sharing U row r (ascending) of GZ[k, :]
+__global__ void k_rowsum(int R, int W2, const int* __restrict__ row_ptr, const int* __restrict__ row_edge,
+                         const float* __restrict__ GZ, float* __restrict__ GZR) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int W4 = W2 / 4;
+    if (idx >= (long)R * W4) return;
+    const int r = (int)(idx / W4), c = (int)(idx % W4) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = row_ptr[r]; q < row_ptr[r + 1]; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(GZ + (size_t)row_edge[q] * W2 + c);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(GZR + (size_t)r * W2 + c) = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_node_energy: dE/dpose for a tile of 16 nodes
+//   grad[n] = sum_CSR (-2 d)  +  W0^T ( SiLU'(y1) (.) W2^T ( SiLU'(y2) (.) sum_rows GP[r] ) )
+// with y1 = W0 x + b0, y2 = W2 SiLU(y1) + b2 the pose-encoder pre-activations (recomputed).
+// Block 0 also folds the per-workgroup energy partials of k_edge into E_out[0].
+// ------------------------------------------------------------------------------------------
+struct EnergyNodeArgs {
+    int N, P;
+    const int* node_ptr;     // node -> CSR range of (edge, slot) entries
+    const float* Ocsr;       // [-2 d] per entry
+    const int* nrow_ptr;     // node -> U rows
+    const int* nrow_idx;
+    const float* GP;         // [R, H]
+    const float* x;          // evaluation point [N, P]
+    float* grad;             // [N, P]
+    const float* partial;    // energy partials
+    int n_partial;
+    float* E_out;
+    const float* W0;         // pose_encoder.0.weight [H/2, P]
+    const float* b0;
+    const float* W2;         // pose_encoder.2.weight [H, H/2]
+    const float* W2T;        // [H/2, H]
+    const float* b2;
+};
+
+template <int H>
+__global__ __launch_bounds__(256) void k_node_energy(EnergyNodeArgs a) {
+    constexpr int KC = H / 2;
+    __shared__ float xs[NODE_TILE][8];
+    __shared__ float dir[NODE_TILE][8];
+    __shared__ float y1[NODE_TILE][KC + 1];     // pre-activation, then g_y1
+    __shared__ float s1[NODE_TILE][KC + 1];
+    __shared__ float gy2[NODE_TILE][H + 1];
+    __shared__ float red[256];
+    const int node0 = blockIdx.x * NODE_TILE;
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && a.E_out) {            // uniform branch: whole block participates
+        float v = 0.0f;
+        for (int i = tid; i < a.n_partial; i += 256) v += a.partial[i];
+        const float s = block_sum_256(v, red);
+        if (tid == 0) a.E_out[0] = s;
+        __syncthreads();
+    }
+    if (tid < NODE_TILE * 8) {
+        const int nl = tid / 8, p = tid % 8, n = node0 + nl;
+        float xv = 0.0f, dv = 0.0f;
+        if (n < a.N && p < a.P) {
+            xv = a.x[(size_t)n * a.P + p];
+            const int beg = a.node_ptr[n], end = a.node_ptr[n + 1];
+            const float* op = a.Ocsr + (size_t)beg * a.P + p;
+            for (int q = 0; q < end - beg; ++q) dv += op[(size_t)q * a.P];
+        }
+        xs[nl][p] = xv;
+        dir[nl][p] = dv;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < NODE_TILE * KC; idx += 256) {
+        const int n = idx / KC, j = idx % KC;
+        float acc = 0.0f;
+        for (int d = 0; d < a.P; ++d) acc = fmaf(xs[n][d], a.W0[j * a.P + d], acc);
+        acc += a.b0[j];
+        y1[n][j] = acc;
+        s1[n][j] = silu_fast(acc);
+    }
+    __syncthreads();
+    {   // y2 and g_y2 = (sum_rows GP) * SiLU'(y2)
+        constexpr int NG = 256 / H, NPT = NODE_TILE / NG;
+        const int j = tid % H, g = tid / H;
+        float acc[NPT];
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) acc[i] = 0.0f;
+        for (int k = 0; k < KC; ++k) {
+            const float wv = a.W2T[(size_t)k * H + j];
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) acc[i] = fmaf(s1[g * NPT + i][k], wv, acc[i]);
+        }
+        const float bj = a.b2[j];
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const int nl = g * NPT + i, n = node0 + nl;
+            float gp = 0.0f;
+            if (n < a.N)
+                for (int q = a.nrow_ptr[n]; q < a.nrow_ptr[n + 1]; ++q) gp += a.GP[(size_t)a.nrow_idx[q] * H + j];
+            gy2[nl][j] = gp * silu_grad_fast(acc[i] + bj);
+        }
+    }
+    __syncthreads();
+    {   // g_s1[k] = sum_j g_y2[j] W2[j, k];  g_y1 = g_s1 * SiLU'(y1)
+        constexpr int NG = 256 / KC, NPT = NODE_TILE / NG;
+        const int k = tid % KC, g = tid / KC;
+        float acc[NPT];
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) acc[i] = 0.0f;
+        for (int j = 0; j < H; ++j) {
+            const float wv = a.W2[(size_t)j * KC + k];
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) acc[i] = fmaf(gy2[g * NPT + i][j], wv, acc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const int nl = g * NPT + i;
+            acc[i] *= silu_grad_fast(y1[nl][k]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) y1[g * NPT + i][k] = acc[i];
+    }
+    __syncthreads();
+    if (tid < NODE_TILE * 8) {
+        const int nl = tid / 8, p = tid % 8, n = node0 + nl;
+        if (n < a.N && p < a.P) {
+            float gx = 0.0f;
+            for (int k = 0; k < KC; ++k) gx = fmaf(y1[nl][k], a.W0[k * a.P + p], gx);
+            a.grad[(size_t)n * a.P + p] = dir[nl][p] + gx;
+        }
+    }
+}
+
+// acceptance counts -> mean acceptance rate per timestep
+__global__ void k_accept_rates(int T, const int* __restrict__ count, const int* __restrict__ denom, float* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < T) out[t] = denom[t] > 0 ? (float)count[t] / (float)denom[t] : 0.0f;
+}

@@ -2,7 +2,7 @@
 // behind the C ABI of include/ccsp.h.  See DESIGN.md for the data layout and the kernel list.
 //
 // One network evaluation (reference networks/denoise_fn.py:453-537) is three launches:
-//   k_ugemm   U[r,:]  = pose_emb[node(r),:] . Wp[type,slot]^T       fp32 MFMA 32x32x2, LDS tiled
+//   k_ugemm   U[r,:]  = pose_emb[node(r),:] . Wp[type,slot]^T       (k_rowgemm<H,2H>) fp32 MFMA 32x32x2, LDS tiled
 //   k_edge    O[k,s,:] = Dec( SiLU( U[u0(k)] + U[u1(k)] )[s-half] )      (U rows carry geometry + time terms)
 //   k_node    eps[n] = ordered sum over the node's CSR / sqrt(cnt), mask fill; then the fused
 //             Langevin / ancestral update of the pose rows and the pose encoder for the next
@@ -283,55 +283,61 @@ __device__ __forceinline__ void lds_store4(float* dst, const float4 v) {
 }
 
 // ------------------------------------------------------------------------------------------
-// k_ugemm: U[row0+r, col0+c] = sum_k A[node(row0+r), k] * W[ts][col0+c, k]  (+ base[row] + tau[type] on slot-0 rows)
-//   grid = n_tiles * (2H / TILE_N), XCD-remapped; 4 waves as 2(M) x 2(N), each 32 x 64.
+// k_rowgemm<KD, ND>: out[row0+r, col0+c] = sum_k A[src(row0+r), k] * W[ts][col0+c, k]  (+ base + tau)
+//   forward  (k_ugemm): KD = H,  ND = 2H, A = pose embeddings gathered by node, W = Wp[type, slot]
+//   backward          : KD = 2H, ND = H,  A = row-summed g_z (identity rows),     W = Wp^T
+//   grid = n_tiles * (ND / TILE_N), XCD-remapped; 4 waves as 2(M) x 2(N), each 32 x (TILE_N / 2).
+//   `base` [R, ND] (chain-constant geometry/grasp term of the row) and `tau_t` [C, ND] (time term + bias,
+//   slot-0 rows only) seed the accumulators, so an edge's pre-activation downstream is U[u0] + U[u1].
 // ------------------------------------------------------------------------------------------
-template <int H>
-__global__ __launch_bounds__(256) void k_ugemm(const float* __restrict__ A, const int* __restrict__ urow_node,
-                                               const int* __restrict__ tile_row0, const int* __restrict__ tile_nrows,
-                                               const int* __restrict__ tile_ts, const float* __restrict__ W,
-                                               size_t w_stride, const float* __restrict__ base /*[R,2H] or null*/,
-                                               const float* __restrict__ tau_t /*[C,2H] or null*/, float* __restrict__ U) {
+template <int KD, int ND>
+__global__ __launch_bounds__(256) void k_rowgemm(const float* __restrict__ A, const int* __restrict__ urow_node,
+                                                 const int* __restrict__ tile_row0, const int* __restrict__ tile_nrows,
+                                                 const int* __restrict__ tile_ts, const float* __restrict__ W,
+                                                 size_t w_stride, const float* __restrict__ base /*[R,ND] or null*/,
+                                                 const float* __restrict__ tau_t /*[C,ND] or null*/, float* __restrict__ U) {
+    constexpr int TN_ = ND >= 128 ? TILE_N : 64;          // column tile
+    constexpr int TNW = TN_ / 64;                         // 32-column MFMA tiles per wave
+    constexpr int BROWS = TN_ / 32;                       // B staging rows per thread
     __shared__ float As[2][TILE_M * LDS_LD];
-    __shared__ float Bs[2][TILE_N * LDS_LD];
-    constexpr int NCT = 2 * H / TILE_N;                 // column tiles per row tile
+    __shared__ float Bs[2][TN_ * LDS_LD];
+    constexpr int NCT = ND / TN_;                         // column tiles per row tile
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tile = bid / NCT;
     const int row0 = tile_row0[tile], nrows = tile_nrows[tile], ts = tile_ts[tile];
-    const int col0 = (bid % NCT) * TILE_N;
-    const float* Wt = W + (size_t)ts * w_stride + (size_t)col0 * H;
+    const int col0 = (bid % NCT) * TN_;
+    const float* Wt = W + (size_t)ts * w_stride + (size_t)col0 * KD;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = tid >> 3, lq = tid & 7;
     const float* a_ptr[2];
-    const float* b_ptr[4];
+    const float* b_ptr[BROWS];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         int r = lr + 32 * i;
         r = r < nrows ? r : nrows - 1;
-        a_ptr[i] = A + (size_t)urow_node[row0 + r] * H + lq * 4;
+        const int src = urow_node ? urow_node[row0 + r] : row0 + r;
+        a_ptr[i] = A + (size_t)src * KD + lq * 4;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) b_ptr[i] = Wt + (size_t)(lr + 32 * i) * H + lq * 4;
-    float4 ra[2], rb[4];
+    for (int i = 0; i < BROWS; ++i) b_ptr[i] = Wt + (size_t)(lr + 32 * i) * KD + lq * 4;
+    float4 ra[2], rb[BROWS];
 #pragma unroll
     for (int i = 0; i < 2; ++i) ra[i] = *reinterpret_cast<const float4*>(a_ptr[i]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const float4*>(b_ptr[i]);
+    for (int i = 0; i < BROWS; ++i) rb[i] = *reinterpret_cast<const float4*>(b_ptr[i]);
 #pragma unroll
     for (int i = 0; i < 2; ++i) lds_store4(&As[0][(lr + 32 * i) * LDS_LD + lq * 4], ra[i]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) lds_store4(&Bs[0][(lr + 32 * i) * LDS_LD + lq * 4], rb[i]);
+    for (int i = 0; i < BROWS; ++i) lds_store4(&Bs[0][(lr + 32 * i) * LDS_LD + lq * 4], rb[i]);
     __syncthreads();
-    // accumulators start from the row's chain-constant term `base` (+ the time term and bias `tau` on
-    // slot-0 rows), so that an edge's pre-activation downstream is simply U[u0] + U[u1]; these loads are
-    // in flight while the first K chunk is staged.  C/D layout of 32x32: col = lane & 31,
-    // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    floatx16 acc[2];
+    // accumulators start from base (+ tau on slot-0 rows); these loads are in flight while the first K
+    // chunk is staged.  C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    floatx16 acc[TNW];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = col0 + wn * 64 + j * 32 + (lane & 31);
-        const float tv = (tau_t && (ts & 1) == 0) ? tau_t[(size_t)(ts >> 1) * (2 * H) + col] : 0.0f;
+    for (int j = 0; j < TNW; ++j) {
+        const int col = col0 + wn * 32 * TNW + j * 32 + (lane & 31);
+        const float tv = (tau_t && (ts & 1) == 0) ? tau_t[(size_t)(ts >> 1) * ND + col] : 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -339,11 +345,11 @@ __global__ __launch_bounds__(256) void k_ugemm(const float* __restrict__ A, cons
 #if CCSP_ABLATE >= 5
             acc[j][r] = tv;
 #else
-            acc[j][r] = (base ? base[(size_t)(row0 + row) * (2 * H) + col] : 0.0f) + tv;
+            acc[j][r] = (base ? base[(size_t)(row0 + row) * ND + col] : 0.0f) + tv;
 #endif
         }
     }
-    constexpr int NCH = H / BK;
+    constexpr int NCH = KD / BK;
     for (int c = 0; c < NCH; ++c) {
 #if CCSP_ABLATE >= 2
         const int buf = 0;
@@ -355,20 +361,20 @@ __global__ __launch_bounds__(256) void k_ugemm(const float* __restrict__ A, cons
 #pragma unroll
             for (int i = 0; i < 2; ++i) ra[i] = *reinterpret_cast<const float4*>(a_ptr[i] + (c + 1) * BK);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const float4*>(b_ptr[i] + (c + 1) * BK);
+            for (int i = 0; i < BROWS; ++i) rb[i] = *reinterpret_cast<const float4*>(b_ptr[i] + (c + 1) * BK);
         }
 #endif
         // keep the prefetch ahead of the MFMA block: without this fence hipcc sinks the global loads to
-        // just before their first use (the LDS stores below) and the whole L2/HBM latency is exposed
+        // just before their first use (the LDS stores below)
         __builtin_amdgcn_sched_barrier(0);
-        mfma_chunk<2>(As[buf], Bs[buf], wm * 32, wn * 64, acc);
+        mfma_chunk<TNW>(As[buf], Bs[buf], wm * 32, wn * 32 * TNW, acc);
         __builtin_amdgcn_sched_barrier(0);
 #if CCSP_ABLATE <= 1
         if (c + 1 < NCH) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) lds_store4(&As[buf ^ 1][(lr + 32 * i) * LDS_LD + lq * 4], ra[i]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) lds_store4(&Bs[buf ^ 1][(lr + 32 * i) * LDS_LD + lq * 4], rb[i]);
+            for (int i = 0; i < BROWS; ++i) lds_store4(&Bs[buf ^ 1][(lr + 32 * i) * LDS_LD + lq * 4], rb[i]);
         }
 #endif
 #if CCSP_ABLATE <= 2
@@ -376,18 +382,21 @@ __global__ __launch_bounds__(256) void k_ugemm(const float* __restrict__ A, cons
 #endif
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TNW; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int col = col0 + wn * 64 + j * 32 + (lane & 31);
+            const int col = col0 + wn * 32 * TNW + j * 32 + (lane & 31);
 #if CCSP_ABLATE >= 5
-            if (row < nrows && acc[j][r] == 123.456f) U[(size_t)(row0 + row) * (2 * H) + col] = acc[j][r];
+            if (row < nrows && acc[j][r] == 123.456f) U[(size_t)(row0 + row) * ND + col] = acc[j][r];
 #else
-            if (row < nrows) U[(size_t)(row0 + row) * (2 * H) + col] = acc[j][r];
+            if (row < nrows) U[(size_t)(row0 + row) * ND + col] = acc[j][r];
 #endif
         }
 }
+
+template <int KD, int ND>
+constexpr int rowgemm_col_tiles() { return ND / (ND >= 128 ? TILE_N : 64); }
 
 // base[r, :] = UG[r, :] (+ UR[r, :] on slot-0 rows: grasp_emb[args_1], denoise_fn.py:337) -- the
 // chain-constant geometry/grasp part of row r's contribution to an edge pre-activation
@@ -406,17 +415,30 @@ __global__ void k_rowbase(int R, int W2, const int* __restrict__ urow_ts, const 
 //   H=64 : 128 rows x 32 cols per workgroup (waves 4x1, 32x32 each)
 // grid = 2 * ceil(E_act / BM), XCD-remapped
 // ------------------------------------------------------------------------------------------
+#include "ccsp_energy_pre.h"
+
 template <int H> struct EdgeCfg;
 template <> struct EdgeCfg<256> { static constexpr int WM = 2, WN = 2, TN = 2; };
 template <> struct EdgeCfg<64> { static constexpr int WM = 4, WN = 1, TN = 1; };
 
-template <int H>
+// ENERGY = true (denoise_fn.py:373-375): the CSR slot receives -2 d = -2 (o - pose) (the direct term of
+// dE/dpose), the decoder pre-activations go to Q (when non-null, for k_edge_bwd) and the workgroup's
+// share of sum d^2 to partial[blockIdx.x].
+struct EdgeEnergyArgs {
+    const int* e_a;          // node of slot 0 / slot 1 of every sorted edge
+    const int* e_b;
+    const float* xeval;      // [N, P] evaluation point
+    float* Q;                // [2 E_act, H/2] or null
+    float* partial;          // [gridDim.x]
+};
+
+template <int H, bool ENERGY>
 __global__ __launch_bounds__(256, 3) void k_edge(int E_act, int P,
                                               const int* __restrict__ e_u0, const int* __restrict__ e_u1,
                                               const float* __restrict__ U, const float* __restrict__ Wd1 /*[H/2,H]*/,
                                               const float* __restrict__ bd1, const float* __restrict__ Wd2 /*[P,H/2]*/,
                                               const float* __restrict__ bd2, const int* __restrict__ ent_pos,
-                                              float* __restrict__ O) {
+                                              float* __restrict__ O, EdgeEnergyArgs en) {
     using Cfg = EdgeCfg<H>;
     constexpr int BM = 32 * Cfg::WM, BN = 32 * Cfg::TN * Cfg::WN, TN = Cfg::TN;
     static_assert(BN == H / 2, "decoder hidden width must fit one column tile");
@@ -493,11 +515,17 @@ __global__ __launch_bounds__(256, 3) void k_edge(int E_act, int P,
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            S1[row * S1_LD + col] = silu_fast(acc[j][r] + bj);
+            const float q = acc[j][r] + bj;
+            S1[row * S1_LD + col] = silu_fast(q);
+            if constexpr (ENERGY) {
+                const int k = e0 + row;
+                if (en.Q && k < E_act) en.Q[((size_t)2 * k + s) * BN + col] = q;
+            }
         }
     }
     __syncthreads();
     // epilogue 2: o[row, p] = bd2[p] + sum_j S1[row, j] Wd2[p, j]
+    float e2 = 0.0f;
     for (int idx = tid; idx < BM * P; idx += 256) {
         const int row = idx % BM, p = idx / BM;
         const float* w = Wd2 + (size_t)p * BN;
@@ -505,7 +533,21 @@ __global__ __launch_bounds__(256, 3) void k_edge(int E_act, int P,
         for (int j = 0; j < BN; ++j) o = fmaf(S1[row * S1_LD + j], w[j], o);
         o += bd2[p];
         const int k = e0 + row;
-        if (k < E_act) O[(size_t)ent_pos[2 * k + s] * P + p] = o;      // straight to the node's CSR slot
+        if (k < E_act) {
+            if constexpr (ENERGY) {
+                const int node = s == 0 ? en.e_a[k] : en.e_b[k];
+                const float d = o - en.xeval[(size_t)node * P + p];
+                e2 = fmaf(d, d, e2);
+                O[(size_t)ent_pos[2 * k + s] * P + p] = -2.0f * d;
+            } else {
+                O[(size_t)ent_pos[2 * k + s] * P + p] = o;             // straight to the node's CSR slot
+            }
+        }
+    }
+    if constexpr (ENERGY) {
+        __syncthreads();                                               // S1 is dead: reuse it for the reduction
+        const float tot = block_sum_256(e2, smem);
+        if (tid == 0) en.partial[blockIdx.x] = tot;
     }
 }
 
@@ -514,7 +556,7 @@ __global__ __launch_bounds__(256, 3) void k_edge(int E_act, int P,
 //                   (2) pose update: ancestral p_sample or one ULA step (+ end-of-timestep reset)
 //                   (3) pose encoder of the updated pose for the next evaluation
 // ------------------------------------------------------------------------------------------
-enum { STEP_NONE = 0, STEP_ANCESTRAL = 1, STEP_ULA = 2, STEP_INIT = 3 };
+enum { STEP_NONE = 0, STEP_ANCESTRAL = 1, STEP_ULA = 2, STEP_INIT = 3, STEP_MALA_PROPOSE = 4, STEP_MALA_ACCEPT = 5 };
 
 struct NoiseArg {
     int mode;               // CCSP_NOISE_*
@@ -522,6 +564,8 @@ struct NoiseArg {
     unsigned long long row_offset;
     const float* normal;    // injected block for this call ([N,P]) or nullptr
     unsigned int call;      // philox call index
+    const float* uniform;   // injected rand(N) block of this MALA inner step or nullptr
+    unsigned int ucall;     // philox uniform-call index
 };
 
 struct NodeArgs {
@@ -541,6 +585,10 @@ struct NodeArgs {
     float* eps_out;         // [N,P] or nullptr
     const float* eps_buf;   // src == 1
     float* hist;            // history slot [N,P] or nullptr (written after the update)
+    float* xhat;            // MALA proposal buffer [N,P]
+    const float* E_x;       // MALA: batch energy at x and at the proposal (device scalars)
+    const float* E_hat;
+    int* acc_count;         // MALA: accepted-node counter of this timestep
     // schedule scalars of this timestep
     float a_t, b_t, c1, c2, sigma, kappa, ss, std_;
     NoiseArg noise;
@@ -574,9 +622,11 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, float* __restr
             if (a.eps_out) a.eps_out[i] = eps;
             float xv = a.x_in ? a.x_in[i] : (a.step == STEP_INIT ? 0.0f : a.x[i]);
             if (a.step != STEP_NONE) {
-                float z;
-                if (a.noise.mode == CCSP_NOISE_INJECTED) z = a.noise.normal[i];
-                else z = ccsp::philox_normal(a.noise.seed, a.noise.row_offset + (unsigned long long)n, a.noise.call, p);
+                float z = 0.0f;
+                if (a.step != STEP_MALA_ACCEPT) {
+                    if (a.noise.mode == CCSP_NOISE_INJECTED) z = a.noise.normal[i];
+                    else z = ccsp::philox_normal(a.noise.seed, a.noise.row_offset + (unsigned long long)n, a.noise.call, p);
+                }
                 if (a.step == STEP_ANCESTRAL) {                 // ddpm.py:230-258
                     const float x0 = a.a_t * xv - a.b_t * eps;
                     const float mean = a.c1 * x0 + a.c2 * xv;
@@ -584,12 +634,40 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, float* __restr
                 } else if (a.step == STEP_ULA) {                // ddpm.py:956-966
                     const float grad = (-eps) * a.kappa;
                     xv = (xv + grad * a.ss) + z * a.std_;
+                } else if (a.step == STEP_MALA_PROPOSE) {       // ddpm.py:1017-1023: x_hat = (x + grad ss) + noise std
+                    const float grad = (-eps) * a.kappa;
+                    xv = (xv + grad * a.ss) + z * a.std_;
+                } else if (a.step == STEP_MALA_ACCEPT) {        // ddpm.py:1026-1041
+                    // one decision per node row from the batch-scalar energies and the proposal densities
+                    // (the reverse density uses the SAME mu as the forward one, like the reference)
+                    const size_t r0 = (size_t)n * a.P;
+                    const float var = a.std_ * a.std_, log_scale = logf(a.std_), lc = 0.918938533204672742f;
+                    float lrev = 0.0f, lfwd = 0.0f;
+                    for (int c = 0; c < a.P; ++c) {
+                        const float xc = a.x[r0 + c], hc = a.xhat[r0 + c];
+                        const float mu = xc + ((-a.eps_buf[r0 + c]) * a.kappa) * a.ss;
+                        const float dr = xc - mu, df = hc - mu;
+                        lrev += -(dr * dr) / (2.0f * var) - log_scale - lc;
+                        lfwd += -(df * df) / (2.0f * var) - log_scale - lc;
+                    }
+                    const float logp_x = (-a.E_x[0]) * a.kappa, logp_h = (-a.E_hat[0]) * a.kappa;
+                    const float la = logp_h - logp_x + lrev - lfwd;
+                    float u;
+                    if (a.noise.mode == CCSP_NOISE_INJECTED) u = a.noise.uniform[n];
+                    else u = ccsp::philox_uniform(a.noise.seed, a.noise.row_offset + (unsigned long long)n, a.noise.ucall);
+                    const float accf = (u < expf(la)) ? 1.0f : 0.0f;
+                    if (p == 0 && accf != 0.0f && a.acc_count) atomicAdd(a.acc_count, 1);
+                    xv = accf * a.xhat[i] + (1.0f - accf) * xv;
                 } else {                                        // ddpm.py:273
                     xv = 0.5f * z;
                 }
-                if (a.reset_mask && masked) xv = a.xfeat[(size_t)n * a.F + a.pose_begin + p];
-                a.x[i] = xv;
-                if (a.hist) a.hist[i] = xv;
+                if (a.step == STEP_MALA_PROPOSE) {
+                    a.xhat[i] = xv;                             // the chain state x is untouched until the accept step
+                } else {
+                    if (a.reset_mask && masked) xv = a.xfeat[(size_t)n * a.F + a.pose_begin + p];
+                    a.x[i] = xv;
+                    if (a.hist) a.hist[i] = xv;
+                }
             }
             xnew = xv;
         }
@@ -599,6 +677,8 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, float* __restr
     __syncthreads();
     encode_tile_mfma<H>(w, xs, s1, node0, a.N, pemb);
 }
+
+#include "ccsp_energy.h"
 
 // NaN rows for the edge-output debug API, then scatter sorted -> original order
 __global__ void k_fill(float* p, long n, float v) {
@@ -630,9 +710,12 @@ struct ccsp_model {
     float *gr0_w, *gr0_b, *gr2_wT, *gr2_b;
     float *pe0_w, *pe0_b, *pe2_wT, *pe2_b, *pe2_wF;
     float *pd0_w, *pd0_b, *pd2_w, *pd2_b;
+    float *pd0_wT;   // [H, H/2]  pose_decoder.0.weight transposed (k_edge_bwd)
+    float *pe2_w;    // [H, H/2]  pose_encoder.2.weight as given (encoder backward)
     float* Wg;     // [C][2][2H][H]   geometry slices (slot 0 = node a, slot 1 = node b)
     float* Wr;     // [C][2][2H][H]   grasp slice in slot 0 (slot 1 unused) or nullptr
     float* Wp;     // [C][2][2H][H]   pose slices
+    float* WpT;    // [C][2][H][2H]   their transposes (energy-mode backward)
     float* temb;   // [T][H]
     float* tau;    // [T][C][2H]      W_t . temb(t) + b_i
     std::vector<float> betas, ac, acp, sqrt_recip_ac, sqrt_recipm1_ac, post_lv, post_var, coef1, coef2, kappa, step;
@@ -651,6 +734,14 @@ struct ccsp_graph {
     int *e_type, *e_u0, *e_u1, *e_orig, *urow_node, *tile_row0, *tile_nrows, *tile_ts, *node_ptr, *node_ent, *ent_pos;
     float *base, *U, *O, *pemb, *x, *eps;
     int* urow_ts;
+    // energy mode (allocated on first use)
+    bool energy_ready = false;
+    int *e_a = nullptr, *e_b = nullptr, *row_ptr = nullptr, *row_edge = nullptr, *nrow_ptr = nullptr, *nrow_idx = nullptr;
+    int *tileb_row0 = nullptr, *tileb_nrows = nullptr, *tileb_ts = nullptr;
+    float *Q = nullptr, *GZ = nullptr, *GZR = nullptr, *GP = nullptr, *xhat = nullptr, *partial = nullptr, *Escal = nullptr;
+    int *acc_count = nullptr, *acc_denom = nullptr;
+    std::vector<int> h_denom;      // host copy kept alive for the async upload
+    int n_edge_blocks = 0;
     std::vector<void*> allocs;
     // profiling
     int profile = 0;
@@ -706,12 +797,12 @@ int launch_eval(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s) {
     if (p.E_act == 0) return 0;
     const bool prof = g->profile && g->kev_used + 3 <= g->kev.size();
     if (prof) HIP_TRY(hipEventRecord(g->kev[g->kev_used], s));
-    hipLaunchKernelGGL(k_ugemm<H>, dim3(g->n_tiles * (2 * H / TILE_N)), dim3(256), 0, s, g->pemb, g->urow_node, g->tile_row0,
+    hipLaunchKernelGGL((k_rowgemm<H, 2 * H>), dim3(g->n_tiles * rowgemm_col_tiles<H, 2 * H>()), dim3(256), 0, s, g->pemb, g->urow_node, g->tile_row0,
                        g->tile_nrows, g->tile_ts, m->Wp, (size_t)2 * H * H, g->base, m->tau + (size_t)t * m->d.n_types * 2 * H, g->U);
     if (prof) HIP_TRY(hipEventRecord(g->kev[g->kev_used + 1], s));
     constexpr int BM = 32 * EdgeCfg<H>::WM;
-    hipLaunchKernelGGL(k_edge<H>, dim3(2 * nblk(p.E_act, BM)), dim3(256), 0, s, p.E_act, m->d.pose_dim, g->e_u0,
-                       g->e_u1, g->U, m->pd0_w, m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O);
+    hipLaunchKernelGGL((k_edge<H, false>), dim3(2 * nblk(p.E_act, BM)), dim3(256), 0, s, p.E_act, m->d.pose_dim, g->e_u0,
+                       g->e_u1, g->U, m->pd0_w, m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, EdgeEnergyArgs{});
     if (prof) { HIP_TRY(hipEventRecord(g->kev[g->kev_used + 2], s)); g->kev_used += 3; }
     g->evals++;
     return 0;
@@ -733,6 +824,66 @@ void launch_node(ccsp_model* m, ccsp_graph* g, const NodeArgs& a, hipStream_t s)
     hipLaunchKernelGGL(k_node<H>, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a, enc_pose(m), g->pemb);
 }
 
+// ---- energy mode -------------------------------------------------------------------------------
+int energy_prepare(ccsp_model* m, ccsp_graph* g, hipStream_t s) {
+    if (g->energy_ready) return 0;
+    const ccsp::Plan& p = g->plan;
+    const int H = m->d.hidden_dim, P = m->d.pose_dim, T = m->d.timesteps;
+    auto& reg = g->allocs;
+    if (dev_upload(reg, &g->e_a, p.e_a, s) || dev_upload(reg, &g->e_b, p.e_b, s) || dev_upload(reg, &g->row_ptr, p.row_ptr, s) ||
+        dev_upload(reg, &g->row_edge, p.row_edge, s) || dev_upload(reg, &g->nrow_ptr, p.nrow_ptr, s) || dev_upload(reg, &g->nrow_idx, p.nrow_idx, s))
+        return 1;
+    // identity row tiles of the backward row GEMM (same tiles, rows taken as they are)
+    if (dev_upload(reg, &g->tileb_row0, p.tile_row0, s) || dev_upload(reg, &g->tileb_nrows, p.tile_nrows, s) || dev_upload(reg, &g->tileb_ts, p.tile_ts, s)) return 1;
+    const int BMf = H == 256 ? 32 * EdgeCfg<256>::WM : 32 * EdgeCfg<64>::WM;
+    g->n_edge_blocks = 2 * nblk(p.E_act, BMf);
+    if (dev_alloc(reg, &g->Q, (size_t)2 * p.E_act * (H / 2)) || dev_alloc(reg, &g->GZ, (size_t)p.E_act * 2 * H) ||
+        dev_alloc(reg, &g->GZR, (size_t)p.R * 2 * H) || dev_alloc(reg, &g->GP, (size_t)p.R * H) ||
+        dev_alloc(reg, &g->xhat, (size_t)g->N * P) || dev_alloc(reg, &g->partial, (size_t)g->n_edge_blocks + 1) ||
+        dev_alloc(reg, &g->Escal, 4) || dev_alloc(reg, &g->acc_count, (size_t)T) || dev_alloc(reg, &g->acc_denom, (size_t)T))
+        return 1;
+    HIP_TRY(hipMemsetAsync(g->Escal, 0, 4 * sizeof(float), s));
+    HIP_TRY(hipMemsetAsync(g->partial, 0, ((size_t)g->n_edge_blocks + 1) * sizeof(float), s));
+    g->energy_ready = true;
+    return 0;
+}
+
+// one energy-mode evaluation at `xeval` (pose embeddings of xeval must already be in g->pemb).
+// with_grad: dE/dposes -> g->eps and E -> E_out;  otherwise only E -> E_out.
+template <int H>
+int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, bool with_grad, float* E_out, hipStream_t s) {
+    const ccsp::Plan& p = g->plan;
+    const int P = m->d.pose_dim;
+    g->evals++;
+    if (p.E_act == 0) {
+        HIP_TRY(hipMemsetAsync(E_out, 0, sizeof(float), s));
+        if (with_grad) HIP_TRY(hipMemsetAsync(g->eps, 0, (size_t)g->N * P * sizeof(float), s));
+        return 0;
+    }
+    hipLaunchKernelGGL((k_rowgemm<H, 2 * H>), dim3(g->n_tiles * rowgemm_col_tiles<H, 2 * H>()), dim3(256), 0, s, g->pemb, g->urow_node, g->tile_row0,
+                       g->tile_nrows, g->tile_ts, m->Wp, (size_t)2 * H * H, g->base, m->tau + (size_t)t * m->d.n_types * 2 * H, g->U);
+    constexpr int BM = 32 * EdgeCfg<H>::WM;
+    EdgeEnergyArgs en{g->e_a, g->e_b, xeval, with_grad ? g->Q : nullptr, g->partial};
+    hipLaunchKernelGGL((k_edge<H, true>), dim3(g->n_edge_blocks), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->U, m->pd0_w,
+                       m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, en);
+    if (!with_grad) {
+        hipLaunchKernelGGL(k_energy_sum, dim3(1), dim3(256), 0, s, g->partial, g->n_edge_blocks, E_out);
+        return 0;
+    }
+    constexpr int BMB = 32 * BwdCfg<H>::WM, NCTB = H / (32 * BwdCfg<H>::TN * BwdCfg<H>::WN);
+    hipLaunchKernelGGL(k_edge_bwd<H>, dim3(nblk(p.E_act, BMB) * 2 * NCTB), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->ent_pos,
+                       g->U, g->O, g->Q, m->pd0_wT, m->pd2_w, g->GZ);
+    hipLaunchKernelGGL(k_rowsum, dim3(nblk((long)p.R * (2 * H / 4), 256)), dim3(256), 0, s, p.R, 2 * H, g->row_ptr, g->row_edge, g->GZ, g->GZR);
+    const int* no_map = nullptr;
+    const float* nof = nullptr;
+    hipLaunchKernelGGL((k_rowgemm<2 * H, H>), dim3(g->n_tiles * rowgemm_col_tiles<2 * H, H>()), dim3(256), 0, s, g->GZR, no_map, g->tileb_row0,
+                       g->tileb_nrows, g->tileb_ts, m->WpT, (size_t)2 * H * H, nof, nof, g->GP);
+    EnergyNodeArgs a{g->N, P, g->node_ptr, g->O, g->nrow_ptr, g->nrow_idx, g->GP, xeval, g->eps, g->partial, g->n_edge_blocks, E_out,
+                     m->pe0_w, m->pe0_b, m->pe2_w, m->pe2_wT, m->pe2_b};
+    hipLaunchKernelGGL(k_node_energy<H>, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a);
+    return 0;
+}
+
 int steps_at(const ccsp_model* m, int sampler, int t) {
     if (sampler == CCSP_SAMPLER_NONE) return 0;
     if (t % m->d.ebm_per_steps != 0) return 0;                 // ddpm.py:330
@@ -750,11 +901,11 @@ int chain_run_impl(ccsp_model* m, ccsp_graph* g, int sampler, const ccsp_noise* 
                    int t_last, float* history, float* accept, hipStream_t s) {
     const int T = m->d.timesteps, P = m->d.pose_dim, N = g->N;
     const size_t NP = (size_t)N * P;
-    (void)accept;
     std::vector<uint64_t> call0(T);
     { uint64_t c = 1; for (int t = T - 1; t >= 0; --t) { call0[t] = c; c += 1 + (uint64_t)steps_at(m, sampler, t); } }
     auto noise_for = [&](uint64_t call, NoiseArg& na) -> int {
         na.mode = nz->mode; na.seed = nz->seed; na.row_offset = nz->row_offset; na.call = (unsigned int)call; na.normal = nullptr;
+        na.uniform = nullptr; na.ucall = 0;
         if (nz->mode == CCSP_NOISE_INJECTED) {
             if (call < nz->call_base || call - nz->call_base >= nz->n_normal) return fail("chain_run: injected normal stream exhausted at call %llu", (unsigned long long)call);
             na.normal = nz->normal + (size_t)(call - nz->call_base) * NP;
@@ -775,7 +926,75 @@ int chain_run_impl(ccsp_model* m, ccsp_graph* g, int sampler, const ccsp_noise* 
         a.src = 2; a.step = STEP_NONE; a.do_encode = 1;
         launch_node<H>(m, g, a, s);
     }
-    for (int t = t_first; t >= t_last; --t) {
+    const bool energy = m->d.energy_wrapper != 0;
+    std::vector<uint64_t> ucall0(T, 0);
+    if (energy) {
+        if (energy_prepare(m, g, s)) return 1;
+        HIP_TRY(hipMemsetAsync(g->acc_count, 0, (size_t)T * sizeof(int), s));
+        HIP_TRY(hipStreamSynchronize(s));      // a previous chain may still be reading h_denom
+        g->h_denom.assign(T, 0);
+        uint64_t uc = 0;
+        for (int t = T - 1; t >= 0; --t) {
+            ucall0[t] = uc;
+            if (sampler == CCSP_SAMPLER_MALA) { uc += (uint64_t)steps_at(m, sampler, t); g->h_denom[t] = N * steps_at(m, sampler, t); }
+        }
+        HIP_TRY(hipMemcpyAsync(g->acc_denom, g->h_denom.data(), (size_t)T * sizeof(int), hipMemcpyHostToDevice, s));
+    }
+    auto sched = [&](NodeArgs& a, int t) {
+        a.a_t = m->sqrt_recip_ac[t]; a.b_t = m->sqrt_recipm1_ac[t]; a.c1 = m->coef1[t]; a.c2 = m->coef2[t];
+        a.sigma = t != 0 ? expf(0.5f * m->post_lv[t]) : 0.0f;
+        a.kappa = m->kappa[t]; a.ss = m->step[t]; a.std_ = sqrtf(2.0f * m->step[t]);
+    };
+    for (int t = t_first; energy && t >= t_last; --t) {
+        // energy mode: epsilon = dE/dposes (ComposedEBMDenoiseFn.forward); MALA re-evaluates E at the
+        // proposal (energy_function, ddpm.py:285-289) -- the gradient pass already gave E(x)
+        const int S = steps_at(m, sampler, t);
+        float* E_x = g->Escal, *E_hat = g->Escal + 1;
+        if (launch_eval_energy<H>(m, g, t, g->x, true, E_x, s)) return 1;
+        {
+            NodeArgs a = node_args(m, g);
+            a.src = 1; a.eps_buf = g->eps; a.do_encode = 1; a.step = STEP_ANCESTRAL;
+            a.reset_mask = (S == 0);
+            a.hist = (S == 0 && history) ? history + (size_t)(T - t) * NP : nullptr;
+            sched(a, t);
+            if (noise_for(call0[t], a.noise)) return 1;
+            launch_node<H>(m, g, a, s);
+        }
+        for (int e = 1; e <= S; ++e) {
+            if (launch_eval_energy<H>(m, g, t, g->x, true, E_x, s)) return 1;
+            NodeArgs a = node_args(m, g);
+            a.src = 1; a.eps_buf = g->eps; a.do_encode = 1; a.xhat = g->xhat;
+            sched(a, t);
+            if (noise_for(call0[t] + (uint64_t)e, a.noise)) return 1;
+            if (sampler != CCSP_SAMPLER_MALA) {
+                a.step = STEP_ULA;
+                a.reset_mask = (e == S);
+                a.hist = (e == S && history) ? history + (size_t)(T - t) * NP : nullptr;
+                launch_node<H>(m, g, a, s);
+                continue;
+            }
+            a.step = STEP_MALA_PROPOSE;
+            launch_node<H>(m, g, a, s);                                   // x_hat, and its pose embedding
+            if (launch_eval_energy<H>(m, g, t, g->xhat, false, E_hat, s)) return 1;
+            NodeArgs b = node_args(m, g);
+            b.src = 1; b.eps_buf = g->eps; b.do_encode = 1; b.xhat = g->xhat; b.step = STEP_MALA_ACCEPT;
+            b.E_x = E_x; b.E_hat = E_hat; b.acc_count = g->acc_count + t;
+            b.reset_mask = (e == S);
+            b.hist = (e == S && history) ? history + (size_t)(T - t) * NP : nullptr;
+            sched(b, t);
+            b.noise.mode = nz->mode; b.noise.seed = nz->seed; b.noise.row_offset = nz->row_offset;
+            const uint64_t uc = ucall0[t] + (uint64_t)(e - 1);
+            b.noise.ucall = (unsigned int)uc;
+            if (nz->mode == CCSP_NOISE_INJECTED) {
+                if (!nz->uniform || uc < nz->ucall_base || uc - nz->ucall_base >= nz->n_uniform)
+                    return fail("chain_run: injected uniform stream exhausted at call %llu", (unsigned long long)uc);
+                b.noise.uniform = nz->uniform + (size_t)(uc - nz->ucall_base) * N;
+            }
+            launch_node<H>(m, g, b, s);
+        }
+    }
+    if (energy && accept) hipLaunchKernelGGL(k_accept_rates, dim3(nblk(T, 256)), dim3(256), 0, s, T, g->acc_count, g->acc_denom, accept);
+    for (int t = t_first; !energy && t >= t_last; --t) {
         const int S = steps_at(m, sampler, t);
         for (int e = 0; e <= S; ++e) {
             if (launch_eval<H>(m, g, t, s)) return 1;
@@ -894,9 +1113,13 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
         TRY(dupT(&m->gr2_wT, H, H / 2)); TRY(dup(&m->gr2_b, H));
     }
     TRY(dup(&m->pe0_w, (size_t)(H / 2) * P)); TRY(dup(&m->pe0_b, H / 2));
+    TRY(dev_alloc(reg, &m->pe2_w, (size_t)H * (H / 2)));
+    HIP_TRY(hipMemcpyAsync(m->pe2_w, params[k], (size_t)H * (H / 2) * sizeof(float), hipMemcpyDeviceToDevice, s));
     TRY(dev_alloc(reg, &m->pe2_wF, (size_t)H * (H / 2)));
     hipLaunchKernelGGL(k_pack_enc_frag, dim3(nblk((long)H * (H / 2), 256)), dim3(256), 0, s, H, params[k], m->pe2_wF);
     TRY(dupT(&m->pe2_wT, H, H / 2)); TRY(dup(&m->pe2_b, H));
+    TRY(dev_alloc(reg, &m->pd0_wT, (size_t)(H / 2) * H));
+    hipLaunchKernelGGL(k_transpose, dim3(nblk((long)(H / 2) * H, 256)), dim3(256), 0, s, H / 2, H, params[k], m->pd0_wT);
     TRY(dup(&m->pd0_w, (size_t)(H / 2) * H)); TRY(dup(&m->pd0_b, H / 2));
     TRY(dup(&m->pd2_w, (size_t)P * (H / 2))); TRY(dup(&m->pd2_b, P));
     const float* tm1_w = params[k]; const float* tm1_b = params[k + 1];
@@ -916,6 +1139,7 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     TRY(dev_alloc(reg, &m->Wp, (size_t)C * 2 * WS));
     m->Wr = nullptr;
     if (grasp) { TRY(dev_alloc(reg, &m->Wr, (size_t)C * 2 * WS)); HIP_TRY(hipMemsetAsync(m->Wr, 0, (size_t)C * 2 * WS * sizeof(float), s)); }
+    TRY(dev_alloc(reg, &m->WpT, (size_t)C * 2 * WS));
     TRY(dev_alloc(reg, &m->tau, (size_t)T * C * 2 * H));
     const int off = grasp ? H : 0;
     for (int i = 0; i < C; ++i) {
@@ -927,6 +1151,8 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
         hipLaunchKernelGGL(k_copy_cols, dim3(gridc), dim3(256), 0, s, 2 * H, H, Wi, m->K_in, off + H, m->Wg + (size_t)(2 * i + 1) * WS, H);
         hipLaunchKernelGGL(k_copy_cols, dim3(gridc), dim3(256), 0, s, 2 * H, H, Wi, m->K_in, off + 2 * H, m->Wp + (size_t)(2 * i) * WS, H);
         hipLaunchKernelGGL(k_copy_cols, dim3(gridc), dim3(256), 0, s, 2 * H, H, Wi, m->K_in, off + 3 * H, m->Wp + (size_t)(2 * i + 1) * WS, H);
+        for (int sl = 0; sl < 2; ++sl)      // WpT[i, sl] [H, 2H] = Wp[i, sl]^T
+            hipLaunchKernelGGL(k_transpose, dim3(gridc), dim3(256), 0, s, 2 * H, H, m->Wp + (size_t)(2 * i + sl) * WS, m->WpT + (size_t)(2 * i + sl) * WS);
         // tau[t, i, :] = Wi[:, time cols] . temb[t] + b_i
         hipLaunchKernelGGL(k_linear_rows, dim3(nblk((long)T * 2 * H, 256)), dim3(256), 0, s, T, H, 2 * H, m->temb, H, Wi + off + 4 * H, m->K_in, bi, 0,
                            m->tau + (size_t)i * 2 * H, C * 2 * H);
@@ -1014,10 +1240,10 @@ int ccsp_graph_create(ccsp_model* m, int32_t N, int32_t E, int32_t F, const floa
         const float* nof = nullptr;
         if (H == 256) {
             hipLaunchKernelGGL(k_encode<256>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, 0, wg, gemb);
-            hipLaunchKernelGGL(k_ugemm<256>, ggrid, dim3(256), 0, s, gemb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wg, (size_t)2 * H * H, nof, nof, g->base);
+            hipLaunchKernelGGL((k_rowgemm<256, 512>), ggrid, dim3(256), 0, s, gemb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wg, (size_t)2 * H * H, nof, nof, g->base);
         } else {
             hipLaunchKernelGGL(k_encode<64>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, 0, wg, gemb);
-            hipLaunchKernelGGL(k_ugemm<64>, ggrid, dim3(256), 0, s, gemb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wg, (size_t)2 * H * H, nof, nof, g->base);
+            hipLaunchKernelGGL((k_rowgemm<64, 128>), ggrid, dim3(256), 0, s, gemb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wg, (size_t)2 * H * H, nof, nof, g->base);
         }
         if (d.grasp_dim > 0) {
             TRY(dev_alloc(reg, &remb, (size_t)N * H));
@@ -1025,10 +1251,10 @@ int ccsp_graph_create(ccsp_model* m, int32_t N, int32_t E, int32_t F, const floa
             const EncW wr{m->gr0_w, m->gr0_b, m->gr2_wT, m->gr2_b, d.grasp_dim, nullptr};
             if (H == 256) {
                 hipLaunchKernelGGL(k_encode<256>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, d.grasp_begin, wr, remb);
-                hipLaunchKernelGGL(k_ugemm<256>, ggrid, dim3(256), 0, s, remb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wr, (size_t)2 * H * H, nof, nof, UR);
+                hipLaunchKernelGGL((k_rowgemm<256, 512>), ggrid, dim3(256), 0, s, remb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wr, (size_t)2 * H * H, nof, nof, UR);
             } else {
                 hipLaunchKernelGGL(k_encode<64>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, d.grasp_begin, wr, remb);
-                hipLaunchKernelGGL(k_ugemm<64>, ggrid, dim3(256), 0, s, remb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wr, (size_t)2 * H * H, nof, nof, UR);
+                hipLaunchKernelGGL((k_rowgemm<64, 128>), ggrid, dim3(256), 0, s, remb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wr, (size_t)2 * H * H, nof, nof, UR);
             }
             hipLaunchKernelGGL(k_rowbase, dim3(nblk((long)p.R * 2 * H, 256)), dim3(256), 0, s, p.R, 2 * H, g->urow_ts, UR, g->base);
         }
@@ -1083,9 +1309,19 @@ int ccsp_edge_outputs(ccsp_model* m, ccsp_graph* g, const float* poses_in, int32
 }
 
 int ccsp_energy_grad(ccsp_model* m, ccsp_graph* g, const float* poses_in, int32_t t, float* grad, float* energy, void* stream) {
-    (void)poses_in; (void)t; (void)grad; (void)energy; (void)stream;
-    if (!m || !g) return fail("energy_grad: null argument");
-    return fail("energy_grad: energy mode (MALA) is not implemented in this build");
+    if (!m || !g || !poses_in || !grad || !energy) return fail("energy_grad: null argument");
+    if (g->m != m) return fail("energy_grad: graph belongs to another model");
+    if (t < 0 || t >= m->d.timesteps) return fail("energy_grad: t=%d out of range", t);
+    hipStream_t s = (hipStream_t)stream;
+    if (energy_prepare(m, g, s)) return 1;
+    const size_t NP = (size_t)g->N * m->d.pose_dim;
+    NodeArgs a = node_args(m, g);
+    a.src = 2; a.step = STEP_NONE; a.do_encode = 1; a.x_in = poses_in;
+    if (m->d.hidden_dim == 256) { launch_node<256>(m, g, a, s); if (launch_eval_energy<256>(m, g, t, poses_in, true, energy, s)) return 1; }
+    else { launch_node<64>(m, g, a, s); if (launch_eval_energy<64>(m, g, t, poses_in, true, energy, s)) return 1; }
+    HIP_TRY(hipMemcpyAsync(grad, g->eps, NP * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 int ccsp_chain_run(ccsp_model* m, ccsp_graph* g, int32_t sampler, const ccsp_noise* nz, float* x, int32_t init,
@@ -1097,7 +1333,7 @@ int ccsp_chain_run(ccsp_model* m, ccsp_graph* g, int32_t sampler, const ccsp_noi
     if (t_first >= T || t_last < 0 || t_first < t_last - 1) return fail("chain_run: bad timestep range [%d,%d]", t_first, t_last);
     if (nz->mode != CCSP_NOISE_PHILOX && nz->mode != CCSP_NOISE_INJECTED) return fail("chain_run: unknown noise mode %d", nz->mode);
     if (nz->mode == CCSP_NOISE_INJECTED && !nz->normal) return fail("chain_run: injected noise without a normal stream");
-    if (sampler == CCSP_SAMPLER_MALA || m->d.energy_wrapper) return fail("chain_run: energy mode (MALA) is not implemented in this build");
+    if (sampler == CCSP_SAMPLER_MALA && !m->d.energy_wrapper) return fail("chain_run: MALA needs an energy_wrapper model (train_utils.py:115-116)");
     hipStream_t s = (hipStream_t)stream;
     if (m->d.hidden_dim == 256) return chain_run_impl<256>(m, g, sampler, nz, x, init, t_first, t_last, history, accept, s);
     return chain_run_impl<64>(m, g, sampler, nz, x, init, t_first, t_last, history, accept, s);

@@ -29,6 +29,8 @@ struct Plan {
     std::vector<int32_t> tile_row0, tile_nrows, tile_ts;          // [n_tiles]
     std::vector<int32_t> node_ptr, node_ent;                      // [N+1], [2*E_act]
     std::vector<int32_t> ent_pos;                                 // [2*E_act] CSR position of flat entry 2k+s
+    std::vector<int32_t> row_ptr, row_edge;                       // [R+1], [2*E_act] sorted edges using each U row (ascending)
+    std::vector<int32_t> nrow_ptr, nrow_idx;                      // [N+1], [R]       U rows of each node (ascending)
     std::vector<int32_t> type_count;                              // [C]
 };
 
@@ -92,6 +94,23 @@ inline int build_plan(int N, int E, int C, int tile_m, const int64_t* ei /*[2,E]
         p.node_ent[pos[p.e_a[k]]++] = 2 * k;
         p.ent_pos[2 * k + 1] = pos[p.e_b[k]];
         p.node_ent[pos[p.e_b[k]]++] = 2 * k + 1;
+    }
+    // energy mode (backward): edges of every U row and U rows of every node, both ascending
+    p.row_ptr.assign(p.R + 1, 0);
+    for (int k = 0; k < p.E_act; ++k) { p.row_ptr[p.e_u0[k] + 1]++; p.row_ptr[p.e_u1[k] + 1]++; }
+    for (int r = 0; r < p.R; ++r) p.row_ptr[r + 1] += p.row_ptr[r];
+    p.row_edge.assign((size_t)2 * p.E_act, 0);
+    {
+        std::vector<int32_t> rp(p.row_ptr.begin(), p.row_ptr.end() - 1);
+        for (int k = 0; k < p.E_act; ++k) { p.row_edge[rp[p.e_u0[k]]++] = k; p.row_edge[rp[p.e_u1[k]]++] = k; }
+    }
+    p.nrow_ptr.assign(N + 1, 0);
+    for (int r = 0; r < p.R; ++r) p.nrow_ptr[p.urow_node[r] + 1]++;
+    for (int n = 0; n < N; ++n) p.nrow_ptr[n + 1] += p.nrow_ptr[n];
+    p.nrow_idx.assign(p.R, 0);
+    {
+        std::vector<int32_t> np(p.nrow_ptr.begin(), p.nrow_ptr.end() - 1);
+        for (int r = 0; r < p.R; ++r) p.nrow_idx[np[p.urow_node[r]]++] = r;
     }
     return 0;
 }

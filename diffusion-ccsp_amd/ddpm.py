@@ -120,16 +120,8 @@ class GaussianDiffusion(object):
         return n_normal_calls(self.num_timesteps, self.samples_per_step if np.isscalar(self.samples_per_step)
                               else np.asarray(self.samples_per_step))
 
-    def p_sample_loop(self, batch, return_history=False, seed=None, noise=None, row_offset=0, **kwargs):
-        """GaussianDiffusion.p_sample_loop (ddpm.py:260-340)"""
-        assert not self.training
-        L = _lib.lib()
-        core = self._core()
-        h = self._handle()
-        g = core._graph(batch)
+    def _noise_struct(self, seed, noise, row_offset):
         dev = self.device
-        P = self.dims[-1][0]
-        T = self.num_timesteps
         nz = _lib.Noise()
         keep = []
         if noise is not None:
@@ -145,15 +137,43 @@ class GaussianDiffusion(object):
             if seed is None:
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())
             nz.mode, nz.seed, nz.row_offset = 0, int(seed), int(row_offset)
-        x = torch.empty((g.N, P), device=dev, dtype=torch.float32)
-        hist = torch.empty((T + 1, g.N, P), device=dev, dtype=torch.float32) if return_history else None
+        return nz, keep
+
+    def _run(self, batch, x, init, t_first, t_last, return_history, seed, noise, row_offset):
+        assert not self.training
+        L = _lib.lib()
+        core = self._core()
+        h = self._handle()
+        g = core._graph(batch)
+        dev = self.device
+        T = self.num_timesteps
+        nz, keep = self._noise_struct(seed, noise, row_offset)
+        hist = torch.empty((T + 1, g.N, self.dims[-1][0]), device=dev, dtype=torch.float32) if return_history else None
+        acc = torch.zeros(T, device=dev, dtype=torch.float32) if self._sampler() == 'MALA' else None
         with torch.cuda.device(dev):
-            _lib.check(L.ccsp_chain_run(h, g.h, _lib.SAMPLERS[self._sampler()], C.byref(nz), _ptr(x), 1, T - 1, 0,
-                                        None if hist is None else _ptr(hist), None, _stream_ptr(dev)))
+            _lib.check(L.ccsp_chain_run(h, g.h, _lib.SAMPLERS[self._sampler()], C.byref(nz), _ptr(x), int(init), int(t_first),
+                                        int(t_last), None if hist is None else _ptr(hist), None if acc is None else _ptr(acc),
+                                        _stream_ptr(dev)))
         self._last_graph = g
         self._keepalive = keep
+        self.last_accept_rates = acc          # MetropolisSampler's per-timestep acceptance (ddpm.py:979-996)
+        return hist
+
+    def p_sample_loop(self, batch, return_history=False, seed=None, noise=None, row_offset=0, **kwargs):
+        """GaussianDiffusion.p_sample_loop (ddpm.py:260-340)"""
+        T = self.num_timesteps
+        g = self._core()._graph(batch)
+        x = torch.empty((g.N, self.dims[-1][0]), device=self.device, dtype=torch.float32)
+        hist = self._run(batch, x, 1, T - 1, 0, return_history, seed, noise, row_offset)
         if return_history:
             return x, [hist[i] for i in range(T + 1)]
+        return x
+
+    def p_sample_segment(self, batch, x, t_first, t_last, seed=None, noise=None, row_offset=0):
+        """timesteps t_first..t_last of the loop starting from the state x [N,P] (a chain split across calls
+        reproduces the unsplit chain: noise draws are indexed by their call number)"""
+        x = x.detach().to(self.device, torch.float32).contiguous().clone()
+        self._run(batch, x, 0, t_first, t_last, False, seed, noise, row_offset)
         return x
 
     def sample(self, batch, **kwargs):
