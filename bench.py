@@ -173,6 +173,7 @@ def main():
                                       n_timesteps=3, budget_s=25.0)
         rec['cpu_baseline'] = {'value': r['samples_per_s'], 'unit': 'samples/s', 'cores': r['cores'], 'kind': 'port',
                                'sample': r['sample'], 'sec_per_timestep': r['sec_per_timestep'],
+                               'sec_per_eval_by_threads': r['sec_per_eval_by_threads'],
                                'speedup_gpu_over_cpu': value / r['samples_per_s']}
     if rank == 0:
         rec['device'] = device_info()
