@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -140,47 +141,80 @@ __global__ void k_pack_enc_frag(int H, const float* __restrict__ W2, float* __re
 // pose encoder of a 16-node tile on the matrix cores: layer 1 (P -> H/2) on the VALU into LDS,
 // layer 2 (H/2 -> H) as 16 x H x H/2 with v_mfma_f32_16x16x4_f32 (M = the 16 nodes of the tile).
 // s1 has row stride H/2 + 1 (conflict-free A-fragment reads).  All 256 threads participate.
+// The node kernel is latency-bound (144 workgroups, a chain of dependent global loads), so every
+// weight the encoder needs that does not depend on the data is requested at kernel entry
+// (enc_prefetch) and is in flight while the CSR reduction and the pose update run.
 template <int H>
-__device__ __forceinline__ void encode_tile_mfma(const EncW w, float (*xs)[8], float (*s1)[H / 2 + 1], int node0, int N,
-                                                 float* __restrict__ out /*[N,H]*/) {
+struct EncPrefetch {
+    static constexpr int TPW = H / 64, KS = H / 8, PF = KS >= 16 ? 8 : KS / 2;   // PF k-steps of layer-2 fragments prefetched
+    float w0[8], b0;                                          // layer-1 row of this thread's output column
+    float wf[PF][TPW];
+    float b2[TPW];
+};
+
+template <int H>
+__device__ __forceinline__ void enc_prefetch(const EncW w, EncPrefetch<H>& pf) {
+    using PFT = EncPrefetch<H>;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int j = tid % (H / 2);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) pf.w0[d] = d < w.in_dim ? w.W0[j * w.in_dim + d] : 0.0f;
+    pf.b0 = w.b0[j];
+    const float* wf = w.W2F + ((size_t)wave * PFT::KS * 64 + lane) * PFT::TPW;
+#pragma unroll
+    for (int ks = 0; ks < PFT::PF; ++ks)
+#pragma unroll
+        for (int q = 0; q < PFT::TPW; ++q) pf.wf[ks][q] = wf[(size_t)ks * 64 * PFT::TPW + q];
+#pragma unroll
+    for (int q = 0; q < PFT::TPW; ++q) pf.b2[q] = w.b2[wave * 16 * PFT::TPW + q * 16 + (lane & 15)];
+    __builtin_amdgcn_sched_barrier(0);      // keep these loads at kernel entry (hipcc would sink them to first use)
+}
+
+template <int H>
+__device__ __forceinline__ void encode_tile_mfma(const EncW w, const EncPrefetch<H>& pf, float (*xs)[8],
+                                                 float (*s1)[H / 2 + 1], int node0, int N, float* __restrict__ out /*[N,H]*/) {
+    using PFT = EncPrefetch<H>;
+    constexpr int TPW = PFT::TPW, KS = PFT::KS, PF = PFT::PF;
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < NODE_TILE * (H / 2); idx += 256) {
-        const int n = idx / (H / 2), j = idx % (H / 2);
-        float acc = 0.0f;
-        for (int d = 0; d < w.in_dim; ++d) acc = fmaf(xs[n][d], w.W0[j * w.in_dim + d], acc);
-        s1[n][j] = silu_fast(acc + w.b0[j]);
+    {
+        const int j = tid % (H / 2);
+#pragma unroll
+        for (int i = 0; i < H / 32; ++i) {
+            const int n = tid / (H / 2) + i * (512 / H);
+            float acc = 0.0f;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) acc = fmaf(xs[n][d], pf.w0[d], acc);     // xs columns >= in_dim are 0
+            s1[n][j] = silu_fast(acc + pf.b0);
+        }
     }
     __syncthreads();
-    constexpr int TPW = H / 64, KS = H / 8;
     const int wave = tid >> 6, lane = tid & 63;
     floatx4 acc[TPW];
 #pragma unroll
     for (int j = 0; j < TPW; ++j) acc[j] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
     const float* wf = w.W2F + ((size_t)wave * KS * 64 + lane) * TPW;
     const float* ap = &s1[lane & 15][lane >> 4];
-#pragma unroll 8
+    // the remaining fragments are requested before the first MFMA is issued
+    float rest[KS - PF][TPW];
+#pragma unroll
+    for (int ks = PF; ks < KS; ++ks)
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) rest[ks - PF][q] = wf[(size_t)ks * 64 * TPW + q];
+#pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         const float a = ap[ks * 4];
-        float b[TPW];
-        if constexpr (TPW == 4) {
-            const float4 v = *reinterpret_cast<const float4*>(wf + (size_t)ks * 64 * TPW);
-            b[0] = v.x; b[1] = v.y; b[2] = v.z; b[3] = v.w;
-        } else {
 #pragma unroll
-            for (int j = 0; j < TPW; ++j) b[j] = wf[(size_t)ks * 64 * TPW + j];
-        }
-#pragma unroll
-        for (int j = 0; j < TPW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[j], acc[j], 0, 0, 0);
+        for (int j = 0; j < TPW; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, ks < PF ? pf.wf[ks][j] : rest[ks - PF][j], acc[j], 0, 0, 0);
     }
     // C/D layout of 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
         const int col = wave * 16 * TPW + j * 16 + (lane & 15);
-        const float bj = w.b2[col];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = node0 + (lane >> 4) * 4 + r;
-            if (n < N) out[(size_t)n * H + col] = silu_fast(acc[j][r] + bj);
+            if (n < N) out[(size_t)n * H + col] = silu_fast(acc[j][r] + pf.b2[j]);
         }
     }
 }
@@ -286,23 +320,28 @@ __device__ __forceinline__ void lds_store4(float* dst, const float4 v) {
 // k_rowgemm<KD, ND>: out[row0+r, col0+c] = sum_k A[src(row0+r), k] * W[ts][col0+c, k]  (+ base + tau)
 //   forward  (k_ugemm): KD = H,  ND = 2H, A = pose embeddings gathered by node, W = Wp[type, slot]
 //   backward          : KD = 2H, ND = H,  A = row-summed g_z (identity rows),     W = Wp^T
-//   grid = n_tiles * (ND / TILE_N), XCD-remapped; 4 waves as 2(M) x 2(N), each 32 x (TILE_N / 2).
+//   work list = n_tiles * (ND / TILE_N) tiles, XCD-remapped, walked by a persistent grid; 4 waves as
+//   2(M) x 2(N), each 32 x (TILE_N / 2).
 //   `base` [R, ND] (chain-constant geometry/grasp term of the row) and `tau_t` [C, ND] (time term + bias,
 //   slot-0 rows only) seed the accumulators, so an edge's pre-activation downstream is U[u0] + U[u1].
 // ------------------------------------------------------------------------------------------
+template <int ND> struct RowGemmCfg {
+    static constexpr int TN_ = ND >= 128 ? TILE_N : 64;   // column tile
+    static constexpr int TNW = TN_ / 64;                  // 32-column MFMA tiles per wave
+    static constexpr int BROWS = TN_ / 32;                // B staging rows per thread
+    static constexpr int NCT = ND / TN_;                  // column tiles per row tile
+};
+
+// one 64 x TN_ output tile; `bid` = (row tile, column tile) work index
 template <int KD, int ND>
-__global__ __launch_bounds__(256) void k_rowgemm(const float* __restrict__ A, const int* __restrict__ urow_node,
-                                                 const int* __restrict__ tile_row0, const int* __restrict__ tile_nrows,
-                                                 const int* __restrict__ tile_ts, const float* __restrict__ W,
-                                                 size_t w_stride, const float* __restrict__ base /*[R,ND] or null*/,
-                                                 const float* __restrict__ tau_t /*[C,ND] or null*/, float* __restrict__ U) {
-    constexpr int TN_ = ND >= 128 ? TILE_N : 64;          // column tile
-    constexpr int TNW = TN_ / 64;                         // 32-column MFMA tiles per wave
-    constexpr int BROWS = TN_ / 32;                       // B staging rows per thread
-    __shared__ float As[2][TILE_M * LDS_LD];
-    __shared__ float Bs[2][TN_ * LDS_LD];
-    constexpr int NCT = ND / TN_;                         // column tiles per row tile
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+__device__ __forceinline__ void rowgemm_tile(int bid, float (*As)[TILE_M * LDS_LD], float (*Bs)[RowGemmCfg<ND>::TN_ * LDS_LD],
+                                             const float* __restrict__ A, const int* __restrict__ urow_node,
+                                             const int* __restrict__ tile_row0, const int* __restrict__ tile_nrows,
+                                             const int* __restrict__ tile_ts, const float* __restrict__ W,
+                                             size_t w_stride, const float* __restrict__ base,
+                                             const float* __restrict__ tau_t, float* __restrict__ U) {
+    using Cfg = RowGemmCfg<ND>;
+    constexpr int TN_ = Cfg::TN_, TNW = Cfg::TNW, BROWS = Cfg::BROWS, NCT = Cfg::NCT;
     const int tile = bid / NCT;
     const int row0 = tile_row0[tile], nrows = tile_nrows[tile], ts = tile_ts[tile];
     const int col0 = (bid % NCT) * TN_;
@@ -395,6 +434,25 @@ __global__ __launch_bounds__(256) void k_rowgemm(const float* __restrict__ A, co
         }
 }
 
+// The grid may be smaller than the work list (persistent launch, stride gridDim.x): a workgroup's
+// epilogue stores then drain under its own next tile.  In an isolated benchmark of this kernel that is
+// worth -12 % (one-tile launches run the resident workgroups in lockstep into the epilogue); inside the
+// chain it measured neutral, and a dynamic atomic tile queue was 2x slower, so the default launch is
+// one tile per workgroup (see ccsp_model_create, CCSP_MAX_WGS).
+template <int KD, int ND>
+__global__ __launch_bounds__(256) void k_rowgemm(int n_work, const float* __restrict__ A, const int* __restrict__ urow_node,
+                                                 const int* __restrict__ tile_row0, const int* __restrict__ tile_nrows,
+                                                 const int* __restrict__ tile_ts, const float* __restrict__ W,
+                                                 size_t w_stride, const float* __restrict__ base /*[R,ND] or null*/,
+                                                 const float* __restrict__ tau_t /*[C,ND] or null*/, float* __restrict__ U) {
+    __shared__ float As[2][TILE_M * LDS_LD];
+    __shared__ float Bs[2][RowGemmCfg<ND>::TN_ * LDS_LD];
+    for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
+        rowgemm_tile<KD, ND>(xcd_remap(w, n_work), As, Bs, A, urow_node, tile_row0, tile_nrows, tile_ts, W, w_stride, base, tau_t, U);
+        __syncthreads();
+    }
+}
+
 template <int KD, int ND>
 constexpr int rowgemm_col_tiles() { return ND / (ND >= 128 ? TILE_N : 64); }
 
@@ -413,12 +471,12 @@ __global__ void k_rowbase(int R, int W2, const int* __restrict__ urow_ts, const 
 // bias + SiLU -> LDS -> pose_decoder.2 (H/2 -> P) -> O[(2k+s)*P ..]   (denoise_fn.py:341-371)
 //   H=256: 64 rows x 128 cols per workgroup (waves 2x2, 32x64 each)
 //   H=64 : 128 rows x 32 cols per workgroup (waves 4x1, 32x32 each)
-// grid = 2 * ceil(E_act / BM), XCD-remapped
+// grid = 2 * ceil(E_act / BM), XCD-remapped (a persistent-loop form of this kernel measured 1.4x slower)
 // ------------------------------------------------------------------------------------------
 #include "ccsp_energy_pre.h"
 
 template <int H> struct EdgeCfg;
-template <> struct EdgeCfg<256> { static constexpr int WM = 2, WN = 2, TN = 2; };
+template <> struct EdgeCfg<256> { static constexpr int WM = 1, WN = 4, TN = 1; };
 template <> struct EdgeCfg<64> { static constexpr int WM = 4, WN = 1, TN = 1; };
 
 // ENERGY = true (denoise_fn.py:373-375): the CSR slot receives -2 d = -2 (o - pose) (the direct term of
@@ -449,12 +507,12 @@ __global__ __launch_bounds__(256, 3) void k_edge(int E_act, int P,
     __shared__ float smem[SMEM];
     auto As = [&](int buf) -> float* { return smem + buf * STAGE; };
     auto Bs = [&](int buf) -> float* { return smem + buf * STAGE + BM * LDS_LD; };
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int e0 = (bid >> 1) * BM;
-    const int s = bid & 1;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
     const int lr = tid >> 3, lq = tid & 7;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int e0 = (bid >> 1) * BM;
+    const int s = bid & 1;
     const float* u0_ptr[A_ROWS_PT];
     const float* u1_ptr[A_ROWS_PT];
     const float* b_ptr[B_ROWS_PT];
@@ -600,6 +658,8 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, float* __restr
     __shared__ float s1[NODE_TILE][H / 2 + 1];
     const int node0 = blockIdx.x * NODE_TILE;
     const int tid = threadIdx.x;
+    EncPrefetch<H> pf;
+    if (a.do_encode) enc_prefetch<H>(w, pf);
     if (tid < NODE_TILE * 8) {
         const int nl = tid / 8, p = tid % 8;
         const int n = node0 + nl;
@@ -675,7 +735,7 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, float* __restr
     }
     if (!a.do_encode) return;
     __syncthreads();
-    encode_tile_mfma<H>(w, xs, s1, node0, a.N, pemb);
+    encode_tile_mfma<H>(w, pf, xs, s1, node0, a.N, pemb);
 }
 
 #include "ccsp_energy.h"
@@ -705,6 +765,7 @@ inline int nblk(long n, int b) { return (int)((n + b - 1) / b); }
 struct ccsp_model {
     ccsp_model_desc d;
     int K_in;
+    int max_wgs;     // grid cap of the tile kernels (persistent loops); unlimited by default
     // device weights (library-owned copies)
     float *ge0_w, *ge0_b, *ge2_wT, *ge2_b;
     float *gr0_w, *gr0_b, *gr2_wT, *gr2_b;
@@ -797,11 +858,13 @@ int launch_eval(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s) {
     if (p.E_act == 0) return 0;
     const bool prof = g->profile && g->kev_used + 3 <= g->kev.size();
     if (prof) HIP_TRY(hipEventRecord(g->kev[g->kev_used], s));
-    hipLaunchKernelGGL((k_rowgemm<H, 2 * H>), dim3(g->n_tiles * rowgemm_col_tiles<H, 2 * H>()), dim3(256), 0, s, g->pemb, g->urow_node, g->tile_row0,
+    const int nw_u = g->n_tiles * rowgemm_col_tiles<H, 2 * H>();
+    hipLaunchKernelGGL((k_rowgemm<H, 2 * H>), dim3(nw_u < m->max_wgs ? nw_u : m->max_wgs), dim3(256), 0, s, nw_u, g->pemb, g->urow_node, g->tile_row0,
                        g->tile_nrows, g->tile_ts, m->Wp, (size_t)2 * H * H, g->base, m->tau + (size_t)t * m->d.n_types * 2 * H, g->U);
     if (prof) HIP_TRY(hipEventRecord(g->kev[g->kev_used + 1], s));
     constexpr int BM = 32 * EdgeCfg<H>::WM;
-    hipLaunchKernelGGL((k_edge<H, false>), dim3(2 * nblk(p.E_act, BM)), dim3(256), 0, s, p.E_act, m->d.pose_dim, g->e_u0,
+    const int nw_e = 2 * nblk(p.E_act, BM);
+    hipLaunchKernelGGL((k_edge<H, false>), dim3(nw_e), dim3(256), 0, s, p.E_act, m->d.pose_dim, g->e_u0,
                        g->e_u1, g->U, m->pd0_w, m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, EdgeEnergyArgs{});
     if (prof) { HIP_TRY(hipEventRecord(g->kev[g->kev_used + 2], s)); g->kev_used += 3; }
     g->evals++;
@@ -860,14 +923,15 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
         if (with_grad) HIP_TRY(hipMemsetAsync(g->eps, 0, (size_t)g->N * P * sizeof(float), s));
         return 0;
     }
-    hipLaunchKernelGGL((k_rowgemm<H, 2 * H>), dim3(g->n_tiles * rowgemm_col_tiles<H, 2 * H>()), dim3(256), 0, s, g->pemb, g->urow_node, g->tile_row0,
+    const int nw_u = g->n_tiles * rowgemm_col_tiles<H, 2 * H>();
+    hipLaunchKernelGGL((k_rowgemm<H, 2 * H>), dim3(nw_u < m->max_wgs ? nw_u : m->max_wgs), dim3(256), 0, s, nw_u, g->pemb, g->urow_node, g->tile_row0,
                        g->tile_nrows, g->tile_ts, m->Wp, (size_t)2 * H * H, g->base, m->tau + (size_t)t * m->d.n_types * 2 * H, g->U);
-    constexpr int BM = 32 * EdgeCfg<H>::WM;
     EdgeEnergyArgs en{g->e_a, g->e_b, xeval, with_grad ? g->Q : nullptr, g->partial};
-    hipLaunchKernelGGL((k_edge<H, true>), dim3(g->n_edge_blocks), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->U, m->pd0_w,
+    const int n_part = g->n_edge_blocks;                                                     // one energy partial per workgroup
+    hipLaunchKernelGGL((k_edge<H, true>), dim3(n_part), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->U, m->pd0_w,
                        m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, en);
     if (!with_grad) {
-        hipLaunchKernelGGL(k_energy_sum, dim3(1), dim3(256), 0, s, g->partial, g->n_edge_blocks, E_out);
+        hipLaunchKernelGGL(k_energy_sum, dim3(1), dim3(256), 0, s, g->partial, n_part, E_out);
         return 0;
     }
     constexpr int BMB = 32 * BwdCfg<H>::WM, NCTB = H / (32 * BwdCfg<H>::TN * BwdCfg<H>::WN);
@@ -876,9 +940,10 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     hipLaunchKernelGGL(k_rowsum, dim3(nblk((long)p.R * (2 * H / 4), 256)), dim3(256), 0, s, p.R, 2 * H, g->row_ptr, g->row_edge, g->GZ, g->GZR);
     const int* no_map = nullptr;
     const float* nof = nullptr;
-    hipLaunchKernelGGL((k_rowgemm<2 * H, H>), dim3(g->n_tiles * rowgemm_col_tiles<2 * H, H>()), dim3(256), 0, s, g->GZR, no_map, g->tileb_row0,
+    const int nw_b = g->n_tiles * rowgemm_col_tiles<2 * H, H>();
+    hipLaunchKernelGGL((k_rowgemm<2 * H, H>), dim3(nw_b < m->max_wgs ? nw_b : m->max_wgs), dim3(256), 0, s, nw_b, g->GZR, no_map, g->tileb_row0,
                        g->tileb_nrows, g->tileb_ts, m->WpT, (size_t)2 * H * H, nof, nof, g->GP);
-    EnergyNodeArgs a{g->N, P, g->node_ptr, g->O, g->nrow_ptr, g->nrow_idx, g->GP, xeval, g->eps, g->partial, g->n_edge_blocks, E_out,
+    EnergyNodeArgs a{g->N, P, g->node_ptr, g->O, g->nrow_ptr, g->nrow_idx, g->GP, xeval, g->eps, g->partial, n_part, E_out,
                      m->pe0_w, m->pe0_b, m->pe2_w, m->pe2_wT, m->pe2_b};
     hipLaunchKernelGGL(k_node_energy<H>, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a);
     return 0;
@@ -1090,6 +1155,11 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     if (m->d.ebm_per_steps < 1) m->d.ebm_per_steps = 1;
     const bool grasp = d->grasp_dim > 0;
     m->K_in = H * (grasp ? 6 : 5);
+    // Grid cap of k_rowgemm (a capped grid walks the work list as a persistent loop).  Inside the chain
+    // one tile per workgroup measured equal or faster on MI355X, so the cap is off by default;
+    // CCSP_MAX_WGS=<n> sets it for experiments.
+    m->max_wgs = 1 << 30;
+    if (const char* e = getenv("CCSP_MAX_WGS")) { const int v = atoi(e); if (v > 0) m->max_wgs = v; }
     auto& reg = m->allocs;
     int k = 0;
     auto dup = [&](float** dst, size_t n) -> int {
@@ -1236,14 +1306,15 @@ int ccsp_graph_create(ccsp_model* m, int32_t N, int32_t E, int32_t F, const floa
         float *gemb = nullptr, *UR = nullptr, *remb = nullptr;
         TRY(dev_alloc(reg, &gemb, (size_t)N * H));
         const EncW wg{m->ge0_w, m->ge0_b, m->ge2_wT, m->ge2_b, d.geom_dim, nullptr};
-        const dim3 ggrid(g->n_tiles * (2 * H / TILE_N));
+        const int gwork = g->n_tiles * (2 * H / TILE_N);
+        const dim3 ggrid(gwork < m->max_wgs ? gwork : m->max_wgs);
         const float* nof = nullptr;
         if (H == 256) {
             hipLaunchKernelGGL(k_encode<256>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, 0, wg, gemb);
-            hipLaunchKernelGGL((k_rowgemm<256, 512>), ggrid, dim3(256), 0, s, gemb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wg, (size_t)2 * H * H, nof, nof, g->base);
+            hipLaunchKernelGGL((k_rowgemm<256, 512>), ggrid, dim3(256), 0, s, gwork, gemb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wg, (size_t)2 * H * H, nof, nof, g->base);
         } else {
             hipLaunchKernelGGL(k_encode<64>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, 0, wg, gemb);
-            hipLaunchKernelGGL((k_rowgemm<64, 128>), ggrid, dim3(256), 0, s, gemb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wg, (size_t)2 * H * H, nof, nof, g->base);
+            hipLaunchKernelGGL((k_rowgemm<64, 128>), ggrid, dim3(256), 0, s, gwork, gemb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wg, (size_t)2 * H * H, nof, nof, g->base);
         }
         if (d.grasp_dim > 0) {
             TRY(dev_alloc(reg, &remb, (size_t)N * H));
@@ -1251,10 +1322,10 @@ int ccsp_graph_create(ccsp_model* m, int32_t N, int32_t E, int32_t F, const floa
             const EncW wr{m->gr0_w, m->gr0_b, m->gr2_wT, m->gr2_b, d.grasp_dim, nullptr};
             if (H == 256) {
                 hipLaunchKernelGGL(k_encode<256>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, d.grasp_begin, wr, remb);
-                hipLaunchKernelGGL((k_rowgemm<256, 512>), ggrid, dim3(256), 0, s, remb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wr, (size_t)2 * H * H, nof, nof, UR);
+                hipLaunchKernelGGL((k_rowgemm<256, 512>), ggrid, dim3(256), 0, s, gwork, remb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wr, (size_t)2 * H * H, nof, nof, UR);
             } else {
                 hipLaunchKernelGGL(k_encode<64>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, d.grasp_begin, wr, remb);
-                hipLaunchKernelGGL((k_rowgemm<64, 128>), ggrid, dim3(256), 0, s, remb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wr, (size_t)2 * H * H, nof, nof, UR);
+                hipLaunchKernelGGL((k_rowgemm<64, 128>), ggrid, dim3(256), 0, s, gwork, remb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wr, (size_t)2 * H * H, nof, nof, UR);
             }
             hipLaunchKernelGGL(k_rowbase, dim3(nblk((long)p.R * 2 * H, 256)), dim3(256), 0, s, p.R, 2 * H, g->urow_ts, UR, g->base);
         }

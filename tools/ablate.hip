@@ -24,7 +24,7 @@ int main(int argc, char** argv) {
     for (int w = 0; w < 2; ++w) {
         hipEventRecord(e0);
         for (int i = 0; i < reps; ++i)
-            hipLaunchKernelGGL(k_ugemm<256>, dim3(NT * 4), dim3(256), 0, 0, A, node, r0, nr, ts, W, (size_t)2 * H * H, base, tau, U);
+            hipLaunchKernelGGL((k_rowgemm<256, 512>), dim3(NT * 4 < 768 ? NT * 4 : 768), dim3(256), 0, 0, NT * 4, A, node, r0, nr, ts, W, (size_t)2 * H * H, base, tau, U);
         hipEventRecord(e1); hipEventSynchronize(e1);
     }
     float ms; hipEventElapsedTime(&ms, e0, e1);
