@@ -1,0 +1,312 @@
+// fp32-accurate GEMMs on the bf16 matrix cores ("bf16x3"): every fp32 operand is split into three
+// bf16 terms x = x1 + x2 + x3 (8 significand bits each, 24 together, fp32 exponent range), and a
+// product a*b is accumulated in fp32 as the six cross terms of weight >= 2^-16:
+//        a1 b1 + (a1 b2 + a2 b1) + (a2 b2 + a1 b3 + a3 b1)
+// Each bf16 x bf16 product is exact in fp32; the dropped terms are <= 2^-24 relative.  Measured on
+// MI355X (tools/bf16x3_probe.hip, K = 256, data scaled 1e-6 .. 1e8): max |err| / sum|a b| = 2.2e-7 ..
+// 2.8e-7, against 2.4e-7 .. 4.5e-7 for the fp32 MFMA chain -- the same accuracy class, so parity bars
+// are unchanged.  v_mfma_f32_32x32x16_bf16 issues in 32 cycles for K = 16: six of them replace eight
+// 64-cycle v_mfma_f32_32x32x2_f32, 2.67x less matrix-pipe time.
+//
+// Operands that are constant (weights) are split once at model creation; the pose embeddings are split
+// by their producer (k_node); the decoder input h = SiLU(U[u0] + U[u1]) is split in registers by the
+// threads that build it.  Included inside the anonymous namespace of ccsp_hip.hip.
+#pragma once
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short ushort8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned short bf16_rn_bits(float x) {          // round-to-nearest-even
+    unsigned int u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_bits_f(unsigned short h) { return __uint_as_float((unsigned int)h << 16); }
+
+// x -> (x1, x2, x3) bf16 bit patterns.  Inf/NaN stay in x1 (x - x1 is NaN/0 there, harmless: NaN is data)
+__device__ __forceinline__ void split3(float x, unsigned short& h1, unsigned short& h2, unsigned short& h3) {
+    h1 = bf16_rn_bits(x);
+    const float r1 = x - bf16_bits_f(h1);
+    h2 = bf16_rn_bits(r1);
+    const float r2 = r1 - bf16_bits_f(h2);
+    h3 = bf16_rn_bits(r2);
+}
+
+// dst[plane][i] = plane-th bf16 term of src[i]   (weights, once per model)
+__global__ void k_split3(long n, const float* __restrict__ src, unsigned short* __restrict__ dst) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned short a, b, c;
+    split3(src[i], a, b, c);
+    dst[i] = a; dst[n + i] = b; dst[2 * n + i] = c;
+}
+
+constexpr int BF_BK = 32;                 // K chunk (two MFMA k-steps of 16)
+constexpr int BF_LD = BF_BK + 8;          // bf16 elements per LDS row: 80 B, conflict-free ds_read_b128
+
+// six-product MFMA block for one k-step: acc[j] += A(32 x 16) * B_j(16 x 32)
+template <int TN>
+__device__ __forceinline__ void mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[TN][3], floatx16 (&acc)[TN]) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[j][1], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][2], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[j][0], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][1], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[j][0], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][0], acc[j], 0, 0, 0);
+    }
+}
+
+// one K chunk from LDS planes.  As/Bs: [3][rows][BF_LD] bf16; lane l reads row (l & 31), k 8*(l>>5)..+7
+template <int TN, int A_ROWS, int B_ROWS>
+__device__ __forceinline__ void bf_chunk(const unsigned short* __restrict__ As, const unsigned short* __restrict__ Bs,
+                                         int a_row0, int b_row0, floatx16 (&acc)[TN]) {
+    const int lane = threadIdx.x & 63;
+    const int aoff = (a_row0 + (lane & 31)) * BF_LD + (lane >> 5) * 8;
+    const int boff = (b_row0 + (lane & 31)) * BF_LD + (lane >> 5) * 8;
+#pragma unroll
+    for (int ks = 0; ks < BF_BK / 16; ++ks) {
+        bf16x8 a[3], b[TN][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            a[p] = *reinterpret_cast<const bf16x8*>(As + p * A_ROWS * BF_LD + aoff + ks * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[j][p] = *reinterpret_cast<const bf16x8*>(Bs + p * B_ROWS * BF_LD + boff + j * 32 * BF_LD + ks * 16);
+        }
+        mfma6<TN>(a, b, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_rowgemm_bf<KD, ND>: the row GEMM of k_rowgemm on the bf16 matrix cores.
+//   A planes  [3][n_src_rows][KD] bf16 (pose embeddings split by k_node), rows gathered by urow_node
+//   W planes  [3][n_ts][ND][KD]   bf16
+//   64 x 128 tile, 4 waves 2(M) x 2(N), single LDS stage (45 KB -> 3 workgroups per CU) with the next
+//   chunk prefetched into registers while the current one is multiplied.
+// ------------------------------------------------------------------------------------------
+template <int KD, int ND>
+__global__ __launch_bounds__(256) void k_rowgemm_bf(const unsigned short* __restrict__ A, size_t a_plane,
+                                                    const int* __restrict__ urow_node, const int* __restrict__ tile_row0,
+                                                    const int* __restrict__ tile_nrows, const int* __restrict__ tile_ts,
+                                                    const unsigned short* __restrict__ W, size_t w_plane, size_t w_stride,
+                                                    const float* __restrict__ base, const float* __restrict__ tau_t,
+                                                    float* __restrict__ U) {
+    using Cfg = RowGemmCfg<ND>;
+    constexpr int TN_ = Cfg::TN_, TNW = Cfg::TNW, NCT = Cfg::NCT;
+    constexpr int A_UNITS = TILE_M * (BF_BK / 8) * 3 / 256;      // 16-byte units per thread (3)
+    constexpr int B_UNITS = TN_ * (BF_BK / 8) * 3 / 256;         // (6 for 128 columns)
+    __shared__ __attribute__((aligned(16))) unsigned short As[3 * TILE_M * BF_LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[3 * TN_ * BF_LD];
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = bid / NCT;
+    const int row0 = tile_row0[tile], nrows = tile_nrows[tile], ts = tile_ts[tile];
+    const int col0 = (bid % NCT) * TN_;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = tid >> 2, lq = tid & 3;                     // 64 rows x 4 sixteen-byte columns per pass
+    // A: the same (row, column) of every plane; B: rows lrow + 64*(i & 1) (TN_ = 128) of plane i >> 1
+    const unsigned short* a_ptr;
+    {
+        const int r = lrow < nrows ? lrow : nrows - 1;
+        const int src = urow_node ? urow_node[row0 + r] : row0 + r;
+        a_ptr = A + (size_t)src * KD + lq * 8;
+    }
+    const unsigned short* b_ptr[B_UNITS];
+    int b_lds[B_UNITS];
+#pragma unroll
+    for (int i = 0; i < B_UNITS; ++i) {
+        const int plane = i / (TN_ / 64), rr = lrow + 64 * (i % (TN_ / 64));
+        b_ptr[i] = W + (size_t)plane * w_plane + (size_t)ts * w_stride + (size_t)(col0 + rr) * KD + lq * 8;
+        b_lds[i] = plane * TN_ * BF_LD + rr * BF_LD + lq * 8;
+    }
+    ushort8 ra[A_UNITS], rb[B_UNITS];
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < A_UNITS; ++i) ra[i] = *reinterpret_cast<const ushort8*>(a_ptr + (size_t)i * a_plane + c * BF_BK);
+#pragma unroll
+        for (int i = 0; i < B_UNITS; ++i) rb[i] = *reinterpret_cast<const ushort8*>(b_ptr[i] + c * BF_BK);
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_UNITS; ++i) *reinterpret_cast<ushort8*>(As + i * TILE_M * BF_LD + lrow * BF_LD + lq * 8) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_UNITS; ++i) *reinterpret_cast<ushort8*>(Bs + b_lds[i]) = rb[i];
+    };
+    gload(0);
+    floatx16 acc[TNW];
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) {
+        const int col = col0 + wn * 32 * TNW + j * 32 + (lane & 31);
+        const float tv = (tau_t && (ts & 1) == 0) ? tau_t[(size_t)(ts >> 1) * ND + col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            row = row < nrows ? row : nrows - 1;
+            acc[j][r] = (base ? base[(size_t)(row0 + row) * ND + col] : 0.0f) + tv;
+        }
+    }
+    lstore();
+    __syncthreads();
+    constexpr int NCH = KD / BF_BK;
+    for (int c = 0; c < NCH; ++c) {
+        if (c + 1 < NCH) gload(c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        bf_chunk<TNW, TILE_M, TN_>(As, Bs, wm * 32, wn * 32 * TNW, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                          // every wave is done reading the stage
+        if (c + 1 < NCH) {
+            lstore();
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TNW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int col = col0 + wn * 32 * TNW + j * 32 + (lane & 31);
+            if (row < nrows) U[(size_t)(row0 + row) * ND + col] = acc[j][r];
+        }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_edge_bf<H>: k_edge (direct mode) on the bf16 matrix cores.  h = SiLU(U[u0] + U[u1]) is built in
+// fp32 and split in registers; B = pose_decoder.0 planes [3][H/2][H].
+//   H=256: 64 rows x 128 cols per workgroup (waves 2x2, 32x64 each);  H=64: 128 rows x 32 cols (4x1)
+// ------------------------------------------------------------------------------------------
+template <int H> struct EdgeBfCfg;
+template <> struct EdgeBfCfg<256> { static constexpr int WM = 2, WN = 2, TN = 2; };
+template <> struct EdgeBfCfg<64> { static constexpr int WM = 4, WN = 1, TN = 1; };
+
+template <int H>
+__global__ __launch_bounds__(256) void k_edge_bf(int E_act, int P, const int* __restrict__ e_u0,
+                                                 const int* __restrict__ e_u1, const float* __restrict__ U,
+                                                 const unsigned short* __restrict__ Wd1S /*[3][H/2][H]*/,
+                                                 const float* __restrict__ bd1, const float* __restrict__ Wd2,
+                                                 const float* __restrict__ bd2, const int* __restrict__ ent_pos,
+                                                 float* __restrict__ O) {
+    using Cfg = EdgeBfCfg<H>;
+    constexpr int BM = 32 * Cfg::WM, BN = 32 * Cfg::TN * Cfg::WN, TN = Cfg::TN;
+    static_assert(BN == H / 2, "decoder hidden width must fit one column tile");
+    constexpr int A_PASSES = BM / 32;             // thread handles rows (tid >> 3) + 32*i, 4 fp32 columns (tid & 7)*4
+    constexpr int B_PASSES = (BN * (BF_BK / 8) + 255) / 256;       // row passes per plane (64 rows each)
+    constexpr int B_UNITS = 3 * B_PASSES;
+    constexpr int STAGE_US = 3 * (BM + BN) * BF_LD;                  // unsigned shorts
+    constexpr int S1_LD = BN + 1;
+    constexpr int SMEM_BYTES = (STAGE_US * 2 > BM * S1_LD * 4) ? STAGE_US * 2 : BM * S1_LD * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
+    unsigned short* As = reinterpret_cast<unsigned short*>(smem_raw);
+    unsigned short* Bs = As + 3 * BM * BF_LD;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int e0 = (bid >> 1) * BM;
+    const int s = bid & 1;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+    const int lr = tid >> 3, lq = tid & 7;
+    const float* u0_ptr[A_PASSES];
+    const float* u1_ptr[A_PASSES];
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+        int k = e0 + lr + 32 * i;
+        k = k < E_act ? k : E_act - 1;
+        const int coff = s * H + lq * 4;
+        u0_ptr[i] = U + (size_t)e_u0[k] * (2 * H) + coff;
+        u1_ptr[i] = U + (size_t)e_u1[k] * (2 * H) + coff;
+    }
+    const int brow = tid >> 2, bq = tid & 3;
+    const unsigned short* b_ptr[B_UNITS];
+    int b_lds[B_UNITS];
+#pragma unroll
+    for (int i = 0; i < B_UNITS; ++i) {
+        const int plane = i / B_PASSES, rr = brow + 64 * (i % B_PASSES);
+        const int rrc = rr < BN ? rr : BN - 1;
+        b_ptr[i] = Wd1S + (size_t)plane * (H / 2) * H + (size_t)rrc * H + bq * 8;
+        b_lds[i] = rr < BN ? plane * BN * BF_LD + rr * BF_LD + bq * 8 : -1;
+    }
+    float4 ua[A_PASSES], ub[A_PASSES];
+    ushort8 rb[B_UNITS];
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) {
+            ua[i] = *reinterpret_cast<const float4*>(u0_ptr[i] + c * BF_BK);
+            ub[i] = *reinterpret_cast<const float4*>(u1_ptr[i] + c * BF_BK);
+        }
+#pragma unroll
+        for (int i = 0; i < B_UNITS; ++i) rb[i] = *reinterpret_cast<const ushort8*>(b_ptr[i] + c * BF_BK);
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) {
+            const float h[4] = {silu_fast(ua[i].x + ub[i].x), silu_fast(ua[i].y + ub[i].y), silu_fast(ua[i].z + ub[i].z),
+                                silu_fast(ua[i].w + ub[i].w)};
+            unsigned short p1[4], p2[4], p3[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split3(h[e], p1[e], p2[e], p3[e]);
+            unsigned short* d = As + (lr + 32 * i) * BF_LD + lq * 4;
+            *reinterpret_cast<uint2*>(d) = make_uint2(p1[0] | ((unsigned)p1[1] << 16), p1[2] | ((unsigned)p1[3] << 16));
+            *reinterpret_cast<uint2*>(d + BM * BF_LD) = make_uint2(p2[0] | ((unsigned)p2[1] << 16), p2[2] | ((unsigned)p2[3] << 16));
+            *reinterpret_cast<uint2*>(d + 2 * BM * BF_LD) = make_uint2(p3[0] | ((unsigned)p3[1] << 16), p3[2] | ((unsigned)p3[3] << 16));
+        }
+#pragma unroll
+        for (int i = 0; i < B_UNITS; ++i)
+            if (b_lds[i] >= 0) *reinterpret_cast<ushort8*>(Bs + b_lds[i]) = rb[i];
+    };
+    gload(0);
+    lstore();
+    __syncthreads();
+    floatx16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    constexpr int NCH = H / BF_BK;
+    for (int c = 0; c < NCH; ++c) {
+        if (c + 1 < NCH) gload(c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        bf_chunk<TN, BM, BN>(As, Bs, wm * 32, wn * 32 * TN, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        if (c + 1 < NCH) {
+            lstore();
+            __syncthreads();
+        }
+    }
+    // epilogue identical to k_edge: bias + SiLU -> LDS -> pose_decoder.2 -> CSR slot
+    float* S1 = reinterpret_cast<float*>(smem_raw);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = wn * 32 * TN + j * 32 + (lane & 31);
+        const float bj = bd1[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            S1[row * S1_LD + col] = silu_fast(acc[j][r] + bj);
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < BM * P; idx += 256) {
+        const int row = idx % BM, p = idx / BM;
+        const float* w = Wd2 + (size_t)p * BN;
+        float o = 0.0f;
+        for (int j = 0; j < BN; ++j) o = fmaf(S1[row * S1_LD + j], w[j], o);
+        o += bd2[p];
+        const int k = e0 + row;
+        if (k < E_act) O[(size_t)ent_pos[2 * k + s] * P + p] = o;
+    }
+}
+
+// pose-embedding planes for k_rowgemm_bf: P3[plane][n][c] = plane-th bf16 term of pemb[n][c]
+__global__ void k_split_rows(long n, const float* __restrict__ src, unsigned short* __restrict__ dst) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float4 v = *reinterpret_cast<const float4*>(src + i);
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    unsigned short a[4], b[4], c[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split3(x[e], a[e], b[e], c[e]);
+    *reinterpret_cast<uint2*>(dst + i) = make_uint2(a[0] | ((unsigned)a[1] << 16), a[2] | ((unsigned)a[3] << 16));
+    *reinterpret_cast<uint2*>(dst + n + i) = make_uint2(b[0] | ((unsigned)b[1] << 16), b[2] | ((unsigned)b[3] << 16));
+    *reinterpret_cast<uint2*>(dst + 2 * n + i) = make_uint2(c[0] | ((unsigned)c[1] << 16), c[2] | ((unsigned)c[3] << 16));
+}

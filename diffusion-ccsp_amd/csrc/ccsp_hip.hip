@@ -739,6 +739,7 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, float* __restr
 }
 
 #include "ccsp_energy.h"
+#include "ccsp_bf16x3.h"
 
 // NaN rows for the edge-output debug API, then scatter sorted -> original order
 __global__ void k_fill(float* p, long n, float v) {
@@ -777,6 +778,9 @@ struct ccsp_model {
     float* Wr;     // [C][2][2H][H]   grasp slice in slot 0 (slot 1 unused) or nullptr
     float* Wp;     // [C][2][2H][H]   pose slices
     float* WpT;    // [C][2][H][2H]   their transposes (energy-mode backward)
+    int bf16x3;    // 1: direct-mode GEMMs on the bf16 matrix cores with 3-way split operands (ccsp_bf16x3.h)
+    unsigned short* WpS;    // [3][C][2][2H][H] bf16 planes of Wp
+    unsigned short* Wd1S;   // [3][H/2][H]      bf16 planes of pose_decoder.0.weight
     float* temb;   // [T][H]
     float* tau;    // [T][C][2H]      W_t . temb(t) + b_i
     std::vector<float> betas, ac, acp, sqrt_recip_ac, sqrt_recipm1_ac, post_lv, post_var, coef1, coef2, kappa, step;
@@ -794,6 +798,7 @@ struct ccsp_graph {
     signed char* mask;
     int *e_type, *e_u0, *e_u1, *e_orig, *urow_node, *tile_row0, *tile_nrows, *tile_ts, *node_ptr, *node_ent, *ent_pos;
     float *base, *U, *O, *pemb, *x, *eps;
+    unsigned short* pembS = nullptr;   // [3][N][H] bf16 planes of pemb (bf16x3 mode)
     int* urow_ts;
     // energy mode (allocated on first use)
     bool energy_ready = false;
@@ -859,13 +864,25 @@ int launch_eval(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s) {
     const bool prof = g->profile && g->kev_used + 3 <= g->kev.size();
     if (prof) HIP_TRY(hipEventRecord(g->kev[g->kev_used], s));
     const int nw_u = g->n_tiles * rowgemm_col_tiles<H, 2 * H>();
+    const float* tau_t = m->tau + (size_t)t * m->d.n_types * 2 * H;
+    if (m->bf16x3) {
+        const long npe = (long)g->N * H;
+        hipLaunchKernelGGL(k_split_rows, dim3(nblk(npe / 4, 256)), dim3(256), 0, s, npe, g->pemb, g->pembS);
+        hipLaunchKernelGGL((k_rowgemm_bf<H, 2 * H>), dim3(nw_u), dim3(256), 0, s, g->pembS, (size_t)npe, g->urow_node, g->tile_row0,
+                           g->tile_nrows, g->tile_ts, m->WpS, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, g->base, tau_t, g->U);
+        if (prof) HIP_TRY(hipEventRecord(g->kev[g->kev_used + 1], s));
+        constexpr int BMB = 32 * EdgeBfCfg<H>::WM;
+        hipLaunchKernelGGL(k_edge_bf<H>, dim3(2 * nblk(p.E_act, BMB)), dim3(256), 0, s, p.E_act, m->d.pose_dim, g->e_u0, g->e_u1, g->U,
+                           m->Wd1S, m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O);
+    } else {
     hipLaunchKernelGGL((k_rowgemm<H, 2 * H>), dim3(nw_u < m->max_wgs ? nw_u : m->max_wgs), dim3(256), 0, s, nw_u, g->pemb, g->urow_node, g->tile_row0,
-                       g->tile_nrows, g->tile_ts, m->Wp, (size_t)2 * H * H, g->base, m->tau + (size_t)t * m->d.n_types * 2 * H, g->U);
+                       g->tile_nrows, g->tile_ts, m->Wp, (size_t)2 * H * H, g->base, tau_t, g->U);
     if (prof) HIP_TRY(hipEventRecord(g->kev[g->kev_used + 1], s));
     constexpr int BM = 32 * EdgeCfg<H>::WM;
     const int nw_e = 2 * nblk(p.E_act, BM);
     hipLaunchKernelGGL((k_edge<H, false>), dim3(nw_e), dim3(256), 0, s, p.E_act, m->d.pose_dim, g->e_u0,
                        g->e_u1, g->U, m->pd0_w, m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, EdgeEnergyArgs{});
+    }
     if (prof) { HIP_TRY(hipEventRecord(g->kev[g->kev_used + 2], s)); g->kev_used += 3; }
     g->evals++;
     return 0;
@@ -1158,6 +1175,9 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     // Grid cap of k_rowgemm (a capped grid walks the work list as a persistent loop).  Inside the chain
     // one tile per workgroup measured equal or faster on MI355X, so the cap is off by default;
     // CCSP_MAX_WGS=<n> sets it for experiments.
+    m->bf16x3 = 0;
+    if (const char* e = getenv("CCSP_MMA")) m->bf16x3 = (strcmp(e, "bf16x3") == 0);
+    m->WpS = nullptr; m->Wd1S = nullptr;
     m->max_wgs = 1 << 30;
     if (const char* e = getenv("CCSP_MAX_WGS")) { const int v = atoi(e); if (v > 0) m->max_wgs = v; }
     auto& reg = m->allocs;
@@ -1226,6 +1246,13 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
         // tau[t, i, :] = Wi[:, time cols] . temb[t] + b_i
         hipLaunchKernelGGL(k_linear_rows, dim3(nblk((long)T * 2 * H, 256)), dim3(256), 0, s, T, H, 2 * H, m->temb, H, Wi + off + 4 * H, m->K_in, bi, 0,
                            m->tau + (size_t)i * 2 * H, C * 2 * H);
+    }
+    {   // bf16 planes of the direct-mode GEMM weights (ccsp_bf16x3.h); 1.5x the fp32 bytes
+        const long nwp = (long)C * 2 * WS, nwd = (long)(H / 2) * H;
+        TRY(dev_alloc(reg, &m->WpS, (size_t)3 * nwp));
+        TRY(dev_alloc(reg, &m->Wd1S, (size_t)3 * nwd));
+        hipLaunchKernelGGL(k_split3, dim3(nblk(nwp, 256)), dim3(256), 0, s, nwp, m->Wp, m->WpS);
+        hipLaunchKernelGGL(k_split3, dim3(nblk(nwd, 256)), dim3(256), 0, s, nwd, m->pd0_w, m->Wd1S);
     }
 #undef TRY
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
@@ -1298,6 +1325,7 @@ int ccsp_graph_create(ccsp_model* m, int32_t N, int32_t E, int32_t F, const floa
     TRY(dev_alloc(reg, &g->U, (size_t)p.R * 2 * H));
     TRY(dev_alloc(reg, &g->O, (size_t)2 * p.E_act * P));
     TRY(dev_alloc(reg, &g->pemb, (size_t)N * H));
+    TRY(dev_alloc(reg, &g->pembS, (size_t)3 * N * H));
     TRY(dev_alloc(reg, &g->x, (size_t)N * P));
     TRY(dev_alloc(reg, &g->eps, (size_t)N * P));
     // chain-constant part: geometry (and grasp) embeddings -> per-row products base[r] (the reference
