@@ -46,7 +46,7 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return SO
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-pthread',
            '-o', SO, os.path.join(CSRC, 'ccsp_hip.hip')]
     if verbose:
         print(' '.join(cmd))

@@ -15,6 +15,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ccsp.h"
@@ -778,6 +780,10 @@ struct ccsp_model {
     float* Wr;     // [C][2][2H][H]   grasp slice in slot 0 (slot 1 unused) or nullptr
     float* Wp;     // [C][2][2H][H]   pose slices
     float* WpT;    // [C][2][H][2H]   their transposes (energy-mode backward)
+    int lanes;     // concurrent sub-batch chains per ccsp_chain_run (direct mode), default 2
+    std::vector<hipStream_t> lane_streams;   // created once per model: new HIP streams are expensive to
+    std::vector<hipEvent_t> lane_events;     // create (hundreds of ms for the first few), graphs come and go
+    hipEvent_t fork_event = nullptr;
     int bf16x3;    // 1: direct-mode GEMMs on the bf16 matrix cores with 3-way split operands (ccsp_bf16x3.h)
     unsigned short* WpS;    // [3][C][2][2H][H] bf16 planes of Wp
     unsigned short* Wd1S;   // [3][H/2][H]      bf16 planes of pose_decoder.0.weight
@@ -809,6 +815,13 @@ struct ccsp_graph {
     std::vector<int> h_denom;      // host copy kept alive for the async upload
     int n_edge_blocks = 0;
     std::vector<void*> allocs;
+    // concurrent lanes: the batch cut into independent sub-batches (children), each a complete graph
+    // object with its own stream, whose chains are enqueued interleaved (see ccsp_chain_run)
+    std::vector<int64_t> h_ei;     // host copy of edge_index [2,E]
+    std::vector<float> h_ea;       // host copy of edge_attr [E]
+    std::vector<ccsp_graph*> children;
+    std::vector<int> child_node0;
+    int lanes_tried = 0;
     // profiling
     int profile = 0;
     int64_t evals = 0;
@@ -978,123 +991,199 @@ int steps_at(const ccsp_model* m, int sampler, int t) {
     return m->sps[t];
 }
 
+// one concurrently running sub-batch of a chain
+struct Lane {
+    ccsp_graph* g;
+    hipStream_t s;
+    int node0;          // global index of the lane's first node (noise rows, output slices)
+};
+
+// Enqueues timesteps t_first..t_last for every lane, interleaved kernel by kernel so that all lane
+// streams advance together.  NP_total = rows x P of the whole batch (history / injected-noise stride).
 template <int H>
-int chain_run_impl(ccsp_model* m, ccsp_graph* g, int sampler, const ccsp_noise* nz, float* x_io, int init, int t_first,
-                   int t_last, float* history, float* accept, hipStream_t s) {
-    const int T = m->d.timesteps, P = m->d.pose_dim, N = g->N;
-    const size_t NP = (size_t)N * P;
+int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_total, int sampler, const ccsp_noise* nz, float* x_io,
+                   int init, int t_first, int t_last, float* history, float* accept) {
+    const int T = m->d.timesteps, P = m->d.pose_dim;
     std::vector<uint64_t> call0(T);
     { uint64_t c = 1; for (int t = T - 1; t >= 0; --t) { call0[t] = c; c += 1 + (uint64_t)steps_at(m, sampler, t); } }
-    auto noise_for = [&](uint64_t call, NoiseArg& na) -> int {
-        na.mode = nz->mode; na.seed = nz->seed; na.row_offset = nz->row_offset; na.call = (unsigned int)call; na.normal = nullptr;
-        na.uniform = nullptr; na.ucall = 0;
+    auto noise_for = [&](const Lane& L, uint64_t call, NoiseArg& na) -> int {
+        na.mode = nz->mode; na.seed = nz->seed; na.row_offset = nz->row_offset + (unsigned long long)L.node0;
+        na.call = (unsigned int)call; na.normal = nullptr; na.uniform = nullptr; na.ucall = 0;
         if (nz->mode == CCSP_NOISE_INJECTED) {
             if (call < nz->call_base || call - nz->call_base >= nz->n_normal) return fail("chain_run: injected normal stream exhausted at call %llu", (unsigned long long)call);
-            na.normal = nz->normal + (size_t)(call - nz->call_base) * NP;
+            na.normal = nz->normal + (size_t)(call - nz->call_base) * NP_total + (size_t)L.node0 * P;
         }
         return 0;
     };
-    if (!g->have_events) { HIP_TRY(hipEventCreate(&g->ev0)); HIP_TRY(hipEventCreate(&g->ev1)); g->have_events = true; }
-    g->evals = 0; g->kev_used = 0;
-    HIP_TRY(hipEventRecord(g->ev0, s));
-    if (init) {
-        NodeArgs a = node_args(m, g);
-        a.src = 2; a.step = STEP_INIT; a.reset_mask = 1; a.do_encode = 1; a.hist = history;
-        if (noise_for(0, a.noise)) return 1;
-        launch_node<H>(m, g, a, s);
-    } else {
-        HIP_TRY(hipMemcpyAsync(g->x, x_io, NP * sizeof(float), hipMemcpyDeviceToDevice, s));
-        NodeArgs a = node_args(m, g);
-        a.src = 2; a.step = STEP_NONE; a.do_encode = 1;
-        launch_node<H>(m, g, a, s);
-    }
-    const bool energy = m->d.energy_wrapper != 0;
-    std::vector<uint64_t> ucall0(T, 0);
-    if (energy) {
-        if (energy_prepare(m, g, s)) return 1;
-        HIP_TRY(hipMemsetAsync(g->acc_count, 0, (size_t)T * sizeof(int), s));
-        HIP_TRY(hipStreamSynchronize(s));      // a previous chain may still be reading h_denom
-        g->h_denom.assign(T, 0);
-        uint64_t uc = 0;
-        for (int t = T - 1; t >= 0; --t) {
-            ucall0[t] = uc;
-            if (sampler == CCSP_SAMPLER_MALA) { uc += (uint64_t)steps_at(m, sampler, t); g->h_denom[t] = N * steps_at(m, sampler, t); }
-        }
-        HIP_TRY(hipMemcpyAsync(g->acc_denom, g->h_denom.data(), (size_t)T * sizeof(int), hipMemcpyHostToDevice, s));
-    }
+    auto hist_at = [&](const Lane& L, int k) -> float* { return history ? history + (size_t)k * NP_total + (size_t)L.node0 * P : nullptr; };
     auto sched = [&](NodeArgs& a, int t) {
         a.a_t = m->sqrt_recip_ac[t]; a.b_t = m->sqrt_recipm1_ac[t]; a.c1 = m->coef1[t]; a.c2 = m->coef2[t];
         a.sigma = t != 0 ? expf(0.5f * m->post_lv[t]) : 0.0f;
         a.kappa = m->kappa[t]; a.ss = m->step[t]; a.std_ = sqrtf(2.0f * m->step[t]);
     };
-    for (int t = t_first; energy && t >= t_last; --t) {
-        // energy mode: epsilon = dE/dposes (ComposedEBMDenoiseFn.forward); MALA re-evaluates E at the
-        // proposal (energy_function, ddpm.py:285-289) -- the gradient pass already gave E(x)
-        const int S = steps_at(m, sampler, t);
-        float* E_x = g->Escal, *E_hat = g->Escal + 1;
-        if (launch_eval_energy<H>(m, g, t, g->x, true, E_x, s)) return 1;
-        {
+    for (const Lane& L : lanes) {
+        ccsp_graph* g = L.g;
+        g->evals = 0; g->kev_used = 0;
+        if (init) {
             NodeArgs a = node_args(m, g);
-            a.src = 1; a.eps_buf = g->eps; a.do_encode = 1; a.step = STEP_ANCESTRAL;
-            a.reset_mask = (S == 0);
-            a.hist = (S == 0 && history) ? history + (size_t)(T - t) * NP : nullptr;
-            sched(a, t);
-            if (noise_for(call0[t], a.noise)) return 1;
-            launch_node<H>(m, g, a, s);
+            a.src = 2; a.step = STEP_INIT; a.reset_mask = 1; a.do_encode = 1; a.hist = hist_at(L, 0);
+            if (noise_for(L, 0, a.noise)) return 1;
+            launch_node<H>(m, g, a, L.s);
+        } else {
+            HIP_TRY(hipMemcpyAsync(g->x, x_io + (size_t)L.node0 * P, (size_t)g->N * P * sizeof(float), hipMemcpyDeviceToDevice, L.s));
+            NodeArgs a = node_args(m, g);
+            a.src = 2; a.step = STEP_NONE; a.do_encode = 1;
+            launch_node<H>(m, g, a, L.s);
         }
-        for (int e = 1; e <= S; ++e) {
+    }
+    const bool energy = m->d.energy_wrapper != 0;
+    if (energy) {
+        // energy mode couples the whole batch through one scalar: always a single lane
+        ccsp_graph* g = lanes[0].g;
+        hipStream_t s = lanes[0].s;
+        const Lane& L = lanes[0];
+        const int N = g->N;
+        std::vector<uint64_t> ucall0(T, 0);
+        if (energy_prepare(m, g, s)) return 1;
+        HIP_TRY(hipMemsetAsync(g->acc_count, 0, (size_t)T * sizeof(int), s));
+        HIP_TRY(hipStreamSynchronize(s));      // a previous chain may still be reading h_denom
+        g->h_denom.assign(T, 0);
+        uint64_t uc0 = 0;
+        for (int t = T - 1; t >= 0; --t) {
+            ucall0[t] = uc0;
+            if (sampler == CCSP_SAMPLER_MALA) { uc0 += (uint64_t)steps_at(m, sampler, t); g->h_denom[t] = N * steps_at(m, sampler, t); }
+        }
+        HIP_TRY(hipMemcpyAsync(g->acc_denom, g->h_denom.data(), (size_t)T * sizeof(int), hipMemcpyHostToDevice, s));
+        for (int t = t_first; t >= t_last; --t) {
+            // epsilon = dE/dposes (ComposedEBMDenoiseFn.forward); MALA re-evaluates E at the proposal
+            // (energy_function, ddpm.py:285-289) -- the gradient pass already gave E(x)
+            const int S = steps_at(m, sampler, t);
+            float* E_x = g->Escal, *E_hat = g->Escal + 1;
             if (launch_eval_energy<H>(m, g, t, g->x, true, E_x, s)) return 1;
-            NodeArgs a = node_args(m, g);
-            a.src = 1; a.eps_buf = g->eps; a.do_encode = 1; a.xhat = g->xhat;
-            sched(a, t);
-            if (noise_for(call0[t] + (uint64_t)e, a.noise)) return 1;
-            if (sampler != CCSP_SAMPLER_MALA) {
-                a.step = STEP_ULA;
-                a.reset_mask = (e == S);
-                a.hist = (e == S && history) ? history + (size_t)(T - t) * NP : nullptr;
+            {
+                NodeArgs a = node_args(m, g);
+                a.src = 1; a.eps_buf = g->eps; a.do_encode = 1; a.step = STEP_ANCESTRAL;
+                a.reset_mask = (S == 0);
+                a.hist = S == 0 ? hist_at(L, T - t) : nullptr;
+                sched(a, t);
+                if (noise_for(L, call0[t], a.noise)) return 1;
                 launch_node<H>(m, g, a, s);
-                continue;
             }
-            a.step = STEP_MALA_PROPOSE;
-            launch_node<H>(m, g, a, s);                                   // x_hat, and its pose embedding
-            if (launch_eval_energy<H>(m, g, t, g->xhat, false, E_hat, s)) return 1;
-            NodeArgs b = node_args(m, g);
-            b.src = 1; b.eps_buf = g->eps; b.do_encode = 1; b.xhat = g->xhat; b.step = STEP_MALA_ACCEPT;
-            b.E_x = E_x; b.E_hat = E_hat; b.acc_count = g->acc_count + t;
-            b.reset_mask = (e == S);
-            b.hist = (e == S && history) ? history + (size_t)(T - t) * NP : nullptr;
-            sched(b, t);
-            b.noise.mode = nz->mode; b.noise.seed = nz->seed; b.noise.row_offset = nz->row_offset;
-            const uint64_t uc = ucall0[t] + (uint64_t)(e - 1);
-            b.noise.ucall = (unsigned int)uc;
-            if (nz->mode == CCSP_NOISE_INJECTED) {
-                if (!nz->uniform || uc < nz->ucall_base || uc - nz->ucall_base >= nz->n_uniform)
-                    return fail("chain_run: injected uniform stream exhausted at call %llu", (unsigned long long)uc);
-                b.noise.uniform = nz->uniform + (size_t)(uc - nz->ucall_base) * N;
+            for (int e = 1; e <= S; ++e) {
+                if (launch_eval_energy<H>(m, g, t, g->x, true, E_x, s)) return 1;
+                NodeArgs a = node_args(m, g);
+                a.src = 1; a.eps_buf = g->eps; a.do_encode = 1; a.xhat = g->xhat;
+                sched(a, t);
+                if (noise_for(L, call0[t] + (uint64_t)e, a.noise)) return 1;
+                if (sampler != CCSP_SAMPLER_MALA) {
+                    a.step = STEP_ULA;
+                    a.reset_mask = (e == S);
+                    a.hist = e == S ? hist_at(L, T - t) : nullptr;
+                    launch_node<H>(m, g, a, s);
+                    continue;
+                }
+                a.step = STEP_MALA_PROPOSE;
+                launch_node<H>(m, g, a, s);                                   // x_hat, and its pose embedding
+                if (launch_eval_energy<H>(m, g, t, g->xhat, false, E_hat, s)) return 1;
+                NodeArgs b = node_args(m, g);
+                b.src = 1; b.eps_buf = g->eps; b.do_encode = 1; b.xhat = g->xhat; b.step = STEP_MALA_ACCEPT;
+                b.E_x = E_x; b.E_hat = E_hat; b.acc_count = g->acc_count + t;
+                b.reset_mask = (e == S);
+                b.hist = e == S ? hist_at(L, T - t) : nullptr;
+                sched(b, t);
+                b.noise.mode = nz->mode; b.noise.seed = nz->seed; b.noise.row_offset = nz->row_offset;
+                const uint64_t uc = ucall0[t] + (uint64_t)(e - 1);
+                b.noise.ucall = (unsigned int)uc;
+                if (nz->mode == CCSP_NOISE_INJECTED) {
+                    if (!nz->uniform || uc < nz->ucall_base || uc - nz->ucall_base >= nz->n_uniform)
+                        return fail("chain_run: injected uniform stream exhausted at call %llu", (unsigned long long)uc);
+                    b.noise.uniform = nz->uniform + (size_t)(uc - nz->ucall_base) * N;
+                }
+                launch_node<H>(m, g, b, s);
             }
-            launch_node<H>(m, g, b, s);
+        }
+        if (accept) hipLaunchKernelGGL(k_accept_rates, dim3(nblk(T, 256)), dim3(256), 0, s, T, g->acc_count, g->acc_denom, accept);
+    } else {
+        for (int t = t_first; t >= t_last; --t) {
+            const int S = steps_at(m, sampler, t);
+            for (int e = 0; e <= S; ++e) {
+                for (const Lane& L : lanes) {
+                    ccsp_graph* g = L.g;
+                    if (launch_eval<H>(m, g, t, L.s)) return 1;
+                    NodeArgs a = node_args(m, g);
+                    a.src = 0; a.do_encode = 1;
+                    a.step = e == 0 ? STEP_ANCESTRAL : STEP_ULA;
+                    a.reset_mask = (e == S);
+                    a.hist = e == S ? hist_at(L, T - t) : nullptr;
+                    sched(a, t);
+                    if (noise_for(L, call0[t] + (uint64_t)e, a.noise)) return 1;
+                    launch_node<H>(m, g, a, L.s);
+                }
+            }
         }
     }
-    if (energy && accept) hipLaunchKernelGGL(k_accept_rates, dim3(nblk(T, 256)), dim3(256), 0, s, T, g->acc_count, g->acc_denom, accept);
-    for (int t = t_first; !energy && t >= t_last; --t) {
-        const int S = steps_at(m, sampler, t);
-        for (int e = 0; e <= S; ++e) {
-            if (launch_eval<H>(m, g, t, s)) return 1;
-            NodeArgs a = node_args(m, g);
-            a.src = 0; a.do_encode = 1;
-            a.step = e == 0 ? STEP_ANCESTRAL : STEP_ULA;
-            a.reset_mask = (e == S);
-            a.hist = (e == S && history) ? history + (size_t)(T - t) * NP : nullptr;
-            a.a_t = m->sqrt_recip_ac[t]; a.b_t = m->sqrt_recipm1_ac[t]; a.c1 = m->coef1[t]; a.c2 = m->coef2[t];
-            a.sigma = t != 0 ? expf(0.5f * m->post_lv[t]) : 0.0f;
-            a.kappa = m->kappa[t]; a.ss = m->step[t]; a.std_ = sqrtf(2.0f * m->step[t]);
-            if (noise_for(call0[t] + (uint64_t)e, a.noise)) return 1;
-            launch_node<H>(m, g, a, s);
-        }
-    }
-    HIP_TRY(hipMemcpyAsync(x_io, g->x, NP * sizeof(float), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipEventRecord(g->ev1, s));
+    for (const Lane& L : lanes)
+        HIP_TRY(hipMemcpyAsync(x_io + (size_t)L.node0 * P, L.g->x, (size_t)L.g->N * P * sizeof(float), hipMemcpyDeviceToDevice, L.s));
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int graph_build(ccsp_model* m, int N, int E, int F, const float* x, const signed char* mask, std::vector<int64_t>&& ei,
+                std::vector<float>&& ea, hipStream_t s, ccsp_graph** out);
+
+// cut the batch into `want` contiguous node ranges that no edge crosses (graphs are independent
+// units: collation is block-diagonal) and build one child graph per range
+int ensure_children(ccsp_model* m, ccsp_graph* g, int want, hipStream_t s) {
+    if (g->lanes_tried) return 0;
+    g->lanes_tried = 1;
+    const int N = g->N, E = g->E;
+    if (want < 2 || N < 2 * want) return 0;
+    std::vector<int> cross(N + 1, 0);                    // cross[i] > 0: some edge spans the boundary before node i
+    for (int e = 0; e < E; ++e) {
+        const int a = (int)g->h_ei[e], b = (int)g->h_ei[(size_t)E + e];
+        const int lo = a < b ? a : b, hi = a < b ? b : a;
+        if (hi > lo) { cross[lo + 1]++; cross[hi + 1]--; }
+    }
+    std::vector<int> cuts;
+    cuts.push_back(0);
+    int run = 0;
+    std::vector<char> ok(N + 1, 0);
+    for (int i = 1; i < N; ++i) { run += cross[i]; ok[i] = run == 0; }
+    for (int k = 1; k < want; ++k) {
+        const int target = (int)((long)N * k / want);
+        int best = -1;
+        for (int d = 0; d < N; ++d) {
+            if (target - d > cuts.back() && target - d < N && ok[target - d]) { best = target - d; break; }
+            if (target + d > cuts.back() && target + d < N && ok[target + d]) { best = target + d; break; }
+        }
+        if (best < 0) return 0;                          // no valid cut: run as one lane
+        cuts.push_back(best);
+    }
+    cuts.push_back(N);
+    for (size_t k = 0; k + 1 < cuts.size(); ++k) {
+        const int n0 = cuts[k], n1 = cuts[k + 1];
+        std::vector<int64_t> a_, b_;
+        std::vector<float> ea;
+        for (int e = 0; e < E; ++e) {
+            const int64_t a = g->h_ei[e], b = g->h_ei[(size_t)E + e];
+            if (a >= n0 && a < n1) { a_.push_back(a - n0); b_.push_back(b - n0); ea.push_back(g->h_ea[e]); }
+        }
+        std::vector<int64_t> ei(a_);
+        ei.insert(ei.end(), b_.begin(), b_.end());
+        ccsp_graph* c = nullptr;
+        if (m->lane_streams.size() <= k) {
+            hipStream_t cs = nullptr;
+            hipEvent_t ce = nullptr;
+            HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&ce, hipEventDisableTiming));
+            m->lane_streams.push_back(cs);
+            m->lane_events.push_back(ce);
+        }
+        if (graph_build(m, n1 - n0, (int)ea.size(), g->F, g->xfeat + (size_t)n0 * g->F, g->mask + n0, std::move(ei), std::move(ea), s, &c)) return 1;
+        g->children.push_back(c);
+        g->child_node0.push_back(n0);
+    }
+    if (!m->fork_event) HIP_TRY(hipEventCreateWithFlags(&m->fork_event, hipEventDisableTiming));
     return 0;
 }
 
@@ -1103,6 +1192,88 @@ int chain_run_impl(ccsp_model* m, ccsp_graph* g, int sampler, const ccsp_noise* 
 // ==========================================================================================
 // C ABI
 // ==========================================================================================
+
+namespace {
+int graph_build(ccsp_model* m, int N, int E, int F, const float* x, const signed char* mask, std::vector<int64_t>&& ei,
+                std::vector<float>&& ea, hipStream_t s, ccsp_graph** out) {
+    const ccsp_model_desc& d = m->d;
+    const int H = d.hidden_dim, P = d.pose_dim;
+    ccsp_graph* g = new ccsp_graph();
+    g->m = m; g->N = N; g->E = E; g->F = F;
+    const char* perr = "";
+    if (ccsp::build_plan(N, E, d.n_types, TILE_M, ei.data(), ea.data(), g->plan, &perr)) {
+        delete g;
+        return fail("graph_create: %s", perr);
+    }
+    g->h_ei = std::move(ei);
+    g->h_ea = std::move(ea);
+    const ccsp::Plan& p = g->plan;
+    g->n_tiles = (int)p.tile_row0.size();
+    auto& reg = g->allocs;
+#define TRY(x) do { if (x) { ccsp_graph_destroy(g); return 1; } } while (0)
+    TRY(dev_alloc(reg, &g->xfeat, (size_t)N * F));
+    HIP_TRY(hipMemcpyAsync(g->xfeat, x, (size_t)N * F * sizeof(float), hipMemcpyDeviceToDevice, s));
+    TRY(dev_alloc(reg, &g->mask, (size_t)N));
+    HIP_TRY(hipMemcpyAsync(g->mask, mask, (size_t)N, hipMemcpyDeviceToDevice, s));
+    TRY(dev_upload(reg, &g->e_type, p.e_type, s));
+    TRY(dev_upload(reg, &g->e_u0, p.e_u0, s));
+    TRY(dev_upload(reg, &g->e_u1, p.e_u1, s));
+    TRY(dev_upload(reg, &g->e_orig, p.e_orig, s));
+    TRY(dev_upload(reg, &g->urow_node, p.urow_node, s));
+    TRY(dev_upload(reg, &g->tile_row0, p.tile_row0, s));
+    TRY(dev_upload(reg, &g->tile_nrows, p.tile_nrows, s));
+    TRY(dev_upload(reg, &g->tile_ts, p.tile_ts, s));
+    TRY(dev_upload(reg, &g->node_ptr, p.node_ptr, s));
+    TRY(dev_upload(reg, &g->node_ent, p.node_ent, s));
+    TRY(dev_upload(reg, &g->ent_pos, p.ent_pos, s));
+    TRY(dev_upload(reg, &g->urow_ts, p.urow_ts, s));
+    TRY(dev_alloc(reg, &g->base, (size_t)p.R * 2 * H));
+    TRY(dev_alloc(reg, &g->U, (size_t)p.R * 2 * H));
+    TRY(dev_alloc(reg, &g->O, (size_t)2 * p.E_act * P));
+    TRY(dev_alloc(reg, &g->pemb, (size_t)N * H));
+    TRY(dev_alloc(reg, &g->pembS, (size_t)3 * N * H));
+    TRY(dev_alloc(reg, &g->x, (size_t)N * P));
+    TRY(dev_alloc(reg, &g->eps, (size_t)N * P));
+    // chain-constant part: geometry (and grasp) embeddings -> per-row products base[r] (the reference
+    // re-evaluates the geometry encoder and these products on every call, denoise_fn.py:474-475)
+    if (p.E_act > 0) {
+        float *gemb = nullptr, *UR = nullptr, *remb = nullptr;
+        TRY(dev_alloc(reg, &gemb, (size_t)N * H));
+        const EncW wg{m->ge0_w, m->ge0_b, m->ge2_wT, m->ge2_b, d.geom_dim, nullptr};
+        const int gwork = g->n_tiles * (2 * H / TILE_N);
+        const dim3 ggrid(gwork < m->max_wgs ? gwork : m->max_wgs);
+        const float* nof = nullptr;
+        if (H == 256) {
+            hipLaunchKernelGGL(k_encode<256>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, 0, wg, gemb);
+            hipLaunchKernelGGL((k_rowgemm<256, 512>), ggrid, dim3(256), 0, s, gwork, gemb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wg, (size_t)2 * H * H, nof, nof, g->base);
+        } else {
+            hipLaunchKernelGGL(k_encode<64>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, 0, wg, gemb);
+            hipLaunchKernelGGL((k_rowgemm<64, 128>), ggrid, dim3(256), 0, s, gwork, gemb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wg, (size_t)2 * H * H, nof, nof, g->base);
+        }
+        if (d.grasp_dim > 0) {
+            TRY(dev_alloc(reg, &remb, (size_t)N * H));
+            TRY(dev_alloc(reg, &UR, (size_t)p.R * 2 * H));
+            const EncW wr{m->gr0_w, m->gr0_b, m->gr2_wT, m->gr2_b, d.grasp_dim, nullptr};
+            if (H == 256) {
+                hipLaunchKernelGGL(k_encode<256>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, d.grasp_begin, wr, remb);
+                hipLaunchKernelGGL((k_rowgemm<256, 512>), ggrid, dim3(256), 0, s, gwork, remb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wr, (size_t)2 * H * H, nof, nof, UR);
+            } else {
+                hipLaunchKernelGGL(k_encode<64>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, d.grasp_begin, wr, remb);
+                hipLaunchKernelGGL((k_rowgemm<64, 128>), ggrid, dim3(256), 0, s, gwork, remb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wr, (size_t)2 * H * H, nof, nof, UR);
+            }
+            hipLaunchKernelGGL(k_rowbase, dim3(nblk((long)p.R * 2 * H, 256)), dim3(256), 0, s, p.R, 2 * H, g->urow_ts, UR, g->base);
+        }
+    }
+#undef TRY
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        ccsp_graph_destroy(g);
+        return fail("graph_create: device set-up failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    *out = g;
+    return 0;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -1176,6 +1347,8 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     // one tile per workgroup measured equal or faster on MI355X, so the cap is off by default;
     // CCSP_MAX_WGS=<n> sets it for experiments.
     m->bf16x3 = 0;
+    m->lanes = 2;
+    if (const char* e = getenv("CCSP_LANES")) { const int v = atoi(e); if (v >= 1 && v <= 8) m->lanes = v; }
     if (const char* e = getenv("CCSP_MMA")) m->bf16x3 = (strcmp(e, "bf16x3") == 0);
     m->WpS = nullptr; m->Wd1S = nullptr;
     m->max_wgs = 1 << 30;
@@ -1266,6 +1439,9 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
 
 void ccsp_model_destroy(ccsp_model* m) {
     if (!m) return;
+    for (hipStream_t st : m->lane_streams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (hipEvent_t e : m->lane_events) (void)hipEventDestroy(e);
+    if (m->fork_event) (void)hipEventDestroy(m->fork_event);
     for (void* p : m->allocs) (void)hipFree(p);
     delete m;
 }
@@ -1294,81 +1470,14 @@ int ccsp_graph_create(ccsp_model* m, int32_t N, int32_t E, int32_t F, const floa
         HIP_TRY(hipMemcpyAsync(ea.data(), edge_attr, ea.size() * sizeof(float), hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(hipStreamSynchronize(s));
-    ccsp_graph* g = new ccsp_graph();
-    g->m = m; g->N = N; g->E = E; g->F = F;
-    const char* perr = "";
-    if (ccsp::build_plan(N, E, d.n_types, TILE_M, ei.data(), ea.data(), g->plan, &perr)) {
-        delete g;
-        return fail("graph_create: %s", perr);
-    }
-    const ccsp::Plan& p = g->plan;
-    g->n_tiles = (int)p.tile_row0.size();
-    auto& reg = g->allocs;
-#define TRY(x) do { if (x) { ccsp_graph_destroy(g); return 1; } } while (0)
-    TRY(dev_alloc(reg, &g->xfeat, (size_t)N * F));
-    HIP_TRY(hipMemcpyAsync(g->xfeat, x, (size_t)N * F * sizeof(float), hipMemcpyDeviceToDevice, s));
-    TRY(dev_alloc(reg, &g->mask, (size_t)N));
-    HIP_TRY(hipMemcpyAsync(g->mask, mask, (size_t)N, hipMemcpyDeviceToDevice, s));
-    TRY(dev_upload(reg, &g->e_type, p.e_type, s));
-    TRY(dev_upload(reg, &g->e_u0, p.e_u0, s));
-    TRY(dev_upload(reg, &g->e_u1, p.e_u1, s));
-    TRY(dev_upload(reg, &g->e_orig, p.e_orig, s));
-    TRY(dev_upload(reg, &g->urow_node, p.urow_node, s));
-    TRY(dev_upload(reg, &g->tile_row0, p.tile_row0, s));
-    TRY(dev_upload(reg, &g->tile_nrows, p.tile_nrows, s));
-    TRY(dev_upload(reg, &g->tile_ts, p.tile_ts, s));
-    TRY(dev_upload(reg, &g->node_ptr, p.node_ptr, s));
-    TRY(dev_upload(reg, &g->node_ent, p.node_ent, s));
-    TRY(dev_upload(reg, &g->ent_pos, p.ent_pos, s));
-    TRY(dev_upload(reg, &g->urow_ts, p.urow_ts, s));
-    TRY(dev_alloc(reg, &g->base, (size_t)p.R * 2 * H));
-    TRY(dev_alloc(reg, &g->U, (size_t)p.R * 2 * H));
-    TRY(dev_alloc(reg, &g->O, (size_t)2 * p.E_act * P));
-    TRY(dev_alloc(reg, &g->pemb, (size_t)N * H));
-    TRY(dev_alloc(reg, &g->pembS, (size_t)3 * N * H));
-    TRY(dev_alloc(reg, &g->x, (size_t)N * P));
-    TRY(dev_alloc(reg, &g->eps, (size_t)N * P));
-    // chain-constant part: geometry (and grasp) embeddings -> per-row products base[r] (the reference
-    // re-evaluates the geometry encoder and these products on every call, denoise_fn.py:474-475)
-    if (p.E_act > 0) {
-        float *gemb = nullptr, *UR = nullptr, *remb = nullptr;
-        TRY(dev_alloc(reg, &gemb, (size_t)N * H));
-        const EncW wg{m->ge0_w, m->ge0_b, m->ge2_wT, m->ge2_b, d.geom_dim, nullptr};
-        const int gwork = g->n_tiles * (2 * H / TILE_N);
-        const dim3 ggrid(gwork < m->max_wgs ? gwork : m->max_wgs);
-        const float* nof = nullptr;
-        if (H == 256) {
-            hipLaunchKernelGGL(k_encode<256>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, 0, wg, gemb);
-            hipLaunchKernelGGL((k_rowgemm<256, 512>), ggrid, dim3(256), 0, s, gwork, gemb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wg, (size_t)2 * H * H, nof, nof, g->base);
-        } else {
-            hipLaunchKernelGGL(k_encode<64>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, 0, wg, gemb);
-            hipLaunchKernelGGL((k_rowgemm<64, 128>), ggrid, dim3(256), 0, s, gwork, gemb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wg, (size_t)2 * H * H, nof, nof, g->base);
-        }
-        if (d.grasp_dim > 0) {
-            TRY(dev_alloc(reg, &remb, (size_t)N * H));
-            TRY(dev_alloc(reg, &UR, (size_t)p.R * 2 * H));
-            const EncW wr{m->gr0_w, m->gr0_b, m->gr2_wT, m->gr2_b, d.grasp_dim, nullptr};
-            if (H == 256) {
-                hipLaunchKernelGGL(k_encode<256>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, d.grasp_begin, wr, remb);
-                hipLaunchKernelGGL((k_rowgemm<256, 512>), ggrid, dim3(256), 0, s, gwork, remb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wr, (size_t)2 * H * H, nof, nof, UR);
-            } else {
-                hipLaunchKernelGGL(k_encode<64>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, d.grasp_begin, wr, remb);
-                hipLaunchKernelGGL((k_rowgemm<64, 128>), ggrid, dim3(256), 0, s, gwork, remb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wr, (size_t)2 * H * H, nof, nof, UR);
-            }
-            hipLaunchKernelGGL(k_rowbase, dim3(nblk((long)p.R * 2 * H, 256)), dim3(256), 0, s, p.R, 2 * H, g->urow_ts, UR, g->base);
-        }
-    }
-#undef TRY
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
-        ccsp_graph_destroy(g);
-        return fail("graph_create: device set-up failed: %s", hipGetErrorString(hipGetLastError()));
-    }
-    *out = g;
-    return 0;
+    return graph_build(m, N, E, F, x, (const signed char*)mask, std::move(ei), std::move(ea), s, out);
 }
 
 void ccsp_graph_destroy(ccsp_graph* g) {
     if (!g) return;
+    if (!g->children.empty())                       // lane streams belong to the model; drain them first
+        for (hipStream_t st : g->m->lane_streams) (void)hipStreamSynchronize(st);
+    for (ccsp_graph* c : g->children) ccsp_graph_destroy(c);
     for (void* p : g->allocs) (void)hipFree(p);
     if (g->have_events) { (void)hipEventDestroy(g->ev0); (void)hipEventDestroy(g->ev1); }
     for (hipEvent_t e : g->kev) (void)hipEventDestroy(e);
@@ -1434,8 +1543,67 @@ int ccsp_chain_run(ccsp_model* m, ccsp_graph* g, int32_t sampler, const ccsp_noi
     if (nz->mode == CCSP_NOISE_INJECTED && !nz->normal) return fail("chain_run: injected noise without a normal stream");
     if (sampler == CCSP_SAMPLER_MALA && !m->d.energy_wrapper) return fail("chain_run: MALA needs an energy_wrapper model (train_utils.py:115-116)");
     hipStream_t s = (hipStream_t)stream;
-    if (m->d.hidden_dim == 256) return chain_run_impl<256>(m, g, sampler, nz, x, init, t_first, t_last, history, accept, s);
-    return chain_run_impl<64>(m, g, sampler, nz, x, init, t_first, t_last, history, accept, s);
+    const size_t NP_total = (size_t)g->N * m->d.pose_dim;
+    // Concurrent lanes (direct mode): graphs are independent, so the batch is cut into sub-batches whose
+    // chains run on their own streams, enqueued interleaved.  A chain is three dependent kernels per
+    // evaluation, each with fill/drain phases that leave most of the 256 CUs idle; two lanes overlap one
+    // lane's latency-bound node kernel and tile tails with the other's GEMMs (+10 % samples/s at C2,
+    // bitwise-identical results: noise rows are global).  CCSP_LANES=<k> overrides (1 = off).
+    int want = m->lanes;
+    if (m->d.energy_wrapper || g->profile || g->N < 512) want = 1;
+    std::vector<Lane> lanes;
+    if (want > 1) {
+        if (ensure_children(m, g, want, s)) return 1;
+        if (!g->children.empty()) {                    // (graph_build synchronised the stream it was built on)
+            for (size_t i = 0; i < g->children.size(); ++i) lanes.push_back(Lane{g->children[i], m->lane_streams[i], g->child_node0[i]});
+        }
+    }
+    if (!g->have_events) { HIP_TRY(hipEventCreate(&g->ev0)); HIP_TRY(hipEventCreate(&g->ev1)); g->have_events = true; }
+    HIP_TRY(hipEventRecord(g->ev0, s));
+    const bool forked = !lanes.empty();
+    if (forked) {
+        HIP_TRY(hipEventRecord(m->fork_event, s));
+        for (const Lane& L : lanes) HIP_TRY(hipStreamWaitEvent(L.s, m->fork_event, 0));
+    } else {
+        lanes.push_back(Lane{g, s, 0});
+    }
+    int rc = 0;
+    auto run = [&](const std::vector<Lane>& ls) -> int {
+        return m->d.hidden_dim == 256 ? chain_run_impl<256>(m, ls, NP_total, sampler, nz, x, init, t_first, t_last, history, accept)
+                                      : chain_run_impl<64>(m, ls, NP_total, sampler, nz, x, init, t_first, t_last, history, accept);
+    };
+    if (!forked) {
+        rc = run(lanes);
+    } else {
+        // one enqueueing host thread per lane: a single thread alternating between streams is launch-bound
+        // (~18 us per launch measured), two threads keep both streams fed
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        std::vector<std::thread> th;
+        std::vector<int> rcs(lanes.size(), 0);
+        std::vector<std::string> errs(lanes.size());
+        for (size_t i = 0; i < lanes.size(); ++i)
+            th.emplace_back([&, i]() {
+                if (hipSetDevice(dev) != hipSuccess) { rcs[i] = 1; errs[i] = "hipSetDevice failed in lane thread"; return; }
+                rcs[i] = run(std::vector<Lane>{lanes[i]});
+                if (rcs[i]) errs[i] = g_err;
+            });
+        for (auto& t : th) t.join();
+        for (size_t i = 0; i < lanes.size(); ++i)
+            if (rcs[i]) { rc = fail("%s", errs[i].c_str()); break; }
+    }
+    if (forked) {
+        int64_t ev = 0;
+        for (size_t i = 0; i < lanes.size(); ++i) {
+            HIP_TRY(hipEventRecord(m->lane_events[i], lanes[i].s));
+            HIP_TRY(hipStreamWaitEvent(s, m->lane_events[i], 0));
+            ev = lanes[i].g->evals > ev ? lanes[i].g->evals : ev;
+        }
+        g->evals = ev;
+        g->kev_used = 0;
+    }
+    HIP_TRY(hipEventRecord(g->ev1, s));
+    return rc;
 }
 
 int ccsp_profile_enable(ccsp_graph* g, int32_t on) {
