@@ -123,6 +123,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     finite = bool(torch.isfinite(x).all().item())
+    # "solved?" check of the last batch (diffusion-ccsp_amd/checker.py); outside the timed region
+    from diffusion_ccsp_amd import checker
+    solved = checker.solved_mask(x.detach().cpu().numpy(), batch_np)
+    n_solved = torch.tensor([int(solved.sum()), int(solved.size)], device=dev, dtype=torch.int64)
+    if dist is not None:
+        dist.all_reduce(n_solved)
+    solved_fraction = float(n_solved[0].item()) / max(1, int(n_solved[1].item()))
     samples = world * B * args.steps
     value = samples / elapsed
 
@@ -137,7 +144,10 @@ def main():
                    'evaluations_per_chain': T_STEPS * (1 + S_LANGEVIN),
                    'parallelism': 'independent graph shards x%d, RCCL weight broadcast + final gather only' % world,
                    'weights': 'trained in-container with the reference loss (tests/golden/weights_qualitative_h256.npz)',
-                   'solved_fraction': None, 'outputs_finite': finite},
+                   'solved_fraction': solved_fraction, 'solved_samples_per_s': value * solved_fraction,
+                   'solved_note': 'fraction of the last batch passing the collision + qualitative-constraint check; the fixture '
+                                  'weights are only 2000 training steps of the reference loss, so this measures the weights, not the sampler',
+                   'outputs_finite': finite},
     }
 
     if rank == 0 and not args.no_roofline:
