@@ -64,6 +64,7 @@ def main():
     ap.add_argument('--graphs-per-gpu', type=int, default=GRAPHS_PER_GPU)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--force-dist', action='store_true', help='initialise RCCL even for one rank (exercises the N>1 code path)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -76,9 +77,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from diffusion_ccsp_amd import ConstraintDiffuser, GaussianDiffusion, device_info, sharding, worlds
@@ -187,10 +189,12 @@ def main():
                                'speedup_gpu_over_cpu': value / r['samples_per_s']}
     if rank == 0:
         rec['device'] = device_info()
-        print(json.dumps(rec))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stderr.flush()
+        print(json.dumps(rec), flush=True)      # the one JSON line, after RCCL's own banner output
 
 
 if __name__ == '__main__':

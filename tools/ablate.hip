@@ -31,5 +31,20 @@ int main(int argc, char** argv) {
     const double fl = 2.0 * R * 2 * H * H;
     printf("CCSP_ABLATE=%d  k_ugemm<256> %d tiles: %.2f us/launch  %.1f TFLOP/s  (%s)\n", CCSP_ABLATE, NT, 1e3 * ms / reps,
            fl / (ms / reps * 1e-3) / 1e12, hipGetErrorString(hipGetLastError()));
+    // bf16x3 variant on the same tile table
+    unsigned short *A3, *W3;
+    hipMalloc(&A3, (size_t)3 * N * H * 2); hipMalloc(&W3, (size_t)3 * C * 2 * 2 * H * H * 2);
+    hipLaunchKernelGGL(k_split3, dim3(((long)N * H + 255) / 256), dim3(256), 0, 0, (long)N * H, A, A3);
+    hipLaunchKernelGGL(k_split3, dim3(((long)C * 4 * H * H + 255) / 256), dim3(256), 0, 0, (long)C * 4 * H * H, W, W3);
+    for (int w = 0; w < 2; ++w) {
+        hipEventRecord(e0);
+        for (int i = 0; i < reps; ++i)
+            hipLaunchKernelGGL((k_rowgemm_bf<256, 512>), dim3(NT * 4), dim3(256), 0, 0, A3, (size_t)N * H, node, r0, nr, ts, W3,
+                               (size_t)C * 4 * H * H, (size_t)2 * H * H, base, tau, U);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+    }
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("CCSP_ABLATE=%d  k_rowgemm_bf<256,512>: %.2f us/launch  %.1f TFLOP/s-equivalent  (%s)\n", CCSP_ABLATE, 1e3 * ms / reps,
+           fl / (ms / reps * 1e-3) / 1e12, hipGetErrorString(hipGetLastError()));
     return 0;
 }
