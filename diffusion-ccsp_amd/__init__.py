@@ -10,4 +10,6 @@ from ._lib import CcspError, build, device_info  # noqa: F401
 from .denoise_fn import ComposedEBMDenoiseFn, ConstraintDiffuser  # noqa: F401
 from .ddpm import GaussianDiffusion  # noqa: F401
 
+from . import evaluate  # noqa: F401,E402
+
 __version__ = "0.1.0"

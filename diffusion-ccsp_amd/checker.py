@@ -34,6 +34,8 @@ UNORDERED = ('close-to', 'away-from', 'h-aligned', 'v-aligned', 'cfree')
 def yaw_from_sn_cs(sn, cs):
     """envs/data_utils.py:360-364"""
     total = math.sqrt(sn ** 2 + cs ** 2)
+    if total == 0.0 or math.isnan(total):
+        return float('nan')                      # numpy gives nan here (0/0); such a sample is never solved
     return math.atan2(sn / total, cs / total)
 
 
@@ -58,6 +60,8 @@ def _corners(cx, cy, bw, bl, yaw):
 
 def rects_overlap(a, b, eps=1e-9):
     """separating-axis test of two oriented rectangles (cx, cy, w, l, yaw); touching is not overlap"""
+    if any(math.isnan(v) for v in a) or any(math.isnan(v) for v in b):
+        return True                              # an undefined pose counts as a violation
     pa, pb = _corners(*a), _corners(*b)
     for rect in (a, b):
         c, s = math.cos(rect[4]), math.sin(rect[4])
