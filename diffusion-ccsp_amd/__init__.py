@@ -5,7 +5,7 @@
 mirror the reference classes of the same names (networks/denoise_fn.py, networks/ddpm.py) for the
 sampling path and run it through libccsp_hip.so (include/ccsp.h).
 """
-from . import checker, noise, sharding, worlds  # noqa: F401
+from . import checker, noise, sharding, transforms, worlds  # noqa: F401
 from ._lib import CcspError, build, device_info  # noqa: F401
 from .denoise_fn import ComposedEBMDenoiseFn, ConstraintDiffuser  # noqa: F401
 from .ddpm import GaussianDiffusion  # noqa: F401

@@ -163,6 +163,66 @@ def gen_labeller():
     print('labeller.npz')
 
 
+def gen_pre_transform():
+    """raw graphs -> normalised Data rows by the reference's data_transform_cn_diffuse_batch
+    (networks/data_transforms.py:26-200) and stability_data_json_to_pt (:272-303)"""
+    import data_transforms as dt
+    from torch_geometric.data import Data
+    rng = np.random.default_rng(7)
+    rec = {}
+    names = {'qualitative': worlds.QUALITATIVE_CONSTRAINTS, 'diffuse_pairwise': worlds.PUZZLE_CONSTRAINTS,
+             'stability_flat': worlds.STABILITY_CONSTRAINTS, 'robot_box': worlds.ROBOT_CONSTRAINTS}
+
+    def run(tag, raw_x, raw_edges, mode):
+        d = Data(x=torch.tensor(raw_x, dtype=torch.float), edge_index=[tuple(e) for e in raw_edges], y=None)
+        out = dt.data_transform_cn_diffuse_batch(d, 0, mode)[0]
+        rec[tag + '/mode'] = np.asarray(mode)
+        rec[tag + '/raw_x'] = np.asarray(raw_x, dtype=np.float64)
+        rec[tag + '/raw_edges'] = np.asarray([[names[mode].index(e[0]), e[1], e[2]] for e in raw_edges], dtype=np.int64)
+        rec[tag + '/x'] = out.x.numpy()
+        rec[tag + '/edge_index'] = out.edge_index.numpy()
+        rec[tag + '/edge_attr'] = out.edge_attr.numpy()
+        rec[tag + '/mask'] = out.mask.numpy()
+        rec[tag + '/world_dims'] = np.asarray(out.world_dims, dtype=np.float64)
+
+    for i in range(3):                                       # qualitative worlds from the generator
+        wd = worlds.sample_qualitative_world(rng, int(rng.integers(2, 7)))
+        run('q%d' % i, wd['nodes'], wd['constraints'], 'qualitative')
+    # triangle P1 with sin/cos (8 columns) and with theta (7 columns), plain boxes (5 columns)
+    n = 5
+    tri8 = [[0, 3, 3, 0, 0, 0, 0, 0]] + [[1] + rng.uniform(0.2, 1.0, 3).tolist() + rng.uniform(-1, 1, 2).tolist()
+                                           + [np.cos(a), np.sin(a)] for a in rng.uniform(-3, 3, n)]
+    edges = [('in', i, 0) for i in range(1, n + 1)] + [('cfree', i, j) for i in range(1, n) for j in range(i + 1, n + 1)]
+    run('tri8', tri8, edges, 'diffuse_pairwise')
+    tri7 = [[0, 3, 3, 0, 0, 0, 0]] + [[1] + rng.uniform(0.2, 1.0, 3).tolist() + rng.uniform(-1, 1, 2).tolist() + [a]
+                                       for a in rng.uniform(-3, 3, n)]
+    run('tri7', tri7, edges, 'diffuse_pairwise')
+    box5 = [[0, 3, 2, 0, 0]] + [[1] + rng.uniform(0.2, 1.0, 2).tolist() + rng.uniform(-1, 1, 2).tolist() for _ in range(n)]
+    run('box5', box5, edges, 'diffuse_pairwise')
+    # stability: json -> raw graph -> Data
+    container = dict(shelf_extent=[1.2, 0.8, 0.02], shelf_pose=[0.3, -0.1, 0.5])
+    placements = [dict(extents=rng.uniform(0.1, 0.4, 3).tolist(), centroid=(rng.uniform(-0.4, 0.4, 3) + [0.3, -0.1, 0.6]).tolist(),
+                       theta=float(rng.uniform(-1.5, 1.5))) for _ in range(4)]
+    supports = [(2, 1), (4, 3)]
+    sd = dt.stability_data_json_to_pt(dict(container=container, placements=placements, supports=supports), 'x', 'stability_flat')
+    rec['stab/container_extent'] = np.asarray(container['shelf_extent'])
+    rec['stab/container_pose'] = np.asarray(container['shelf_pose'])
+    rec['stab/extents'] = np.asarray([p['extents'] for p in placements])
+    rec['stab/centroids'] = np.asarray([p['centroid'] for p in placements])
+    rec['stab/thetas'] = np.asarray([p['theta'] for p in placements])
+    rec['stab/supports'] = np.asarray(supports, dtype=np.int64)
+    rec['stab/ref_raw_x'] = sd.x.numpy()
+    rec['stab/ref_raw_edges'] = np.asarray([[worlds.STABILITY_CONSTRAINTS.index(e[0]), e[1], e[2]] for e in sd.edge_index], dtype=np.int64)
+    run('stab', sd.x.numpy().astype(np.float64), sd.edge_index, 'stability_flat')
+    # robot rows (29 columns): geometry 8 + the rest, world_dims from the container row
+    rob = worlds.robot_box_batch(1, 4, seed=3)
+    raw = np.concatenate([np.asarray([[0]] + [[1]] * 4, dtype=np.float64), rob.x.astype(np.float64)], axis=1)
+    redges = [('gin', i, 0) for i in range(1, 5)] + [('gfree', j, i) for i in range(1, 4) for j in range(i + 1, 5)]
+    run('robot', raw, redges, 'robot_box')
+    np.savez_compressed(os.path.join(GOLD, 'pre_transform.npz'), **rec)
+    print('pre_transform.npz')
+
+
 def synth_weights(mode, H, seed):
     """untrained nn.Linear-style weights (single evaluations do not need contractive weights)"""
     dims = worlds.MODE_DIMS[mode]
@@ -274,4 +334,6 @@ if __name__ == '__main__':
         gen_labeller()
     if not which or 'single_eval' in which:
         gen_single_eval()
+    if not which or 'pre_transform' in which:
+        gen_pre_transform()
     gen_chains(which)
