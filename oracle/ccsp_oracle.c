@@ -31,6 +31,10 @@ struct ccspo_model {
     int K_in;                 /* 5H, or 6H for robot modes (denoise_fn.py:298-303) */
     linear_t ge0, ge2, gr0, gr2, pe0, pe2, pd0, pd2, tm1, tm3;
     linear_t* mlps;
+    /* StructDiffusion baseline (denoise_fn.py:270-282): 4 pre-LN blocks, 2 heads, max 8 tokens */
+    int W;                    /* transformer width: 2H, or 3H for robot modes */
+    linear_t ln_pre, ln_post; /* LayerNorm weight/bias stored as w[1 x W], b[W] */
+    linear_t sd_in[4], sd_out[4], sd_ln1[4], sd_fc[4], sd_proj[4], sd_ln2[4];
     /* schedule buffers, fp32 like the reference's registered buffers (ddpm.py:200-226) */
     float *betas, *ac, *acp, *sqrt_recip_ac, *sqrt_recipm1_ac, *post_lv, *post_var, *coef1, *coef2, *kappa, *step;
     int32_t* sps;
@@ -48,16 +52,20 @@ struct ccspo_graph {
     real* grasp_emb;          /* [N,H] or NULL */
     int* order;               /* edges in evaluation order: type asc, then original order */
     int n_active;
+    int64_t* seq_batch;       /* StructDiffusion: graph id per node, or NULL */
+    int64_t* seq_shuffled;    /* batch.shuffled or NULL */
 };
 
 static void* xcalloc(size_t n, size_t sz) { void* p = calloc(n ? n : 1, sz); if (!p) { fprintf(stderr, "ccspo: out of memory\n"); abort(); } return p; }
 
 static void lin_load(linear_t* L, int out, int in, const float* w, const float* b) {
+    /* out == 1 is used for LayerNorm parameters: weight [in], bias [in] */
+    const int nb = out == 1 ? in : out;
     L->in = in; L->out = out;
     L->w = (real*)xcalloc((size_t)out * in, sizeof(real));
-    L->b = (real*)xcalloc((size_t)out, sizeof(real));
+    L->b = (real*)xcalloc((size_t)nb, sizeof(real));
     for (size_t i = 0; i < (size_t)out * in; ++i) L->w[i] = (real)w[i];
-    for (int i = 0; i < out; ++i) L->b[i] = (real)b[i];
+    for (int i = 0; i < nb; ++i) L->b[i] = (real)b[i];
 }
 static void lin_free(linear_t* L) { free(L->w); free(L->b); L->w = L->b = NULL; }
 
@@ -84,6 +92,7 @@ static void lin_bwd_in(const linear_t* L, const real* gy, real* gx, int col0, in
 }
 
 static inline real r_exp(real v) { return sizeof(real) == 4 ? (real)expf((float)v) : (real)exp((double)v); }
+static inline real r_sqrt(real v) { return sizeof(real) == 4 ? (real)sqrtf((float)v) : (real)sqrt((double)v); }
 static inline real sigmoid_(real v) { return (real)1 / ((real)1 + r_exp(-v)); }
 static inline real silu(real v) { return v * sigmoid_(v); }                     /* nn.SiLU */
 static inline real silu_grad(real v) { real s = sigmoid_(v); return s * ((real)1 + v * ((real)1 - s)); }
@@ -172,8 +181,24 @@ int ccspo_model_create(const ccspo_desc* d, const float* const* p, ccspo_model**
     lin_load(&m->pd2, P, H / 2, p[k], p[k + 1]); k += 2;
     lin_load(&m->tm1, 4 * H, H, p[k], p[k + 1]); k += 2;                     /* denoise_fn.py:259-264 */
     lin_load(&m->tm3, H, 4 * H, p[k], p[k + 1]); k += 2;
+    m->W = H * (d->grasp_dim > 0 ? 3 : 2);
+    if (d->model_kind == 1) {
+        int W = m->W;
+        lin_load(&m->ln_pre, 1, W, p[k], p[k + 1]); k += 2;              /* LayerNorm: weight as [1,W], bias... */
+        for (int l = 0; l < 4; ++l) {                                     /* transformer.py:43-71 */
+            lin_load(&m->sd_in[l], 3 * W, W, p[k], p[k + 1]); k += 2;
+            lin_load(&m->sd_out[l], W, W, p[k], p[k + 1]); k += 2;
+            lin_load(&m->sd_ln1[l], 1, W, p[k], p[k + 1]); k += 2;
+            lin_load(&m->sd_fc[l], 4 * W, W, p[k], p[k + 1]); k += 2;
+            lin_load(&m->sd_proj[l], W, 4 * W, p[k], p[k + 1]); k += 2;
+            lin_load(&m->sd_ln2[l], 1, W, p[k], p[k + 1]); k += 2;
+        }
+        lin_load(&m->ln_post, 1, W, p[k], p[k + 1]); k += 2;
+        m->mlps = NULL;
+    } else {
     m->mlps = (linear_t*)xcalloc(d->n_types, sizeof(linear_t));
     for (int i = 0; i < d->n_types; ++i) { lin_load(&m->mlps[i], 2 * H, m->K_in, p[k], p[k + 1]); k += 2; }
+    }
     float** bufs[] = { &m->betas, &m->ac, &m->acp, &m->sqrt_recip_ac, &m->sqrt_recipm1_ac, &m->post_lv,
                        &m->post_var, &m->coef1, &m->coef2, &m->kappa, &m->step };
     for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); ++i) *bufs[i] = (float*)xcalloc(T, sizeof(float));
@@ -190,8 +215,10 @@ void ccspo_model_destroy(ccspo_model* m) {
     lin_free(&m->ge0); lin_free(&m->ge2); lin_free(&m->gr0); lin_free(&m->gr2);
     lin_free(&m->pe0); lin_free(&m->pe2); lin_free(&m->pd0); lin_free(&m->pd2);
     lin_free(&m->tm1); lin_free(&m->tm3);
-    for (int i = 0; i < m->d.n_types; ++i) lin_free(&m->mlps[i]);
+    if (m->mlps) for (int i = 0; i < m->d.n_types; ++i) lin_free(&m->mlps[i]);
     free(m->mlps);
+    lin_free(&m->ln_pre); lin_free(&m->ln_post);
+    for (int l = 0; l < 4; ++l) { lin_free(&m->sd_in[l]); lin_free(&m->sd_out[l]); lin_free(&m->sd_ln1[l]); lin_free(&m->sd_fc[l]); lin_free(&m->sd_proj[l]); lin_free(&m->sd_ln2[l]); }
     free(m->betas); free(m->ac); free(m->acp); free(m->sqrt_recip_ac); free(m->sqrt_recipm1_ac);
     free(m->post_lv); free(m->post_var); free(m->coef1); free(m->coef2); free(m->kappa); free(m->step);
     free(m->sps); free(m->temb); free(m->temb_ok);
@@ -295,6 +322,7 @@ int ccspo_graph_create(ccspo_model* m, int32_t N, int32_t E, int32_t F, const fl
 void ccspo_graph_destroy(ccspo_graph* g) {
     if (!g) return;
     free(g->x); free(g->ei); free(g->etype); free(g->mask); free(g->geoms_emb); free(g->grasp_emb); free(g->order);
+    free(g->seq_batch); free(g->seq_shuffled);
     free(g);
 }
 
@@ -396,9 +424,151 @@ static void eval_forward(ccspo_model* m, const ccspo_graph* g, eval_ws* ws, int 
     free(ga);
 }
 
+int ccspo_graph_set_sequences(ccspo_graph* g, const int64_t* batch, const int64_t* shuffled) {
+    if (!g || !batch) FAIL("graph_set_sequences: null argument");
+    free(g->seq_batch); free(g->seq_shuffled);
+    g->seq_batch = (int64_t*)xcalloc(g->N, sizeof(int64_t));
+    memcpy(g->seq_batch, batch, sizeof(int64_t) * g->N);
+    g->seq_shuffled = NULL;
+    if (shuffled) {
+        g->seq_shuffled = (int64_t*)xcalloc(g->N, sizeof(int64_t));
+        memcpy(g->seq_shuffled, shuffled, sizeof(int64_t) * g->N);
+    }
+    return 0;
+}
+
+static void layer_norm(const linear_t* ln, const real* x, real* y, int W) {      /* nn.LayerNorm, eps 1e-5 */
+    real mean = 0, var = 0;
+    for (int k = 0; k < W; ++k) mean += x[k];
+    mean /= (real)W;
+    for (int k = 0; k < W; ++k) { real dlt = x[k] - mean; var += dlt * dlt; }
+    var /= (real)W;
+    real inv = (real)1 / r_sqrt(var + (real)1e-5);
+    for (int k = 0; k < W; ++k) y[k] = (x[k] - mean) * inv * ln->w[k] + ln->b[k];
+}
+
+/* _forward_struct_diffusion (denoise_fn.py:391-451) + Transformer (transformer.py:43-82), eval mode.
+ * Quirks kept: the pad mask is a FLOAT 0/1 tensor added to the scores (:426-428); with no padding
+ * `[-0:]` selects everything (all ones); the per-head mask of (graph b, head h) is the mask of graph
+ * (b*heads + h) mod B because of the `(repeat b)` ordering (:434); ln_2 is applied to the MLP output. */
+static int struct_diffusion_real(ccspo_model* m, const ccspo_graph* g, eval_ws* ws, int t, real* out) {
+    const ccspo_desc* d = &m->d;
+    const int H = d->hidden_dim, P = d->pose_dim, N = g->N, W = m->W, L = 8, NH = 2, DH = W / NH;
+    if (!g->seq_batch) FAIL("StructDiffusion needs ccspo_graph_set_sequences (batch.batch)");
+    const real* temb = time_emb(m, t);
+    for (int n = 0; n < N; ++n)
+        encode(&m->pe0, &m->pe2, ws->poses + (size_t)n * P, ws->pemb + (size_t)n * H, NULL, NULL);
+    int B = 0;
+    for (int n = 0; n < N; ++n) if ((int)g->seq_batch[n] + 1 > B) B = (int)g->seq_batch[n] + 1;
+    int* cnt = (int*)xcalloc(B, sizeof(int));
+    int* node_of = (int*)xcalloc((size_t)B * L, sizeof(int));
+    for (int n = 0; n < N; ++n) {
+        int b = (int)g->seq_batch[n];
+        if (cnt[b] >= L) { free(cnt); free(node_of); FAIL("StructDiffusion: a graph has more than 8 nodes (max_seq_len, denoise_fn.py:272)"); }
+        node_of[b * L + cnt[b]++] = n;
+    }
+    real* X = (real*)xcalloc((size_t)B * L * W, sizeof(real));
+    real* Y = (real*)xcalloc((size_t)B * L * W, sizeof(real));
+    real* QKV = (real*)xcalloc((size_t)B * L * 3 * W, sizeof(real));
+    real* A = (real*)xcalloc((size_t)B * L * W, sizeof(real));
+    real* F = (real*)xcalloc((size_t)B * L * 4 * W, sizeof(real));
+    real* T = (real*)xcalloc((size_t)W, sizeof(real));
+    real* seq = (real*)xcalloc((size_t)W, sizeof(real));
+    /* positional encoding rows (transformer.py:22-28): fp32 arithmetic like the reference */
+    for (int b = 0; b < B; ++b)
+        for (int l = 0; l < cnt[b]; ++l) {
+            int n = node_of[b * L + l];
+            int off = 0;
+            if (d->grasp_dim > 0) { memcpy(seq, g->grasp_emb + (size_t)n * H, sizeof(real) * H); off = H; }
+            memcpy(seq + off, g->geoms_emb + (size_t)n * H, sizeof(real) * H);
+            for (int k = 0; k < H; ++k) seq[off + H + k] = ws->pemb[(size_t)n * H + k] + temb[k];
+            int pos = g->seq_shuffled ? (int)g->seq_shuffled[n] : l;
+            for (int k = 0; k < W; k += 2) {
+                real pe_s, pe_c;
+                if (sizeof(real) == 4) {
+                    float dv = expf((float)k * (float)(-(log(10000.0) / (double)W)));
+                    float a = (float)pos * dv;
+                    pe_s = (real)sinf(a); pe_c = (real)cosf(a);
+                } else {
+                    double a = (double)pos * exp((double)k * -(log(10000.0) / (double)W));
+                    pe_s = (real)sin(a); pe_c = (real)cos(a);
+                }
+                seq[k] += pe_s; seq[k + 1] += pe_c;
+            }
+            layer_norm(&m->ln_pre, seq, X + ((size_t)b * L + l) * W, W);
+        }
+    /* pad masks */
+    real* mask = (real*)xcalloc((size_t)B * L * L, sizeof(real));
+    for (int b = 0; b < B; ++b) {
+        int pad = L - cnt[b];
+        int from = pad == 0 ? 0 : L - pad;                              /* [-0:] == everything */
+        for (int i = 0; i < L; ++i)
+            for (int j = 0; j < L; ++j) mask[((size_t)b * L + i) * L + j] = (i >= from || j >= from) ? (real)1 : (real)0;
+    }
+    const real scale = (real)1 / r_sqrt((real)DH);
+    for (int l4 = 0; l4 < 4; ++l4) {
+        for (int r = 0; r < B * L; ++r) {
+            layer_norm(&m->sd_ln1[l4], X + (size_t)r * W, Y + (size_t)r * W, W);
+            lin_fwd(&m->sd_in[l4], Y + (size_t)r * W, QKV + (size_t)r * 3 * W);
+        }
+        for (int b = 0; b < B; ++b)
+            for (int h = 0; h < NH; ++h) {
+                const real* mk = mask + (size_t)((b * NH + h) % B) * L * L;
+                for (int i = 0; i < L; ++i) {
+                    real sc[8], mx = -INFINITY, den = 0;
+                    const real* q = QKV + ((size_t)b * L + i) * 3 * W + h * DH;
+                    for (int j = 0; j < L; ++j) {
+                        const real* kk = QKV + ((size_t)b * L + j) * 3 * W + W + h * DH;
+                        real dt = 0;
+                        for (int c = 0; c < DH; ++c) dt += (q[c] * scale) * kk[c];
+                        sc[j] = dt + mk[i * L + j];
+                        if (sc[j] > mx) mx = sc[j];
+                    }
+                    for (int j = 0; j < L; ++j) { sc[j] = r_exp(sc[j] - mx); den += sc[j]; }
+                    real* o = A + ((size_t)b * L + i) * W + h * DH;
+                    for (int c = 0; c < DH; ++c) o[c] = 0;
+                    for (int j = 0; j < L; ++j) {
+                        const real* v = QKV + ((size_t)b * L + j) * 3 * W + 2 * W + h * DH;
+                        real pj = sc[j] / den;
+                        for (int c = 0; c < DH; ++c) o[c] += pj * v[c];
+                    }
+                }
+            }
+        for (int r = 0; r < B * L; ++r) {
+            real* x = X + (size_t)r * W;
+            lin_fwd(&m->sd_out[l4], A + (size_t)r * W, T);
+            for (int k = 0; k < W; ++k) x[k] += T[k];
+            real* f = F + (size_t)r * 4 * W;
+            lin_fwd(&m->sd_fc[l4], x, f);
+            for (int k = 0; k < 4 * W; ++k) f[k] = f[k] * sigmoid_((real)1.702 * f[k]);       /* QuickGELU */
+            lin_fwd(&m->sd_proj[l4], f, T);
+            layer_norm(&m->sd_ln2[l4], T, Y + (size_t)r * W, W);
+            for (int k = 0; k < W; ++k) x[k] += Y[(size_t)r * W + k];
+        }
+    }
+    real q1[1024], s1v[1024];
+    for (int b = 0; b < B; ++b)
+        for (int l = 0; l < cnt[b]; ++l) {
+            int n = node_of[b * L + l];
+            layer_norm(&m->ln_post, X + ((size_t)b * L + l) * W, Y, W);
+            lin_fwd(&m->pd0, Y + (W - H), q1);                                  /* x[:, :, -H:] -> pose_decoder */
+            for (int k = 0; k < H / 2; ++k) s1v[k] = silu(q1[k]);
+            lin_fwd(&m->pd2, s1v, out + (size_t)n * P);
+        }
+    for (int n = 0; n < N; ++n)
+        if (g->mask[n]) for (int p = 0; p < P; ++p) out[(size_t)n * P + p] = g->x[(size_t)n * g->F + g->F - P + p];
+    free(cnt); free(node_of); free(X); free(Y); free(QKV); free(A); free(F); free(T); free(seq); free(mask);
+    return 0;
+}
+
 /* ConstraintDiffuser.forward, direct mode (denoise_fn.py:508-537) */
 static void denoise_real(ccspo_model* m, const ccspo_graph* g, eval_ws* ws, int t, real* out) {
     int P = m->d.pose_dim, N = g->N;
+    if (m->d.model_kind == 1) {
+        if (struct_diffusion_real(m, g, ws, t, out))
+            for (size_t i = 0; i < (size_t)N * P; ++i) out[i] = NAN;
+        return;
+    }
     eval_forward(m, g, ws, t, 0, NULL);
     real* cnt = (real*)xcalloc(N, sizeof(real));
     memset(out, 0, sizeof(real) * (size_t)N * P);
@@ -562,7 +732,6 @@ static int steps_at(const ccspo_model* m, int sampler, int t) {
     return m->sps[t];
 }
 
-static inline real r_sqrt(real v) { return sizeof(real) == 4 ? (real)sqrtf((float)v) : (real)sqrt((double)v); }
 static inline real r_log(real v) { return sizeof(real) == 4 ? (real)logf((float)v) : (real)log((double)v); }
 
 int ccspo_chain_run(ccspo_model* m, ccspo_graph* g, int32_t sampler, const ccspo_noise* nz,

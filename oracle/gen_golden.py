@@ -76,13 +76,14 @@ class PatchedNoise(object):
         torch.randn, torch.rand = self.orig
 
 
-def build_reference(mode, H, weights, energy=False, EBM='ULA', T=1000, S=10, dtype=torch.float32):
+def build_reference(mode, H, weights, energy=False, EBM='ULA', T=1000, S=10, dtype=torch.float32,
+                    model_name='Diffusion-CCSP'):
     dims = worlds.MODE_DIMS[mode]
     if dtype == torch.float64:
         torch.set_default_dtype(torch.float64)
     try:
         model = dfn.ConstraintDiffuser(dims=dims, hidden_dim=H, EBM=EBM, input_mode=mode, energy_wrapper=energy,
-                                       device='cpu', verbose=False)
+                                       device='cpu', verbose=False, model=model_name)
         model.load_state_dict({k: torch.from_numpy(v).to(dtype) for k, v in weights.items()})
         den = dfn.ComposedEBMDenoiseFn(model) if energy else model
         gd = ddpm.GaussianDiffusion(den, timesteps=T, EBM=EBM, samples_per_step=S, step_sizes='2*self.betas')
@@ -103,9 +104,10 @@ def batch_arrays(b):
 HIST_IDX = [0, 1, 2, 3, 4, 5, 10, 50, 100, 200, 300, 400, 500, 600, 700, 800, 900, 950, 990, 998, 999, 1000]
 
 
-def run_chain(name, mode, H, wfile, batch, EBM, T=1000, S=10, seed=7, energy=False, dtype=torch.float32):
+def run_chain(name, mode, H, wfile, batch, EBM, T=1000, S=10, seed=7, energy=False, dtype=torch.float32,
+              model_name='Diffusion-CCSP'):
     W = oracle_mod.load_weights(os.path.join(GOLD, wfile))
-    model, gd = build_reference(mode, H, W, energy=energy, EBM=EBM, T=T, S=S, dtype=dtype)
+    model, gd = build_reference(mode, H, W, energy=energy, EBM=EBM, T=T, S=S, dtype=dtype, model_name=model_name)
     b = batch.clone()
     if dtype == torch.float64:
         b.x = b.x.double()
@@ -121,11 +123,15 @@ def run_chain(name, mode, H, wfile, batch, EBM, T=1000, S=10, seed=7, energy=Fal
     hist = np.stack([h.detach().numpy() for h in hist])
     idx = sorted(set(i for i in HIST_IDX if i <= T) | {T})
     rec = dict(batch_arrays(batch))
+    if model_name == 'StructDiffusion':
+        rec['batch'] = batch.batch.numpy().astype(np.int64)
+        if hasattr(batch, 'shuffled'):
+            rec['shuffled'] = batch.shuffled.numpy().astype(np.int64)
     rec.update(final=out.astype(np.float64 if dtype == torch.float64 else np.float32),
                hist_idx=np.asarray(idx, dtype=np.int32), hist=hist[idx].astype(out.dtype),
                seed=np.int64(seed), T=np.int32(T), S=np.int32(S), H=np.int32(H), n_randn=np.int64(pn.c),
                n_rand=np.int64(pn.uc), ref_seconds=np.float64(dt), threads=np.int32(torch.get_num_threads()))
-    meta = dict(mode=mode, EBM=str(EBM), weights=wfile, energy=bool(energy), dtype=str(dtype))
+    meta = dict(mode=mode, EBM=str(EBM), weights=wfile, energy=bool(energy), dtype=str(dtype), model=model_name)
     np.savez_compressed(os.path.join(GOLD, name + '.npz'), meta=np.asarray(repr(meta)), **rec)
     print('%-34s %6.1fs  randn calls %d  |final|max %.3f  |hist|max %.3g' %
           (name, dt, pn.c, np.abs(out).max(), np.abs(hist).max()), flush=True)
@@ -288,8 +294,55 @@ def gen_single_eval():
     print('single_eval.npz')
 
 
+def sd_batch(sizes, seed, shuffled=False):
+    """qualitative graphs with the given numbers of tiles (<= 7: 8 tokens with the container)"""
+    rng = np.random.default_rng(seed)
+    gs = []
+    for n in sizes:
+        wd = worlds.sample_qualitative_world(rng, n)
+        gs.append(worlds.encode_qualitative(wd['nodes'], wd['constraints']))
+    b = worlds.collate(gs).to_torch()
+    if shuffled:                                   # data.py-style per-graph permutation of the token positions
+        sh = [torch.from_numpy(rng.permutation(n + 1)) for n in sizes]
+        b.shuffled = torch.cat(sh).long()
+    return b
+
+
+def gen_struct_diffusion():
+    """single evaluations of the StructDiffusion baseline (denoise_fn.py:391-451): ragged graphs (3, 6, 8
+    tokens -> padded and unpadded masks, head/graph mask mix-up with B = 3 and B = 2), batch.shuffled"""
+    rec = {}
+    rng = np.random.default_rng(123)
+    wfile = 'weights_qualitative_h64_sd.npz'
+    W = oracle_mod.load_weights(os.path.join(GOLD, wfile))
+    model, gd = build_reference('qualitative', 64, W, model_name='StructDiffusion')
+    cases = [('ragged3', sd_batch((2, 5, 7), 51)), ('full2', sd_batch((7, 7), 52)), ('single', sd_batch((3,), 53)),
+             ('shuffled', sd_batch((4, 7, 2, 6), 54, shuffled=True))]
+    for tag, b in cases:
+        for key, val in batch_arrays(b).items():
+            rec['%s/%s' % (tag, key)] = val
+        rec['%s/batch' % tag] = b.batch.numpy().astype(np.int64)
+        if hasattr(b, 'shuffled'):
+            rec['%s/shuffled' % tag] = b.shuffled.numpy().astype(np.int64)
+        ts = [0, 3, 500, 999]
+        poses = (rng.standard_normal((len(ts), b.x.shape[0], 4)) * 0.7).astype(np.float32)
+        outs = []
+        for i, t in enumerate(ts):
+            with torch.no_grad():
+                outs.append(model(torch.from_numpy(poses[i]).clone(), b, torch.tensor([t]), eval=True).numpy())
+        rec['%s/t' % tag] = np.asarray(ts, dtype=np.int32)
+        rec['%s/poses' % tag] = poses
+        rec['%s/out' % tag] = np.stack(outs)
+    np.savez_compressed(os.path.join(GOLD, 'struct_diffusion.npz'), **rec)
+    print('struct_diffusion.npz')
+
+
 def gen_chains(which):
     jobs = {
+        'chain_sd64_ula': lambda: run_chain('chain_sd64_ula', 'qualitative', 64, 'weights_qualitative_h64_sd.npz',
+                                            sd_batch((3, 7, 5), 61), 'ULA', S=4, model_name='StructDiffusion'),
+        'chain_sd64_noebm': lambda: run_chain('chain_sd64_noebm', 'qualitative', 64, 'weights_qualitative_h64_sd.npz',
+                                              sd_batch((6, 2), 62), False, model_name='StructDiffusion'),
         'chain_q64_T1000_B4': lambda: run_chain('chain_q64_T1000_B4', 'qualitative', 64, 'weights_qualitative_h64.npz',
                                                 worlds.qualitative_batch(4, 8, seed=31).to_torch(), 'ULA'),
         'chain_q64_T100_B1': lambda: run_chain('chain_q64_T100_B1', 'qualitative', 64, 'weights_qualitative_h64.npz',
@@ -336,4 +389,6 @@ if __name__ == '__main__':
         gen_single_eval()
     if not which or 'pre_transform' in which:
         gen_pre_transform()
+    if not which or 'struct_diffusion' in which:
+        gen_struct_diffusion()
     gen_chains(which)

@@ -20,7 +20,7 @@ SCHEDULE_KEYS = ['betas', 'alphas_cumprod', 'alphas_cumprod_prev', 'sqrt_recip_a
 class Desc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'hidden_dim', 'pose_dim', 'pose_begin', 'geom_dim', 'grasp_dim', 'grasp_begin', 'n_types',
-        'timesteps', 'normalize', 'energy_wrapper', 'ebm_per_steps')]
+        'timesteps', 'normalize', 'energy_wrapper', 'ebm_per_steps', 'model_kind')]
 
 
 class Noise(C.Structure):
@@ -62,6 +62,7 @@ def lib(f64=False):
     L.ccspo_schedule_get.argtypes = [vp, C.c_int32, vp]
     L.ccspo_time_embedding.argtypes = [vp, C.c_int32, vp]
     L.ccspo_graph_create.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, C.POINTER(vp)]
+    L.ccspo_graph_set_sequences.argtypes = [vp, vp, vp]
     L.ccspo_graph_destroy.argtypes = [vp]
     L.ccspo_graph_destroy.restype = None
     L.ccspo_denoise.argtypes = [vp, vp, vp, C.c_int32, vp]
@@ -72,13 +73,23 @@ def lib(f64=False):
     return L
 
 
-def param_order(n_types, grasp):
+def param_order(n_types, grasp, struct_diffusion=False):
+    """(module name, weight key suffix, bias key suffix) in the order the C side expects"""
     names = ['geom_encoder.0', 'geom_encoder.2']
     if grasp:
         names += ['grasp_encoder.0', 'grasp_encoder.2']
     names += ['pose_encoder.0', 'pose_encoder.2', 'pose_decoder.0', 'pose_decoder.2', 'time_mlp.1', 'time_mlp.3']
-    names += ['mlps.%d.0' % i for i in range(n_types)]
-    return names
+    out = [(n, '.weight', '.bias') for n in names]
+    if not struct_diffusion:
+        return out + [('mlps.%d.0' % i, '.weight', '.bias') for i in range(n_types)]
+    out.append(('ln_pre', '.weight', '.bias'))
+    for l in range(4):
+        pre = 'transformer.resblocks.%d.' % l
+        out += [(pre + 'attn', '.in_proj_weight', '.in_proj_bias'), (pre + 'attn.out_proj', '.weight', '.bias'),
+                (pre + 'ln_1', '.weight', '.bias'), (pre + 'mlp.c_fc', '.weight', '.bias'),
+                (pre + 'mlp.c_proj', '.weight', '.bias'), (pre + 'ln_2', '.weight', '.bias')]
+    out.append(('ln_post', '.weight', '.bias'))
+    return out
 
 
 def _f32(a):
@@ -93,19 +104,20 @@ class OracleModel(object):
     """the denoiser + schedule of one GaussianDiffusion (reference networks/ddpm.py:168-228)"""
 
     def __init__(self, weights, dims, hidden_dim, n_types, timesteps=1000, normalize=True,
-                 energy_wrapper=False, ebm_per_steps=1, samples_per_step=10, f64=False):
+                 energy_wrapper=False, ebm_per_steps=1, samples_per_step=10, f64=False, model='Diffusion-CCSP'):
         self.L = lib(f64)
         grasp = len(dims) == 3
         self.dims, self.H, self.P, self.T, self.C = dims, hidden_dim, dims[-1][0], timesteps, n_types
         d = Desc(hidden_dim=hidden_dim, pose_dim=dims[-1][0], pose_begin=dims[-1][1], geom_dim=dims[0][0],
                  grasp_dim=dims[1][0] if grasp else 0, grasp_begin=dims[1][1] if grasp else 0,
                  n_types=n_types, timesteps=timesteps, normalize=int(bool(normalize)),
-                 energy_wrapper=int(bool(energy_wrapper)), ebm_per_steps=ebm_per_steps)
+                 energy_wrapper=int(bool(energy_wrapper)), ebm_per_steps=ebm_per_steps,
+                 model_kind=int(model == 'StructDiffusion'))
         self.energy_wrapper = bool(energy_wrapper)
         self._keep = []
         ptrs = []
-        for name in param_order(n_types, grasp):
-            for suffix in ('.weight', '.bias'):
+        for name, ws, bs in param_order(n_types, grasp, model == 'StructDiffusion'):
+            for suffix in (ws, bs):
                 a = _f32(weights[name + suffix])
                 self._keep.append(a)
                 ptrs.append(a.ctypes.data)
@@ -173,6 +185,11 @@ class OracleGraph(object):
         model._check(L.ccspo_graph_create(model.h, self.N, self.E, self.F, _ptr(self.x), _ptr(self.ei),
                                           _ptr(self.ea), _ptr(self.mask), C.byref(h)))
         self.h = h
+        if getattr(batch, 'batch', None) is not None:
+            self.seq = np.ascontiguousarray(_np(batch.batch), dtype=np.int64)
+            sh = getattr(batch, 'shuffled', None)
+            self.shuf = None if sh is None else np.ascontiguousarray(_np(sh), dtype=np.int64)
+            model._check(L.ccspo_graph_set_sequences(h, _ptr(self.seq), None if self.shuf is None else _ptr(self.shuf)))
 
     def denoise(self, poses, t):
         p = _f32(poses)

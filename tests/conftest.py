@@ -38,8 +38,12 @@ def golden_meta(z):
 
 def golden_batch(z, prefix=''):
     import torch
-    return Batch(x=torch.from_numpy(z[prefix + 'x']), edge_index=torch.from_numpy(z[prefix + 'edge_index']),
-                 edge_attr=torch.from_numpy(z[prefix + 'edge_attr']), mask=torch.from_numpy(z[prefix + 'mask']))
+    b = Batch(x=torch.from_numpy(z[prefix + 'x']), edge_index=torch.from_numpy(z[prefix + 'edge_index']),
+              edge_attr=torch.from_numpy(z[prefix + 'edge_attr']), mask=torch.from_numpy(z[prefix + 'mask']))
+    for extra in ('batch', 'shuffled'):                      # StructDiffusion fixtures carry the sequences
+        if prefix + extra in z.files:
+            setattr(b, extra, torch.from_numpy(z[prefix + extra]))
+    return b
 
 
 MODE_TYPES = {'qualitative': 13, 'diffuse_pairwise': 2, 'robot_box': 2, 'stability_flat': 3}
@@ -52,9 +56,9 @@ def weights(wfile):
     return _weights[wfile]
 
 
-def oracle_model(mode, H, wfile, T=1000, S=10, energy=False, f64=False):
+def oracle_model(mode, H, wfile, T=1000, S=10, energy=False, f64=False, model='Diffusion-CCSP'):
     return oracle.OracleModel(weights(wfile), worlds.MODE_DIMS[mode], H, MODE_TYPES[mode], timesteps=T,
-                              energy_wrapper=energy, samples_per_step=S, f64=f64)
+                              energy_wrapper=energy, samples_per_step=S, f64=f64, model=model)
 
 
 def rel_err(a, b):

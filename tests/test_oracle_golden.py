@@ -66,7 +66,8 @@ CHAINS = ['chain_q64_T1000_B4', 'chain_q64_T100_B1', 'chain_q256_T100_B1', 'chai
 def _run_oracle_chain(z, f64=False, history=True):
     meta = golden_meta(z)
     EBM = {'False': False}.get(meta['EBM'], meta['EBM'])
-    m = oracle_model(meta['mode'], int(z['H']), meta['weights'], T=int(z['T']), S=int(z['S']), energy=meta['energy'], f64=f64)
+    m = oracle_model(meta['mode'], int(z['H']), meta['weights'], T=int(z['T']), S=int(z['S']), energy=meta['energy'], f64=f64,
+                     model=meta.get('model', 'Diffusion-CCSP'))
     g = m.graph(golden_batch(z))
     return g.chain(EBM, seed=int(z['seed']), history=history)
 
@@ -81,6 +82,45 @@ def test_full_chain_final_poses(name):
     # history checkpoints (relative: early timesteps pass through very large transients)
     for k, idx in enumerate(z['hist_idx']):
         assert rel_err(hist[idx], z['hist'][k]) < 2e-3, (name, int(idx))
+
+
+SD_CASES = ['ragged3', 'full2', 'single', 'shuffled']
+
+
+@pytest.mark.parametrize('tag', SD_CASES)
+def test_struct_diffusion_single_evaluation(tag):
+    """the transformer baseline: ragged token counts, the all-ones mask of an unpadded graph,
+    the head/graph mask mix-up and batch.shuffled are all in these cases"""
+    z = golden('struct_diffusion')
+    m = oracle_model('qualitative', 64, 'weights_qualitative_h64_sd.npz', model='StructDiffusion')
+    g = m.graph(golden_batch(z, tag + '/'))
+    for i, t in enumerate(z[tag + '/t']):
+        out = g.denoise(z[tag + '/poses'][i], int(t))
+        assert rel_err(out, z[tag + '/out'][i]) < 2e-5, (tag, int(t))
+
+
+def test_struct_diffusion_rejects_long_sequences():
+    m = oracle_model('qualitative', 64, 'weights_qualitative_h64_sd.npz', model='StructDiffusion')
+    b = worlds.qualitative_batch(1, 8, seed=3)                 # 9 tokens > max_seq_len 8: the reference raises too
+    g = m.graph(b)
+    out = g.denoise(np.zeros((9, 4), dtype=np.float32), 5)
+    assert np.isnan(out).all()
+
+
+def test_struct_diffusion_chains():
+    z = golden('chain_sd64_ula')
+    final, hist = _run_oracle_chain(z)
+    assert np.abs(final - z['final']).max() < 1e-4
+    for k, idx in enumerate(z['hist_idx']):
+        assert rel_err(hist[idx], z['hist'][k]) < 2e-3, int(idx)
+    # plain ancestral sampling with B = 2 drifts linearly to |x| ~ 1e3 in the reference itself (graph 1 attends
+    # with graph 0's pad mask, denoise_fn.py:434): parity is relative there
+    z = golden('chain_sd64_noebm')
+    final, hist = _run_oracle_chain(z)
+    assert np.abs(z['final']).max() > 100.0
+    assert rel_err(final, z['final']) < 1e-4
+    for k, idx in enumerate(z['hist_idx']):
+        assert rel_err(hist[idx], z['hist'][k]) < 1e-4, int(idx)
 
 
 MALA_SEGMENTS = [(0, 1), (1, 2), (50, 100), (100, 200), (200, 300), (900, 950), (950, 990), (990, 998),
