@@ -25,7 +25,7 @@ class CcspError(RuntimeError):
 class ModelDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'hidden_dim', 'pose_dim', 'pose_begin', 'geom_dim', 'grasp_dim', 'grasp_begin', 'n_types',
-        'timesteps', 'normalize', 'energy_wrapper', 'ebm_per_steps')]
+        'timesteps', 'normalize', 'energy_wrapper', 'ebm_per_steps', 'model_kind')]
 
 
 class Noise(C.Structure):
@@ -83,6 +83,7 @@ def lib():
     L.ccsp_time_embedding.argtypes = [vp, i32, vp, vp]
     L.ccsp_graph_create.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, C.POINTER(vp)]
     L.ccsp_graph_destroy.argtypes = [vp]
+    L.ccsp_graph_set_sequences.argtypes = [vp, vp, vp, vp]
     L.ccsp_graph_destroy.restype = None
     L.ccsp_denoise.argtypes = [vp, vp, vp, i32, vp, vp]
     L.ccsp_energy_grad.argtypes = [vp, vp, vp, i32, vp, vp, vp]

@@ -742,6 +742,7 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, float* __restr
 
 #include "ccsp_energy.h"
 #include "ccsp_bf16x3.h"
+#include "ccsp_struct.h"
 
 // NaN rows for the edge-output debug API, then scatter sorted -> original order
 __global__ void k_fill(float* p, long n, float v) {
@@ -787,6 +788,12 @@ struct ccsp_model {
     int bf16x3;    // 1: direct-mode GEMMs on the bf16 matrix cores with 3-way split operands (ccsp_bf16x3.h)
     unsigned short* WpS;    // [3][C][2][2H][H] bf16 planes of Wp
     unsigned short* Wd1S;   // [3][H/2][H]      bf16 planes of pose_decoder.0.weight
+    // StructDiffusion baseline (model_kind 1): transformer weights as given ([out, in] row-major)
+    struct SdLayer { float *in_w, *in_b, *out_w, *out_b, *ln1_g, *ln1_b, *fc_w, *fc_b, *proj_w, *proj_b, *ln2_g, *ln2_b; };
+    int Wd = 0;            // transformer width: 2H, or 3H with a grasp group
+    float *lnpre_g = nullptr, *lnpre_b = nullptr, *lnpost_g = nullptr, *lnpost_b = nullptr;
+    float* sd_pe = nullptr;   // [8][Wd] positional-encoding rows (transformer.py:22-28)
+    SdLayer sd[4];
     float* temb;   // [T][H]
     float* tau;    // [T][C][2H]      W_t . temb(t) + b_i
     std::vector<float> betas, ac, acp, sqrt_recip_ac, sqrt_recipm1_ac, post_lv, post_var, coef1, coef2, kappa, step;
@@ -822,6 +829,12 @@ struct ccsp_graph {
     std::vector<ccsp_graph*> children;
     std::vector<int> child_node0;
     int lanes_tried = 0;
+    // StructDiffusion: token layout (ccsp_graph_set_sequences) and activations
+    bool seq_ready = false;
+    int sd_B = 0, sd_M = 0;
+    int *tok_node = nullptr, *tok_pos = nullptr, *node_tok = nullptr, *mask_from = nullptr;
+    float *gemb = nullptr, *remb = nullptr;
+    float *sdX = nullptr, *sdY = nullptr, *sdQKV = nullptr, *sdA = nullptr, *sdF = nullptr;
     // profiling
     int profile = 0;
     int64_t evals = 0;
@@ -915,6 +928,39 @@ NodeArgs node_args(ccsp_model* m, ccsp_graph* g) {
 template <int H>
 void launch_node(ccsp_model* m, ccsp_graph* g, const NodeArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_node<H>, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a, enc_pose(m), g->pemb);
+}
+
+// ---- StructDiffusion baseline ------------------------------------------------------------------
+template <int EPI>
+void sd_gemm(int M, int K, int N, const float* A, const float* W, const float* b, float* Cm, hipStream_t s) {
+    const int rt = nblk(M, TILE_M);
+    if (N % 128 == 0 && (long)rt * (N / 128) >= 512)
+        hipLaunchKernelGGL((k_sd_gemm<2, EPI>), dim3(rt * (N / 128)), dim3(256), 0, s, M, K, N, A, W, b, Cm);
+    else
+        hipLaunchKernelGGL((k_sd_gemm<1, EPI>), dim3(rt * (N / 64)), dim3(256), 0, s, M, K, N, A, W, b, Cm);
+}
+
+// one evaluation of the transformer at the poses whose embeddings are in g->pemb; result -> g->eps
+template <int H>
+int launch_eval_sd(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s) {
+    if (!g->seq_ready) return fail("StructDiffusion: call ccsp_graph_set_sequences (batch.batch) before evaluating");
+    const int M = g->sd_M, Wd = m->Wd, P = m->d.pose_dim;
+    hipLaunchKernelGGL(k_sd_embed, dim3(nblk(M, 4)), dim3(256), 0, s, M, H, Wd, m->d.grasp_dim > 0 ? 1 : 0, g->tok_node, g->tok_pos, g->gemb,
+                       g->remb, g->pemb, m->temb + (size_t)t * H, m->sd_pe, m->lnpre_g, m->lnpre_b, g->sdX);
+    for (int l = 0; l < SD_LAYERS; ++l) {
+        const ccsp_model::SdLayer& w = m->sd[l];
+        hipLaunchKernelGGL(k_sd_ln<0>, dim3(nblk(M, 4)), dim3(256), 0, s, M, Wd, g->sdX, w.ln1_g, w.ln1_b, g->sdY);
+        sd_gemm<SD_EPI_BIAS>(M, Wd, 3 * Wd, g->sdY, w.in_w, w.in_b, g->sdQKV, s);
+        hipLaunchKernelGGL(k_sd_attn, dim3(g->sd_B * SD_HEADS), dim3(64), 0, s, Wd, g->sdQKV, g->mask_from, g->sdA);
+        sd_gemm<SD_EPI_RESID>(M, Wd, Wd, g->sdA, w.out_w, w.out_b, g->sdX, s);
+        sd_gemm<SD_EPI_QGELU>(M, Wd, 4 * Wd, g->sdX, w.fc_w, w.fc_b, g->sdF, s);
+        sd_gemm<SD_EPI_BIAS>(M, 4 * Wd, Wd, g->sdF, w.proj_w, w.proj_b, g->sdY, s);
+        hipLaunchKernelGGL(k_sd_ln<1>, dim3(nblk(M, 4)), dim3(256), 0, s, M, Wd, g->sdY, w.ln2_g, w.ln2_b, g->sdX);
+    }
+    hipLaunchKernelGGL(k_sd_decode<H>, dim3(nblk(g->N, 4)), dim3(256), 0, s, g->N, Wd, P, g->F, g->node_tok, g->sdX, m->lnpost_g, m->lnpost_b,
+                       m->pd0_wT, m->pd0_b, m->pd2_w, m->pd2_b, g->xfeat, g->mask, g->eps);
+    g->evals++;
+    return 0;
 }
 
 // ---- energy mode -------------------------------------------------------------------------------
@@ -1109,9 +1155,15 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
             for (int e = 0; e <= S; ++e) {
                 for (const Lane& L : lanes) {
                     ccsp_graph* g = L.g;
-                    if (launch_eval<H>(m, g, t, L.s)) return 1;
                     NodeArgs a = node_args(m, g);
-                    a.src = 0; a.do_encode = 1;
+                    if (m->d.model_kind == CCSP_MODEL_STRUCT_DIFFUSION) {
+                        if (launch_eval_sd<H>(m, g, t, L.s)) return 1;
+                        a.src = 1; a.eps_buf = g->eps;
+                    } else {
+                        if (launch_eval<H>(m, g, t, L.s)) return 1;
+                        a.src = 0;
+                    }
+                    a.do_encode = 1;
                     a.step = e == 0 ? STEP_ANCESTRAL : STEP_ULA;
                     a.reset_mask = (e == S);
                     a.hist = e == S ? hist_at(L, T - t) : nullptr;
@@ -1236,7 +1288,20 @@ int graph_build(ccsp_model* m, int N, int E, int F, const float* x, const signed
     TRY(dev_alloc(reg, &g->eps, (size_t)N * P));
     // chain-constant part: geometry (and grasp) embeddings -> per-row products base[r] (the reference
     // re-evaluates the geometry encoder and these products on every call, denoise_fn.py:474-475)
-    if (p.E_act > 0) {
+    if (d.model_kind == CCSP_MODEL_STRUCT_DIFFUSION) {
+        // the transformer reads the embeddings themselves; the constraint edges are not used
+        TRY(dev_alloc(reg, &g->gemb, (size_t)N * H));
+        const EncW wg{m->ge0_w, m->ge0_b, m->ge2_wT, m->ge2_b, d.geom_dim, nullptr};
+        const EncW wr{m->gr0_w, m->gr0_b, m->gr2_wT, m->gr2_b, d.grasp_dim, nullptr};
+        if (d.grasp_dim > 0) TRY(dev_alloc(reg, &g->remb, (size_t)N * H));
+        if (H == 256) {
+            hipLaunchKernelGGL(k_encode<256>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, 0, wg, g->gemb);
+            if (d.grasp_dim > 0) hipLaunchKernelGGL(k_encode<256>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, d.grasp_begin, wr, g->remb);
+        } else {
+            hipLaunchKernelGGL(k_encode<64>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, 0, wg, g->gemb);
+            if (d.grasp_dim > 0) hipLaunchKernelGGL(k_encode<64>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, d.grasp_begin, wr, g->remb);
+        }
+    } else if (p.E_act > 0) {
         float *gemb = nullptr, *UR = nullptr, *remb = nullptr;
         TRY(dev_alloc(reg, &gemb, (size_t)N * H));
         const EncW wg{m->ge0_w, m->ge0_b, m->ge2_wT, m->ge2_b, d.geom_dim, nullptr};
@@ -1337,6 +1402,8 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     if (P < 1 || P > 8) return fail("model_create: pose_dim %d not supported (1..8)", P);
     if (d->geom_dim < 1 || d->geom_dim > 8 || d->grasp_dim < 0 || d->grasp_dim > 8) return fail("model_create: geometry/grasp width not supported (1..8)");
     if (C < 1 || T < 1) return fail("model_create: bad n_types/timesteps");
+    if (d->model_kind != CCSP_MODEL_DIFFUSION_CCSP && d->model_kind != CCSP_MODEL_STRUCT_DIFFUSION) return fail("model_create: unknown model_kind %d", d->model_kind);
+    if (d->model_kind == CCSP_MODEL_STRUCT_DIFFUSION && d->energy_wrapper) return fail("model_create: StructDiffusion has no energy mode");
     hipStream_t s = (hipStream_t)stream;
     ccsp_model* m = new ccsp_model();
     m->d = *d;
@@ -1396,6 +1463,41 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     hipLaunchKernelGGL(k_sinusoid, dim3(nblk((long)T * (H / 2), 256)), dim3(256), 0, s, T, H, sinus);
     hipLaunchKernelGGL(k_linear_rows, dim3(nblk((long)T * 4 * H, 256)), dim3(256), 0, s, T, H, 4 * H, sinus, H, tm1_w, H, tm1_b, 1, hid, 4 * H);
     hipLaunchKernelGGL(k_linear_rows, dim3(nblk((long)T * H, 256)), dim3(256), 0, s, T, 4 * H, H, hid, 4 * H, tm3_w, 4 * H, tm3_b, 0, m->temb, H);
+    m->Wg = m->Wp = m->Wr = m->WpT = m->tau = nullptr;
+    if (d->model_kind == CCSP_MODEL_STRUCT_DIFFUSION) {
+        const int Wd = H * (grasp ? 3 : 2);
+        m->Wd = Wd;
+        m->lanes = 1;       // the head/graph mask mix-up (denoise_fn.py:434) couples the graphs of a batch: never split it
+        TRY(dup(&m->lnpre_g, Wd)); TRY(dup(&m->lnpre_b, Wd));
+        for (int l = 0; l < SD_LAYERS; ++l) {
+            ccsp_model::SdLayer& w = m->sd[l];
+            TRY(dup(&w.in_w, (size_t)3 * Wd * Wd)); TRY(dup(&w.in_b, (size_t)3 * Wd));
+            TRY(dup(&w.out_w, (size_t)Wd * Wd)); TRY(dup(&w.out_b, Wd));
+            TRY(dup(&w.ln1_g, Wd)); TRY(dup(&w.ln1_b, Wd));
+            TRY(dup(&w.fc_w, (size_t)4 * Wd * Wd)); TRY(dup(&w.fc_b, (size_t)4 * Wd));
+            TRY(dup(&w.proj_w, (size_t)4 * Wd * Wd)); TRY(dup(&w.proj_b, Wd));
+            TRY(dup(&w.ln2_g, Wd)); TRY(dup(&w.ln2_b, Wd));
+        }
+        TRY(dup(&m->lnpost_g, Wd)); TRY(dup(&m->lnpost_b, Wd));
+        // PositionalEncoding.pe rows 0..7 in fp32 like the reference buffer (transformer.py:22-28)
+        std::vector<float> pe((size_t)SD_L * Wd);
+        for (int pos = 0; pos < SD_L; ++pos)
+            for (int c = 0; c < Wd; c += 2) {
+                const float dv = expf((float)c * (float)(-(log(10000.0) / (double)Wd)));
+                const float a = (float)pos * dv;
+                pe[(size_t)pos * Wd + c] = sinf(a);
+                pe[(size_t)pos * Wd + c + 1] = cosf(a);
+            }
+        TRY(dev_alloc(reg, &m->sd_pe, pe.size()));
+        HIP_TRY(hipMemcpy(m->sd_pe, pe.data(), pe.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+            ccsp_model_destroy(m);
+            return fail("model_create: device set-up failed: %s", hipGetErrorString(hipGetLastError()));
+        }
+        ccsp_schedule_set(m, nullptr, nullptr, nullptr, 10);
+        *out = m;
+        return 0;
+    }
     // per-type slices of mlps.i.0.weight [2H, K_in]: [grasp_a] geom_a geom_b pose_a pose_b time
     const size_t WS = (size_t)2 * H * H;
     TRY(dev_alloc(reg, &m->Wg, (size_t)C * 2 * WS));
@@ -1493,15 +1595,70 @@ int ccsp_denoise(ccsp_model* m, ccsp_graph* g, const float* poses_in, int32_t t,
     a.src = 2; a.step = STEP_NONE; a.do_encode = 1; a.x_in = poses_in;
     NodeArgs b = node_args(m, g);
     b.src = 0; b.step = STEP_NONE; b.do_encode = 0; b.eps_out = out; b.x_in = poses_in;
+    if (m->d.model_kind == CCSP_MODEL_STRUCT_DIFFUSION) {
+        if (m->d.hidden_dim == 256) { launch_node<256>(m, g, a, s); if (launch_eval_sd<256>(m, g, t, s)) return 1; }
+        else { launch_node<64>(m, g, a, s); if (launch_eval_sd<64>(m, g, t, s)) return 1; }
+        HIP_TRY(hipMemcpyAsync(out, g->eps, (size_t)g->N * m->d.pose_dim * sizeof(float), hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (m->d.hidden_dim == 256) { launch_node<256>(m, g, a, s); if (launch_eval<256>(m, g, t, s)) return 1; launch_node<256>(m, g, b, s); }
     else { launch_node<64>(m, g, a, s); if (launch_eval<64>(m, g, t, s)) return 1; launch_node<64>(m, g, b, s); }
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
+int ccsp_graph_set_sequences(ccsp_graph* g, const int64_t* batch, const int64_t* shuffled, void* stream) {
+    if (!g || !batch) return fail("graph_set_sequences: null argument");
+    ccsp_model* m = g->m;
+    if (m->d.model_kind != CCSP_MODEL_STRUCT_DIFFUSION) return fail("graph_set_sequences: the model is not a StructDiffusion model");
+    if (g->seq_ready) return fail("graph_set_sequences: sequences already set for this graph");
+    hipStream_t s = (hipStream_t)stream;
+    const int N = g->N;
+    std::vector<int64_t> hb(N), hs;
+    HIP_TRY(hipMemcpyAsync(hb.data(), batch, (size_t)N * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    if (shuffled) { hs.resize(N); HIP_TRY(hipMemcpyAsync(hs.data(), shuffled, (size_t)N * sizeof(int64_t), hipMemcpyDeviceToHost, s)); }
+    HIP_TRY(hipStreamSynchronize(s));
+    int B = 0;
+    for (int n = 0; n < N; ++n) {
+        if (hb[n] < 0 || hb[n] >= N) return fail("graph_set_sequences: batch[%d]=%lld out of range", n, (long long)hb[n]);
+        if ((int)hb[n] + 1 > B) B = (int)hb[n] + 1;
+    }
+    std::vector<int> cnt(B, 0), tok_node((size_t)B * SD_L, -1), tok_pos((size_t)B * SD_L, 0), node_tok(N), mask_from((size_t)B * SD_HEADS);
+    for (int n = 0; n < N; ++n) {
+        const int b = (int)hb[n];
+        if (cnt[b] >= SD_L) return fail("graph_set_sequences: graph %d has more than %d nodes (max_seq_len, denoise_fn.py:272)", b, SD_L);
+        node_tok[n] = b * SD_L + cnt[b];
+        tok_node[(size_t)b * SD_L + cnt[b]] = n;
+        tok_pos[(size_t)b * SD_L + cnt[b]] = cnt[b];
+        cnt[b]++;
+    }
+    if (shuffled)
+        for (int n = 0; n < N; ++n) {
+            if (hs[n] < 0 || hs[n] >= cnt[hb[n]]) return fail("graph_set_sequences: shuffled[%d]=%lld outside its graph's %d positions", n, (long long)hs[n], cnt[hb[n]]);
+            tok_pos[node_tok[n]] = (int)hs[n];
+        }
+    for (int b = 0; b < B; ++b)
+        for (int h = 0; h < SD_HEADS; ++h) {
+            const int c = cnt[(b * SD_HEADS + h) % B];      // `(repeat b)` vs MHA's (b heads) ordering, denoise_fn.py:434
+            mask_from[(size_t)b * SD_HEADS + h] = c == SD_L ? 0 : c;   // no padding: `[-0:]` marks everything
+        }
+    const int M = B * SD_L, Wd = m->Wd;
+    auto& reg = g->allocs;
+    if (dev_upload(reg, &g->tok_node, tok_node, s) || dev_upload(reg, &g->tok_pos, tok_pos, s) || dev_upload(reg, &g->node_tok, node_tok, s) ||
+        dev_upload(reg, &g->mask_from, mask_from, s) || dev_alloc(reg, &g->sdX, (size_t)M * Wd) || dev_alloc(reg, &g->sdY, (size_t)M * Wd) ||
+        dev_alloc(reg, &g->sdQKV, (size_t)M * 3 * Wd) || dev_alloc(reg, &g->sdA, (size_t)M * Wd) || dev_alloc(reg, &g->sdF, (size_t)M * 4 * Wd))
+        return 1;
+    HIP_TRY(hipStreamSynchronize(s));       // the host vectors go out of scope
+    g->sd_B = B; g->sd_M = M;
+    g->seq_ready = true;
+    return 0;
+}
+
 int ccsp_edge_outputs(ccsp_model* m, ccsp_graph* g, const float* poses_in, int32_t t, float* out, void* stream) {
     if (!m || !g || !poses_in || !out) return fail("edge_outputs: null argument");
     if (g->m != m) return fail("edge_outputs: graph belongs to another model");
+    if (m->d.model_kind != CCSP_MODEL_DIFFUSION_CCSP) return fail("edge_outputs: StructDiffusion has no per-edge outputs");
     if (t < 0 || t >= m->d.timesteps) return fail("edge_outputs: t=%d out of range", t);
     hipStream_t s = (hipStream_t)stream;
     const int P = m->d.pose_dim;
@@ -1519,6 +1676,7 @@ int ccsp_edge_outputs(ccsp_model* m, ccsp_graph* g, const float* poses_in, int32
 int ccsp_energy_grad(ccsp_model* m, ccsp_graph* g, const float* poses_in, int32_t t, float* grad, float* energy, void* stream) {
     if (!m || !g || !poses_in || !grad || !energy) return fail("energy_grad: null argument");
     if (g->m != m) return fail("energy_grad: graph belongs to another model");
+    if (m->d.model_kind != CCSP_MODEL_DIFFUSION_CCSP) return fail("energy_grad: StructDiffusion has no energy mode");
     if (t < 0 || t >= m->d.timesteps) return fail("energy_grad: t=%d out of range", t);
     hipStream_t s = (hipStream_t)stream;
     if (energy_prepare(m, g, s)) return 1;

@@ -19,14 +19,27 @@ from . import _lib
 from .worlds import constraint_set
 
 
-def param_names(n_types, grasp):
-    """nn.Linear modules in reference state_dict order (networks/denoise_fn.py:227-308)"""
+MODEL_KINDS = {'Diffusion-CCSP': 0, 'StructDiffusion': 1}
+
+
+def param_names(n_types, grasp, model='Diffusion-CCSP'):
+    """(weight key, bias key) pairs in reference state_dict order (networks/denoise_fn.py:227-308; the
+    StructDiffusion tail follows networks/transformer.py:43-57)"""
     names = ['geom_encoder.0', 'geom_encoder.2']
     if grasp:
         names += ['grasp_encoder.0', 'grasp_encoder.2']
     names += ['pose_encoder.0', 'pose_encoder.2', 'pose_decoder.0', 'pose_decoder.2', 'time_mlp.1', 'time_mlp.3']
-    names += ['mlps.%d.0' % i for i in range(n_types)]
-    return names
+    if model != 'StructDiffusion':
+        names += ['mlps.%d.0' % i for i in range(n_types)]
+        return [(n + '.weight', n + '.bias') for n in names]
+    out = [(n + '.weight', n + '.bias') for n in names]
+    out.append(('ln_pre.weight', 'ln_pre.bias'))
+    for l in range(4):
+        pre = 'transformer.resblocks.%d.' % l
+        out += [(pre + 'attn.in_proj_weight', pre + 'attn.in_proj_bias')]
+        out += [(pre + n + '.weight', pre + n + '.bias') for n in ('attn.out_proj', 'ln_1', 'mlp.c_fc', 'mlp.c_proj', 'ln_2')]
+    out.append(('ln_post.weight', 'ln_post.bias'))
+    return out
 
 
 def _stream_ptr(device):
@@ -55,6 +68,13 @@ class _Graph(object):
                                        _ptr(self.edge_attr), _ptr(self.mask), _stream_ptr(dev), C.byref(h)))
         self.h = h
         self.model_handle = owner._h.value
+        if owner.model == 'StructDiffusion':
+            # the token sequences: batch.batch, and batch.shuffled when the dataset carries it (denoise_fn.py:408-417)
+            self.seq = batch.batch.detach().to(dev, torch.int64).contiguous()
+            sh = getattr(batch, 'shuffled', None)
+            self.shuffled = None if sh is None else sh.detach().to(dev, torch.int64).contiguous()
+            _lib.check(L.ccsp_graph_set_sequences(h, _ptr(self.seq), None if self.shuffled is None else _ptr(self.shuffled),
+                                                  _stream_ptr(dev)))
 
     def __del__(self):
         try:
@@ -66,13 +86,16 @@ class _Graph(object):
 
 
 class ConstraintDiffuser(object):
-    """drop-in for the reference class of the same name (model='Diffusion-CCSP' only)."""
+    """drop-in for the reference class of the same name; model='Diffusion-CCSP' (the paper's method) or
+    'StructDiffusion' (the transformer baseline, denoise_fn.py:267-282,391-451)."""
 
     def __init__(self, dims=((2, 0, 2), (2, 2, 4)), hidden_dim=256, max_num_obj=12, input_mode=None,
                  EBM=False, pretrained=False, normalize=True, energy_wrapper=False, device='cuda',
                  model='Diffusion-CCSP', verbose=True, timesteps=1000):
-        if model != 'Diffusion-CCSP':
-            raise NotImplementedError("model=%r: only 'Diffusion-CCSP' is built (StructDiffusion baseline: see DESIGN.md)" % model)
+        if model not in MODEL_KINDS:
+            raise NotImplementedError("model=%r: 'Diffusion-CCSP' and 'StructDiffusion' are built" % model)
+        if model == 'StructDiffusion' and energy_wrapper:
+            raise ValueError('StructDiffusion has no energy mode')
         if input_mode is None:
             raise ValueError('input_mode is required')
         self.hidden_dim = hidden_dim
@@ -110,9 +133,24 @@ class ConstraintDiffuser(object):
               'time_mlp.1': (4 * H, H), 'time_mlp.3': (H, 4 * H)}
         if self._grasp:
             sh.update({'grasp_encoder.0': (H // 2, self.dims[1][0]), 'grasp_encoder.2': (H, H // 2)})
+        if self.model == 'StructDiffusion':
+            W = H * (3 if self._grasp else 2)
+            sh.update({'ln_pre': (W,), 'ln_post': (W,)})
+            for l in range(4):
+                pre = 'transformer.resblocks.%d.' % l
+                sh.update({pre + 'attn.in_proj_': (3 * W, W), pre + 'attn.out_proj': (W, W), pre + 'ln_1': (W,),
+                           pre + 'mlp.c_fc': (4 * W, W), pre + 'mlp.c_proj': (W, 4 * W), pre + 'ln_2': (W,)})
+            return sh
         for i in range(len(self.constraint_sets)):
             sh['mlps.%d.0' % i] = (2 * H, kin)
         return sh
+
+    @staticmethod
+    def _keys(name):
+        """state_dict keys of one module: nn.MultiheadAttention stores in_proj_weight / in_proj_bias"""
+        if name.endswith('in_proj_'):
+            return name + 'weight', name + 'bias'
+        return name + '.weight', name + '.bias'
 
     def load_state_dict(self, sd, strict=True):
         """accepts the reference's key names, bare or with the 'denoise_fn.' / 'denoise_fn.model.' prefixes
@@ -126,8 +164,8 @@ class ConstraintDiffuser(object):
             clean[k] = v
         params = {}
         for name, shape in self.shapes().items():
-            for suffix, shp in (('.weight', shape), ('.bias', (shape[0],))):
-                key = name + suffix
+            wk, bk = self._keys(name)
+            for key, shp in ((wk, shape), (bk, (shape[0],))):
                 if key not in clean:
                     raise KeyError('missing key %s in state_dict' % key)
                 t = clean[key]
@@ -145,10 +183,15 @@ class ConstraintDiffuser(object):
         """nn.Linear default init (uniform +-1/sqrt(fan_in)), for plumbing runs without a checkpoint"""
         g = torch.Generator().manual_seed(seed)
         sd = {}
-        for name, (o, i) in self.shapes().items():
+        for name, shape in self.shapes().items():
+            wk, bk = self._keys(name)
+            if len(shape) == 1:                         # nn.LayerNorm
+                sd[wk], sd[bk] = torch.ones(shape), torch.zeros(shape)
+                continue
+            o, i = shape
             bound = 1.0 / math.sqrt(i)
-            sd[name + '.weight'] = (torch.rand((o, i), generator=g) * 2 - 1) * bound
-            sd[name + '.bias'] = (torch.rand((o,), generator=g) * 2 - 1) * bound
+            sd[wk] = (torch.rand((o, i), generator=g) * 2 - 1) * bound
+            sd[bk] = (torch.rand((o,), generator=g) * 2 - 1) * bound
         return self.load_state_dict(sd)
 
     def state_dict(self):
@@ -200,11 +243,12 @@ class ConstraintDiffuser(object):
                            geom_dim=self.dims[0][0], grasp_dim=self.dims[1][0] if grasp else 0,
                            grasp_begin=self.dims[1][1] if grasp else 0, n_types=len(self.constraint_sets),
                            timesteps=self.timesteps, normalize=int(bool(self.normalize)),
-                           energy_wrapper=int(bool(self.energy_wrapper)), ebm_per_steps=int(self.ebm_per_steps))
+                           energy_wrapper=int(bool(self.energy_wrapper)), ebm_per_steps=int(self.ebm_per_steps),
+                           model_kind=MODEL_KINDS[self.model])
         ptrs = []
-        for name in param_names(len(self.constraint_sets), grasp):
-            ptrs.append(self._params[name + '.weight'].data_ptr())
-            ptrs.append(self._params[name + '.bias'].data_ptr())
+        for wk, bk in param_names(len(self.constraint_sets), grasp, self.model):
+            ptrs.append(self._params[wk].data_ptr())
+            ptrs.append(self._params[bk].data_ptr())
         arr = (C.c_void_p * len(ptrs))(*ptrs)
         h = C.c_void_p()
         with torch.cuda.device(self.device):

@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define CCSP_VERSION_MAJOR 0
-#define CCSP_VERSION_MINOR 1
+#define CCSP_VERSION_MINOR 2
 
 typedef struct ccsp_model ccsp_model;   /* ConstraintDiffuser weights + GaussianDiffusion schedule */
 typedef struct ccsp_graph ccsp_graph;   /* one collated batch of constraint graphs              */
@@ -47,7 +47,12 @@ typedef struct {
     int32_t normalize;      /* -normalize (denoise_fn.py:523)                                    */
     int32_t energy_wrapper; /* 1 when wrapped in ComposedEBMDenoiseFn (denoise_fn.py:57-83)      */
     int32_t ebm_per_steps;  /* denoise_fn.ebm_per_steps (denoise_fn.py:284; ddpm.py:330)         */
+    int32_t model_kind;     /* CCSP_MODEL_*: ConstraintDiffuser(model=...) (denoise_fn.py:205,267-282) */
 } ccsp_model_desc;
+
+/* 'Diffusion-CCSP': per-constraint-type MLPs over the edges.  'StructDiffusion': the transformer
+ * baseline over each graph's object sequence (denoise_fn.py:391-451, transformer.py). */
+enum { CCSP_MODEL_DIFFUSION_CCSP = 0, CCSP_MODEL_STRUCT_DIFFUSION = 1 };
 
 enum { CCSP_SAMPLER_NONE = 0, CCSP_SAMPLER_ULA = 1, CCSP_SAMPLER_ULA_PLUS = 2, CCSP_SAMPLER_MALA = 3 };
 enum { CCSP_NOISE_PHILOX = 0, CCSP_NOISE_INJECTED = 1 };
@@ -76,7 +81,9 @@ int ccsp_device_info(char* name, int32_t name_len, int32_t* compute_units, uint6
 /* Replaces ConstraintDiffuser.__init__ + load_state_dict (denoise_fn.py:184-308,
  * ddpm.py:503-514).  params: host array of 2*n_linear DEVICE pointers, weight then bias, in the
  * reference state_dict order: geom_encoder.{0,2}, [grasp_encoder.{0,2}], pose_encoder.{0,2},
- * pose_decoder.{0,2}, time_mlp.{1,3}, mlps.i.0 (i < n_types).  Weights are copied (and re-laid
+ * pose_decoder.{0,2}, time_mlp.{1,3}, mlps.i.0 (i < n_types).  For CCSP_MODEL_STRUCT_DIFFUSION the
+ * mlps are replaced by (weight, bias) pairs of: ln_pre; per block l < 4: attn.in_proj, attn.out_proj,
+ * ln_1, mlp.c_fc, mlp.c_proj, ln_2; ln_post (transformer.py:43-57).  Weights are copied (and re-laid
  * out) into library-owned HBM; the cosine schedule (ddpm.py:152-162) and the per-type time-term
  * table are built here. */
 int ccsp_model_create(const ccsp_model_desc* desc, const float* const* params, void* stream,
@@ -106,6 +113,11 @@ int ccsp_graph_create(ccsp_model* model, int32_t N, int32_t E, int32_t F, const 
                       const int64_t* edge_index, const float* edge_attr, const int8_t* mask,
                       void* stream, ccsp_graph** out);
 void ccsp_graph_destroy(ccsp_graph* graph);
+/* StructDiffusion only (denoise_fn.py:408-423): batch [N] int64 DEVICE = graph id of every node
+ * (PyG batch.batch; a graph's nodes in order are its tokens, at most 8), shuffled [N] int64 DEVICE or
+ * NULL = batch.shuffled, the positional-encoding row of every token.  Once per graph handle. */
+int ccsp_graph_set_sequences(ccsp_graph* graph, const int64_t* batch, const int64_t* shuffled,
+                             void* stream);
 
 /* ConstraintDiffuser.forward(poses_in, batch, t, eval=True), direct mode
  * (denoise_fn.py:453-537): poses_in [N,P] -> out [N,P]. */
