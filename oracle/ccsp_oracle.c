@@ -723,6 +723,7 @@ static int noise_uniform(const ccspo_noise* nz, uint64_t call, int N, real* out)
 static int steps_at(const ccspo_model* m, int sampler, int t) {
     if (sampler == CCSPO_SAMPLER_NONE) return 0;
     if (t % m->d.ebm_per_steps != 0) return 0;                              /* ddpm.py:330 */
+    if (sampler == CCSPO_SAMPLER_HMC) return 4;                              /* samples_per_step = 4, ddpm.py:311 */
     if (sampler == CCSPO_SAMPLER_ULA_PLUS) {                                 /* ddpm.py:297-299 */
         int n = m->d.timesteps / 4;
         int q = n > 0 ? t / n : 3;
@@ -739,9 +740,10 @@ int ccspo_chain_run(ccspo_model* m, ccspo_graph* g, int32_t sampler, const ccspo
     const ccspo_desc* d = &m->d;
     int T = d->timesteps, P = d->pose_dim, N = g->N;
     size_t NP = (size_t)N * P;
-    if (sampler < 0 || sampler > 3) FAIL("chain_run: unknown sampler %d", sampler);
+    if (sampler < 0 || sampler > 4) FAIL("chain_run: unknown sampler %d", sampler);
     if (t_first >= T || t_last < 0 || t_first < t_last - 1) FAIL("chain_run: bad timestep range [%d,%d]", t_first, t_last);
-    if (sampler == CCSPO_SAMPLER_MALA && !d->energy_wrapper) FAIL("chain_run: MALA needs energy_wrapper (train_utils.py:115-116)");
+    if ((sampler == CCSPO_SAMPLER_MALA || sampler == CCSPO_SAMPLER_HMC) && !d->energy_wrapper) FAIL("chain_run: MALA/HMC need energy_wrapper (train_utils.py:115-116)");
+    if (sampler == CCSPO_SAMPLER_HMC && T < 4) FAIL("chain_run: HMC indexes the schedule with its inner step 0..3 (ddpm.py:1076-1084)");
     eval_ws ws; ws_alloc(&ws, m, g);
     real* x = (real*)xcalloc(NP, sizeof(real));
     real* eps = (real*)xcalloc(NP, sizeof(real));
@@ -759,7 +761,10 @@ int ccspo_chain_run(ccspo_model* m, ccspo_graph* g, int32_t sampler, const ccspo
     uint64_t* call0 = (uint64_t*)xcalloc(T, sizeof(uint64_t));
     uint64_t* ucall0 = (uint64_t*)xcalloc(T, sizeof(uint64_t));
     { uint64_t c = 1, uc = 0;
-      for (int t = T - 1; t >= 0; --t) { call0[t] = c; ucall0[t] = uc; int S = steps_at(m, sampler, t); c += 1 + (uint64_t)S; if (sampler == CCSPO_SAMPLER_MALA) uc += (uint64_t)S; } }
+      for (int t = T - 1; t >= 0; --t) { call0[t] = c; ucall0[t] = uc; int S = steps_at(m, sampler, t);
+          /* HMC draws the momentum once per timestep on top of its S refreshments (ddpm.py:1090,1096) */
+          c += 1 + (uint64_t)S + (sampler == CCSPO_SAMPLER_HMC && S > 0 ? 1 : 0);
+          if (sampler == CCSPO_SAMPLER_MALA || sampler == CCSPO_SAMPLER_HMC) uc += (uint64_t)S; } }
 
     if (init) {                                                              /* ddpm.py:273-274 */
         if ((rc = noise_normal(nz, 0, N, P, z))) goto done;
@@ -787,6 +792,67 @@ int ccspo_chain_run(ccspo_model* m, ccspo_graph* g, int32_t sampler, const ccspo
         int S = steps_at(m, sampler, t);
         real std = r_sqrt((real)2 * ss);
         real acc_sum = 0;
+        if (sampler == CCSPO_SAMPLER_HMC && S > 0) {
+            /* AnnealedMUHASampler.sample_step (ddpm.py:1087-1128), damping 0, mass_diag_sqrt = 9 betas,
+             * 2 leapfrogs (:311-316).  Kept quirk: leapfrog_step receives the INNER index i, so its step
+             * size, mass and the timestep of its gradients are those of timestep i in 0..3 (:1076-1084),
+             * while the momentum scale and both energies use the real t. */
+            real* vk = (real*)xcalloc(NP, sizeof(real));
+            real* vp = (real*)xcalloc(NP, sizeof(real));
+            real* vl = (real*)xcalloc(NP, sizeof(real));
+            real m_t = (real)(9.0f * m->betas[t]);
+            if ((rc = noise_normal(nz, call0[t] + 1, N, P, z))) { free(vk); free(vp); free(vl); goto done; }
+            for (size_t i = 0; i < NP; ++i) vk[i] = z[i] * m_t;
+            real var = m_t * m_t, log_scale = r_log(m_t);
+            real lc = sizeof(real) == 4 ? (real)(float)log(sqrt(2 * M_PI)) : (real)log(sqrt(2 * M_PI));
+            for (int s = 0; s < S; ++s) {
+                if ((rc = noise_normal(nz, call0[t] + 2 + (uint64_t)s, N, P, z))) break;
+                for (size_t i = 0; i < NP; ++i) { vp[i] = vk[i] * (real)0 + ((real)1 * z[i]) * m_t; vl[i] = vp[i]; xhat[i] = x[i]; }
+                real ss_i = (real)m->step[s], m_i = (real)(9.0f * m->betas[s]), kap_i = (real)m->kappa[s];
+                real md = m_i * m_i, half = (real)0.5 * ss_i, Etmp;
+                for (int lf = 0; lf < 2; ++lf) {                                /* leapfrog_step (ddpm.py:917-937) */
+                    memcpy(ws.poses, xhat, sizeof(real) * NP);
+                    energy_real(m, g, &ws, s, eps, &Etmp);
+                    for (size_t i = 0; i < NP; ++i) {
+                        vl[i] = vl[i] + half * ((-eps[i]) * kap_i);
+                        xhat[i] = xhat[i] + ss_i * vl[i] / md;
+                    }
+                    memcpy(ws.poses, xhat, sizeof(real) * NP);
+                    energy_real(m, g, &ws, s, eps, &Etmp);
+                    for (size_t i = 0; i < NP; ++i) vl[i] = vl[i] + half * ((-eps[i]) * kap_i);
+                }
+                real Ex = 0, Ehat = 0;
+                memcpy(ws.poses, x, sizeof(real) * NP);
+                energy_real(m, g, &ws, t, scratch, &Ex);
+                memcpy(ws.poses, xhat, sizeof(real) * NP);
+                energy_real(m, g, &ws, t, scratch, &Ehat);
+                real logp_x = (-Ex) * kappa, logp_xhat = (-Ehat) * kappa;
+                if ((rc = noise_uniform(nz, ucall0[t] + (uint64_t)s, N, u))) break;
+                real n_acc = 0;
+                for (int n = 0; n < N; ++n) {
+                    real lvp = 0, lv = 0;                                       /* Normal(0, m_t).log_prob(.).sum(1) */
+                    for (int p = 0; p < P; ++p) {
+                        size_t i = (size_t)n * P + p;
+                        lvp += -(vp[i] * vp[i]) / ((real)2 * var) - log_scale - lc;
+                        lv += -(vl[i] * vl[i]) / ((real)2 * var) - log_scale - lc;
+                    }
+                    real la = (logp_xhat + lv) - (logp_x + lvp);
+                    real acc = (u[n] < r_exp(la)) ? (real)1 : (real)0;
+                    n_acc += acc;
+                    for (int p = 0; p < P; ++p) {
+                        size_t i = (size_t)n * P + p;
+                        x[i] = acc * xhat[i] + ((real)1 - acc) * x[i];
+                        vk[i] = acc * vl[i] + ((real)1 - acc) * vp[i];
+                    }
+                }
+                acc_sum += n_acc / (real)N;
+            }
+            free(vk); free(vp); free(vl);
+            if (rc) goto done;
+            S = 0;                                                              /* skip the ULA / MALA loop below */
+            if (accept_out) accept_out[t] = (float)(acc_sum / (real)4);
+        }
+        const int S_hmc_done = (sampler == CCSPO_SAMPLER_HMC);
         for (int s = 0; s < S; ++s) {
             memcpy(ws.poses, x, sizeof(real) * NP);
             real Ex = 0;
@@ -833,7 +899,7 @@ int ccspo_chain_run(ccspo_model* m, ccspo_graph* g, int32_t sampler, const ccspo
                 acc_sum += n_acc / (real)N;
             }
         }
-        if (accept_out) accept_out[t] = S > 0 ? (float)(acc_sum / (real)S) : 0.0f;
+        if (accept_out && !S_hmc_done) accept_out[t] = S > 0 ? (float)(acc_sum / (real)S) : 0.0f;
         for (int n = 0; n < N; ++n) if (g->mask[n]) for (int p = 0; p < P; ++p) x[(size_t)n * P + p] = gt[(size_t)n * P + p];   /* ddpm.py:334 */
         if (history) for (size_t i = 0; i < NP; ++i) history[(size_t)(T - t) * NP + i] = (float)x[i];
     }

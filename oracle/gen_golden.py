@@ -55,7 +55,7 @@ class PatchedNoise(object):
         return tuple(shape)
 
     def __enter__(self):
-        self.orig = (torch.randn, torch.rand)
+        self.orig = (torch.randn, torch.rand, torch.randn_like)
 
         def randn(*shape, **kw):
             shape = self._shape(shape)
@@ -69,11 +69,12 @@ class PatchedNoise(object):
             self.uc += 1
             return torch.from_numpy(u).to(self.dtype)
 
-        torch.randn, torch.rand = randn, rand
+        # AnnealedMUHASampler draws with torch.randn_like (ddpm.py:1090,1096): same stream, same call counter
+        torch.randn, torch.rand, torch.randn_like = randn, rand, (lambda t, **kw: randn(*t.shape))
         return self
 
     def __exit__(self, *a):
-        torch.randn, torch.rand = self.orig
+        torch.randn, torch.rand, torch.randn_like = self.orig
 
 
 def build_reference(mode, H, weights, energy=False, EBM='ULA', T=1000, S=10, dtype=torch.float32,
@@ -113,15 +114,23 @@ def run_chain(name, mode, H, wfile, batch, EBM, T=1000, S=10, seed=7, energy=Fal
         b.x = b.x.double()
     t0 = time.time()
     torch.set_default_dtype(dtype)          # SinusoidalPosEmb builds its table in the default dtype
+    rates = {}
+    orig_upd = ddpm.MetropolisSampler._update_acceptance_rate
+
+    def record(self, accept_rate, t, debug=False):          # mean acceptance of the timestep, as the reference logs it
+        rates[int(t)] = float(accept_rate)
+        return orig_upd(self, accept_rate, t, debug)
+    ddpm.MetropolisSampler._update_acceptance_rate = record
     try:
         with PatchedNoise(seed, dtype) as pn, contextlib.redirect_stdout(io.StringIO()):
             out, hist = gd.sample(b, return_history=True)
     finally:
         torch.set_default_dtype(torch.float32)
+        ddpm.MetropolisSampler._update_acceptance_rate = orig_upd
     dt = time.time() - t0
     out = out.detach().numpy()
     hist = np.stack([h.detach().numpy() for h in hist])
-    idx = sorted(set(i for i in HIST_IDX if i <= T) | {T})
+    idx = list(range(T + 1)) if T <= 20 else sorted(set(i for i in HIST_IDX if i <= T) | {T})
     rec = dict(batch_arrays(batch))
     if model_name == 'StructDiffusion':
         rec['batch'] = batch.batch.numpy().astype(np.int64)
@@ -131,6 +140,8 @@ def run_chain(name, mode, H, wfile, batch, EBM, T=1000, S=10, seed=7, energy=Fal
                hist_idx=np.asarray(idx, dtype=np.int32), hist=hist[idx].astype(out.dtype),
                seed=np.int64(seed), T=np.int32(T), S=np.int32(S), H=np.int32(H), n_randn=np.int64(pn.c),
                n_rand=np.int64(pn.uc), ref_seconds=np.float64(dt), threads=np.int32(torch.get_num_threads()))
+    if rates:
+        rec['accept'] = np.asarray([rates.get(t, 0.0) for t in range(T)], dtype=np.float32)
     meta = dict(mode=mode, EBM=str(EBM), weights=wfile, energy=bool(energy), dtype=str(dtype), model=model_name)
     np.savez_compressed(os.path.join(GOLD, name + '.npz'), meta=np.asarray(repr(meta)), **rec)
     print('%-34s %6.1fs  randn calls %d  |final|max %.3f  |hist|max %.3g' %
@@ -357,6 +368,10 @@ def gen_chains(which):
                                                worlds.qualitative_batch(1, 5, seed=33).to_torch(), 'ULA+'),
         'chain_t64_mala': lambda: run_chain('chain_t64_mala', 'diffuse_pairwise', 64, 'weights_diffuse_pairwise_h64_energy.npz',
                                             worlds.triangular_batch(2, 12, seed=34).to_torch(), 'MALA', S=2, energy=True),
+        'chain_t64_hmc': lambda: run_chain('chain_t64_hmc', 'diffuse_pairwise', 64, 'weights_diffuse_pairwise_h64_energy.npz',
+                                           worlds.triangular_batch(2, 12, seed=37).to_torch(), 'HMC', energy=True),
+        'chain_t64_hmc_T20': lambda: run_chain('chain_t64_hmc_T20', 'diffuse_pairwise', 64, 'weights_diffuse_pairwise_h64_energy.npz',
+                                               worlds.triangular_batch(2, 12, seed=38).to_torch(), 'HMC', T=20, energy=True),
         'chain_t64_ula': lambda: run_chain('chain_t64_ula', 'diffuse_pairwise', 64, 'weights_diffuse_pairwise_h64.npz',
                                            worlds.triangular_batch(2, 12, seed=35).to_torch(), 'ULA', S=3),
         'chain_r64_ula': lambda: run_chain('chain_r64_ula', 'robot_box', 64, 'weights_robot_box_h64.npz',

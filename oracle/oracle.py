@@ -11,7 +11,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-SAMPLERS = {False: 0, None: 0, 'NONE': 0, 'ULA': 1, 'ULA+': 2, 'MALA': 3}
+SAMPLERS = {False: 0, None: 0, 'NONE': 0, 'ULA': 1, 'ULA+': 2, 'MALA': 3, 'HMC': 4}
 SCHEDULE_KEYS = ['betas', 'alphas_cumprod', 'alphas_cumprod_prev', 'sqrt_recip_alphas_cumprod',
                  'sqrt_recipm1_alphas_cumprod', 'posterior_log_variance_clipped', 'posterior_mean_coef1',
                  'posterior_mean_coef2', 'kappa', 'step_sizes', 'posterior_variance']

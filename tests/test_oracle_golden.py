@@ -127,7 +127,7 @@ MALA_SEGMENTS = [(0, 1), (1, 2), (50, 100), (100, 200), (200, 300), (900, 950), 
                  (998, 999), (999, 1000), (900, 1000)]
 
 
-def mala_segment_errors(run_segment, z):
+def mala_segment_errors(run_segment, z, segments=None):
     """MALA (ddpm.py:999-1047) accepts per node with a *discrete* test u < exp(.), and this fixture's
     chain passes through a 1e8 transient in its first ~50 timesteps, so a full chain from the initial
     draw is chaotic (two fp32 runs of the reference itself would not agree).  Parity is therefore
@@ -137,7 +137,7 @@ def mala_segment_errors(run_segment, z):
     segments may contain flipped rows, all others must match within 1e-4 (early segments: relative)."""
     idx = list(z['hist_idx'])
     bad = []
-    for i0, i1 in MALA_SEGMENTS:
+    for i0, i1 in (segments or MALA_SEGMENTS):
         k0, k1 = idx.index(i0), idx.index(i1)
         x = run_segment(z['hist'][k0], 999 - i0, 1000 - i1)
         want = z['hist'][k1]
@@ -158,6 +158,45 @@ def test_mala_segments_vs_reference():
     # acceptance bookkeeping (MetropolisSampler, ddpm.py:969-996): rates in [0,1], high at low noise
     _, acc = g.chain('MALA', seed=int(z['seed']), x=z['hist'][list(z['hist_idx']).index(990)], t_first=9, t_last=0, accept=True)
     assert (acc[:10] >= 0).all() and (acc[:10] <= 1).all() and acc[:10].mean() > 0.5
+
+
+def hmc_T20_errors(run_step, z):
+    """AnnealedMUHASampler (ddpm.py:1050-1128) at T = 20, where its proposals do get accepted: every timestep is
+    run from the reference's recorded state; returns the timesteps whose next state or mean acceptance differ"""
+    T = int(z['T'])
+    bad = []
+    for k in range(T):
+        t = T - 1 - k
+        x, acc = run_step(z['hist'][k], t)
+        if rel_err(x, z['hist'][k + 1]) > 2e-4 or abs(float(acc[t]) - float(z['accept'][t])) > 1e-6:
+            bad.append((t, rel_err(x, z['hist'][k + 1]), float(acc[t]), float(z['accept'][t])))
+    return bad
+
+
+def test_hmc_vs_reference():
+    """SURVEY 8a row 13.  The inner-index-as-timestep quirk makes the leapfrog use step size 2 beta_i and mass
+    (9 beta_i)^2 of i in 0..3: at T = 1000 that is a ~600x blow-up of every proposal and the reference never
+    accepts one (recorded acceptance is 0 at all 1000 timesteps); at T = 20 acceptance is mixed."""
+    z = golden('chain_t64_hmc_T20')
+    m = oracle_model('diffuse_pairwise', 64, 'weights_diffuse_pairwise_h64_energy.npz', T=20, energy=True)
+    g = m.graph(golden_batch(z))
+    assert int(z['n_randn']) == 1 + 20 * 6 and int(z['n_rand']) == 20 * 4
+    assert 0 < (z['accept'] > 0).sum() and len(set(np.round(z['accept'], 4))) >= 4     # the fixture exercises partial accepts
+    bad = hmc_T20_errors(lambda x, t: g.chain('HMC', seed=int(z['seed']), x=x, t_first=t, t_last=t, accept=True), z)
+    assert not bad, bad
+    z = golden('chain_t64_hmc')
+    assert not z['accept'].any()
+    m = oracle_model('diffuse_pairwise', 64, 'weights_diffuse_pairwise_h64_energy.npz', T=1000, energy=True)
+    g = m.graph(golden_batch(z))
+    acc_seen = []
+
+    def seg(x, tf, tl):
+        out, acc = g.chain('HMC', seed=int(z['seed']), x=x, t_first=tf, t_last=tl, accept=True)
+        acc_seen.append(acc[tl:tf + 1])
+        return out
+    bad = mala_segment_errors(seg, z, segments=[(0, 1), (1, 2), (100, 200), (900, 950), (990, 998), (998, 999), (999, 1000)])
+    assert not bad, bad
+    assert not np.concatenate(acc_seen).any()
 
 
 def test_fp32_noise_floor_of_the_reference():
