@@ -9,9 +9,10 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 SO = os.path.join(CSRC, 'libccsp_hip.so')
-SOURCES = ['ccsp_hip.hip', 'ccsp_philox.h', 'ccsp_plan.h', os.path.join('..', '..', 'include', 'ccsp.h')]
+SOURCES = ['ccsp_hip.hip', 'ccsp_philox.h', 'ccsp_plan.h', 'ccsp_energy_pre.h', 'ccsp_energy.h', 'ccsp_bf16x3.h',
+           'ccsp_struct.h', 'ccsp_hmc.h', os.path.join('..', '..', 'include', 'ccsp.h')]
 
-SAMPLERS = {False: 0, None: 0, 'NONE': 0, 'ULA': 1, 'ULA+': 2, 'MALA': 3}
+SAMPLERS = {False: 0, None: 0, 'NONE': 0, 'ULA': 1, 'ULA+': 2, 'MALA': 3, 'HMC': 4}
 SCHEDULE_KEYS = ['betas', 'alphas_cumprod', 'alphas_cumprod_prev', 'sqrt_recip_alphas_cumprod',
                  'sqrt_recipm1_alphas_cumprod', 'posterior_log_variance_clipped', 'posterior_mean_coef1',
                  'posterior_mean_coef2', '_sqrt_recipm1_alphas_cumprod_custom', 'step_sizes',

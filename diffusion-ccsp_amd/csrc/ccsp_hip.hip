@@ -743,6 +743,7 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, float* __restr
 #include "ccsp_energy.h"
 #include "ccsp_bf16x3.h"
 #include "ccsp_struct.h"
+#include "ccsp_hmc.h"
 
 // NaN rows for the edge-output debug API, then scatter sorted -> original order
 __global__ void k_fill(float* p, long n, float v) {
@@ -819,6 +820,7 @@ struct ccsp_graph {
     int *tileb_row0 = nullptr, *tileb_nrows = nullptr, *tileb_ts = nullptr;
     float *Q = nullptr, *GZ = nullptr, *GZR = nullptr, *GP = nullptr, *xhat = nullptr, *partial = nullptr, *Escal = nullptr;
     int *acc_count = nullptr, *acc_denom = nullptr;
+    float *hmc_vk = nullptr, *hmc_vp = nullptr, *hmc_vl = nullptr;   // HMC momenta (allocated on first use)
     std::vector<int> h_denom;      // host copy kept alive for the async upload
     int n_edge_blocks = 0;
     std::vector<void*> allocs;
@@ -1028,6 +1030,7 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
 int steps_at(const ccsp_model* m, int sampler, int t) {
     if (sampler == CCSP_SAMPLER_NONE) return 0;
     if (t % m->d.ebm_per_steps != 0) return 0;                 // ddpm.py:330
+    if (sampler == CCSP_SAMPLER_HMC) return 4;                 // samples_per_step = 4, ddpm.py:311
     if (sampler == CCSP_SAMPLER_ULA_PLUS) {                    // ddpm.py:297-299
         const int n = m->d.timesteps / 4;
         int q = n > 0 ? t / n : 3;
@@ -1051,7 +1054,14 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
                    int init, int t_first, int t_last, float* history, float* accept) {
     const int T = m->d.timesteps, P = m->d.pose_dim;
     std::vector<uint64_t> call0(T);
-    { uint64_t c = 1; for (int t = T - 1; t >= 0; --t) { call0[t] = c; c += 1 + (uint64_t)steps_at(m, sampler, t); } }
+    {   // HMC draws the momentum once per timestep on top of its S refreshments (ddpm.py:1090,1096)
+        uint64_t c = 1;
+        for (int t = T - 1; t >= 0; --t) {
+            call0[t] = c;
+            const int S = steps_at(m, sampler, t);
+            c += 1 + (uint64_t)S + (sampler == CCSP_SAMPLER_HMC && S > 0 ? 1 : 0);
+        }
+    }
     auto noise_for = [&](const Lane& L, uint64_t call, NoiseArg& na) -> int {
         na.mode = nz->mode; na.seed = nz->seed; na.row_offset = nz->row_offset + (unsigned long long)L.node0;
         na.call = (unsigned int)call; na.normal = nullptr; na.uniform = nullptr; na.ucall = 0;
@@ -1097,7 +1107,7 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
         uint64_t uc0 = 0;
         for (int t = T - 1; t >= 0; --t) {
             ucall0[t] = uc0;
-            if (sampler == CCSP_SAMPLER_MALA) { uc0 += (uint64_t)steps_at(m, sampler, t); g->h_denom[t] = N * steps_at(m, sampler, t); }
+            if (sampler == CCSP_SAMPLER_MALA || sampler == CCSP_SAMPLER_HMC) { uc0 += (uint64_t)steps_at(m, sampler, t); g->h_denom[t] = N * steps_at(m, sampler, t); }
         }
         HIP_TRY(hipMemcpyAsync(g->acc_denom, g->h_denom.data(), (size_t)T * sizeof(int), hipMemcpyHostToDevice, s));
         for (int t = t_first; t >= t_last; --t) {
@@ -1114,6 +1124,70 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
                 sched(a, t);
                 if (noise_for(L, call0[t], a.noise)) return 1;
                 launch_node<H>(m, g, a, s);
+            }
+            if (sampler == CCSP_SAMPLER_HMC && S > 0) {
+                // AnnealedMUHASampler.sample_step (ddpm.py:1087-1128); see ccsp_hmc.h.  The leapfrog runs at
+                // the INNER index e (step size, mass, gradient timestep), the energies at the real t.
+                if (!g->hmc_vk && (dev_alloc(g->allocs, &g->hmc_vk, (size_t)N * P) || dev_alloc(g->allocs, &g->hmc_vp, (size_t)N * P) ||
+                                   dev_alloc(g->allocs, &g->hmc_vl, (size_t)N * P))) return 1;
+                const dim3 hgrid(nblk((long)N * P, 256));
+                auto hargs = [&](int mode) {
+                    HmcArgs h;
+                    memset(&h, 0, sizeof(h));
+                    h.N = N; h.P = P; h.F = g->F; h.mode = mode;
+                    h.x = g->x; h.xl = g->xhat; h.vk = g->hmc_vk; h.vp = g->hmc_vp; h.vl = g->hmc_vl; h.eps = g->eps;
+                    h.m_t = 9.0f * m->betas[t]; h.kappa_t = m->kappa[t];
+                    h.mask = g->mask; h.xfeat = g->xfeat; h.pose_begin = m->d.pose_begin;
+                    return h;
+                };
+                auto encode_at = [&](const float* xe) {          // pose embeddings of xe -> g->pemb
+                    NodeArgs a = node_args(m, g);
+                    a.src = 2; a.step = STEP_NONE; a.do_encode = 1; a.x_in = xe;
+                    launch_node<H>(m, g, a, s);
+                };
+                {
+                    HmcArgs h = hargs(HMC_MOMENTUM);
+                    if (noise_for(L, call0[t] + 1, h.noise)) return 1;
+                    hipLaunchKernelGGL(k_hmc, hgrid, dim3(256), 0, s, h);
+                }
+                for (int e = 0; e < S; ++e) {
+                    HmcArgs r = hargs(HMC_REFRESH);
+                    if (noise_for(L, call0[t] + 2 + (uint64_t)e, r.noise)) return 1;
+                    hipLaunchKernelGGL(k_hmc, hgrid, dim3(256), 0, s, r);
+                    const float m_i = 9.0f * m->betas[e];
+                    for (int lf = 0; lf < 2; ++lf) {
+                        // (the reference re-evaluates the gradient at an unchanged x between leapfrogs; it is
+                        // deterministic, so the evaluation after LEAP_A serves both half steps around it)
+                        if (lf == 0) { encode_at(g->xhat); if (launch_eval_energy<H>(m, g, e, g->xhat, true, E_hat, s)) return 1; }
+                        HmcArgs a = hargs(HMC_LEAP_A);
+                        a.ss_i = m->step[e]; a.md_i = m_i * m_i; a.kap_i = m->kappa[e];
+                        hipLaunchKernelGGL(k_hmc, hgrid, dim3(256), 0, s, a);
+                        encode_at(g->xhat);
+                        if (launch_eval_energy<H>(m, g, e, g->xhat, true, E_hat, s)) return 1;
+                        HmcArgs b = a;
+                        b.mode = HMC_LEAP_B;
+                        hipLaunchKernelGGL(k_hmc, hgrid, dim3(256), 0, s, b);
+                    }
+                    encode_at(g->x);
+                    if (launch_eval_energy<H>(m, g, t, g->x, false, E_x, s)) return 1;
+                    encode_at(g->xhat);
+                    if (launch_eval_energy<H>(m, g, t, g->xhat, false, E_hat, s)) return 1;
+                    HmcArgs c = hargs(HMC_ACCEPT);
+                    c.E_x = E_x; c.E_hat = E_hat; c.acc_count = g->acc_count + t;
+                    c.reset_mask = (e == S - 1);
+                    c.hist = e == S - 1 ? hist_at(L, T - t) : nullptr;
+                    c.noise.mode = nz->mode; c.noise.seed = nz->seed; c.noise.row_offset = nz->row_offset;
+                    const uint64_t uc = ucall0[t] + (uint64_t)e;
+                    c.noise.ucall = (unsigned int)uc;
+                    if (nz->mode == CCSP_NOISE_INJECTED) {
+                        if (!nz->uniform || uc < nz->ucall_base || uc - nz->ucall_base >= nz->n_uniform)
+                            return fail("chain_run: injected uniform stream exhausted at call %llu", (unsigned long long)uc);
+                        c.noise.uniform = nz->uniform + (size_t)(uc - nz->ucall_base) * N;
+                    }
+                    hipLaunchKernelGGL(k_hmc, hgrid, dim3(256), 0, s, c);
+                }
+                encode_at(g->x);          // pose embeddings of the state for the next timestep's p_sample
+                continue;
             }
             for (int e = 1; e <= S; ++e) {
                 if (launch_eval_energy<H>(m, g, t, g->x, true, E_x, s)) return 1;
@@ -1695,11 +1769,12 @@ int ccsp_chain_run(ccsp_model* m, ccsp_graph* g, int32_t sampler, const ccsp_noi
     if (!m || !g || !nz || !x) return fail("chain_run: null argument");
     if (g->m != m) return fail("chain_run: graph belongs to another model");
     const int T = m->d.timesteps;
-    if (sampler < 0 || sampler > 3) return fail("chain_run: unknown sampler %d", sampler);
+    if (sampler < 0 || sampler > 4) return fail("chain_run: unknown sampler %d", sampler);
     if (t_first >= T || t_last < 0 || t_first < t_last - 1) return fail("chain_run: bad timestep range [%d,%d]", t_first, t_last);
     if (nz->mode != CCSP_NOISE_PHILOX && nz->mode != CCSP_NOISE_INJECTED) return fail("chain_run: unknown noise mode %d", nz->mode);
     if (nz->mode == CCSP_NOISE_INJECTED && !nz->normal) return fail("chain_run: injected noise without a normal stream");
-    if (sampler == CCSP_SAMPLER_MALA && !m->d.energy_wrapper) return fail("chain_run: MALA needs an energy_wrapper model (train_utils.py:115-116)");
+    if ((sampler == CCSP_SAMPLER_MALA || sampler == CCSP_SAMPLER_HMC) && !m->d.energy_wrapper) return fail("chain_run: MALA / HMC need an energy_wrapper model (train_utils.py:115-116)");
+    if (sampler == CCSP_SAMPLER_HMC && T < 4) return fail("chain_run: HMC indexes the schedule with its inner step 0..3 (ddpm.py:1076-1084); timesteps=%d is too short", T);
     hipStream_t s = (hipStream_t)stream;
     const size_t NP_total = (size_t)g->N * m->d.pose_dim;
     // Concurrent lanes (direct mode): graphs are independent, so the batch is cut into sub-batches whose

@@ -104,11 +104,11 @@ class GaussianDiffusion(object):
     def _sampler(self):
         if not self.EBM:
             return 'NONE'
-        if self.EBM in ('ULA', 'ULA+', 'MALA'):
+        if self.EBM in ('ULA', 'ULA+', 'MALA', 'HMC'):
             return self.EBM
         if 'ULA' in self.EBM:
             return 'ULA'
-        raise NotImplementedError('EBM=%r (HMC is out of scope, SURVEY 8a-13)' % (self.EBM,))
+        raise NotImplementedError('EBM=%r' % (self.EBM,))
 
     def n_normal_calls(self):
         from .noise import n_normal_calls
@@ -117,6 +117,8 @@ class GaussianDiffusion(object):
         if self._sampler() == 'ULA+':
             n = self.num_timesteps // 4
             return 1 + self.num_timesteps + n * (4 + 8 + 12 + 16)
+        if self._sampler() == 'HMC':                 # p_sample + momentum + 4 refreshments per timestep (ddpm.py:1090,1096)
+            return 1 + 6 * self.num_timesteps
         return n_normal_calls(self.num_timesteps, self.samples_per_step if np.isscalar(self.samples_per_step)
                               else np.asarray(self.samples_per_step))
 
@@ -149,7 +151,7 @@ class GaussianDiffusion(object):
         T = self.num_timesteps
         nz, keep = self._noise_struct(seed, noise, row_offset)
         hist = torch.empty((T + 1, g.N, self.dims[-1][0]), device=dev, dtype=torch.float32) if return_history else None
-        acc = torch.zeros(T, device=dev, dtype=torch.float32) if self._sampler() == 'MALA' else None
+        acc = torch.zeros(T, device=dev, dtype=torch.float32) if self._sampler() in ('MALA', 'HMC') else None
         with torch.cuda.device(dev):
             _lib.check(L.ccsp_chain_run(h, g.h, _lib.SAMPLERS[self._sampler()], C.byref(nz), _ptr(x), int(init), int(t_first),
                                         int(t_last), None if hist is None else _ptr(hist), None if acc is None else _ptr(acc),

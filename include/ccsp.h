@@ -54,7 +54,8 @@ typedef struct {
  * baseline over each graph's object sequence (denoise_fn.py:391-451, transformer.py). */
 enum { CCSP_MODEL_DIFFUSION_CCSP = 0, CCSP_MODEL_STRUCT_DIFFUSION = 1 };
 
-enum { CCSP_SAMPLER_NONE = 0, CCSP_SAMPLER_ULA = 1, CCSP_SAMPLER_ULA_PLUS = 2, CCSP_SAMPLER_MALA = 3 };
+enum { CCSP_SAMPLER_NONE = 0, CCSP_SAMPLER_ULA = 1, CCSP_SAMPLER_ULA_PLUS = 2, CCSP_SAMPLER_MALA = 3,
+       CCSP_SAMPLER_HMC = 4 /* AnnealedMUHASampler, ddpm.py:1050-1128: S = 4, 2 leapfrogs, mass 9 betas */ };
 enum { CCSP_NOISE_PHILOX = 0, CCSP_NOISE_INJECTED = 1 };
 
 /* Where the chain's torch.randn / torch.rand draws come from (ddpm.py:255,273,292,1037).
