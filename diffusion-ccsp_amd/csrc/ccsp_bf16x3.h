@@ -9,28 +9,14 @@
 // 64-cycle v_mfma_f32_32x32x2_f32, 2.67x less matrix-pipe time.
 //
 // Operands that are constant (weights) are split once at model creation; the pose embeddings are split
-// by their producer (k_node); the decoder input h = SiLU(U[u0] + U[u1]) is split in registers by the
+// by their producer (the encoder epilogue of k_node); the decoder input h = SiLU(U[u0] + U[u1]) is split in registers by the
 // threads that build it.  Included inside the anonymous namespace of ccsp_hip.hip.
 #pragma once
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short ushort8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ unsigned short bf16_rn_bits(float x) {          // round-to-nearest-even
-    unsigned int u = __float_as_uint(x);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-__device__ __forceinline__ float bf16_bits_f(unsigned short h) { return __uint_as_float((unsigned int)h << 16); }
-
-// x -> (x1, x2, x3) bf16 bit patterns.  Inf/NaN stay in x1 (x - x1 is NaN/0 there, harmless: NaN is data)
-__device__ __forceinline__ void split3(float x, unsigned short& h1, unsigned short& h2, unsigned short& h3) {
-    h1 = bf16_rn_bits(x);
-    const float r1 = x - bf16_bits_f(h1);
-    h2 = bf16_rn_bits(r1);
-    const float r2 = r1 - bf16_bits_f(h2);
-    h3 = bf16_rn_bits(r2);
-}
+// (bf16_rn_bits / bf16_bits_f / split3 live in ccsp_hip.hip: the node kernel's encoder writes planes too)
 
 // dst[plane][i] = plane-th bf16 term of src[i]   (weights, once per model)
 __global__ void k_split3(long n, const float* __restrict__ src, unsigned short* __restrict__ dst) {
@@ -309,16 +295,3 @@ __global__ __launch_bounds__(256) void k_edge_bf(int E_act, int P, const int* __
     }
 }
 
-// pose-embedding planes for k_rowgemm_bf: P3[plane][n][c] = plane-th bf16 term of pemb[n][c]
-__global__ void k_split_rows(long n, const float* __restrict__ src, unsigned short* __restrict__ dst) {
-    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i >= n) return;
-    const float4 v = *reinterpret_cast<const float4*>(src + i);
-    const float x[4] = {v.x, v.y, v.z, v.w};
-    unsigned short a[4], b[4], c[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) split3(x[e], a[e], b[e], c[e]);
-    *reinterpret_cast<uint2*>(dst + i) = make_uint2(a[0] | ((unsigned)a[1] << 16), a[2] | ((unsigned)a[3] << 16));
-    *reinterpret_cast<uint2*>(dst + n + i) = make_uint2(b[0] | ((unsigned)b[1] << 16), b[2] | ((unsigned)b[3] << 16));
-    *reinterpret_cast<uint2*>(dst + 2 * n + i) = make_uint2(c[0] | ((unsigned)c[1] << 16), c[2] | ((unsigned)c[3] << 16));
-}

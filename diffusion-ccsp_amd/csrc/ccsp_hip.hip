@@ -70,6 +70,23 @@ __device__ __forceinline__ float mish_f(float v) {
 // one-time model kernels
 // ------------------------------------------------------------------------------------------
 
+// fp32 -> three bf16 terms (ccsp_bf16x3.h explains the scheme)
+__device__ __forceinline__ unsigned short bf16_rn_bits(float x) {          // round-to-nearest-even
+    unsigned int u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_bits_f(unsigned short h) { return __uint_as_float((unsigned int)h << 16); }
+
+// x -> (x1, x2, x3) bf16 bit patterns.  Inf/NaN stay in x1 (x - x1 is NaN/0 there, harmless: NaN is data)
+__device__ __forceinline__ void split3(float x, unsigned short& h1, unsigned short& h2, unsigned short& h3) {
+    h1 = bf16_rn_bits(x);
+    const float r1 = x - bf16_bits_f(h1);
+    h2 = bf16_rn_bits(r1);
+    const float r2 = r1 - bf16_bits_f(h2);
+    h3 = bf16_rn_bits(r2);
+}
+
 // SinusoidalPosEmb (denoise_fn.py:38-50) for every t: e[t, :] fp32, evaluated like the reference
 __global__ void k_sinusoid(int T, int H, float* __restrict__ e) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -174,7 +191,8 @@ __device__ __forceinline__ void enc_prefetch(const EncW w, EncPrefetch<H>& pf) {
 
 template <int H>
 __device__ __forceinline__ void encode_tile_mfma(const EncW w, const EncPrefetch<H>& pf, float (*xs)[8],
-                                                 float (*s1)[H / 2 + 1], int node0, int N, float* __restrict__ out /*[N,H]*/) {
+                                                 float (*s1)[H / 2 + 1], int node0, int N, float* __restrict__ out /*[N,H]*/,
+                                                 unsigned short* __restrict__ outS = nullptr /*[3][N][H] bf16 planes or null*/) {
     using PFT = EncPrefetch<H>;
     constexpr int TPW = PFT::TPW, KS = PFT::KS, PF = PFT::PF;
     const int tid = threadIdx.x;
@@ -216,7 +234,16 @@ __device__ __forceinline__ void encode_tile_mfma(const EncW w, const EncPrefetch
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = node0 + (lane >> 4) * 4 + r;
-            if (n < N) out[(size_t)n * H + col] = silu_fast(acc[j][r] + pf.b2[j]);
+            if (n < N) {
+                const float v = silu_fast(acc[j][r] + pf.b2[j]);
+                out[(size_t)n * H + col] = v;
+                if (outS) {                                   // operand planes of k_rowgemm_bf, written by the producer
+                    unsigned short h1, h2, h3;
+                    split3(v, h1, h2, h3);
+                    const size_t pl = (size_t)N * H, o = (size_t)n * H + col;
+                    outS[o] = h1; outS[pl + o] = h2; outS[2 * pl + o] = h3;
+                }
+            }
         }
     }
 }
@@ -655,7 +682,7 @@ struct NodeArgs {
 };
 
 template <int H>
-__global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, float* __restrict__ pemb) {
+__global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, float* __restrict__ pemb, unsigned short* __restrict__ pembS) {
     __shared__ float xs[NODE_TILE][8];
     __shared__ float s1[NODE_TILE][H / 2 + 1];
     const int node0 = blockIdx.x * NODE_TILE;
@@ -737,7 +764,7 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, float* __restr
     }
     if (!a.do_encode) return;
     __syncthreads();
-    encode_tile_mfma<H>(w, pf, xs, s1, node0, a.N, pemb);
+    encode_tile_mfma<H>(w, pf, xs, s1, node0, a.N, pemb, pembS);
 }
 
 #include "ccsp_energy.h"
@@ -895,7 +922,6 @@ int launch_eval(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s) {
     const float* tau_t = m->tau + (size_t)t * m->d.n_types * 2 * H;
     if (m->bf16x3) {
         const long npe = (long)g->N * H;
-        hipLaunchKernelGGL(k_split_rows, dim3(nblk(npe / 4, 256)), dim3(256), 0, s, npe, g->pemb, g->pembS);
         hipLaunchKernelGGL((k_rowgemm_bf<H, 2 * H>), dim3(nw_u), dim3(256), 0, s, g->pembS, (size_t)npe, g->urow_node, g->tile_row0,
                            g->tile_nrows, g->tile_ts, m->WpS, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, g->base, tau_t, g->U);
         if (prof) HIP_TRY(hipEventRecord(g->kev[g->kev_used + 1], s));
@@ -929,7 +955,8 @@ NodeArgs node_args(ccsp_model* m, ccsp_graph* g) {
 
 template <int H>
 void launch_node(ccsp_model* m, ccsp_graph* g, const NodeArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_node<H>, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a, enc_pose(m), g->pemb);
+    hipLaunchKernelGGL(k_node<H>, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a, enc_pose(m), g->pemb,
+                       (m->bf16x3 && m->d.model_kind == CCSP_MODEL_DIFFUSION_CCSP) ? g->pembS : (unsigned short*)nullptr);
 }
 
 // ---- StructDiffusion baseline ------------------------------------------------------------------
@@ -1487,10 +1514,10 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     // Grid cap of k_rowgemm (a capped grid walks the work list as a persistent loop).  Inside the chain
     // one tile per workgroup measured equal or faster on MI355X, so the cap is off by default;
     // CCSP_MAX_WGS=<n> sets it for experiments.
-    m->bf16x3 = 0;
+    m->bf16x3 = 1;     // direct-mode GEMMs on the bf16 matrix cores, fp32-accurate (ccsp_bf16x3.h); CCSP_MMA=f32 selects the fp32 MFMA kernels
     m->lanes = 2;
     if (const char* e = getenv("CCSP_LANES")) { const int v = atoi(e); if (v >= 1 && v <= 8) m->lanes = v; }
-    if (const char* e = getenv("CCSP_MMA")) m->bf16x3 = (strcmp(e, "bf16x3") == 0);
+    if (const char* e = getenv("CCSP_MMA")) m->bf16x3 = (strcmp(e, "f32") != 0);
     m->WpS = nullptr; m->Wd1S = nullptr;
     m->max_wgs = 1 << 30;
     if (const char* e = getenv("CCSP_MAX_WGS")) { const int v = atoi(e); if (v > 0) m->max_wgs = v; }

@@ -67,7 +67,7 @@ class GaussianDiffusion(object):
         ss = np.ascontiguousarray(np.broadcast_to(ss, (self.num_timesteps,)), dtype=np.float32)
         _lib.check(L.ccsp_schedule_set(h, None if b is None else b.ctypes.data, ss.ctypes.data,
                                        None if sp_arr is None else sp_arr.ctypes.data, default))
-        self._schedule_owner = h.value
+        self._schedule_owner = self._core()._generation
 
     def _read_buffers(self):
         L = _lib.lib()
@@ -80,7 +80,7 @@ class GaussianDiffusion(object):
 
     def _handle(self):
         h = self._core()._handle()
-        if getattr(self, '_schedule_owner', None) != h.value:   # weights were reloaded -> new native model
+        if getattr(self, '_schedule_owner', None) != self._core()._generation:   # weights were reloaded -> new native model
             self._apply_schedule()
             h = self._core()._handle()
         return h

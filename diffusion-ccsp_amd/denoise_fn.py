@@ -67,7 +67,7 @@ class _Graph(object):
         _lib.check(L.ccsp_graph_create(owner._handle(), self.N, self.E, self.F, _ptr(self.x), _ptr(self.edge_index),
                                        _ptr(self.edge_attr), _ptr(self.mask), _stream_ptr(dev), C.byref(h)))
         self.h = h
-        self.model_handle = owner._h.value
+        self.model_handle = owner._generation       # (a new native model may reuse a freed one's address)
         if owner.model == 'StructDiffusion':
             # the token sequences: batch.batch, and batch.shuffled when the dataset carries it (denoise_fn.py:408-417)
             self.seq = batch.batch.detach().to(dev, torch.int64).contiguous()
@@ -118,6 +118,7 @@ class ConstraintDiffuser(object):
             raise ValueError("'robot' input modes need dims with a grasp group")
         self._params = None       # name -> device tensor
         self._h = None
+        self._generation = 0      # bumped for every native model created: handles are compared by this, not by address
         self._graphs = {}
         if self.device.type != 'cuda':
             raise _lib.CcspError("ConstraintDiffuser(device=%r): the HIP path needs a GPU device ('cuda'); "
@@ -254,6 +255,7 @@ class ConstraintDiffuser(object):
         with torch.cuda.device(self.device):
             _lib.check(L.ccsp_model_create(C.byref(d), arr, _stream_ptr(self.device), C.byref(h)))
         self._h = h
+        self._generation += 1
         return h
 
     def _graph(self, batch):
@@ -262,7 +264,7 @@ class ConstraintDiffuser(object):
                tuple(batch.edge_index.shape))
         self._handle()
         g = self._graphs.get(key)
-        if g is None or g.model_handle != self._h.value:
+        if g is None or g.model_handle != self._generation:
             if len(self._graphs) > 8:
                 self._graphs.clear()
             with torch.cuda.device(self.device):

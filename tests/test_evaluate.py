@@ -82,3 +82,19 @@ def test_real_sampler_and_checkpoint_roundtrip(device, tmp_path):
                                   checkpoint=path)
     b = worlds.collate(sets[3]).to_torch(device)
     assert torch.equal(gd.sample(b, seed=9), gd2.sample(b, seed=9))
+
+
+@pytest.mark.gpu
+def test_schedule_follows_reloaded_weights(device):
+    """regression: reloading weights destroys and re-creates the native model, which may land on the freed
+    address; the GaussianDiffusion schedule (samples_per_step, step sizes) must be re-applied to it regardless"""
+    gd = evaluate.create_sampler('qualitative', hidden_dim=64, timesteps=20, EBM='ULA', samples_per_step=3, device=device)
+    sd = {'denoise_fn.' + k: v for k, v in weights('weights_qualitative_h64.npz').items()}
+    b = worlds.collate(make_sets(2, 3)[3]).to_torch(device)
+    ref = None
+    for _ in range(6):
+        gd.load_state_dict(sd)
+        x = gd.sample(b, seed=4)
+        assert gd.chain_stats()['evals'] == 20 * (1 + 3)
+        ref = x if ref is None else ref
+        assert torch.equal(x, ref)

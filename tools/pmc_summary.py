@@ -13,7 +13,7 @@ for f in files:
         name = row['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
         acc[name][row['Counter_Name']].append(float(row['Counter_Value']))
 for name in sorted(acc):
-    if not any(k in name for k in ('k_ugemm', 'k_edge', 'k_node')):
+    if not any(k in name for k in ('k_ugemm', 'k_rowgemm', 'k_edge', 'k_node', 'k_split', 'k_sd_', 'k_fused')):
         continue
     print(name)
     for c in sorted(acc[name]):
