@@ -170,6 +170,110 @@ __global__ __launch_bounds__(256) void k_rowgemm_bf(const unsigned short* __rest
 }
 
 // ------------------------------------------------------------------------------------------
+// k_rowgemm_bf2<KD, ND>: 128 x 128 tiles, 512 threads (8 waves as 4(M) x 2(N), 32 x 64 each).
+// A 128-row tile reads each weight slice half as often as the 64 x 128 kernel above (253 instead of
+// 380 MB of operand planes from L2 per launch at C2) and halves the number of workgroups, so that a
+// half-batch launch of the two-lane chain is a single resident wave of workgroups.  LDS rows are
+// unpadded 64-byte K chunks with the 16-byte piece index XOR-swizzled by (row >> 2) & 3: both the
+// ds_read_b128 fragment reads (lane groups of MI355X_MICROARCH.md, LDS table) and the 8-lane
+// ds_write_b128 groups are conflict-free, and the stage is 48 KB.
+// ------------------------------------------------------------------------------------------
+constexpr int RB2_TM = 128, RB2_TN = 128;
+
+__device__ __forceinline__ int rb2_off(int row, int piece) { return row * BF_BK + ((piece ^ ((row >> 2) & 3)) << 3); }
+
+template <int KD, int ND>
+__global__ __launch_bounds__(512) void k_rowgemm_bf2(const unsigned short* __restrict__ A, size_t a_plane,
+                                                     const int* __restrict__ urow_node, const int* __restrict__ tile_row0,
+                                                     const int* __restrict__ tile_nrows, const int* __restrict__ tile_ts,
+                                                     const unsigned short* __restrict__ W, size_t w_plane, size_t w_stride,
+                                                     const float* __restrict__ base, const float* __restrict__ tau_t,
+                                                     float* __restrict__ U) {
+    static_assert(ND % RB2_TN == 0 && KD % BF_BK == 0, "shape");
+    constexpr int NCT = ND / RB2_TN;
+    constexpr int PLANE = RB2_TM * BF_BK;                         // ushorts per plane of a stage (A and B alike)
+    __shared__ __attribute__((aligned(16))) unsigned short As[3 * PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[3 * PLANE];
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = bid / NCT;
+    const int row0 = tile_row0[tile], nrows = tile_nrows[tile], ts = tile_ts[tile];
+    const int col0 = (bid % NCT) * RB2_TN;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = tid >> 2, lq = tid & 3;                      // one (row, 16-byte piece) of every plane, for A and for B
+    const unsigned short* a_ptr;
+    {
+        const int r = lrow < nrows ? lrow : nrows - 1;
+        const int src = urow_node ? urow_node[row0 + r] : row0 + r;
+        a_ptr = A + (size_t)src * KD + lq * 8;
+    }
+    const unsigned short* b_ptr = W + (size_t)ts * w_stride + (size_t)(col0 + lrow) * KD + lq * 8;
+    const int st_off = rb2_off(lrow, lq);
+    ushort8 ra[3], rb[3];
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            ra[i] = *reinterpret_cast<const ushort8*>(a_ptr + (size_t)i * a_plane + c * BF_BK);
+            rb[i] = *reinterpret_cast<const ushort8*>(b_ptr + (size_t)i * w_plane + c * BF_BK);
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            *reinterpret_cast<ushort8*>(As + i * PLANE + st_off) = ra[i];
+            *reinterpret_cast<ushort8*>(Bs + i * PLANE + st_off) = rb[i];
+        }
+    };
+    gload(0);
+    floatx16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = col0 + wn * 64 + j * 32 + (lane & 31);
+        const float tv = (tau_t && (ts & 1) == 0) ? tau_t[(size_t)(ts >> 1) * ND + col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            row = row < nrows ? row : nrows - 1;
+            acc[j][r] = (base ? base[(size_t)(row0 + row) * ND + col] : 0.0f) + tv;
+        }
+    }
+    lstore();
+    __syncthreads();
+    const int arow = wm * 32 + (lane & 31), brow = wn * 64 + (lane & 31);
+    constexpr int NCH = KD / BF_BK;
+    for (int c = 0; c < NCH; ++c) {
+        if (c + 1 < NCH) gload(c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < BF_BK / 16; ++ks) {
+            const int piece = (lane >> 5) + 2 * ks;
+            bf16x8 a[3], b[2][3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                a[p] = *reinterpret_cast<const bf16x8*>(As + p * PLANE + rb2_off(arow, piece));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j][p] = *reinterpret_cast<const bf16x8*>(Bs + p * PLANE + rb2_off(brow + 32 * j, piece));
+            }
+            mfma6<2>(a, b, acc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        if (c + 1 < NCH) {
+            lstore();
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int col = col0 + wn * 64 + j * 32 + (lane & 31);
+            if (row < nrows) U[(size_t)(row0 + row) * ND + col] = acc[j][r];
+        }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_edge_bf<H>: k_edge (direct mode) on the bf16 matrix cores.  h = SiLU(U[u0] + U[u1]) is built in
 // fp32 and split in registers; B = pose_decoder.0 planes [3][H/2][H].
 //   H=256: 64 rows x 128 cols per workgroup (waves 2x2, 32x64 each);  H=64: 128 rows x 32 cols (4x1)
@@ -285,11 +389,9 @@ __global__ __launch_bounds__(256) void k_edge_bf(int E_act, int P, const int* __
     }
     __syncthreads();
     for (int idx = tid; idx < BM * P; idx += 256) {
-        const int row = idx % BM, p = idx / BM;
-        const float* w = Wd2 + (size_t)p * BN;
-        float o = 0.0f;
-        for (int j = 0; j < BN; ++j) o = fmaf(S1[row * S1_LD + j], w[j], o);
-        o += bd2[p];
+        const int row = idx % BM;
+        const int p = (BM % 64 == 0) ? __builtin_amdgcn_readfirstlane(idx / BM) : idx / BM;
+        const float o = dot4<BN>(S1 + row * S1_LD, Wd2 + (size_t)p * BN) + bd2[p];
         const int k = e0 + row;
         if (k < E_act) O[(size_t)ent_pos[2 * k + s] * P + p] = o;
     }

@@ -504,6 +504,21 @@ __global__ void k_rowbase(int R, int W2, const int* __restrict__ urow_ts, const 
 // ------------------------------------------------------------------------------------------
 #include "ccsp_energy_pre.h"
 
+// sum_j a[j] w[j] over N (multiple of 4) as four independent chains: the serial fma chain of the naive loop,
+// one exposed LDS/scalar-load round trip per element, was 8 us of k_edge's 39 (tools/abl_run.sh)
+template <int N>
+__device__ __forceinline__ float dot4(const float* __restrict__ a, const float* __restrict__ w) {
+    float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;
+#pragma unroll 8
+    for (int j = 0; j < N; j += 4) {
+        o0 = fmaf(a[j], w[j], o0);
+        o1 = fmaf(a[j + 1], w[j + 1], o1);
+        o2 = fmaf(a[j + 2], w[j + 2], o2);
+        o3 = fmaf(a[j + 3], w[j + 3], o3);
+    }
+    return (o0 + o1) + (o2 + o3);
+}
+
 template <int H> struct EdgeCfg;
 template <> struct EdgeCfg<256> { static constexpr int WM = 1, WN = 4, TN = 1; };
 template <> struct EdgeCfg<64> { static constexpr int WM = 4, WN = 1, TN = 1; };
@@ -614,11 +629,9 @@ __global__ __launch_bounds__(256, 3) void k_edge(int E_act, int P,
     // epilogue 2: o[row, p] = bd2[p] + sum_j S1[row, j] Wd2[p, j]
     float e2 = 0.0f;
     for (int idx = tid; idx < BM * P; idx += 256) {
-        const int row = idx % BM, p = idx / BM;
-        const float* w = Wd2 + (size_t)p * BN;
-        float o = 0.0f;
-        for (int j = 0; j < BN; ++j) o = fmaf(S1[row * S1_LD + j], w[j], o);
-        o += bd2[p];
+        const int row = idx % BM;
+        const int p = (BM % 64 == 0) ? __builtin_amdgcn_readfirstlane(idx / BM) : idx / BM;   // uniform per wave when BM % 64 == 0: scalar weight loads
+        float o = dot4<BN>(S1 + row * S1_LD, Wd2 + (size_t)p * BN) + bd2[p];
         const int k = e0 + row;
         if (k < E_act) {
             if constexpr (ENERGY) {
@@ -685,6 +698,9 @@ template <int H>
 __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, float* __restrict__ pemb, unsigned short* __restrict__ pembS) {
     __shared__ float xs[NODE_TILE][8];
     __shared__ float s1[NODE_TILE][H / 2 + 1];
+    // the node kernel is a short latency chain on the critical path of every evaluation; when it shares the
+    // CUs with the other lane's GEMM kernels its waves should win the issue arbitration
+    __builtin_amdgcn_s_setprio(3);
     const int node0 = blockIdx.x * NODE_TILE;
     const int tid = threadIdx.x;
     EncPrefetch<H> pf;
@@ -813,6 +829,7 @@ struct ccsp_model {
     std::vector<hipStream_t> lane_streams;   // created once per model: new HIP streams are expensive to
     std::vector<hipEvent_t> lane_events;     // create (hundreds of ms for the first few), graphs come and go
     hipEvent_t fork_event = nullptr;
+    int row_tile;  // 128: k_rowgemm_bf2 (default); 64: k_rowgemm_bf (CCSP_ROW_TILE=64)
     int bf16x3;    // 1: direct-mode GEMMs on the bf16 matrix cores with 3-way split operands (ccsp_bf16x3.h)
     unsigned short* WpS;    // [3][C][2][2H][H] bf16 planes of Wp
     unsigned short* Wd1S;   // [3][H/2][H]      bf16 planes of pose_decoder.0.weight
@@ -840,6 +857,8 @@ struct ccsp_graph {
     int *e_type, *e_u0, *e_u1, *e_orig, *urow_node, *tile_row0, *tile_nrows, *tile_ts, *node_ptr, *node_ent, *ent_pos;
     float *base, *U, *O, *pemb, *x, *eps;
     unsigned short* pembS = nullptr;   // [3][N][H] bf16 planes of pemb (bf16x3 mode)
+    int *t2_row0 = nullptr, *t2_nrows = nullptr, *t2_ts = nullptr;   // 128-row tiles of k_rowgemm_bf2 (pairs of plan tiles)
+    int n_tiles2 = 0;
     int* urow_ts;
     // energy mode (allocated on first use)
     bool energy_ready = false;
@@ -849,6 +868,7 @@ struct ccsp_graph {
     int *acc_count = nullptr, *acc_denom = nullptr;
     float *hmc_vk = nullptr, *hmc_vp = nullptr, *hmc_vl = nullptr;   // HMC momenta (allocated on first use)
     std::vector<int> h_denom;      // host copy kept alive for the async upload
+    std::vector<int> h_t2;         // (row0 | nrows | ts) of the 128-row tiles, kept alive for the async upload
     int n_edge_blocks = 0;
     std::vector<void*> allocs;
     // concurrent lanes: the batch cut into independent sub-batches (children), each a complete graph
@@ -922,6 +942,10 @@ int launch_eval(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s) {
     const float* tau_t = m->tau + (size_t)t * m->d.n_types * 2 * H;
     if (m->bf16x3) {
         const long npe = (long)g->N * H;
+        if (m->row_tile == 128)
+            hipLaunchKernelGGL((k_rowgemm_bf2<H, 2 * H>), dim3(g->n_tiles2 * (2 * H / RB2_TN)), dim3(512), 0, s, g->pembS, (size_t)npe, g->urow_node,
+                               g->t2_row0, g->t2_nrows, g->t2_ts, m->WpS, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, g->base, tau_t, g->U);
+        else
         hipLaunchKernelGGL((k_rowgemm_bf<H, 2 * H>), dim3(nw_u), dim3(256), 0, s, g->pembS, (size_t)npe, g->urow_node, g->tile_row0,
                            g->tile_nrows, g->tile_ts, m->WpS, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, g->base, tau_t, g->U);
         if (prof) HIP_TRY(hipEventRecord(g->kev[g->kev_used + 1], s));
@@ -1380,6 +1404,24 @@ int graph_build(ccsp_model* m, int N, int E, int F, const float* x, const signed
     TRY(dev_upload(reg, &g->node_ent, p.node_ent, s));
     TRY(dev_upload(reg, &g->ent_pos, p.ent_pos, s));
     TRY(dev_upload(reg, &g->urow_ts, p.urow_ts, s));
+    {   // 128-row tiles: consecutive 64-row plan tiles of one (type, slot) group, two at a time
+        std::vector<int> r0, nr, tsv;
+        for (size_t i = 0; i < p.tile_row0.size();) {
+            const bool pair = i + 1 < p.tile_row0.size() && p.tile_ts[i + 1] == p.tile_ts[i] &&
+                              p.tile_row0[i + 1] == p.tile_row0[i] + p.tile_nrows[i];
+            r0.push_back(p.tile_row0[i]);
+            nr.push_back(p.tile_nrows[i] + (pair ? p.tile_nrows[i + 1] : 0));
+            tsv.push_back(p.tile_ts[i]);
+            i += pair ? 2 : 1;
+        }
+        g->n_tiles2 = (int)r0.size();
+        g->h_t2.assign(r0.begin(), r0.end());
+        g->h_t2.insert(g->h_t2.end(), nr.begin(), nr.end());
+        g->h_t2.insert(g->h_t2.end(), tsv.begin(), tsv.end());
+        int* t2 = nullptr;
+        TRY(dev_upload(reg, &t2, g->h_t2, s));
+        g->t2_row0 = t2; g->t2_nrows = t2 + g->n_tiles2; g->t2_ts = t2 + 2 * g->n_tiles2;
+    }
     TRY(dev_alloc(reg, &g->base, (size_t)p.R * 2 * H));
     TRY(dev_alloc(reg, &g->U, (size_t)p.R * 2 * H));
     TRY(dev_alloc(reg, &g->O, (size_t)2 * p.E_act * P));
@@ -1518,6 +1560,8 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     m->lanes = 2;
     if (const char* e = getenv("CCSP_LANES")) { const int v = atoi(e); if (v >= 1 && v <= 8) m->lanes = v; }
     if (const char* e = getenv("CCSP_MMA")) m->bf16x3 = (strcmp(e, "f32") != 0);
+    m->row_tile = 128;
+    if (const char* e = getenv("CCSP_ROW_TILE")) m->row_tile = atoi(e) == 64 ? 64 : 128;
     m->WpS = nullptr; m->Wd1S = nullptr;
     m->max_wgs = 1 << 30;
     if (const char* e = getenv("CCSP_MAX_WGS")) { const int v = atoi(e); if (v > 0) m->max_wgs = v; }

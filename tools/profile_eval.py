@@ -9,7 +9,10 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 from bench import load_weights
-from diffusion_ccsp_amd import ConstraintDiffuser, worlds
+from diffusion_ccsp_amd import ConstraintDiffuser, worlds, _lib
+if os.environ.get('CCSP_SO'):          # ablation builds (tools only)
+    _lib.SO = os.environ['CCSP_SO']
+    _lib._stale = lambda: False
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
