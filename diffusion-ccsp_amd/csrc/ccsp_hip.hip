@@ -168,7 +168,7 @@ struct EncPrefetch {
     static constexpr int TPW = H / 64, KS = H / 8, PF = KS >= 16 ? 8 : KS / 2;   // PF k-steps of layer-2 fragments prefetched
     float w0[8], b0;                                          // layer-1 row of this thread's output column
     float wf[PF][TPW];
-    float b2[TPW];
+    float b2[TPW][4];                                         // bias of this lane's 4 consecutive output columns per tile
 };
 
 template <int H>
@@ -185,14 +185,17 @@ __device__ __forceinline__ void enc_prefetch(const EncW w, EncPrefetch<H>& pf) {
 #pragma unroll
         for (int q = 0; q < PFT::TPW; ++q) pf.wf[ks][q] = wf[(size_t)ks * 64 * PFT::TPW + q];
 #pragma unroll
-    for (int q = 0; q < PFT::TPW; ++q) pf.b2[q] = w.b2[wave * 16 * PFT::TPW + q * 16 + (lane & 15)];
+    for (int q = 0; q < PFT::TPW; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pf.b2[q][r] = w.b2[wave * 16 * PFT::TPW + q * 16 + 4 * (lane >> 4) + r];
     __builtin_amdgcn_sched_barrier(0);      // keep these loads at kernel entry (hipcc would sink them to first use)
 }
 
 template <int H>
 __device__ __forceinline__ void encode_tile_mfma(const EncW w, const EncPrefetch<H>& pf, float (*xs)[8],
                                                  float (*s1)[H / 2 + 1], int node0, int N, float* __restrict__ out /*[N,H]*/,
-                                                 unsigned short* __restrict__ outS = nullptr /*[3][N][H] bf16 planes or null*/) {
+                                                 unsigned short* __restrict__ outS = nullptr /*[3][N][H] bf16 planes or null*/,
+                                                 bool write_f32 = true) {
     using PFT = EncPrefetch<H>;
     constexpr int TPW = PFT::TPW, KS = PFT::KS, PF = PFT::PF;
     const int tid = threadIdx.x;
@@ -225,24 +228,30 @@ __device__ __forceinline__ void encode_tile_mfma(const EncW w, const EncPrefetch
         const float a = ap[ks * 4];
 #pragma unroll
         for (int j = 0; j < TPW; ++j)
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, ks < PF ? pf.wf[ks][j] : rest[ks - PF][j], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ks < PF ? pf.wf[ks][j] : rest[ks - PF][j], a, acc[j], 0, 0, 0);
     }
-    // C/D layout of 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg
+    // The weight fragment is the A operand, so the product comes out transposed: C/D layout of 16x16 is
+    // col = lane & 15 -> the node, row = (lane >> 4) * 4 + reg -> four CONSECUTIVE output columns per lane.
+    // One 16-byte store per tile (and 8 bytes per bf16 plane) instead of four scattered ones: the 2-byte
+    // plane stores of the untransposed layout cost 5 % of the whole chain (tools/ab.sh).
+    const int n = node0 + (lane & 15);
+    if (n < N) {
 #pragma unroll
-    for (int j = 0; j < TPW; ++j) {
-        const int col = wave * 16 * TPW + j * 16 + (lane & 15);
+        for (int j = 0; j < TPW; ++j) {
+            const int c0 = wave * 16 * TPW + j * 16 + 4 * (lane >> 4);
+            float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = node0 + (lane >> 4) * 4 + r;
-            if (n < N) {
-                const float v = silu_fast(acc[j][r] + pf.b2[j]);
-                out[(size_t)n * H + col] = v;
-                if (outS) {                                   // operand planes of k_rowgemm_bf, written by the producer
-                    unsigned short h1, h2, h3;
-                    split3(v, h1, h2, h3);
-                    const size_t pl = (size_t)N * H, o = (size_t)n * H + col;
-                    outS[o] = h1; outS[pl + o] = h2; outS[2 * pl + o] = h3;
-                }
+            for (int r = 0; r < 4; ++r) v[r] = silu_fast(acc[j][r] + pf.b2[j][r]);
+            const size_t o = (size_t)n * H + c0;
+            if (write_f32) *reinterpret_cast<float4*>(out + o) = float4{v[0], v[1], v[2], v[3]};
+            if (outS) {                                       // operand planes of k_rowgemm_bf*, written by the producer
+                unsigned short h1[4], h2[4], h3[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) split3(v[r], h1[r], h2[r], h3[r]);
+                const size_t pl = (size_t)N * H;
+                *reinterpret_cast<uint2*>(outS + o) = make_uint2(h1[0] | ((unsigned)h1[1] << 16), h1[2] | ((unsigned)h1[3] << 16));
+                *reinterpret_cast<uint2*>(outS + pl + o) = make_uint2(h2[0] | ((unsigned)h2[1] << 16), h2[2] | ((unsigned)h2[3] << 16));
+                *reinterpret_cast<uint2*>(outS + 2 * pl + o) = make_uint2(h3[0] | ((unsigned)h3[1] << 16), h3[2] | ((unsigned)h3[3] << 16));
             }
         }
     }
@@ -695,7 +704,7 @@ struct NodeArgs {
 };
 
 template <int H>
-__global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, float* __restrict__ pemb, unsigned short* __restrict__ pembS) {
+__global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, float* __restrict__ pemb, unsigned short* __restrict__ pembS, int write_f32) {
     __shared__ float xs[NODE_TILE][8];
     __shared__ float s1[NODE_TILE][H / 2 + 1];
     // the node kernel is a short latency chain on the critical path of every evaluation; when it shares the
@@ -780,7 +789,7 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, float* __restr
     }
     if (!a.do_encode) return;
     __syncthreads();
-    encode_tile_mfma<H>(w, pf, xs, s1, node0, a.N, pemb, pembS);
+    encode_tile_mfma<H>(w, pf, xs, s1, node0, a.N, pemb, pembS, write_f32 != 0);
 }
 
 #include "ccsp_energy.h"
@@ -979,8 +988,10 @@ NodeArgs node_args(ccsp_model* m, ccsp_graph* g) {
 
 template <int H>
 void launch_node(ccsp_model* m, ccsp_graph* g, const NodeArgs& a, hipStream_t s) {
+    // direct-mode bf16x3 evaluations read the planes only; the fp32 embeddings are for the fp32 / energy / transformer paths
+    const bool planes = m->bf16x3 && m->d.model_kind == CCSP_MODEL_DIFFUSION_CCSP;
     hipLaunchKernelGGL(k_node<H>, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a, enc_pose(m), g->pemb,
-                       (m->bf16x3 && m->d.model_kind == CCSP_MODEL_DIFFUSION_CCSP) ? g->pembS : (unsigned short*)nullptr);
+                       planes ? g->pembS : (unsigned short*)nullptr, (!planes || m->d.energy_wrapper) ? 1 : 0);
 }
 
 // ---- StructDiffusion baseline ------------------------------------------------------------------
