@@ -397,3 +397,142 @@ __global__ __launch_bounds__(256) void k_edge_bf(int E_act, int P, const int* __
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_edge_bf2: k_edge_bf for H = 256 with the activation work taken off the critical path.  In k_edge_bf
+// a chunk is  wait(U rows) -> SiLU + split (VALU) -> LDS write -> barrier -> LDS read -> MFMA -> barrier,
+// all in series; removing the MFMAs alone was worth 15 % of the whole chain (tools/ab.sh).  Here the A
+// stage (the activations) is double-buffered, so the SiLU/split of chunk c+1 is issued between the MFMA
+// groups of chunk c and runs in their shadow; only the plain copy of the next weight chunk sits between
+// the two barriers.  Unpadded swizzled stages (rb2_off): 2 x 12 KB (A) + 24 KB (B) = 48 KB.
+// 64 edges x 128 columns per workgroup, waves 2 x 2, one slot-half per workgroup like k_edge_bf.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_edge_bf2(int E_act, int P, const int* __restrict__ e_u0, const int* __restrict__ e_u1,
+                                                  const float* __restrict__ U, const unsigned short* __restrict__ Wd1S /*[3][128][256]*/,
+                                                  const float* __restrict__ bd1, const float* __restrict__ Wd2,
+                                                  const float* __restrict__ bd2, const int* __restrict__ ent_pos, float* __restrict__ O) {
+    constexpr int H = 256, BM = 64, BN = 128;
+    constexpr int APL = BM * BF_BK, BPL = BN * BF_BK;             // ushorts per plane
+    constexpr int S1_LD = BN + 1;
+    constexpr int STAGE_BYTES = (2 * 3 * APL + 3 * BPL) * 2;      // 49152
+    static_assert(STAGE_BYTES >= BM * S1_LD * 4, "epilogue tile must fit the stage");
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[STAGE_BYTES];
+    unsigned short* As = reinterpret_cast<unsigned short*>(smem_raw);         // [2][3][APL]
+    unsigned short* Bs = As + 2 * 3 * APL;                                    // [3][BPL]
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int e0 = (bid >> 1) * BM;
+    const int s = bid & 1;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = tid >> 3, lq = tid & 7;                        // A producer: rows lr, lr + 32; fp32 columns lq*4 .. +3 of the chunk
+    const float* u0_ptr[2];
+    const float* u1_ptr[2];
+    int a_st[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int k = e0 + lr + 32 * i;
+        k = k < E_act ? k : E_act - 1;
+        const int coff = s * H + lq * 4;
+        u0_ptr[i] = U + (size_t)e_u0[k] * (2 * H) + coff;
+        u1_ptr[i] = U + (size_t)e_u1[k] * (2 * H) + coff;
+        a_st[i] = rb2_off(lr + 32 * i, lq >> 1) + (lq & 1) * 4;
+    }
+    const int brow = tid >> 2, bq = tid & 3;                      // B copy: rows brow, brow + 64, piece bq, every plane
+    const unsigned short* b_ptr = Wd1S + (size_t)brow * H + bq * 8;
+    const int b_st0 = rb2_off(brow, bq), b_st1 = rb2_off(brow + 64, bq);
+    float4 ua[2][2], ub[2][2];                                    // [register set][pass]
+    ushort8 rb[6];
+    auto gload_a = [&](int c, int set) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ua[set][i] = *reinterpret_cast<const float4*>(u0_ptr[i] + c * BF_BK);
+            ub[set][i] = *reinterpret_cast<const float4*>(u1_ptr[i] + c * BF_BK);
+        }
+    };
+    auto gload_b = [&](int c) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            rb[2 * pl] = *reinterpret_cast<const ushort8*>(b_ptr + (size_t)pl * BN * H + c * BF_BK);
+            rb[2 * pl + 1] = *reinterpret_cast<const ushort8*>(b_ptr + (size_t)pl * BN * H + (size_t)64 * H + c * BF_BK);
+        }
+    };
+    auto store_a = [&](unsigned short* st, int set, int i) {     // SiLU + 3-way split of one pass -> the A stage
+        const float h[4] = {silu_fast(ua[set][i].x + ub[set][i].x), silu_fast(ua[set][i].y + ub[set][i].y),
+                            silu_fast(ua[set][i].z + ub[set][i].z), silu_fast(ua[set][i].w + ub[set][i].w)};
+        unsigned short p1[4], p2[4], p3[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split3(h[e], p1[e], p2[e], p3[e]);
+        unsigned short* d = st + a_st[i];
+        *reinterpret_cast<uint2*>(d) = make_uint2(p1[0] | ((unsigned)p1[1] << 16), p1[2] | ((unsigned)p1[3] << 16));
+        *reinterpret_cast<uint2*>(d + APL) = make_uint2(p2[0] | ((unsigned)p2[1] << 16), p2[2] | ((unsigned)p2[3] << 16));
+        *reinterpret_cast<uint2*>(d + 2 * APL) = make_uint2(p3[0] | ((unsigned)p3[1] << 16), p3[2] | ((unsigned)p3[3] << 16));
+    };
+    auto store_b = [&]() {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            *reinterpret_cast<ushort8*>(Bs + pl * BPL + b_st0) = rb[2 * pl];
+            *reinterpret_cast<ushort8*>(Bs + pl * BPL + b_st1) = rb[2 * pl + 1];
+        }
+    };
+    constexpr int NCH = H / BF_BK;
+    gload_a(0, 0);
+    gload_b(0);
+    gload_a(1, 1);
+    floatx16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    store_a(As, 0, 0);
+    store_a(As, 0, 1);
+    store_b();
+    gload_b(1);
+    gload_a(2, 0);
+    __syncthreads();
+    const int arow = wm * 32 + (lane & 31), brw = wn * 64 + (lane & 31);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {                               // fully unrolled: the register-set index is a constant
+        const unsigned short* st = As + (c & 1) * 3 * APL;
+        unsigned short* nx = As + ((c + 1) & 1) * 3 * APL;
+        const int set = (c + 1) & 1;                              // registers holding the U rows of chunk c+1
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int piece = (lane >> 5) + 2 * ks;
+            bf16x8 a[3], b[2][3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                a[p] = *reinterpret_cast<const bf16x8*>(st + p * APL + rb2_off(arow, piece));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j][p] = *reinterpret_cast<const bf16x8*>(Bs + p * BPL + rb2_off(brw + 32 * j, piece));
+            }
+            mfma6<2>(a, b, acc);
+            if (c + 1 < NCH) store_a(nx, set, ks);                // runs in the shadow of the 12 MFMAs just issued
+        }
+        if (c + 3 < NCH) gload_a(c + 3, set);                     // that register set is free again
+        __syncthreads();                                          // every wave is done with Bs (and with stage c & 1)
+        if (c + 1 < NCH) {
+            store_b();
+            if (c + 2 < NCH) gload_b(c + 2);
+            __syncthreads();
+        }
+    }
+    // epilogue identical to k_edge_bf: bias + SiLU -> LDS -> pose_decoder.2 -> CSR slot
+    float* S1 = reinterpret_cast<float*>(smem_raw);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = wn * 64 + j * 32 + (lane & 31);
+        const float bj = bd1[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            S1[row * S1_LD + col] = silu_fast(acc[j][r] + bj);
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < BM * P; idx += 256) {
+        const int row = idx % BM;
+        const int p = __builtin_amdgcn_readfirstlane(idx / BM);
+        const float o = dot4<BN>(S1 + row * S1_LD, Wd2 + (size_t)p * BN) + bd2[p];
+        const int k = e0 + row;
+        if (k < E_act) O[(size_t)ent_pos[2 * k + s] * P + p] = o;
+    }
+}

@@ -838,6 +838,7 @@ struct ccsp_model {
     std::vector<hipStream_t> lane_streams;   // created once per model: new HIP streams are expensive to
     std::vector<hipEvent_t> lane_events;     // create (hundreds of ms for the first few), graphs come and go
     hipEvent_t fork_event = nullptr;
+    int edge_kernel;   // 2: k_edge_bf2 (default, H = 256); 1: k_edge_bf (CCSP_EDGE_KERNEL=1)
     int row_tile;  // 128: k_rowgemm_bf2 (default); 64: k_rowgemm_bf (CCSP_ROW_TILE=64)
     int bf16x3;    // 1: direct-mode GEMMs on the bf16 matrix cores with 3-way split operands (ccsp_bf16x3.h)
     unsigned short* WpS;    // [3][C][2][2H][H] bf16 planes of Wp
@@ -959,6 +960,15 @@ int launch_eval(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s) {
                            g->tile_nrows, g->tile_ts, m->WpS, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, g->base, tau_t, g->U);
         if (prof) HIP_TRY(hipEventRecord(g->kev[g->kev_used + 1], s));
         constexpr int BMB = 32 * EdgeBfCfg<H>::WM;
+        if constexpr (H == 256) {
+            if (m->edge_kernel == 2) {
+                hipLaunchKernelGGL(k_edge_bf2, dim3(2 * nblk(p.E_act, 64)), dim3(256), 0, s, p.E_act, m->d.pose_dim, g->e_u0, g->e_u1, g->U,
+                                   m->Wd1S, m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O);
+                if (prof) { HIP_TRY(hipEventRecord(g->kev[g->kev_used + 2], s)); g->kev_used += 3; }
+                g->evals++;
+                return 0;
+            }
+        }
         hipLaunchKernelGGL(k_edge_bf<H>, dim3(2 * nblk(p.E_act, BMB)), dim3(256), 0, s, p.E_act, m->d.pose_dim, g->e_u0, g->e_u1, g->U,
                            m->Wd1S, m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O);
     } else {
@@ -1572,6 +1582,8 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     if (const char* e = getenv("CCSP_LANES")) { const int v = atoi(e); if (v >= 1 && v <= 8) m->lanes = v; }
     if (const char* e = getenv("CCSP_MMA")) m->bf16x3 = (strcmp(e, "f32") != 0);
     m->row_tile = 128;
+    m->edge_kernel = 2;
+    if (const char* e = getenv("CCSP_EDGE_KERNEL")) m->edge_kernel = atoi(e) == 1 ? 1 : 2;
     if (const char* e = getenv("CCSP_ROW_TILE")) m->row_tile = atoi(e) == 64 ? 64 : 128;
     m->WpS = nullptr; m->Wd1S = nullptr;
     m->max_wgs = 1 << 30;
