@@ -263,6 +263,116 @@ __global__ __launch_bounds__(256) void k_node_energy(EnergyNodeArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_node_energy_mfma: the same computation with both H x H/2 products of the pose-encoder forward /
+// backward on v_mfma_f32_16x16x4_f32 (M = the 16 nodes of the tile) instead of 256 threads walking the
+// K loops with one global weight load per step: 55 us -> see DESIGN.md (it was 17 % of a MALA chain).
+// Products are computed transposed (weights as the A operand) so that a lane owns four consecutive
+// columns of one node: the GP row sums are float4 loads and the LDS tiles are written 16 bytes at a time.
+// ------------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(256) void k_node_energy_mfma(EnergyNodeArgs a, const float* __restrict__ W2F /*pose_encoder.2 in fragment order*/) {
+    constexpr int KC = H / 2, TPW = H / 64, KS = H / 8;          // forward: K = H/2 in steps of 4, TPW column tiles per wave
+    constexpr int BT = KC / 16;                                   // backward: 16-wide tiles of the H/2 hidden units
+    constexpr int BTW = BT >= 4 ? BT / 4 : 1;                     // ... per wave
+    __shared__ float xs[NODE_TILE][8];
+    __shared__ float dir[NODE_TILE][8];
+    __shared__ float y1[NODE_TILE][KC + 4];                       // pre-activation, later g_y1
+    __shared__ float s1[NODE_TILE][KC + 1];
+    __shared__ float gy2[NODE_TILE][H + 4];
+    __shared__ float red[256];
+    const int node0 = blockIdx.x * NODE_TILE;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (blockIdx.x == 0 && a.E_out) {            // uniform branch: whole block participates
+        float v = 0.0f;
+        for (int i = tid; i < a.n_partial; i += 256) v += a.partial[i];
+        const float s = block_sum_256(v, red);
+        if (tid == 0) a.E_out[0] = s;
+        __syncthreads();
+    }
+    if (tid < NODE_TILE * 8) {
+        const int nl = tid / 8, p = tid % 8, n = node0 + nl;
+        float xv = 0.0f, dv = 0.0f;
+        if (n < a.N && p < a.P) {
+            xv = a.x[(size_t)n * a.P + p];
+            const int beg = a.node_ptr[n], end = a.node_ptr[n + 1];
+            const float* op = a.Ocsr + (size_t)beg * a.P + p;
+#pragma unroll 8
+            for (int q = 0; q < end - beg; ++q) dv += op[(size_t)q * a.P];
+        }
+        xs[nl][p] = xv;
+        dir[nl][p] = dv;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < NODE_TILE * KC; idx += 256) {
+        const int n = idx / KC, j = idx % KC;
+        float acc = 0.0f;
+        for (int d = 0; d < a.P; ++d) acc = fmaf(xs[n][d], a.W0[j * a.P + d], acc);
+        acc += a.b0[j];
+        y1[n][j] = acc;
+        s1[n][j] = silu_fast(acc);
+    }
+    __syncthreads();
+    const int nl = lane & 15, n = node0 + nl;
+    {   // y2^T tiles = W2 . s1^T; g_y2 = (sum of the node's GP rows) * SiLU'(y2)
+        floatx4 acc[TPW];
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) acc[j] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+        const float* wf = W2F + ((size_t)wave * KS * 64 + lane) * TPW;
+        const float* bp = &s1[nl][lane >> 4];
+#pragma unroll 8
+        for (int ks = 0; ks < KS; ++ks) {
+            const float b = bp[ks * 4];
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[(size_t)ks * 64 * TPW + j], b, acc[j], 0, 0, 0);
+        }
+        const int rb = n < a.N ? a.nrow_ptr[n] : 0, re = n < a.N ? a.nrow_ptr[n + 1] : 0;
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+            const int c0 = wave * 16 * TPW + j * 16 + 4 * (lane >> 4);
+            float4 gp = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = rb; q < re; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(a.GP + (size_t)a.nrow_idx[q] * H + c0);
+                gp.x += v.x; gp.y += v.y; gp.z += v.z; gp.w += v.w;
+            }
+            const float4 bj = *reinterpret_cast<const float4*>(a.b2 + c0);
+            *reinterpret_cast<float4*>(&gy2[nl][c0]) = make_float4(gp.x * silu_grad_fast(acc[j][0] + bj.x), gp.y * silu_grad_fast(acc[j][1] + bj.y),
+                                                                    gp.z * silu_grad_fast(acc[j][2] + bj.z), gp.w * silu_grad_fast(acc[j][3] + bj.w));
+        }
+    }
+    __syncthreads();
+    if (wave < BT) {   // g_s1^T tiles = W2^T . g_y2^T  (contraction over the H outputs);  g_y1 = g_s1 * SiLU'(y1)
+        floatx4 acc[BTW];
+#pragma unroll
+        for (int t = 0; t < BTW; ++t) acc[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+        const float* bp = &gy2[nl][lane >> 4];
+        const float* ap = a.W2 + (size_t)(lane >> 4) * KC + wave * 16 * BTW + (lane & 15);     // A[i = hidden unit][c] = W2[c][i]
+#pragma unroll 8
+        for (int ks = 0; ks < H / 4; ++ks) {
+            const float b = bp[ks * 4];
+#pragma unroll
+            for (int t = 0; t < BTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[(size_t)ks * 4 * KC + t * 16], b, acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < BTW; ++t) {
+            const int k0 = wave * 16 * BTW + t * 16 + 4 * (lane >> 4);
+            float4 g;
+            g.x = acc[t][0] * silu_grad_fast(y1[nl][k0]);     g.y = acc[t][1] * silu_grad_fast(y1[nl][k0 + 1]);
+            g.z = acc[t][2] * silu_grad_fast(y1[nl][k0 + 2]); g.w = acc[t][3] * silu_grad_fast(y1[nl][k0 + 3]);
+            *reinterpret_cast<float4*>(&y1[nl][k0]) = g;      // each (node, unit) is read and written by this lane only
+        }
+    }
+    __syncthreads();
+    if (tid < NODE_TILE * 8) {
+        const int nl2 = tid / 8, p = tid % 8, n2 = node0 + nl2;
+        if (n2 < a.N && p < a.P) {
+            float gx = 0.0f;
+            for (int k = 0; k < KC; ++k) gx = fmaf(y1[nl2][k], a.W0[k * a.P + p], gx);
+            a.grad[(size_t)n2 * a.P + p] = dir[nl2][p] + gx;
+        }
+    }
+}
+
 // acceptance counts -> mean acceptance rate per timestep
 __global__ void k_accept_rates(int T, const int* __restrict__ count, const int* __restrict__ denom, float* __restrict__ out) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;

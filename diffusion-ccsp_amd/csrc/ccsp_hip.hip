@@ -1074,8 +1074,13 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
         return 0;
     }
     const int nw_u = g->n_tiles * rowgemm_col_tiles<H, 2 * H>();
+    const float* tau_t = m->tau + (size_t)t * m->d.n_types * 2 * H;
+    if (m->bf16x3)       // the forward row GEMM is the direct-mode one: same bf16x3 kernel, planes written by k_node
+        hipLaunchKernelGGL((k_rowgemm_bf2<H, 2 * H>), dim3(g->n_tiles2 * (2 * H / RB2_TN)), dim3(512), 0, s, g->pembS, (size_t)g->N * H, g->urow_node,
+                           g->t2_row0, g->t2_nrows, g->t2_ts, m->WpS, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, g->base, tau_t, g->U);
+    else
     hipLaunchKernelGGL((k_rowgemm<H, 2 * H>), dim3(nw_u < m->max_wgs ? nw_u : m->max_wgs), dim3(256), 0, s, nw_u, g->pemb, g->urow_node, g->tile_row0,
-                       g->tile_nrows, g->tile_ts, m->Wp, (size_t)2 * H * H, g->base, m->tau + (size_t)t * m->d.n_types * 2 * H, g->U);
+                       g->tile_nrows, g->tile_ts, m->Wp, (size_t)2 * H * H, g->base, tau_t, g->U);
     EdgeEnergyArgs en{g->e_a, g->e_b, xeval, with_grad ? g->Q : nullptr, g->partial};
     const int n_part = g->n_edge_blocks;                                                     // one energy partial per workgroup
     hipLaunchKernelGGL((k_edge<H, true>), dim3(n_part), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->U, m->pd0_w,
@@ -1095,7 +1100,9 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
                        g->tileb_nrows, g->tileb_ts, m->WpT, (size_t)2 * H * H, nof, nof, g->GP);
     EnergyNodeArgs a{g->N, P, g->node_ptr, g->O, g->nrow_ptr, g->nrow_idx, g->GP, xeval, g->eps, g->partial, n_part, E_out,
                      m->pe0_w, m->pe0_b, m->pe2_w, m->pe2_wT, m->pe2_b};
-    hipLaunchKernelGGL(k_node_energy<H>, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a);
+    static const bool valu_node_energy = getenv("CCSP_NODE_ENERGY_VALU") != nullptr;     // the pre-MFMA kernel, kept for A/B runs
+    if (valu_node_energy) hipLaunchKernelGGL(k_node_energy<H>, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_node_energy_mfma<H>, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a, (const float*)m->pe2_wF);
     return 0;
 }
 
