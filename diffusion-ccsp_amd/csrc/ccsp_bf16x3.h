@@ -406,10 +406,12 @@ __global__ __launch_bounds__(256) void k_edge_bf(int E_act, int P, const int* __
 // the two barriers.  Unpadded swizzled stages (rb2_off): 2 x 12 KB (A) + 24 KB (B) = 48 KB.
 // 64 edges x 128 columns per workgroup, waves 2 x 2, one slot-half per workgroup like k_edge_bf.
 // ------------------------------------------------------------------------------------------
+template <bool ENERGY>
 __global__ __launch_bounds__(256) void k_edge_bf2(int E_act, int P, const int* __restrict__ e_u0, const int* __restrict__ e_u1,
                                                   const float* __restrict__ U, const unsigned short* __restrict__ Wd1S /*[3][128][256]*/,
                                                   const float* __restrict__ bd1, const float* __restrict__ Wd2,
-                                                  const float* __restrict__ bd2, const int* __restrict__ ent_pos, float* __restrict__ O) {
+                                                  const float* __restrict__ bd2, const int* __restrict__ ent_pos, float* __restrict__ O,
+                                                  EdgeEnergyArgs en) {
     constexpr int H = 256, BM = 64, BN = 128;
     constexpr int APL = BM * BF_BK, BPL = BN * BF_BK;             // ushorts per plane
     constexpr int S1_LD = BN + 1;
@@ -524,15 +526,35 @@ __global__ __launch_bounds__(256) void k_edge_bf2(int E_act, int P, const int* _
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            S1[row * S1_LD + col] = silu_fast(acc[j][r] + bj);
+            const float q = acc[j][r] + bj;
+            S1[row * S1_LD + col] = silu_fast(q);
+            if constexpr (ENERGY) {                               // decoder pre-activations for k_edge_bwd
+                const int k = e0 + row;
+                if (en.Q && k < E_act) en.Q[((size_t)2 * k + s) * BN + col] = q;
+            }
         }
     }
     __syncthreads();
+    float e2 = 0.0f;
     for (int idx = tid; idx < BM * P; idx += 256) {
         const int row = idx % BM;
         const int p = __builtin_amdgcn_readfirstlane(idx / BM);
         const float o = dot4<BN>(S1 + row * S1_LD, Wd2 + (size_t)p * BN) + bd2[p];
         const int k = e0 + row;
-        if (k < E_act) O[(size_t)ent_pos[2 * k + s] * P + p] = o;
+        if (k < E_act) {
+            if constexpr (ENERGY) {                               // same epilogue as k_edge<H, true>
+                const int node = s == 0 ? en.e_a[k] : en.e_b[k];
+                const float d = o - en.xeval[(size_t)node * P + p];
+                e2 = fmaf(d, d, e2);
+                O[(size_t)ent_pos[2 * k + s] * P + p] = -2.0f * d;
+            } else {
+                O[(size_t)ent_pos[2 * k + s] * P + p] = o;
+            }
+        }
+    }
+    if constexpr (ENERGY) {
+        __syncthreads();
+        const float tot = block_sum_256(e2, reinterpret_cast<float*>(smem_raw));
+        if (tid == 0) en.partial[blockIdx.x] = tot;
     }
 }

@@ -962,8 +962,8 @@ int launch_eval(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s) {
         constexpr int BMB = 32 * EdgeBfCfg<H>::WM;
         if constexpr (H == 256) {
             if (m->edge_kernel == 2) {
-                hipLaunchKernelGGL(k_edge_bf2, dim3(2 * nblk(p.E_act, 64)), dim3(256), 0, s, p.E_act, m->d.pose_dim, g->e_u0, g->e_u1, g->U,
-                                   m->Wd1S, m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O);
+                hipLaunchKernelGGL(k_edge_bf2<false>, dim3(2 * nblk(p.E_act, 64)), dim3(256), 0, s, p.E_act, m->d.pose_dim, g->e_u0, g->e_u1, g->U,
+                                   m->Wd1S, m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, EdgeEnergyArgs{});
                 if (prof) { HIP_TRY(hipEventRecord(g->kev[g->kev_used + 2], s)); g->kev_used += 3; }
                 g->evals++;
                 return 0;
@@ -1082,7 +1082,17 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     hipLaunchKernelGGL((k_rowgemm<H, 2 * H>), dim3(nw_u < m->max_wgs ? nw_u : m->max_wgs), dim3(256), 0, s, nw_u, g->pemb, g->urow_node, g->tile_row0,
                        g->tile_nrows, g->tile_ts, m->Wp, (size_t)2 * H * H, g->base, tau_t, g->U);
     EdgeEnergyArgs en{g->e_a, g->e_b, xeval, with_grad ? g->Q : nullptr, g->partial};
-    const int n_part = g->n_edge_blocks;                                                     // one energy partial per workgroup
+    int n_part = g->n_edge_blocks;                                                           // one energy partial per workgroup
+    bool edge_done = false;
+    if constexpr (H == 256) {
+        if (m->bf16x3 && m->edge_kernel == 2) {
+            n_part = 2 * nblk(p.E_act, 64);
+            hipLaunchKernelGGL(k_edge_bf2<true>, dim3(n_part), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->U, m->Wd1S, m->pd0_b, m->pd2_w,
+                               m->pd2_b, g->ent_pos, g->O, en);
+            edge_done = true;
+        }
+    }
+    if (!edge_done)
     hipLaunchKernelGGL((k_edge<H, true>), dim3(n_part), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->U, m->pd0_w,
                        m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, en);
     if (!with_grad) {
