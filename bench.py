@@ -115,7 +115,10 @@ def main():
     dims = worlds.MODE_DIMS['qualitative']
 
     # weights: rank 0 reads the fixture, every other rank receives them over RCCL (xGMI)
-    wpath = os.path.join(ROOT, 'tests', 'golden', 'weights_qualitative_h%d.npz' % HIDDEN)
+    # weights: the checkpoint trained on an MI355X with tools/train_gpu.py (the reference's recipe; the reference's own
+    # checkpoints are not in its tree) when it is in the tree, else the parity fixture
+    trained = os.path.join(ROOT, 'weights', 'qualitative_h%d_trained.npz' % HIDDEN)
+    wpath = trained if os.path.isfile(trained) else os.path.join(ROOT, 'tests', 'golden', 'weights_qualitative_h%d.npz' % HIDDEN)
     den = ConstraintDiffuser(dims=dims, hidden_dim=HIDDEN, input_mode='qualitative', EBM='ULA', device=dev, verbose=False)
     sd = load_weights(wpath) if rank == 0 else None
     sd = sharding.broadcast_state_dict(sd, den.shapes(), dev, dist)
@@ -169,10 +172,13 @@ def main():
                    'graphs_per_gpu': B, 'nodes_per_gpu': n_nodes, 'edges_per_gpu': n_edges,
                    'evaluations_per_chain': T_STEPS * (1 + S_LANGEVIN),
                    'parallelism': 'independent graph shards x%d, RCCL weight broadcast + final gather only' % world,
-                   'weights': 'trained in-container with the reference loss (tests/golden/weights_qualitative_h256.npz)',
+                   'weights': ('weights/qualitative_h256_trained.npz: trained on one MI355X by tools/train_gpu.py with the reference recipe '
+                               '(p_losses l2, one t per batch, Adam 5e-4, batch 128) on worlds of 2-8 objects from this package\'s generator'
+                               if wpath == trained else
+                               'parity fixture tests/golden/weights_qualitative_h256.npz (2000 CPU steps of the reference loss)'),
                    'solved_fraction': solved_fraction, 'solved_samples_per_s': value * solved_fraction,
-                   'solved_note': 'fraction of the last batch passing the collision + qualitative-constraint check; the fixture '
-                                  'weights are only 2000 training steps of the reference loss, so this measures the weights, not the sampler',
+                   'solved_note': 'fraction of the last batch (one try per graph, no rejection) passing the collision + qualitative-'
+                                  'constraint check of diffusion-ccsp_amd/checker.py; value counts all samples, solved_samples_per_s the solved ones',
                    'outputs_finite': finite},
     }
 
