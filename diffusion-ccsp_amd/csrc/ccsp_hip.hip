@@ -1025,7 +1025,7 @@ int launch_eval_sd(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s) {
         const ccsp_model::SdLayer& w = m->sd[l];
         hipLaunchKernelGGL(k_sd_ln<0>, dim3(nblk(M, 4)), dim3(256), 0, s, M, Wd, g->sdX, w.ln1_g, w.ln1_b, g->sdY);
         sd_gemm<SD_EPI_BIAS>(M, Wd, 3 * Wd, g->sdY, w.in_w, w.in_b, g->sdQKV, s);
-        hipLaunchKernelGGL(k_sd_attn, dim3(g->sd_B * SD_HEADS), dim3(64), 0, s, Wd, g->sdQKV, g->mask_from, g->sdA);
+        hipLaunchKernelGGL(k_sd_attn, dim3(g->sd_B * SD_HEADS), dim3(256), 0, s, Wd, g->sdQKV, g->mask_from, g->sdA);
         sd_gemm<SD_EPI_RESID>(M, Wd, Wd, g->sdA, w.out_w, w.out_b, g->sdX, s);
         sd_gemm<SD_EPI_QGELU>(M, Wd, 4 * Wd, g->sdX, w.fc_w, w.fc_b, g->sdF, s);
         sd_gemm<SD_EPI_BIAS>(M, 4 * Wd, Wd, g->sdF, w.proj_w, w.proj_b, g->sdY, s);

@@ -176,14 +176,15 @@ __global__ __launch_bounds__(256) void k_sd_embed(int M, int H, int Wd, int gras
 // sees, (b heads + h) mod B -- the reference repeats the masks graph-major while MHA reads them
 // head-major.
 constexpr int SD_DH_MAX = 384;
-__global__ __launch_bounds__(64) void k_sd_attn(int Wd, const float* __restrict__ QKV, const int* __restrict__ mask_from,
-                                                float* __restrict__ Aout) {
+__global__ __launch_bounds__(256) void k_sd_attn(int Wd, const float* __restrict__ QKV, const int* __restrict__ mask_from,
+                                                 float* __restrict__ Aout) {
     __shared__ float qkv[3][SD_L][SD_DH_MAX + 1];
+    __shared__ float part[4][SD_L * SD_L];
     __shared__ float ps[SD_L][SD_L];
     const int b = blockIdx.x / SD_HEADS, h = blockIdx.x % SD_HEADS;
-    const int DH = Wd / SD_HEADS, lane = threadIdx.x;
+    const int DH = Wd / SD_HEADS, tid = threadIdx.x;
     const float* base = QKV + (size_t)b * SD_L * 3 * Wd + h * DH;
-    for (int idx = lane; idx < SD_L * DH; idx += 64) {
+    for (int idx = tid; idx < SD_L * DH; idx += 256) {
         const int r = idx / DH, c = idx % DH;
         const float* src = base + (size_t)r * 3 * Wd + c;
         qkv[0][r][c] = src[0];
@@ -191,22 +192,32 @@ __global__ __launch_bounds__(64) void k_sd_attn(int Wd, const float* __restrict_
         qkv[2][r][c] = src[2 * Wd];
     }
     __syncthreads();
-    const int i = lane >> 3, j = lane & 7;
+    // 64 (query, key) pairs x 4 quarters of the head dimension; the quarters are added in order 0..3
+    const int pair = tid & 63, qt = tid >> 6;
+    const int i = pair >> 3, j = pair & 7;
     const float scale = 1.0f / sqrtf((float)DH);          // q is scaled before the product, like F.multi_head_attention_forward
-    float s = 0.0f;
-    for (int c = 0; c < DH; ++c) s += (qkv[0][i][c] * scale) * qkv[1][j][c];
-    const int from = mask_from[blockIdx.x];
-    s += (i >= from || j >= from) ? 1.0f : 0.0f;
-    float mx = s;
-#pragma unroll
-    for (int o = 1; o < 8; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    const float e = expf(s - mx);
-    float den = e;
-#pragma unroll
-    for (int o = 1; o < 8; o <<= 1) den += __shfl_xor(den, o);
-    ps[i][j] = e / den;
+    {
+        const int c0 = qt * (DH / 4), c1 = c0 + DH / 4;
+        float s = 0.0f;
+        for (int c = c0; c < c1; ++c) s += (qkv[0][i][c] * scale) * qkv[1][j][c];
+        part[qt][pair] = s;
+    }
     __syncthreads();
-    for (int idx = lane; idx < SD_L * DH; idx += 64) {
+    if (tid < 64) {
+        float s = ((part[0][pair] + part[1][pair]) + part[2][pair]) + part[3][pair];
+        const int from = mask_from[blockIdx.x];
+        s += (i >= from || j >= from) ? 1.0f : 0.0f;
+        float mx = s;
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        const float e = expf(s - mx);
+        float den = e;
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) den += __shfl_xor(den, o);
+        ps[i][j] = e / den;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < SD_L * DH; idx += 256) {
         const int r = idx / DH, c = idx % DH;
         float o = 0.0f;
 #pragma unroll
