@@ -152,6 +152,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     finite = bool(torch.isfinite(x).all().item())
+    nan_graphs = len(set(batch_np.batch[(~torch.isfinite(x).all(dim=1)).cpu().numpy()].tolist()))
     # "solved?" check of the last batch (diffusion-ccsp_amd/checker.py); outside the timed region
     from diffusion_ccsp_amd import checker
     solved = checker.solved_mask(x.detach().cpu().numpy(), batch_np)
@@ -172,14 +173,16 @@ def main():
                    'graphs_per_gpu': B, 'nodes_per_gpu': n_nodes, 'edges_per_gpu': n_edges,
                    'evaluations_per_chain': T_STEPS * (1 + S_LANGEVIN),
                    'parallelism': 'independent graph shards x%d, RCCL weight broadcast + final gather only' % world,
-                   'weights': ('weights/qualitative_h256_trained.npz: trained on one MI355X by tools/train_gpu.py with the reference recipe '
+                   'weights': ('weights/qualitative_h256_trained.npz: 12 000 steps on one MI355X by tools/train_gpu.py with the reference recipe '
                                '(p_losses l2, one t per batch, Adam 5e-4, batch 128) on worlds of 2-8 objects from this package\'s generator'
                                if wpath == trained else
                                'parity fixture tests/golden/weights_qualitative_h256.npz (2000 CPU steps of the reference loss)'),
                    'solved_fraction': solved_fraction, 'solved_samples_per_s': value * solved_fraction,
                    'solved_note': 'fraction of the last batch (one try per graph, no rejection) passing the collision + qualitative-'
                                   'constraint check of diffusion-ccsp_amd/checker.py; value counts all samples, solved_samples_per_s the solved ones',
-                   'outputs_finite': finite},
+                   'outputs_finite': finite, 'graphs_with_nonfinite_poses': nan_graphs,
+                   'nonfinite_note': 'the reference sampler itself overflows fp32 in its first timesteps on some graphs (ULA step 2*beta with beta -> 0.999; '
+                                     'Trainer.evaluate skips such graphs, ddpm.py:644); the CPU oracle reproduces the same rows, see DESIGN.md'},
     }
 
     if rank == 0 and not args.no_roofline:
