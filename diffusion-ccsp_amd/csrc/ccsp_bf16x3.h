@@ -78,7 +78,8 @@ __global__ __launch_bounds__(256) void k_rowgemm_bf(const unsigned short* __rest
                                                     const int* __restrict__ tile_nrows, const int* __restrict__ tile_ts,
                                                     const unsigned short* __restrict__ W, size_t w_plane, size_t w_stride,
                                                     const float* __restrict__ base, const float* __restrict__ tau_t,
-                                                    float* __restrict__ U) {
+                                                    float* __restrict__ U, StepRef ref, size_t tau_stride) {
+    if (ref.tab) tau_t += (size_t)ref.tab[*ref.counter].t * tau_stride;      // hipGraph mode: timestep from the device table
     using Cfg = RowGemmCfg<ND>;
     constexpr int TN_ = Cfg::TN_, TNW = Cfg::TNW, NCT = Cfg::NCT;
     constexpr int A_UNITS = TILE_M * (BF_BK / 8) * 3 / 256;      // 16-byte units per thread (3)
@@ -188,8 +189,9 @@ __global__ __launch_bounds__(512) void k_rowgemm_bf2(const unsigned short* __res
                                                      const int* __restrict__ tile_nrows, const int* __restrict__ tile_ts,
                                                      const unsigned short* __restrict__ W, size_t w_plane, size_t w_stride,
                                                      const float* __restrict__ base, const float* __restrict__ tau_t,
-                                                     float* __restrict__ U) {
+                                                     float* __restrict__ U, StepRef ref, size_t tau_stride) {
     static_assert(ND % RB2_TN == 0 && KD % BF_BK == 0, "shape");
+    if (ref.tab) tau_t += (size_t)ref.tab[*ref.counter].t * tau_stride;      // hipGraph mode: timestep from the device table
     constexpr int NCT = ND / RB2_TN;
     constexpr int PLANE = RB2_TM * BF_BK;                         // ushorts per plane of a stage (A and B alike)
     __shared__ __attribute__((aligned(16))) unsigned short As[3 * PLANE];
@@ -288,7 +290,8 @@ __global__ __launch_bounds__(256) void k_edge_bf(int E_act, int P, const int* __
                                                  const unsigned short* __restrict__ Wd1S /*[3][H/2][H]*/,
                                                  const float* __restrict__ bd1, const float* __restrict__ Wd2,
                                                  const float* __restrict__ bd2, const int* __restrict__ ent_pos,
-                                                 float* __restrict__ O) {
+                                                 float* __restrict__ O, int* __restrict__ counter_inc) {
+    if (counter_inc && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(counter_inc, 1);     // hipGraph mode: next table entry
     using Cfg = EdgeBfCfg<H>;
     constexpr int BM = 32 * Cfg::WM, BN = 32 * Cfg::TN * Cfg::WN, TN = Cfg::TN;
     static_assert(BN == H / 2, "decoder hidden width must fit one column tile");
@@ -411,7 +414,8 @@ __global__ __launch_bounds__(256) void k_edge_bf2(int E_act, int P, const int* _
                                                   const float* __restrict__ U, const unsigned short* __restrict__ Wd1S /*[3][128][256]*/,
                                                   const float* __restrict__ bd1, const float* __restrict__ Wd2,
                                                   const float* __restrict__ bd2, const int* __restrict__ ent_pos, float* __restrict__ O,
-                                                  EdgeEnergyArgs en) {
+                                                  EdgeEnergyArgs en, int* __restrict__ counter_inc) {
+    if (counter_inc && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(counter_inc, 1);     // hipGraph mode: next table entry
     constexpr int H = 256, BM = 64, BN = 128;
     constexpr int APL = BM * BF_BK, BPL = BN * BF_BK;             // ushorts per plane
     constexpr int S1_LD = BN + 1;

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <thread>
 #include <vector>
@@ -677,6 +678,28 @@ struct NoiseArg {
     unsigned int ucall;     // philox uniform-call index
 };
 
+// Replayable launches (hipGraph mode of ccsp_chain_run): everything that changes from one evaluation to the
+// next -- timestep, update type, schedule scalars, noise call index, history slot -- is read from a device table
+// at the position of a device counter instead of arriving as kernel arguments, so one captured graph of
+// (1 + S) x 3 launches serves every timestep of every chain on the same ccsp_graph.  The row GEMM reads
+// entry [counter] (its timestep), the edge kernel advances the counter, the node kernel reads entry [counter - 1].
+struct StepEntry {
+    int t, step, reset_mask, hist_slot;
+    unsigned int call;
+    float a_t, b_t, c1, c2, sigma, kappa, ss, std_;
+    int pad[3];
+};
+struct ChainHeader {
+    unsigned long long seed, row_offset, call_base, np_total;
+    float* hist;
+    const float* normal;
+    int noise_mode, pad;
+};
+struct StepRef {
+    const StepEntry* tab;
+    int* counter;
+};
+
 struct NodeArgs {
     int N, P, F;
     int normalize;
@@ -701,6 +724,10 @@ struct NodeArgs {
     // schedule scalars of this timestep
     float a_t, b_t, c1, c2, sigma, kappa, ss, std_;
     NoiseArg noise;
+    // hipGraph mode: the step-dependent fields above come from tab[*counter - 1] and *hdr
+    const StepEntry* tab;
+    const int* counter;
+    const ChainHeader* hdr;
 };
 
 template <int H>
@@ -710,6 +737,15 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, float* __restr
     // the node kernel is a short latency chain on the critical path of every evaluation; when it shares the
     // CUs with the other lane's GEMM kernels its waves should win the issue arbitration
     __builtin_amdgcn_s_setprio(3);
+    if (a.tab) {
+        const StepEntry e = a.tab[*a.counter - 1];
+        const ChainHeader h = *a.hdr;
+        a.step = e.step; a.reset_mask = e.reset_mask;
+        a.a_t = e.a_t; a.b_t = e.b_t; a.c1 = e.c1; a.c2 = e.c2; a.sigma = e.sigma; a.kappa = e.kappa; a.ss = e.ss; a.std_ = e.std_;
+        a.noise.mode = h.noise_mode; a.noise.seed = h.seed; a.noise.row_offset = h.row_offset; a.noise.call = e.call;
+        a.noise.normal = h.normal ? h.normal + (size_t)(e.call - h.call_base) * h.np_total : nullptr;
+        a.hist = (h.hist && e.hist_slot >= 0) ? h.hist + (size_t)e.hist_slot * h.np_total : nullptr;
+    }
     const int node0 = blockIdx.x * NODE_TILE;
     const int tid = threadIdx.x;
     EncPrefetch<H> pf;
@@ -838,6 +874,8 @@ struct ccsp_model {
     std::vector<hipStream_t> lane_streams;   // created once per model: new HIP streams are expensive to
     std::vector<hipEvent_t> lane_events;     // create (hundreds of ms for the first few), graphs come and go
     hipEvent_t fork_event = nullptr;
+    hipStream_t capture_stream = nullptr;    // hipGraph captures (the caller's stream may be the legacy default stream)
+    int graph_mode;    // CCSP_GRAPH=1: small batches replay captured hipGraphs; default 0 -- measured no faster
     int edge_kernel;   // 2: k_edge_bf2 (default, H = 256); 1: k_edge_bf (CCSP_EDGE_KERNEL=1)
     int row_tile;  // 128: k_rowgemm_bf2 (default); 64: k_rowgemm_bf (CCSP_ROW_TILE=64)
     int bf16x3;    // 1: direct-mode GEMMs on the bf16 matrix cores with 3-way split operands (ccsp_bf16x3.h)
@@ -894,6 +932,14 @@ struct ccsp_graph {
     int *tok_node = nullptr, *tok_pos = nullptr, *node_tok = nullptr, *mask_from = nullptr;
     float *gemb = nullptr, *remb = nullptr;
     float *sdX = nullptr, *sdY = nullptr, *sdQKV = nullptr, *sdA = nullptr, *sdF = nullptr;
+    // hipGraph mode (small batches): step table, header, counter and the instantiated per-S graphs
+    StepEntry* d_tab = nullptr;
+    ChainHeader* d_hdr = nullptr;
+    int* d_counter = nullptr;
+    size_t tab_cap = 0;
+    std::vector<StepEntry> h_tab;
+    ChainHeader h_hdr;
+    std::map<int, hipGraphExec_t> execs;       // inner steps S -> graph of (1 + S) evaluations
     // profiling
     int profile = 0;
     int64_t evals = 0;
@@ -942,35 +988,41 @@ void cosine_betas(int T, std::vector<double>& betas) {   // ddpm.py:152-162
 EncW enc_pose(const ccsp_model* m) { return EncW{m->pe0_w, m->pe0_b, m->pe2_wT, m->pe2_b, m->d.pose_dim, m->pe2_wF}; }
 
 template <int H>
-int launch_eval(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s) {
+int launch_eval(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s, bool tabled = false) {
     // U = pose_emb . Wp^T ; O = decoder(...)
+    // tabled (hipGraph mode, bf16x3 kernels only): the timestep comes from the device step table, see StepEntry
     const ccsp::Plan& p = g->plan;
     if (p.E_act == 0) return 0;
     const bool prof = g->profile && g->kev_used + 3 <= g->kev.size();
     if (prof) HIP_TRY(hipEventRecord(g->kev[g->kev_used], s));
     const int nw_u = g->n_tiles * rowgemm_col_tiles<H, 2 * H>();
-    const float* tau_t = m->tau + (size_t)t * m->d.n_types * 2 * H;
+    const size_t tau_stride = (size_t)m->d.n_types * 2 * H;
+    const float* tau_t = m->tau + (tabled ? 0 : (size_t)t * tau_stride);
+    const StepRef ref{tabled ? g->d_tab : nullptr, tabled ? g->d_counter : nullptr};
+    int* const cinc = tabled ? g->d_counter : nullptr;
     if (m->bf16x3) {
         const long npe = (long)g->N * H;
         if (m->row_tile == 128)
             hipLaunchKernelGGL((k_rowgemm_bf2<H, 2 * H>), dim3(g->n_tiles2 * (2 * H / RB2_TN)), dim3(512), 0, s, g->pembS, (size_t)npe, g->urow_node,
-                               g->t2_row0, g->t2_nrows, g->t2_ts, m->WpS, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, g->base, tau_t, g->U);
+                               g->t2_row0, g->t2_nrows, g->t2_ts, m->WpS, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, g->base, tau_t, g->U,
+                               ref, tau_stride);
         else
         hipLaunchKernelGGL((k_rowgemm_bf<H, 2 * H>), dim3(nw_u), dim3(256), 0, s, g->pembS, (size_t)npe, g->urow_node, g->tile_row0,
-                           g->tile_nrows, g->tile_ts, m->WpS, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, g->base, tau_t, g->U);
+                           g->tile_nrows, g->tile_ts, m->WpS, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, g->base, tau_t, g->U,
+                           ref, tau_stride);
         if (prof) HIP_TRY(hipEventRecord(g->kev[g->kev_used + 1], s));
         constexpr int BMB = 32 * EdgeBfCfg<H>::WM;
         if constexpr (H == 256) {
             if (m->edge_kernel == 2) {
                 hipLaunchKernelGGL(k_edge_bf2<false>, dim3(2 * nblk(p.E_act, 64)), dim3(256), 0, s, p.E_act, m->d.pose_dim, g->e_u0, g->e_u1, g->U,
-                                   m->Wd1S, m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, EdgeEnergyArgs{});
+                                   m->Wd1S, m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, EdgeEnergyArgs{}, cinc);
                 if (prof) { HIP_TRY(hipEventRecord(g->kev[g->kev_used + 2], s)); g->kev_used += 3; }
                 g->evals++;
                 return 0;
             }
         }
         hipLaunchKernelGGL(k_edge_bf<H>, dim3(2 * nblk(p.E_act, BMB)), dim3(256), 0, s, p.E_act, m->d.pose_dim, g->e_u0, g->e_u1, g->U,
-                           m->Wd1S, m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O);
+                           m->Wd1S, m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, cinc);
     } else {
     hipLaunchKernelGGL((k_rowgemm<H, 2 * H>), dim3(nw_u < m->max_wgs ? nw_u : m->max_wgs), dim3(256), 0, s, nw_u, g->pemb, g->urow_node, g->tile_row0,
                        g->tile_nrows, g->tile_ts, m->Wp, (size_t)2 * H * H, g->base, tau_t, g->U);
@@ -1077,7 +1129,8 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     const float* tau_t = m->tau + (size_t)t * m->d.n_types * 2 * H;
     if (m->bf16x3)       // the forward row GEMM is the direct-mode one: same bf16x3 kernel, planes written by k_node
         hipLaunchKernelGGL((k_rowgemm_bf2<H, 2 * H>), dim3(g->n_tiles2 * (2 * H / RB2_TN)), dim3(512), 0, s, g->pembS, (size_t)g->N * H, g->urow_node,
-                           g->t2_row0, g->t2_nrows, g->t2_ts, m->WpS, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, g->base, tau_t, g->U);
+                           g->t2_row0, g->t2_nrows, g->t2_ts, m->WpS, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, g->base, tau_t, g->U,
+                           StepRef{nullptr, nullptr}, (size_t)0);
     else
     hipLaunchKernelGGL((k_rowgemm<H, 2 * H>), dim3(nw_u < m->max_wgs ? nw_u : m->max_wgs), dim3(256), 0, s, nw_u, g->pemb, g->urow_node, g->tile_row0,
                        g->tile_nrows, g->tile_ts, m->Wp, (size_t)2 * H * H, g->base, tau_t, g->U);
@@ -1088,7 +1141,7 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
         if (m->bf16x3 && m->edge_kernel == 2) {
             n_part = 2 * nblk(p.E_act, 64);
             hipLaunchKernelGGL(k_edge_bf2<true>, dim3(n_part), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->U, m->Wd1S, m->pd0_b, m->pd2_w,
-                               m->pd2_b, g->ent_pos, g->O, en);
+                               m->pd2_b, g->ent_pos, g->O, en, (int*)nullptr);
             edge_done = true;
         }
     }
@@ -1312,6 +1365,75 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
             }
         }
         if (accept) hipLaunchKernelGGL(k_accept_rates, dim3(nblk(T, 256)), dim3(256), 0, s, T, g->acc_count, g->acc_denom, accept);
+    } else if (m->graph_mode && lanes.size() == 1 && lanes[0].g->N < 512 && m->bf16x3 && m->d.model_kind == CCSP_MODEL_DIFFUSION_CCSP &&
+               !lanes[0].g->profile && lanes[0].g->plan.E_act > 0 && t_first >= t_last) {
+        // hipGraph mode (opt-in): a small batch is three short dependent launches per evaluation.  One graph of
+        // (1 + S) evaluations per distinct S is captured once per ccsp_graph and replayed for every timestep; what
+        // differs between evaluations is in the device step table (StepEntry), filled here for this chain.
+        const Lane& L = lanes[0];
+        ccsp_graph* g = L.g;
+        hipStream_t s = L.s;
+        size_t n_ent = 0;
+        for (int t = t_first; t >= t_last; --t) n_ent += 1 + (size_t)steps_at(m, sampler, t);
+        HIP_TRY(hipStreamSynchronize(s));                       // a previous chain may still be reading the host copies
+        if (n_ent > g->tab_cap) {
+            if (dev_alloc(g->allocs, &g->d_tab, n_ent)) return 1;
+            g->tab_cap = n_ent;
+        }
+        if (!g->d_hdr && (dev_alloc(g->allocs, &g->d_hdr, 1) || dev_alloc(g->allocs, &g->d_counter, 1))) return 1;
+        g->h_tab.resize(n_ent);
+        size_t k = 0;
+        for (int t = t_first; t >= t_last; --t) {
+            const int S = steps_at(m, sampler, t);
+            for (int e = 0; e <= S; ++e) {
+                NodeArgs a;
+                sched(a, t);
+                NoiseArg na;
+                if (noise_for(L, call0[t] + (uint64_t)e, na)) return 1;          // (bounds check of an injected stream)
+                StepEntry& en = g->h_tab[k++];
+                en.t = t; en.step = e == 0 ? STEP_ANCESTRAL : STEP_ULA; en.reset_mask = (e == S); en.hist_slot = e == S ? T - t : -1;
+                en.call = (unsigned int)(call0[t] + (uint64_t)e);
+                en.a_t = a.a_t; en.b_t = a.b_t; en.c1 = a.c1; en.c2 = a.c2; en.sigma = a.sigma; en.kappa = a.kappa; en.ss = a.ss; en.std_ = a.std_;
+            }
+        }
+        ChainHeader& hd = g->h_hdr;
+        memset(&hd, 0, sizeof(hd));
+        hd.seed = nz->seed; hd.row_offset = nz->row_offset + (unsigned long long)L.node0; hd.call_base = nz->call_base; hd.np_total = NP_total;
+        hd.hist = history ? history + (size_t)L.node0 * P : nullptr;
+        hd.normal = nz->mode == CCSP_NOISE_INJECTED ? nz->normal + (size_t)L.node0 * P : nullptr;
+        hd.noise_mode = nz->mode;
+        HIP_TRY(hipMemcpyAsync(g->d_tab, g->h_tab.data(), n_ent * sizeof(StepEntry), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(g->d_hdr, &hd, sizeof(hd), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemsetAsync(g->d_counter, 0, sizeof(int), s));
+        for (int t = t_first; t >= t_last; --t) {
+            const int S = steps_at(m, sampler, t);
+            auto it = g->execs.find(S);
+            if (it == g->execs.end()) {
+                hipGraph_t graph = nullptr;
+                hipGraphExec_t exec = nullptr;
+                // captured on a stream of our own: the caller's may be the legacy default stream, which cannot capture
+                if (!m->capture_stream) HIP_TRY(hipStreamCreateWithFlags(&m->capture_stream, hipStreamNonBlocking));
+                hipStream_t cs = m->capture_stream;
+                HIP_TRY(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+                int rc = 0;
+                for (int e = 0; e <= S && !rc; ++e) {
+                    rc = launch_eval<H>(m, g, 0, cs, true);
+                    NodeArgs a = node_args(m, g);
+                    a.src = 0; a.do_encode = 1; a.step = STEP_ULA;
+                    a.tab = g->d_tab; a.counter = g->d_counter; a.hdr = g->d_hdr;
+                    launch_node<H>(m, g, a, cs);
+                }
+                const hipError_t ce = hipStreamEndCapture(cs, &graph);
+                if (rc || ce != hipSuccess) return rc ? 1 : fail("chain_run: hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+                const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);
+                if (ie != hipSuccess) return fail("chain_run: hipGraphInstantiate failed: %s", hipGetErrorString(ie));
+                g->evals -= 1 + S;                                  // (counted by launch_eval during the capture)
+                it = g->execs.emplace(S, exec).first;
+            }
+            HIP_TRY(hipGraphLaunch(it->second, s));
+            g->evals += 1 + S;
+        }
     } else {
         for (int t = t_first; t >= t_last; --t) {
             const int S = steps_at(m, sampler, t);
@@ -1600,6 +1722,8 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     if (const char* e = getenv("CCSP_MMA")) m->bf16x3 = (strcmp(e, "f32") != 0);
     m->row_tile = 128;
     m->edge_kernel = 2;
+    m->graph_mode = 0;
+    if (const char* e = getenv("CCSP_GRAPH")) m->graph_mode = atoi(e) != 0;
     if (const char* e = getenv("CCSP_EDGE_KERNEL")) m->edge_kernel = atoi(e) == 1 ? 1 : 2;
     if (const char* e = getenv("CCSP_ROW_TILE")) m->row_tile = atoi(e) == 64 ? 64 : 128;
     m->WpS = nullptr; m->Wd1S = nullptr;
@@ -1729,6 +1853,7 @@ void ccsp_model_destroy(ccsp_model* m) {
     for (hipStream_t st : m->lane_streams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (hipEvent_t e : m->lane_events) (void)hipEventDestroy(e);
     if (m->fork_event) (void)hipEventDestroy(m->fork_event);
+    if (m->capture_stream) (void)hipStreamDestroy(m->capture_stream);
     for (void* p : m->allocs) (void)hipFree(p);
     delete m;
 }
@@ -1765,6 +1890,7 @@ void ccsp_graph_destroy(ccsp_graph* g) {
     if (!g->children.empty())                       // lane streams belong to the model; drain them first
         for (hipStream_t st : g->m->lane_streams) (void)hipStreamSynchronize(st);
     for (ccsp_graph* c : g->children) ccsp_graph_destroy(c);
+    for (auto& kv : g->execs) (void)hipGraphExecDestroy(kv.second);
     for (void* p : g->allocs) (void)hipFree(p);
     if (g->have_events) { (void)hipEventDestroy(g->ev0); (void)hipEventDestroy(g->ev1); }
     for (hipEvent_t e : g->kev) (void)hipEventDestroy(e);
