@@ -871,6 +871,7 @@ struct ccsp_model {
     float* Wp;     // [C][2][2H][H]   pose slices
     float* WpT;    // [C][2][H][2H]   their transposes (energy-mode backward)
     int lanes;     // concurrent sub-batch chains per ccsp_chain_run (direct mode), default 2
+    int lane_min_edges;   // batches with fewer active edges run as one lane
     std::vector<hipStream_t> lane_streams;   // created once per model: new HIP streams are expensive to
     std::vector<hipEvent_t> lane_events;     // create (hundreds of ms for the first few), graphs come and go
     hipEvent_t fork_event = nullptr;
@@ -1718,6 +1719,8 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     // CCSP_MAX_WGS=<n> sets it for experiments.
     m->bf16x3 = 1;     // direct-mode GEMMs on the bf16 matrix cores, fp32-accurate (ccsp_bf16x3.h); CCSP_MMA=f32 selects the fp32 MFMA kernels
     m->lanes = 2;
+    m->lane_min_edges = 6144;
+    if (const char* e = getenv("CCSP_LANE_MIN_EDGES")) m->lane_min_edges = atoi(e);
     if (const char* e = getenv("CCSP_LANES")) { const int v = atoi(e); if (v >= 1 && v <= 8) m->lanes = v; }
     if (const char* e = getenv("CCSP_MMA")) m->bf16x3 = (strcmp(e, "f32") != 0);
     m->row_tile = 128;
@@ -2020,7 +2023,9 @@ int ccsp_chain_run(ccsp_model* m, ccsp_graph* g, int32_t sampler, const ccsp_noi
     // lane's latency-bound node kernel and tile tails with the other's GEMMs (+10 % samples/s at C2,
     // bitwise-identical results: noise rows are global).  CCSP_LANES=<k> overrides (1 = off).
     int want = m->lanes;
-    if (m->d.energy_wrapper || g->profile || g->N < 512) want = 1;
+    // below ~6000 edges the half-batch kernels are too small to overlap usefully (C2-shaped batches: 64 graphs / 5.1 k
+    // edges 143 vs 132 samples/s with 1 vs 2 lanes, 96 graphs / 7.6 k edges 167 vs 188); CCSP_LANE_MIN_EDGES overrides
+    if (m->d.energy_wrapper || g->profile || g->plan.E_act < m->lane_min_edges || g->N < 2 * want) want = 1;
     std::vector<Lane> lanes;
     if (want > 1) {
         if (ensure_children(m, g, want, s)) return 1;
