@@ -562,3 +562,158 @@ __global__ __launch_bounds__(256) void k_edge_bf2(int E_act, int P, const int* _
         if (tid == 0) en.partial[blockIdx.x] = tot;
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// k_edge_bwd_bf: k_edge_bwd (ccsp_energy.h) for H = 256 on the bf16 matrix pipe, with k_edge_bf2's pipeline.
+// Rows = (sorted edge, slot s); K = H/2 = 128 decoder hidden units; N = 128 of the H columns per workgroup.
+// A[row, j] = (sum_p go[p] Wd2[p, j]) * SiLU'(q[row, j]) is built on the VALU for chunk c+1 between the MFMA
+// groups of chunk c and split into planes (double-buffered stage); B = planes of Wd1^T [H, H/2].
+// Epilogue: GZ[k, s H + n] = acc * SiLU'(U[u0] + U[u1])[s H + n].
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_edge_bwd_bf(int E_act, int P, const int* __restrict__ e_u0, const int* __restrict__ e_u1,
+                                                     const int* __restrict__ ent_pos, const float* __restrict__ U,
+                                                     const float* __restrict__ Ocsr, const float* __restrict__ Q /*[2E,128]*/,
+                                                     const unsigned short* __restrict__ Wd1TS /*[3][256][128]*/,
+                                                     const float* __restrict__ Wd2 /*[P,128]*/, float* __restrict__ GZ) {
+    constexpr int H = 256, KD = 128, BM = 64, BN = 128;
+    constexpr int APL = BM * BF_BK, BPL = BN * BF_BK;
+    __shared__ __attribute__((aligned(16))) unsigned short smem_us[2 * 3 * APL + 3 * BPL];      // 48 KB: A stages, then the B stage
+    unsigned short* As = smem_us;
+    unsigned short* Bs = smem_us + 2 * 3 * APL;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int ct = bid & 1, s = (bid >> 1) & 1, e0 = (bid >> 2) * BM;
+    const int n0 = ct * BN;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = tid >> 3, lq = tid & 7;
+    float go[2][8];
+    const float* q_ptr[2];
+    int a_st[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int k = e0 + lr + 32 * i;
+        k = k < E_act ? k : E_act - 1;
+        const size_t row = (size_t)2 * k + s;
+        const float* o = Ocsr + (size_t)ent_pos[row] * P;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) go[i][p] = p < P ? -o[p] : 0.0f;       // 2 d = -(-2 d)
+        q_ptr[i] = Q + row * KD + lq * 4;
+        a_st[i] = rb2_off(lr + 32 * i, lq >> 1) + (lq & 1) * 4;
+    }
+    const int brow = tid >> 2, bq = tid & 3;
+    const unsigned short* b_ptr = Wd1TS + (size_t)(n0 + brow) * KD + bq * 8;
+    const int b_st0 = rb2_off(brow, bq), b_st1 = rb2_off(brow + 64, bq);
+    float4 rq[2][2];                                              // [register set][pass]: decoder pre-activations
+    ushort8 rb[6];
+    auto gload_a = [&](int c, int set) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) rq[set][i] = *reinterpret_cast<const float4*>(q_ptr[i] + c * BF_BK);
+    };
+    auto gload_b = [&](int c) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            rb[2 * pl] = *reinterpret_cast<const ushort8*>(b_ptr + (size_t)pl * H * KD + c * BF_BK);
+            rb[2 * pl + 1] = *reinterpret_cast<const ushort8*>(b_ptr + (size_t)pl * H * KD + (size_t)64 * KD + c * BF_BK);
+        }
+    };
+    auto store_a = [&](unsigned short* st, int c, int set, int i) {
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            if (p < P) {
+                const float4 w2 = *reinterpret_cast<const float4*>(Wd2 + (size_t)p * KD + c * BF_BK + lq * 4);
+                g.x = fmaf(go[i][p], w2.x, g.x); g.y = fmaf(go[i][p], w2.y, g.y);
+                g.z = fmaf(go[i][p], w2.z, g.z); g.w = fmaf(go[i][p], w2.w, g.w);
+            }
+        }
+        const float4 q = rq[set][i];
+        const float h[4] = {g.x * silu_grad_fast(q.x), g.y * silu_grad_fast(q.y), g.z * silu_grad_fast(q.z), g.w * silu_grad_fast(q.w)};
+        unsigned short p1[4], p2[4], p3[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split3(h[e], p1[e], p2[e], p3[e]);
+        unsigned short* d = st + a_st[i];
+        *reinterpret_cast<uint2*>(d) = make_uint2(p1[0] | ((unsigned)p1[1] << 16), p1[2] | ((unsigned)p1[3] << 16));
+        *reinterpret_cast<uint2*>(d + APL) = make_uint2(p2[0] | ((unsigned)p2[1] << 16), p2[2] | ((unsigned)p2[3] << 16));
+        *reinterpret_cast<uint2*>(d + 2 * APL) = make_uint2(p3[0] | ((unsigned)p3[1] << 16), p3[2] | ((unsigned)p3[3] << 16));
+    };
+    auto store_b = [&]() {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            *reinterpret_cast<ushort8*>(Bs + pl * BPL + b_st0) = rb[2 * pl];
+            *reinterpret_cast<ushort8*>(Bs + pl * BPL + b_st1) = rb[2 * pl + 1];
+        }
+    };
+    constexpr int NCH = KD / BF_BK;                               // 4
+    gload_a(0, 0);
+    gload_b(0);
+    gload_a(1, 1);
+    floatx16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    store_a(As, 0, 0, 0);
+    store_a(As, 0, 0, 1);
+    store_b();
+    gload_b(1);
+    gload_a(2, 0);
+    __syncthreads();
+    const int arow = wm * 32 + (lane & 31), brw = wn * 64 + (lane & 31);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const unsigned short* st = As + (c & 1) * 3 * APL;
+        unsigned short* nx = As + ((c + 1) & 1) * 3 * APL;
+        const int set = (c + 1) & 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int piece = (lane >> 5) + 2 * ks;
+            bf16x8 a[3], b[2][3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                a[p] = *reinterpret_cast<const bf16x8*>(st + p * APL + rb2_off(arow, piece));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j][p] = *reinterpret_cast<const bf16x8*>(Bs + p * BPL + rb2_off(brw + 32 * j, piece));
+            }
+            mfma6<2>(a, b, acc);
+            if (c + 1 < NCH) store_a(nx, c + 1, set, ks);
+        }
+        if (c + 3 < NCH) gload_a(c + 3, set);
+        __syncthreads();
+        if (c + 1 < NCH) {
+            store_b();
+            if (c + 2 < NCH) gload_b(c + 2);
+            __syncthreads();
+        }
+    }
+    // epilogue through LDS: the accumulators (MFMA layout: one column, 16 rows per lane) are re-read as rows of
+    // float4, so the U gathers and the GZ stores are 128-byte row segments instead of 4-byte scattered accesses
+    constexpr int C_LD = BN + 4;
+    static_assert((2 * 3 * APL + 3 * BPL) * 2 >= BM * C_LD * 4, "epilogue tile must fit the stages");
+    float* Cs = reinterpret_cast<float*>(As);                     // 64 x 132 floats = 33 KB <= the two stages (As 24 KB + Bs 24 KB are contiguous)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            Cs[row * C_LD + wn * 64 + j * 32 + (lane & 31)] = acc[j][r];
+        }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = lr + 32 * i;
+        const int k = e0 + row;
+        if (k >= E_act) continue;
+        const float* u0 = U + (size_t)e_u0[k] * (2 * H) + s * H + n0;
+        const float* u1 = U + (size_t)e_u1[k] * (2 * H) + s * H + n0;
+        float* gz = GZ + (size_t)k * (2 * H) + s * H + n0;
+#pragma unroll
+        for (int mcol = 0; mcol < 4; ++mcol) {
+            const int c = lq * 4 + 32 * mcol;
+            const float4 a = *reinterpret_cast<const float4*>(u0 + c);
+            const float4 b = *reinterpret_cast<const float4*>(u1 + c);
+            const float4 v = *reinterpret_cast<const float4*>(Cs + row * C_LD + c);
+            *reinterpret_cast<float4*>(gz + c) = make_float4(v.x * silu_grad_fast(a.x + b.x), v.y * silu_grad_fast(a.y + b.y),
+                                                             v.z * silu_grad_fast(a.z + b.z), v.w * silu_grad_fast(a.w + b.w));
+        }
+    }
+}

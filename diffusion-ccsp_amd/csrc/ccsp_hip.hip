@@ -882,6 +882,7 @@ struct ccsp_model {
     int bf16x3;    // 1: direct-mode GEMMs on the bf16 matrix cores with 3-way split operands (ccsp_bf16x3.h)
     unsigned short* WpS;    // [3][C][2][2H][H] bf16 planes of Wp
     unsigned short* Wd1S;   // [3][H/2][H]      bf16 planes of pose_decoder.0.weight
+    unsigned short* Wd1TS;  // [3][H][H/2]      planes of its transpose (k_edge_bwd_bf)
     // StructDiffusion baseline (model_kind 1): transformer weights as given ([out, in] row-major)
     struct SdLayer { float *in_w, *in_b, *out_w, *out_b, *ln1_g, *ln1_b, *fc_w, *fc_b, *proj_w, *proj_b, *ln2_g, *ln2_b; };
     int Wd = 0;            // transformer width: 2H, or 3H with a grasp group
@@ -1154,6 +1155,15 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
         return 0;
     }
     constexpr int BMB = 32 * BwdCfg<H>::WM, NCTB = H / (32 * BwdCfg<H>::TN * BwdCfg<H>::WN);
+    bool bwd_done = false;
+    if constexpr (H == 256) {
+        if (m->bf16x3 && m->edge_kernel == 2) {
+            hipLaunchKernelGGL(k_edge_bwd_bf, dim3(nblk(p.E_act, 64) * 4), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->ent_pos, g->U, g->O, g->Q,
+                               m->Wd1TS, m->pd2_w, g->GZ);
+            bwd_done = true;
+        }
+    }
+    if (!bwd_done)
     hipLaunchKernelGGL(k_edge_bwd<H>, dim3(nblk(p.E_act, BMB) * 2 * NCTB), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->ent_pos,
                        g->U, g->O, g->Q, m->pd0_wT, m->pd2_w, g->GZ);
     hipLaunchKernelGGL(k_rowsum, dim3(nblk((long)p.R * (2 * H / 4), 256)), dim3(256), 0, s, p.R, 2 * H, g->row_ptr, g->row_edge, g->GZ, g->GZR);
@@ -1729,7 +1739,7 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     if (const char* e = getenv("CCSP_GRAPH")) m->graph_mode = atoi(e) != 0;
     if (const char* e = getenv("CCSP_EDGE_KERNEL")) m->edge_kernel = atoi(e) == 1 ? 1 : 2;
     if (const char* e = getenv("CCSP_ROW_TILE")) m->row_tile = atoi(e) == 64 ? 64 : 128;
-    m->WpS = nullptr; m->Wd1S = nullptr;
+    m->WpS = nullptr; m->Wd1S = nullptr; m->Wd1TS = nullptr;
     m->max_wgs = 1 << 30;
     if (const char* e = getenv("CCSP_MAX_WGS")) { const int v = atoi(e); if (v > 0) m->max_wgs = v; }
     auto& reg = m->allocs;
@@ -1840,6 +1850,8 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
         TRY(dev_alloc(reg, &m->Wd1S, (size_t)3 * nwd));
         hipLaunchKernelGGL(k_split3, dim3(nblk(nwp, 256)), dim3(256), 0, s, nwp, m->Wp, m->WpS);
         hipLaunchKernelGGL(k_split3, dim3(nblk(nwd, 256)), dim3(256), 0, s, nwd, m->pd0_w, m->Wd1S);
+        TRY(dev_alloc(reg, &m->Wd1TS, (size_t)3 * nwd));
+        hipLaunchKernelGGL(k_split3, dim3(nblk(nwd, 256)), dim3(256), 0, s, nwd, m->pd0_wT, m->Wd1TS);
     }
 #undef TRY
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
