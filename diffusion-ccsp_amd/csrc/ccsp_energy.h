@@ -130,9 +130,10 @@ __global__ __launch_bounds__(256) void k_edge_bwd(int E_act, int P, const int* _
     }
 }
 
-// GZR[r, :] = sum over the sorted edges sharing U row r (ascending) of GZ[k, :]
+// GZR[r, :] = sum over the sorted edges sharing U row r (ascending) of GZ[k, :]; optionally also as the three bf16
+// planes [3][R][W2] that k_rowgemm_bf2<2H, H> (the transpose row GEMM on the bf16 pipe) reads
 __global__ void k_rowsum(int R, int W2, const int* __restrict__ row_ptr, const int* __restrict__ row_edge,
-                         const float* __restrict__ GZ, float* __restrict__ GZR) {
+                         const float* __restrict__ GZ, float* __restrict__ GZR, unsigned short* __restrict__ GZRS) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int W4 = W2 / 4;
     if (idx >= (long)R * W4) return;
@@ -142,7 +143,18 @@ __global__ void k_rowsum(int R, int W2, const int* __restrict__ row_ptr, const i
         const float4 v = *reinterpret_cast<const float4*>(GZ + (size_t)row_edge[q] * W2 + c);
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
-    *reinterpret_cast<float4*>(GZR + (size_t)r * W2 + c) = acc;
+    if (GZRS) {
+        const float h[4] = {acc.x, acc.y, acc.z, acc.w};
+        unsigned short p1[4], p2[4], p3[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split3(h[e], p1[e], p2[e], p3[e]);
+        const size_t o = (size_t)r * W2 + c, pl = (size_t)R * W2;
+        *reinterpret_cast<uint2*>(GZRS + o) = make_uint2(p1[0] | ((unsigned)p1[1] << 16), p1[2] | ((unsigned)p1[3] << 16));
+        *reinterpret_cast<uint2*>(GZRS + pl + o) = make_uint2(p2[0] | ((unsigned)p2[1] << 16), p2[2] | ((unsigned)p2[3] << 16));
+        *reinterpret_cast<uint2*>(GZRS + 2 * pl + o) = make_uint2(p3[0] | ((unsigned)p3[1] << 16), p3[2] | ((unsigned)p3[3] << 16));
+    } else {
+        *reinterpret_cast<float4*>(GZR + (size_t)r * W2 + c) = acc;
+    }
 }
 
 // ------------------------------------------------------------------------------------------

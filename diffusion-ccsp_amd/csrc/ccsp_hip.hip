@@ -883,6 +883,7 @@ struct ccsp_model {
     unsigned short* WpS;    // [3][C][2][2H][H] bf16 planes of Wp
     unsigned short* Wd1S;   // [3][H/2][H]      bf16 planes of pose_decoder.0.weight
     unsigned short* Wd1TS;  // [3][H][H/2]      planes of its transpose (k_edge_bwd_bf)
+    unsigned short* WpTS;   // [3][C][2][H][2H] planes of WpT (transpose row GEMM of the energy backward)
     // StructDiffusion baseline (model_kind 1): transformer weights as given ([out, in] row-major)
     struct SdLayer { float *in_w, *in_b, *out_w, *out_b, *ln1_g, *ln1_b, *fc_w, *fc_b, *proj_w, *proj_b, *ln2_g, *ln2_b; };
     int Wd = 0;            // transformer width: 2H, or 3H with a grasp group
@@ -914,6 +915,7 @@ struct ccsp_graph {
     bool energy_ready = false;
     int *e_a = nullptr, *e_b = nullptr, *row_ptr = nullptr, *row_edge = nullptr, *nrow_ptr = nullptr, *nrow_idx = nullptr;
     int *tileb_row0 = nullptr, *tileb_nrows = nullptr, *tileb_ts = nullptr;
+    unsigned short* GZRS = nullptr;    // [3][R][2H] bf16 planes of GZR (energy backward on the bf16 pipe)
     float *Q = nullptr, *GZ = nullptr, *GZR = nullptr, *GP = nullptr, *xhat = nullptr, *partial = nullptr, *Escal = nullptr;
     int *acc_count = nullptr, *acc_denom = nullptr;
     float *hmc_vk = nullptr, *hmc_vp = nullptr, *hmc_vl = nullptr;   // HMC momenta (allocated on first use)
@@ -1166,12 +1168,22 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     if (!bwd_done)
     hipLaunchKernelGGL(k_edge_bwd<H>, dim3(nblk(p.E_act, BMB) * 2 * NCTB), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->ent_pos,
                        g->U, g->O, g->Q, m->pd0_wT, m->pd2_w, g->GZ);
-    hipLaunchKernelGGL(k_rowsum, dim3(nblk((long)p.R * (2 * H / 4), 256)), dim3(256), 0, s, p.R, 2 * H, g->row_ptr, g->row_edge, g->GZ, g->GZR);
+    const bool bf_bwd = H == 256 && m->bf16x3 && m->WpTS != nullptr;      // (the 128-column tiles need H >= 128)
+    if (bf_bwd && !g->GZRS && dev_alloc(g->allocs, &g->GZRS, (size_t)3 * p.R * 2 * H)) return 1;
+    hipLaunchKernelGGL(k_rowsum, dim3(nblk((long)p.R * (2 * H / 4), 256)), dim3(256), 0, s, p.R, 2 * H, g->row_ptr, g->row_edge, g->GZ, g->GZR,
+                       bf_bwd ? g->GZRS : (unsigned short*)nullptr);
     const int* no_map = nullptr;
     const float* nof = nullptr;
+    if (bf_bwd) {
+        if constexpr (H == 256)
+            hipLaunchKernelGGL((k_rowgemm_bf2<2 * H, H>), dim3(g->n_tiles2 * (H / RB2_TN)), dim3(512), 0, s, g->GZRS, (size_t)p.R * 2 * H, no_map,
+                               g->t2_row0, g->t2_nrows, g->t2_ts, m->WpTS, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, nof, nof, g->GP,
+                               StepRef{nullptr, nullptr}, (size_t)0);
+    } else {
     const int nw_b = g->n_tiles * rowgemm_col_tiles<2 * H, H>();
     hipLaunchKernelGGL((k_rowgemm<2 * H, H>), dim3(nw_b < m->max_wgs ? nw_b : m->max_wgs), dim3(256), 0, s, nw_b, g->GZR, no_map, g->tileb_row0,
                        g->tileb_nrows, g->tileb_ts, m->WpT, (size_t)2 * H * H, nof, nof, g->GP);
+    }
     EnergyNodeArgs a{g->N, P, g->node_ptr, g->O, g->nrow_ptr, g->nrow_idx, g->GP, xeval, g->eps, g->partial, n_part, E_out,
                      m->pe0_w, m->pe0_b, m->pe2_w, m->pe2_wT, m->pe2_b};
     static const bool valu_node_energy = getenv("CCSP_NODE_ENERGY_VALU") != nullptr;     // the pre-MFMA kernel, kept for A/B runs
@@ -1739,7 +1751,7 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     if (const char* e = getenv("CCSP_GRAPH")) m->graph_mode = atoi(e) != 0;
     if (const char* e = getenv("CCSP_EDGE_KERNEL")) m->edge_kernel = atoi(e) == 1 ? 1 : 2;
     if (const char* e = getenv("CCSP_ROW_TILE")) m->row_tile = atoi(e) == 64 ? 64 : 128;
-    m->WpS = nullptr; m->Wd1S = nullptr; m->Wd1TS = nullptr;
+    m->WpS = nullptr; m->Wd1S = nullptr; m->Wd1TS = nullptr; m->WpTS = nullptr;
     m->max_wgs = 1 << 30;
     if (const char* e = getenv("CCSP_MAX_WGS")) { const int v = atoi(e); if (v > 0) m->max_wgs = v; }
     auto& reg = m->allocs;
@@ -1850,6 +1862,10 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
         TRY(dev_alloc(reg, &m->Wd1S, (size_t)3 * nwd));
         hipLaunchKernelGGL(k_split3, dim3(nblk(nwp, 256)), dim3(256), 0, s, nwp, m->Wp, m->WpS);
         hipLaunchKernelGGL(k_split3, dim3(nblk(nwd, 256)), dim3(256), 0, s, nwd, m->pd0_w, m->Wd1S);
+        if (d->energy_wrapper) {       // only the energy backward reads these (another 1.5x the fp32 bytes of Wp)
+            TRY(dev_alloc(reg, &m->WpTS, (size_t)3 * nwp));
+            hipLaunchKernelGGL(k_split3, dim3(nblk(nwp, 256)), dim3(256), 0, s, nwp, m->WpT, m->WpTS);
+        }
         TRY(dev_alloc(reg, &m->Wd1TS, (size_t)3 * nwd));
         hipLaunchKernelGGL(k_split3, dim3(nblk(nwd, 256)), dim3(256), 0, s, nwd, m->pd0_wT, m->Wd1TS);
     }
