@@ -33,15 +33,12 @@ constexpr int BF_LD = BF_BK + 8;          // bf16 elements per LDS row: 80 B, co
 // six-product MFMA block for one k-step: acc[j] += A(32 x 16) * B_j(16 x 32)
 template <int TN>
 __device__ __forceinline__ void mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[TN][3], floatx16 (&acc)[TN]) {
+    // product-major, tile-minor: consecutive MFMAs go to different accumulators (same sums, same order per accumulator)
+    constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[j][1], acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][2], acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[j][0], acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][1], acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[j][0], acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[j][0], acc[j], 0, 0, 0);
-    }
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]], b[j][PB[q]], acc[j], 0, 0, 0);
 }
 
 // one K chunk from LDS planes.  As/Bs: [3][rows][BF_LD] bf16; lane l reads row (l & 31), k 8*(l>>5)..+7
