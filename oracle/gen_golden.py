@@ -348,6 +348,33 @@ def gen_struct_diffusion():
     print('struct_diffusion.npz')
 
 
+def gen_stability():
+    """'stability_flat' (three constraint types, denoise_fn.py:209-210): the reference's data for it needs pybullet, its
+    network does not -- single evaluations and a short ULA chain on a synthetic graph with all three edge types.
+    The (untrained, seeded) weights travel inside the fixture."""
+    mode, H = 'stability_flat', 64
+    W = synth_weights(mode, H, 77)
+    model, gd = build_reference(mode, H, W, T=50, S=3)
+    bn = worlds.qualitative_batch(4, 5, seed=88)
+    bn.edge_attr = (bn.edge_attr.astype(np.int64) % 3).astype(np.float32)
+    b = bn.to_torch()
+    rec = {'w/' + k: v for k, v in W.items()}
+    rec.update(batch_arrays(b))
+    rng = np.random.default_rng(5)
+    ts = [0, 17, 49]
+    poses = (rng.standard_normal((len(ts), b.x.shape[0], 4)) * 0.7).astype(np.float32)
+    outs = []
+    for i, t in enumerate(ts):
+        with torch.no_grad():
+            outs.append(model(torch.from_numpy(poses[i]).clone(), b, torch.tensor([t]), eval=True).numpy())
+    rec.update(t=np.asarray(ts, dtype=np.int32), poses=poses, out=np.stack(outs))
+    with PatchedNoise(9) as pn, contextlib.redirect_stdout(io.StringIO()):
+        final, hist = gd.sample(b.clone(), return_history=True)
+    rec.update(final=final.detach().numpy(), hist=np.stack([h.detach().numpy() for h in hist]), seed=np.int64(9), n_randn=np.int64(pn.c))
+    np.savez_compressed(os.path.join(GOLD, 'stability.npz'), **rec)
+    print('stability.npz  |final|max %.3g  |hist|max %.3g' % (np.abs(rec['final']).max(), np.abs(rec['hist']).max()))
+
+
 def gen_chains(which):
     jobs = {
         'chain_sd64_ula': lambda: run_chain('chain_sd64_ula', 'qualitative', 64, 'weights_qualitative_h64_sd.npz',
@@ -406,4 +433,6 @@ if __name__ == '__main__':
         gen_pre_transform()
     if not which or 'struct_diffusion' in which:
         gen_struct_diffusion()
+    if not which or 'stability' in which:
+        gen_stability()
     gen_chains(which)

@@ -123,6 +123,20 @@ def test_struct_diffusion_chains():
         assert rel_err(hist[idx], z['hist'][k]) < 1e-4, int(idx)
 
 
+def test_stability_mode_vs_reference():
+    """'stability_flat' (three constraint types): single evaluations and a ULA chain of the reference on a synthetic graph"""
+    z = golden('stability')
+    W = {k[2:]: z[k] for k in z.files if k.startswith('w/')}
+    m = oracle.OracleModel(W, worlds.MODE_DIMS['stability_flat'], 64, 3, timesteps=50, samples_per_step=3)
+    g = m.graph(golden_batch(z))
+    for i, t in enumerate(z['t']):
+        assert rel_err(g.denoise(z['poses'][i], int(t)), z['out'][i]) < 2e-5
+    final, hist = g.chain('ULA', seed=int(z['seed']), history=True)
+    assert int(z['n_randn']) == 1 + 50 * 4
+    for k in range(51):                                   # untrained weights: the chain grows to ~5e3, parity is relative
+        assert rel_err(hist[k], z['hist'][k]) < 1e-4, k
+
+
 MALA_SEGMENTS = [(0, 1), (1, 2), (50, 100), (100, 200), (200, 300), (900, 950), (950, 990), (990, 998),
                  (998, 999), (999, 1000), (900, 1000)]
 
