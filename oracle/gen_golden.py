@@ -375,6 +375,31 @@ def gen_stability():
     print('stability.npz  |final|max %.3g  |hist|max %.3g' % (np.abs(rec['final']).max(), np.abs(rec['hist']).max()))
 
 
+def gen_robot_energy():
+    """energy mode with a grasp group (robot_box, K_in = 6H): the reference's autograd gradient and batch energy on a synthetic
+    graph, untrained seeded weights inside the fixture"""
+    mode, H = 'robot_box', 64
+    dims = worlds.MODE_DIMS[mode]
+    torch.manual_seed(78)
+    m = dfn.ConstraintDiffuser(dims=dims, hidden_dim=H, EBM='MALA', input_mode=mode, energy_wrapper=True, device='cpu', verbose=False)
+    W = {k: v.detach().numpy().astype(np.float32) for k, v in m.state_dict().items()}
+    b = worlds.robot_box_batch(2, 6, seed=79).to_torch()
+    rec = {'w/' + k: v for k, v in W.items()}
+    rec.update(batch_arrays(b))
+    rng = np.random.default_rng(6)
+    ts = [0, 400, 999]
+    P = dims[-1][0]
+    poses = (rng.standard_normal((len(ts), b.x.shape[0], P)) * 0.7).astype(np.float32)
+    grads, energies = [], []
+    for i, t in enumerate(ts):
+        g, e = m(torch.from_numpy(poses[i]).clone(), b, torch.tensor([t]), eval=True, tag='EBM')
+        grads.append(g.detach().numpy())
+        energies.append(float(e.detach()))
+    rec.update(t=np.asarray(ts, dtype=np.int32), poses=poses, grad=np.stack(grads), energy=np.asarray(energies, dtype=np.float64))
+    np.savez_compressed(os.path.join(GOLD, 'robot_energy.npz'), **rec)
+    print('robot_energy.npz  |grad|max %.3g  E %s' % (np.abs(rec['grad']).max(), energies))
+
+
 def gen_chains(which):
     jobs = {
         'chain_sd64_ula': lambda: run_chain('chain_sd64_ula', 'qualitative', 64, 'weights_qualitative_h64_sd.npz',
@@ -435,4 +460,6 @@ if __name__ == '__main__':
         gen_struct_diffusion()
     if not which or 'stability' in which:
         gen_stability()
+    if not which or 'robot_energy' in which:
+        gen_robot_energy()
     gen_chains(which)

@@ -137,6 +137,16 @@ def test_stability_mode_vs_reference():
         assert rel_err(hist[k], z['hist'][k]) < 1e-4, k
 
 
+def test_robot_energy_mode_vs_reference():
+    """energy mode with a grasp group (K_in = 6H): the reference's autograd gradient and batch energy"""
+    z = golden('robot_energy')
+    W = {k[2:]: z[k] for k in z.files if k.startswith('w/')}
+    g = oracle.OracleModel(W, worlds.MODE_DIMS['robot_box'], 64, 2, energy_wrapper=True).graph(golden_batch(z))
+    for i, t in enumerate(z['t']):
+        grad, E = g.energy_grad(z['poses'][i], int(t))
+        assert rel_err(grad, z['grad'][i]) < 5e-5 and abs(E - z['energy'][i]) < 1e-4 * (1 + abs(z['energy'][i]))
+
+
 MALA_SEGMENTS = [(0, 1), (1, 2), (50, 100), (100, 200), (200, 300), (900, 950), (950, 990), (990, 998),
                  (998, 999), (999, 1000), (900, 1000)]
 
