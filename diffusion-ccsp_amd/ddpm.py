@@ -111,16 +111,25 @@ class GaussianDiffusion(object):
         raise NotImplementedError('EBM=%r' % (self.EBM,))
 
     def n_normal_calls(self):
-        from .noise import n_normal_calls
-        if self._sampler() == 'NONE':
-            return 1 + self.num_timesteps
-        if self._sampler() == 'ULA+':
-            n = self.num_timesteps // 4
-            return 1 + self.num_timesteps + n * (4 + 8 + 12 + 16)
-        if self._sampler() == 'HMC':                 # p_sample + momentum + 4 refreshments per timestep (ddpm.py:1090,1096)
-            return 1 + 6 * self.num_timesteps
-        return n_normal_calls(self.num_timesteps, self.samples_per_step if np.isscalar(self.samples_per_step)
-                              else np.asarray(self.samples_per_step))
+        """randn(N, P) draws of one full chain: the initial state, one per ancestral step, and the sampler's own draws on the
+        timesteps where it runs (j % ebm_per_steps == 0, ddpm.py:330)"""
+        T = self.num_timesteps
+        eps = max(1, int(getattr(self.denoise_fn, 'ebm_per_steps', 1)))
+        active = [t for t in range(T) if t % eps == 0]
+        kind = self._sampler()
+        if kind == 'NONE':
+            return 1 + T
+        if kind == 'ULA+':
+            n = T // 4
+            return 1 + T + sum(4 * (min(3, t // n if n else 3) + 1) for t in active)
+        if kind == 'HMC':                                # momentum + 4 refreshments (ddpm.py:1090,1096)
+            return 1 + T + 5 * len(active)
+        sps = self.samples_per_step
+        if torch.is_tensor(sps):
+            sps = sps.cpu().numpy()
+        if np.isscalar(sps):
+            return 1 + T + int(sps) * len(active)
+        return 1 + T + int(sum(int(np.asarray(sps)[t]) for t in active))
 
     def _noise_struct(self, seed, noise, row_offset):
         dev = self.device

@@ -78,7 +78,7 @@ class PatchedNoise(object):
 
 
 def build_reference(mode, H, weights, energy=False, EBM='ULA', T=1000, S=10, dtype=torch.float32,
-                    model_name='Diffusion-CCSP'):
+                    model_name='Diffusion-CCSP', ebm_per_steps=1):
     dims = worlds.MODE_DIMS[mode]
     if dtype == torch.float64:
         torch.set_default_dtype(torch.float64)
@@ -86,7 +86,7 @@ def build_reference(mode, H, weights, energy=False, EBM='ULA', T=1000, S=10, dty
         model = dfn.ConstraintDiffuser(dims=dims, hidden_dim=H, EBM=EBM, input_mode=mode, energy_wrapper=energy,
                                        device='cpu', verbose=False, model=model_name)
         model.load_state_dict({k: torch.from_numpy(v).to(dtype) for k, v in weights.items()})
-        den = dfn.ComposedEBMDenoiseFn(model) if energy else model
+        den = dfn.ComposedEBMDenoiseFn(model, ebm_per_steps) if energy else model
         gd = ddpm.GaussianDiffusion(den, timesteps=T, EBM=EBM, samples_per_step=S, step_sizes='2*self.betas')
         if dtype == torch.float64:
             gd = gd.double()
@@ -106,9 +106,10 @@ HIST_IDX = [0, 1, 2, 3, 4, 5, 10, 50, 100, 200, 300, 400, 500, 600, 700, 800, 90
 
 
 def run_chain(name, mode, H, wfile, batch, EBM, T=1000, S=10, seed=7, energy=False, dtype=torch.float32,
-              model_name='Diffusion-CCSP'):
+              model_name='Diffusion-CCSP', ebm_per_steps=1):
     W = oracle_mod.load_weights(os.path.join(GOLD, wfile))
-    model, gd = build_reference(mode, H, W, energy=energy, EBM=EBM, T=T, S=S, dtype=dtype, model_name=model_name)
+    model, gd = build_reference(mode, H, W, energy=energy, EBM=EBM, T=T, S=S, dtype=dtype, model_name=model_name,
+                                ebm_per_steps=ebm_per_steps)
     b = batch.clone()
     if dtype == torch.float64:
         b.x = b.x.double()
@@ -142,7 +143,8 @@ def run_chain(name, mode, H, wfile, batch, EBM, T=1000, S=10, seed=7, energy=Fal
                n_rand=np.int64(pn.uc), ref_seconds=np.float64(dt), threads=np.int32(torch.get_num_threads()))
     if rates:
         rec['accept'] = np.asarray([rates.get(t, 0.0) for t in range(T)], dtype=np.float32)
-    meta = dict(mode=mode, EBM=str(EBM), weights=wfile, energy=bool(energy), dtype=str(dtype), model=model_name)
+    meta = dict(mode=mode, EBM=str(EBM), weights=wfile, energy=bool(energy), dtype=str(dtype), model=model_name,
+                ebm_per_steps=int(ebm_per_steps))
     np.savez_compressed(os.path.join(GOLD, name + '.npz'), meta=np.asarray(repr(meta)), **rec)
     print('%-34s %6.1fs  randn calls %d  |final|max %.3f  |hist|max %.3g' %
           (name, dt, pn.c, np.abs(out).max(), np.abs(hist).max()), flush=True)
@@ -424,6 +426,9 @@ def gen_chains(which):
                                            worlds.triangular_batch(2, 12, seed=37).to_torch(), 'HMC', energy=True),
         'chain_t64_hmc_T20': lambda: run_chain('chain_t64_hmc_T20', 'diffuse_pairwise', 64, 'weights_diffuse_pairwise_h64_energy.npz',
                                                worlds.triangular_batch(2, 12, seed=38).to_torch(), 'HMC', T=20, energy=True),
+        'chain_t64_ula_energy_eps2': lambda: run_chain('chain_t64_ula_energy_eps2', 'diffuse_pairwise', 64, 'weights_diffuse_pairwise_h64_energy.npz',
+                                                       worlds.triangular_batch(2, 8, seed=39).to_torch(), 'ULA', T=100, S=3, energy=True,
+                                                       ebm_per_steps=2),
         'chain_t64_ula': lambda: run_chain('chain_t64_ula', 'diffuse_pairwise', 64, 'weights_diffuse_pairwise_h64.npz',
                                            worlds.triangular_batch(2, 12, seed=35).to_torch(), 'ULA', S=3),
         'chain_r64_ula': lambda: run_chain('chain_r64_ula', 'robot_box', 64, 'weights_robot_box_h64.npz',

@@ -147,6 +147,26 @@ def test_robot_energy_mode_vs_reference():
         assert rel_err(grad, z['grad'][i]) < 5e-5 and abs(E - z['energy'][i]) < 1e-4 * (1 + abs(z['energy'][i]))
 
 
+EPS2_SEGMENTS = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 10), (50, 100)]
+
+
+def eps2_segment_errors(run_segment, z):
+    """ULA on an energy-wrapped model with ebm_per_steps = 2 (Langevin steps on even timesteps only, ddpm.py:330): the
+    fixture passes a 1e22 transient, so segments from recorded reference states (odd and even timesteps both covered)"""
+    idx = list(z['hist_idx'])
+    return [(a, b, rel_err(run_segment(z['hist'][idx.index(a)], 99 - a, 100 - b), z['hist'][idx.index(b)])) for a, b in EPS2_SEGMENTS]
+
+
+def test_ebm_per_steps_vs_reference():
+    z = golden('chain_t64_ula_energy_eps2')
+    assert int(z['n_randn']) == 1 + 100 + 50 * 3
+    m = oracle.OracleModel(weights('weights_diffuse_pairwise_h64_energy.npz'), worlds.MODE_DIMS['diffuse_pairwise'], 64, 2, timesteps=100,
+                           samples_per_step=3, energy_wrapper=True, ebm_per_steps=2)
+    g = m.graph(golden_batch(z))
+    errs = eps2_segment_errors(lambda x, tf, tl: g.chain('ULA', seed=int(z['seed']), x=x, t_first=tf, t_last=tl), z)
+    assert all(e[2] < 1e-4 for e in errs), errs
+
+
 MALA_SEGMENTS = [(0, 1), (1, 2), (50, 100), (100, 200), (200, 300), (900, 950), (950, 990), (990, 998),
                  (998, 999), (999, 1000), (900, 1000)]
 
