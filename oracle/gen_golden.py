@@ -402,6 +402,33 @@ def gen_robot_energy():
     print('robot_energy.npz  |grad|max %.3g  E %s' % (np.abs(rec['grad']).max(), energies))
 
 
+def gen_options():
+    """constructor options the other fixtures leave at their defaults: ConstraintDiffuser(normalize=False) (denoise_fn.py:523),
+    GaussianDiffusion(step_sizes='0.5*self.betas', samples_per_step=<tensor schedule>, betas=<custom>) (ddpm.py:169-228)"""
+    mode, H, T = 'qualitative', 64, 60
+    W = oracle_mod.load_weights(os.path.join(GOLD, 'weights_qualitative_h64.npz'))
+    dims = worlds.MODE_DIMS[mode]
+    model = dfn.ConstraintDiffuser(dims=dims, hidden_dim=H, EBM='ULA', input_mode=mode, normalize=False, device='cpu', verbose=False)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()})
+    betas = np.linspace(1e-4, 0.05, T).astype(np.float64)
+    sps = torch.tensor([1 + (t % 3) for t in range(T)])
+    gd = ddpm.GaussianDiffusion(model, timesteps=T, EBM='ULA', betas=betas, samples_per_step=sps, step_sizes='0.5*self.betas').eval()
+    b = worlds.qualitative_batch(2, 4, seed=91).to_torch()
+    rec = dict(batch_arrays(b))
+    rng = np.random.default_rng(7)
+    poses = (rng.standard_normal((2, b.x.shape[0], 4)) * 0.7).astype(np.float32)
+    with torch.no_grad():
+        rec['out'] = np.stack([model(torch.from_numpy(poses[i]).clone(), b, torch.tensor([t]), eval=True).numpy() for i, t in enumerate((3, 55))])
+    rec['poses'], rec['t'] = poses, np.asarray([3, 55], dtype=np.int32)
+    with PatchedNoise(13) as pn, contextlib.redirect_stdout(io.StringIO()):
+        final, hist = gd.sample(b.clone(), return_history=True)
+    rec.update(final=final.detach().numpy(), hist=np.stack([h.detach().numpy() for h in hist]), seed=np.int64(13), n_randn=np.int64(pn.c),
+               betas=betas, sps=sps.numpy().astype(np.int32), step_sizes=gd.step_sizes.numpy().astype(np.float32),
+               posterior_log_variance_clipped=gd.posterior_log_variance_clipped.numpy())
+    np.savez_compressed(os.path.join(GOLD, 'options.npz'), **rec)
+    print('options.npz  randn calls %d  |final|max %.3g  |hist|max %.3g' % (pn.c, np.abs(rec['final']).max(), np.abs(rec['hist']).max()))
+
+
 def gen_chains(which):
     jobs = {
         'chain_sd64_ula': lambda: run_chain('chain_sd64_ula', 'qualitative', 64, 'weights_qualitative_h64_sd.npz',
@@ -467,4 +494,6 @@ if __name__ == '__main__':
         gen_stability()
     if not which or 'robot_energy' in which:
         gen_robot_energy()
+    if not which or 'options' in which:
+        gen_options()
     gen_chains(which)

@@ -167,6 +167,22 @@ def test_ebm_per_steps_vs_reference():
     assert all(e[2] < 1e-4 for e in errs), errs
 
 
+def test_constructor_options_vs_reference():
+    """normalize=False, custom betas, a per-timestep samples_per_step schedule and step_sizes='0.5*self.betas'"""
+    z = golden('options')
+    m = oracle.OracleModel(weights('weights_qualitative_h64.npz'), worlds.MODE_DIMS['qualitative'], 64, 13, timesteps=60, normalize=False)
+    m.set_schedule(betas=z['betas'], step_sizes=z['step_sizes'], samples_per_step=z['sps'])
+    s = m.schedule()
+    assert np.array_equal(s['step_sizes'], z['step_sizes']) and np.array_equal(s['posterior_log_variance_clipped'], z['posterior_log_variance_clipped'])
+    g = m.graph(golden_batch(z))
+    for i, t in enumerate(z['t']):
+        assert rel_err(g.denoise(z['poses'][i], int(t)), z['out'][i]) < 2e-5
+    final, hist = g.chain('ULA', seed=int(z['seed']), history=True)
+    assert np.abs(final - z['final']).max() < 1e-4
+    for k in range(61):
+        assert rel_err(hist[k], z['hist'][k]) < 1e-4, k
+
+
 MALA_SEGMENTS = [(0, 1), (1, 2), (50, 100), (100, 200), (200, 300), (900, 950), (950, 990), (990, 998),
                  (998, 999), (999, 1000), (900, 1000)]
 
