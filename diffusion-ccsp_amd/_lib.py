@@ -16,7 +16,14 @@ SAMPLERS = {False: 0, None: 0, 'NONE': 0, 'ULA': 1, 'ULA+': 2, 'MALA': 3, 'HMC':
 SCHEDULE_KEYS = ['betas', 'alphas_cumprod', 'alphas_cumprod_prev', 'sqrt_recip_alphas_cumprod',
                  'sqrt_recipm1_alphas_cumprod', 'posterior_log_variance_clipped', 'posterior_mean_coef1',
                  'posterior_mean_coef2', '_sqrt_recipm1_alphas_cumprod_custom', 'step_sizes',
-                 'posterior_variance']
+                 'posterior_variance', 'sqrt_alphas_cumprod', 'sqrt_one_minus_alphas_cumprod',
+                 'log_one_minus_alphas_cumprod']
+# the twelve buffers GaussianDiffusion registers, in registration order (networks/ddpm.py:200-228): a checkpoint's
+# 'model' dict holds exactly these next to the denoise_fn.* weights, and Trainer.load is a strict load_state_dict
+REGISTERED_BUFFERS = ['betas', 'alphas_cumprod', 'alphas_cumprod_prev', 'sqrt_alphas_cumprod',
+                      'sqrt_one_minus_alphas_cumprod', 'log_one_minus_alphas_cumprod', 'sqrt_recip_alphas_cumprod',
+                      'sqrt_recipm1_alphas_cumprod', 'posterior_variance', 'posterior_log_variance_clipped',
+                      'posterior_mean_coef1', 'posterior_mean_coef2']
 
 
 class CcspError(RuntimeError):
@@ -79,7 +86,7 @@ def lib():
     L.ccsp_model_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(vp), vp, C.POINTER(vp)]
     L.ccsp_model_destroy.argtypes = [vp]
     L.ccsp_model_destroy.restype = None
-    L.ccsp_schedule_set.argtypes = [vp, vp, vp, vp, i32]
+    L.ccsp_schedule_set.argtypes = [vp, i32, vp, vp, vp, i32]
     L.ccsp_schedule_get.argtypes = [vp, i32, vp]
     L.ccsp_time_embedding.argtypes = [vp, i32, vp, vp]
     L.ccsp_graph_create.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, C.POINTER(vp)]

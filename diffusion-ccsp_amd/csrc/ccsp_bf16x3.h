@@ -128,30 +128,22 @@ __global__ __launch_bounds__(256) void k_rowgemm_bf(const unsigned short* __rest
         for (int r = 0; r < 16; ++r) {
             int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             row = row < nrows ? row : nrows - 1;
-#if CCSP_ABLATE >= 5
-            acc[j][r] = tv;
-#else
             acc[j][r] = (base ? base[(size_t)(row0 + row) * ND + col] : 0.0f) + tv;
-#endif
         }
     }
     lstore();
     __syncthreads();
     constexpr int NCH = KD / BF_BK;
     for (int c = 0; c < NCH; ++c) {
-#if CCSP_ABLATE == 0
         if (c + 1 < NCH) gload(c + 1);
-#endif
         __builtin_amdgcn_sched_barrier(0);
         bf_chunk<TNW, TILE_M, TN_>(As, Bs, wm * 32, wn * 32 * TNW, acc);
         __builtin_amdgcn_sched_barrier(0);
-#if CCSP_ABLATE <= 1
         __syncthreads();                          // every wave is done reading the stage
         if (c + 1 < NCH) {
             lstore();
             __syncthreads();
         }
-#endif
     }
 #pragma unroll
     for (int j = 0; j < TNW; ++j)
@@ -159,11 +151,7 @@ __global__ __launch_bounds__(256) void k_rowgemm_bf(const unsigned short* __rest
         for (int r = 0; r < 16; ++r) {
             const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             const int col = col0 + wn * 32 * TNW + j * 32 + (lane & 31);
-#if CCSP_ABLATE >= 5
-            if (row < nrows && acc[j][r] == 123.456f) U[(size_t)(row0 + row) * ND + col] = acc[j][r];
-#else
             if (row < nrows) U[(size_t)(row0 + row) * ND + col] = acc[j][r];
-#endif
         }
 }
 

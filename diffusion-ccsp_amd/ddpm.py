@@ -54,18 +54,23 @@ class GaussianDiffusion(object):
         sps = self.samples_per_step
         if torch.is_tensor(sps):
             sps = sps.cpu().numpy()
+        T = self.num_timesteps
         if np.isscalar(sps):
             sp_arr, default = None, int(sps)
         else:
             sp_arr, default = np.ascontiguousarray(sps, dtype=np.int32), 0
-        _lib.check(L.ccsp_schedule_set(h, None if b is None else b.ctypes.data, None,
+            if sp_arr.shape != (T,):
+                raise ValueError('samples_per_step has shape %s, expected (%d,)' % (sp_arr.shape, T))
+        if b is not None and b.shape != (T,):
+            raise ValueError('betas has shape %s, expected (%d,)' % (b.shape, T))
+        _lib.check(L.ccsp_schedule_set(h, T, None if b is None else b.ctypes.data, None,
                                        None if sp_arr is None else sp_arr.ctypes.data, default))
         self._read_buffers()
         # `step_sizes` is a Python expression of self.betas evaluated in the module (ddpm.py:207)
         self.step_sizes = eval(self._step_sizes_expr) if isinstance(self._step_sizes_expr, str) else self._step_sizes_expr
         ss = torch.as_tensor(self.step_sizes, dtype=torch.float32).cpu().numpy()
         ss = np.ascontiguousarray(np.broadcast_to(ss, (self.num_timesteps,)), dtype=np.float32)
-        _lib.check(L.ccsp_schedule_set(h, None if b is None else b.ctypes.data, ss.ctypes.data,
+        _lib.check(L.ccsp_schedule_set(h, T, None if b is None else b.ctypes.data, ss.ctypes.data,
                                        None if sp_arr is None else sp_arr.ctypes.data, default))
         self._schedule_owner = self._core()._generation
 
@@ -79,7 +84,12 @@ class GaussianDiffusion(object):
                 setattr(self, k, torch.from_numpy(a).to(self.device))
 
     def _handle(self):
-        h = self._core()._handle()
+        core = self._core()
+        if core.timesteps != self.num_timesteps:
+            # two GaussianDiffusion objects with different `timesteps` on ONE ConstraintDiffuser: the native model (time
+            # table, schedule) has one length -- re-bind it to this object's rather than replaying a wrong-length schedule
+            core._bind(self.num_timesteps)
+        h = core._handle()
         if getattr(self, '_schedule_owner', None) != self._core()._generation:   # weights were reloaded -> new native model
             self._apply_schedule()
             h = self._core()._handle()
@@ -90,12 +100,30 @@ class GaussianDiffusion(object):
         return self
 
     def load_state_dict(self, sd, strict=True):
-        """a reference checkpoint's 'model' dict: schedule buffers are recomputed, denoiser weights loaded"""
+        """a reference checkpoint's 'model' dict (Trainer.load, ddpm.py:503-514): denoiser weights are loaded; the stored
+        `betas` must describe the schedule this object was built with (the reference would overwrite its buffers with
+        them while keeping num_timesteps, step_sizes and the custom kappa of the constructor -- a silent mix); if they
+        differ, the stored betas are adopted through the constructor path so that every derived buffer follows them."""
+        if 'betas' in sd:
+            stored = sd['betas']
+            stored = stored.detach().cpu().numpy() if torch.is_tensor(stored) else np.asarray(stored)
+            if stored.shape != (self.num_timesteps,):
+                raise ValueError('checkpoint betas have shape %s, this GaussianDiffusion has %d timesteps' % (stored.shape, self.num_timesteps))
+            if not np.array_equal(stored.astype(np.float32), self.betas.cpu().numpy()):
+                self._betas_arg = np.ascontiguousarray(stored, dtype=np.float64)
+                self._apply_schedule()
+        present = [k for k in _lib.REGISTERED_BUFFERS if k in sd]
+        if strict and present and len(present) != len(_lib.REGISTERED_BUFFERS):
+            # (a dict with NO schedule buffer is taken as weights-only -- a convenience the reference does not have)
+            raise KeyError('missing schedule buffers in state_dict: %s' % ', '.join(k for k in _lib.REGISTERED_BUFFERS if k not in sd))
         self._core().load_state_dict({k: v for k, v in sd.items() if k.startswith('denoise_fn.')}, strict)
         return self
 
     def state_dict(self):
-        out = {k: getattr(self, k) for k in _lib.SCHEDULE_KEYS if hasattr(self, k) and not k.startswith('_') and k != 'step_sizes'}
+        """the key set of the reference module's state_dict: its twelve registered buffers (ddpm.py:200-228) and
+        the denoiser weights, so that a checkpoint written here loads strictly in the reference's Trainer.load"""
+        self._handle()
+        out = {k: getattr(self, k) for k in _lib.REGISTERED_BUFFERS}
         pre = 'denoise_fn.model.' if self._core() is not self.denoise_fn else 'denoise_fn.'
         out.update({pre + k: v for k, v in self._core().state_dict().items()})
         return out
@@ -173,6 +201,7 @@ class GaussianDiffusion(object):
     def p_sample_loop(self, batch, return_history=False, seed=None, noise=None, row_offset=0, **kwargs):
         """GaussianDiffusion.p_sample_loop (ddpm.py:260-340)"""
         T = self.num_timesteps
+        self._handle()                         # (binds the denoiser's native model to this object's schedule first)
         g = self._core()._graph(batch)
         x = torch.empty((g.N, self.dims[-1][0]), device=self.device, dtype=torch.float32)
         hist = self._run(batch, x, 1, T - 1, 0, return_history, seed, noise, row_offset)

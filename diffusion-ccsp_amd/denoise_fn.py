@@ -11,6 +11,7 @@ PyTorch is used for device memory and streams only.
 """
 import ctypes as C
 import math
+import weakref
 
 import numpy as np
 import torch
@@ -68,6 +69,7 @@ class _Graph(object):
                                        _ptr(self.edge_attr), _ptr(self.mask), _stream_ptr(dev), C.byref(h)))
         self.h = h
         self.model_handle = owner._generation       # (a new native model may reuse a freed one's address)
+        owner._live_graphs.add(self)
         if owner.model == 'StructDiffusion':
             # the token sequences: batch.batch, and batch.shuffled when the dataset carries it (denoise_fn.py:408-417)
             self.seq = batch.batch.detach().to(dev, torch.int64).contiguous()
@@ -76,11 +78,14 @@ class _Graph(object):
             _lib.check(L.ccsp_graph_set_sequences(h, _ptr(self.seq), None if self.shuffled is None else _ptr(self.shuffled),
                                                   _stream_ptr(dev)))
 
+    def destroy(self):
+        if getattr(self, 'h', None):
+            _lib.lib().ccsp_graph_destroy(self.h)
+            self.h = None
+
     def __del__(self):
         try:
-            if getattr(self, 'h', None):
-                _lib.lib().ccsp_graph_destroy(self.h)
-                self.h = None
+            self.destroy()
         except Exception:
             pass
 
@@ -119,7 +124,8 @@ class ConstraintDiffuser(object):
         self._params = None       # name -> device tensor
         self._h = None
         self._generation = 0      # bumped for every native model created: handles are compared by this, not by address
-        self._graphs = {}
+        self._graphs = {}                     # id(batch) -> (weakref to the batch, content key, _Graph)
+        self._live_graphs = weakref.WeakSet()  # every _Graph built on the current native model, wherever it is referenced
         if self.device.type != 'cuda':
             raise _lib.CcspError("ConstraintDiffuser(device=%r): the HIP path needs a GPU device ('cuda'); "
                                  "there is no CPU fallback" % (device,))
@@ -217,6 +223,11 @@ class ConstraintDiffuser(object):
 
     # ---- native handles -----------------------------------------------------------------
     def _drop_handle(self):
+        # graphs first, then the model they were built on (a GaussianDiffusion may still hold one as _last_graph; the
+        # library also tolerates the other order: ccsp_model_destroy orphans the graphs it leaves behind)
+        for g in list(self._live_graphs):
+            g.destroy()
+        self._live_graphs = weakref.WeakSet()
         self._graphs.clear()
         if self._h is not None:
             _lib.lib().ccsp_model_destroy(self._h)
@@ -259,17 +270,28 @@ class ConstraintDiffuser(object):
         return h
 
     def _graph(self, batch):
-        """graph handle for this batch, cached on the batch's tensors (static over a chain)"""
-        key = (id(batch), batch.x.data_ptr(), batch.edge_index.data_ptr(), tuple(batch.x.shape),
-               tuple(batch.edge_index.shape))
+        """graph handle for this batch (static over a chain), cached per batch OBJECT: the entry dies with the
+        batch (weak reference), and is rebuilt when one of its four tensors was replaced or edited in place
+        (storage pointer, shape and torch's in-place version counter of x / edge_index / edge_attr / mask)"""
+        fields = (batch.x, batch.edge_index, batch.edge_attr, batch.mask)
+        key = tuple((t.data_ptr(), tuple(t.shape), t._version) for t in fields)
         self._handle()
-        g = self._graphs.get(key)
-        if g is None or g.model_handle != self._generation:
-            if len(self._graphs) > 8:
-                self._graphs.clear()
-            with torch.cuda.device(self.device):
-                g = _Graph(self, batch)
-            self._graphs[key] = g
+        ent = self._graphs.get(id(batch))
+        if ent is not None:
+            ref, k, g = ent
+            if ref() is batch and k == key and g.h and g.model_handle == self._generation:
+                return g
+            del self._graphs[id(batch)]
+        with torch.cuda.device(self.device):
+            g = _Graph(self, batch)
+        bid = id(batch)
+        try:
+            ref = weakref.ref(batch, lambda _r, d=self._graphs, i=bid: d.pop(i, None))
+        except TypeError:                         # a batch type without weak-reference support: not cached
+            return g
+        while len(self._graphs) > 8:
+            self._graphs.pop(next(iter(self._graphs)))
+        self._graphs[bid] = (ref, key, g)
         return g
 
     # ---- the reference's call surface ---------------------------------------------------

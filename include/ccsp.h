@@ -9,9 +9,12 @@
  *  - every array pointer is a DEVICE pointer owned by the caller (e.g. torch tensor.data_ptr()),
  *    fp32 / int64 / int8 row-major contiguous, unless the parameter is documented "host";
  *  - every call enqueues its work on the caller-supplied hipStream_t (`stream`, passed as
- *    void*; NULL = the default stream).  Only ccsp_model_create / ccsp_schedule_set /
- *    ccsp_graph_create (one-time set-up: they read small arrays back to build index tables) and
- *    ccsp_*_get synchronise; the evaluation and chain calls never do;
+ *    void*; NULL = the default stream).  ccsp_model_create / ccsp_graph_create /
+ *    ccsp_graph_set_sequences (one-time set-up: they read small arrays back to build index tables),
+ *    ccsp_chain_stats and the ccsp_*_get calls synchronise.  ccsp_denoise / ccsp_energy_grad /
+ *    ccsp_edge_outputs never do.  ccsp_chain_run does not wait for the chain it enqueues; it waits
+ *    for EARLIER work on the stream only where a host table of a previous chain on the same graph is
+ *    about to be rewritten (energy-mode samplers, the opt-in hipGraph mode);
  *  - return value 0 = ok, non-zero = error; ccsp_last_error() gives the thread-local message;
  *  - no exceptions cross the boundary; handles are not thread-safe (one per device & stream);
  *  - NaN is data, not an error (isolated nodes give 0/0 exactly like the reference,
@@ -27,7 +30,8 @@ extern "C" {
 #endif
 
 #define CCSP_VERSION_MAJOR 0
-#define CCSP_VERSION_MINOR 2
+#define CCSP_VERSION_MINOR 3
+#define CCSP_MAX_SAMPLES_PER_STEP 100000
 
 typedef struct ccsp_model ccsp_model;   /* ConstraintDiffuser weights + GaussianDiffusion schedule */
 typedef struct ccsp_graph ccsp_graph;   /* one collated batch of constraint graphs              */
@@ -89,17 +93,22 @@ int ccsp_device_info(char* name, int32_t name_len, int32_t* compute_units, uint6
  * table are built here. */
 int ccsp_model_create(const ccsp_model_desc* desc, const float* const* params, void* stream,
                       ccsp_model** out);
+/* Graph handles built on the model stay valid to DESTROY afterwards (any other call on them fails). */
 void ccsp_model_destroy(ccsp_model* model);
 
 /* Replaces GaussianDiffusion.__init__'s betas / step_sizes / samples_per_step arguments
- * (ddpm.py:169-228).  betas: HOST double[T] or NULL (cosine); step_sizes: HOST float[T] or NULL
- * ('2*self.betas'); samples_per_step: HOST int32[T] or NULL (default_samples for every t). */
-int ccsp_schedule_set(ccsp_model* model, const double* betas, const float* step_sizes,
+ * (ddpm.py:169-228).  n: length of every non-NULL array, must equal the model's timesteps (the
+ * reference takes T from betas.shape, ddpm.py:189).  betas: HOST double[n] in [0, 1) or NULL
+ * (cosine); step_sizes: HOST float[n] or NULL ('2*self.betas'); samples_per_step: HOST int32[n]
+ * in [0, CCSP_MAX_SAMPLES_PER_STEP] or NULL (default_samples for every t). */
+int ccsp_schedule_set(ccsp_model* model, int32_t n, const double* betas, const float* step_sizes,
                       const int32_t* samples_per_step, int32_t default_samples);
 /* Copies one schedule buffer to HOST float[T].  which: 0 betas, 1 alphas_cumprod,
  * 2 alphas_cumprod_prev, 3 sqrt_recip_alphas_cumprod, 4 sqrt_recipm1_alphas_cumprod,
  * 5 posterior_log_variance_clipped, 6 posterior_mean_coef1, 7 posterior_mean_coef2,
- * 8 _sqrt_recipm1_alphas_cumprod_custom, 9 step_sizes, 10 posterior_variance. */
+ * 8 _sqrt_recipm1_alphas_cumprod_custom, 9 step_sizes, 10 posterior_variance,
+ * 11 sqrt_alphas_cumprod, 12 sqrt_one_minus_alphas_cumprod, 13 log_one_minus_alphas_cumprod
+ * (ddpm.py:200-228: the twelve registered buffers of a checkpoint, plus 8 and 9). */
 int ccsp_schedule_get(const ccsp_model* model, int32_t which, float* out_host);
 /* time_mlp(t) (denoise_fn.py:259-264) for one t -> DEVICE float[H] (visualize_energy.py:402-450
  * reads denoise_fn.time_mlp) */

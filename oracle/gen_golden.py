@@ -106,7 +106,7 @@ HIST_IDX = [0, 1, 2, 3, 4, 5, 10, 50, 100, 200, 300, 400, 500, 600, 700, 800, 90
 
 
 def run_chain(name, mode, H, wfile, batch, EBM, T=1000, S=10, seed=7, energy=False, dtype=torch.float32,
-              model_name='Diffusion-CCSP', ebm_per_steps=1):
+              model_name='Diffusion-CCSP', ebm_per_steps=1, full_hist=False):
     W = oracle_mod.load_weights(os.path.join(GOLD, wfile))
     model, gd = build_reference(mode, H, W, energy=energy, EBM=EBM, T=T, S=S, dtype=dtype, model_name=model_name,
                                 ebm_per_steps=ebm_per_steps)
@@ -131,7 +131,7 @@ def run_chain(name, mode, H, wfile, batch, EBM, T=1000, S=10, seed=7, energy=Fal
     dt = time.time() - t0
     out = out.detach().numpy()
     hist = np.stack([h.detach().numpy() for h in hist])
-    idx = list(range(T + 1)) if T <= 20 else sorted(set(i for i in HIST_IDX if i <= T) | {T})
+    idx = list(range(T + 1)) if (T <= 20 or full_hist) else sorted(set(i for i in HIST_IDX if i <= T) | {T})
     rec = dict(batch_arrays(batch))
     if model_name == 'StructDiffusion':
         rec['batch'] = batch.batch.numpy().astype(np.int64)
@@ -157,8 +157,11 @@ def gen_schedule():
         _, gd = build_reference('qualitative', 64, W, T=T)
         for k in ['betas', 'alphas_cumprod', 'alphas_cumprod_prev', 'sqrt_recip_alphas_cumprod',
                   'sqrt_recipm1_alphas_cumprod', 'posterior_log_variance_clipped', 'posterior_mean_coef1',
-                  'posterior_mean_coef2', 'posterior_variance']:
+                  'posterior_mean_coef2', 'posterior_variance', 'sqrt_alphas_cumprod', 'sqrt_one_minus_alphas_cumprod',
+                  'log_one_minus_alphas_cumprod']:
             rec['T%d/%s' % (T, k)] = getattr(gd, k).numpy()
+        # key names of the reference module's state_dict (what Trainer.save writes, ddpm.py:496-501), in order
+        rec['T%d/state_dict_keys' % T] = np.asarray(list(gd.state_dict().keys()))
         rec['T%d/kappa' % T] = gd._sqrt_recipm1_alphas_cumprod_custom.numpy()
         rec['T%d/step_sizes' % T] = gd.step_sizes.numpy()
     np.savez_compressed(os.path.join(GOLD, 'schedule.npz'), **rec)
@@ -250,11 +253,20 @@ def synth_weights(mode, H, seed):
     return {k: v.detach().numpy().astype(np.float32) for k, v in m.state_dict().items()}
 
 
-def gen_single_eval():
+def gen_single_eval_h256():
+    """the BASELINE widths of C4 / C5: energy-mode gradients on 12-triangle graphs and the grasp branch on
+    10-object robot_box graphs at hidden_dim 256"""
+    gen_single_eval('single_eval_h256', 98, [
+        ('t256e', 'diffuse_pairwise', 256, 'weights_diffuse_pairwise_h256_energy.npz', worlds.triangular_batch(3, 12, seed=27)),
+        ('r256', 'robot_box', 256, 'weights_robot_box_h256.npz', worlds.robot_box_batch(3, 10, seed=28)),
+    ])
+
+
+def gen_single_eval(out_name='single_eval', rng_seed=99, cases=None):
     """single network evaluations, direct mode and energy mode"""
     rec = {}
-    rng = np.random.default_rng(99)
-    cases = [
+    rng = np.random.default_rng(rng_seed)
+    cases = cases or [
         ('q64', 'qualitative', 64, 'weights_qualitative_h64.npz', worlds.qualitative_batch(3, 8, seed=21)),
         ('q64small', 'qualitative', 64, 'weights_qualitative_h64.npz', worlds.qualitative_batch(1, 3, seed=22)),
         ('q256', 'qualitative', 256, 'weights_qualitative_h256.npz', worlds.qualitative_batch(2, 8, seed=23)),
@@ -303,8 +315,8 @@ def gen_single_eval():
     # untrained H=256 weights for every mode: regenerated from the seed by the reference here and
     # by the tests through the committed outputs only (weights are not stored: they are inputs of
     # a pure function of the seed -> stored as a checksum + outputs on the fixed graphs)
-    np.savez_compressed(os.path.join(GOLD, 'single_eval.npz'), **rec)
-    print('single_eval.npz')
+    np.savez_compressed(os.path.join(GOLD, out_name + '.npz'), **rec)
+    print(out_name + '.npz')
 
 
 def sd_batch(sizes, seed, shuffled=False):
@@ -460,6 +472,12 @@ def gen_chains(which):
                                            worlds.triangular_batch(2, 12, seed=35).to_torch(), 'ULA', S=3),
         'chain_r64_ula': lambda: run_chain('chain_r64_ula', 'robot_box', 64, 'weights_robot_box_h64.npz',
                                            worlds.robot_box_batch(2, 10, seed=36).to_torch(), 'ULA', S=5),
+        # BASELINE configs C4 / C5 at their hidden width (H = 256): 12-triangle graphs under MALA S = 10 with the
+        # reference's logged acceptance per timestep and EVERY state recorded; 10-object robot_box graphs under ULA S = 10
+        'chain_t256_mala': lambda: run_chain('chain_t256_mala', 'diffuse_pairwise', 256, 'weights_diffuse_pairwise_h256_energy.npz',
+                                             worlds.triangular_batch(4, 12, seed=44).to_torch(), 'MALA', S=10, energy=True, full_hist=True),
+        'chain_r256_ula': lambda: run_chain('chain_r256_ula', 'robot_box', 256, 'weights_robot_box_h256.npz',
+                                            worlds.robot_box_batch(3, 10, seed=45).to_torch(), 'ULA', S=10),
         'chain_q64_T1000_B4_f64': lambda: run_chain('chain_q64_T1000_B4_f64', 'qualitative', 64, 'weights_qualitative_h64.npz',
                                                     worlds.qualitative_batch(4, 8, seed=31).to_torch(), 'ULA', dtype=torch.float64),
     }
@@ -486,6 +504,8 @@ if __name__ == '__main__':
         gen_labeller()
     if not which or 'single_eval' in which:
         gen_single_eval()
+    if not which or 'single_eval_h256' in which:
+        gen_single_eval_h256()
     if not which or 'pre_transform' in which:
         gen_pre_transform()
     if not which or 'struct_diffusion' in which:

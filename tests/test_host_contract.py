@@ -1,0 +1,103 @@
+"""Host-object contracts of the drop-in classes that are not arithmetic: handle lifetimes (a graph may
+outlive its model), the per-batch graph cache, and the argument checks of ccsp_schedule_set."""
+import ctypes as C
+import gc
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import weights, worlds
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(device, T=20, S=2, H=64):
+    from diffusion_ccsp_amd import ConstraintDiffuser, GaussianDiffusion
+    den = ConstraintDiffuser(dims=worlds.MODE_DIMS['qualitative'], hidden_dim=H, input_mode='qualitative', EBM='ULA',
+                             device=device, verbose=False)
+    den.load_state_dict(weights('weights_qualitative_h%d.npz' % H))
+    return den, GaussianDiffusion(den, timesteps=T, EBM='ULA', samples_per_step=S)
+
+
+def test_graph_may_outlive_its_model(device, monkeypatch):
+    """sample a batch that runs as concurrent lanes (child graphs on model-owned streams), reload the weights
+    (destroys the native model), sample again, then drop everything in the 'wrong' order"""
+    from diffusion_ccsp_amd import _lib
+    monkeypatch.setenv('CCSP_LANE_MIN_EDGES', '0')
+    den, gd = _model(device)
+    b = worlds.qualitative_batch(40, 6, seed=3).to_torch()
+    x1 = gd.sample(b, seed=1)
+    g_old = gd._last_graph
+    assert g_old.h
+    den.load_state_dict(weights('weights_qualitative_h64.npz'))      # _drop_handle: graphs, then the model
+    assert g_old.h is None                                            # destroyed with the model it was built on
+    x2 = gd.sample(b, seed=1)
+    assert torch.equal(x1, x2)
+    # raw handles: destroy the model first, the graph afterwards (ccsp_model_destroy orphans it)
+    L = _lib.lib()
+    g = den._graph(b)
+    h_graph, h_model = g.h, den._h
+    g.h = None
+    den._h = None
+    den._graphs.clear()
+    L.ccsp_model_destroy(h_model)
+    L.ccsp_graph_destroy(h_graph)
+    torch.cuda.synchronize()
+    del gd, den
+    gc.collect()
+
+
+def test_graph_cache_follows_the_batch_object(device):
+    den, gd = _model(device)
+    outs = []
+    for seed in (5, 6, 5):
+        b = worlds.qualitative_batch(2, 4, seed=seed).to_torch()      # CPU tensors: the library works on copies
+        outs.append(den(torch.zeros(b.x.shape[0], 4), b, torch.tensor([3]), eval=True).cpu().numpy())
+        del b
+        gc.collect()
+    assert np.array_equal(outs[0], outs[2]) and not np.array_equal(outs[0], outs[1])
+    assert len(den._graphs) == 0                                      # entries die with their batch
+    b = worlds.qualitative_batch(2, 4, seed=5).to_torch()
+    g1 = den._graph(b)
+    assert den._graph(b) is g1
+    b.x[1, 0] += 0.25                                                 # in-place edit of the geometry -> new tables
+    g2 = den._graph(b)
+    assert g2 is not g1
+    want = b.clone()
+    assert np.array_equal(den(torch.zeros(b.x.shape[0], 4), b, torch.tensor([3]), eval=True).cpu().numpy(),
+                          den(torch.zeros(b.x.shape[0], 4), want, torch.tensor([3]), eval=True).cpu().numpy())
+    b.edge_attr = b.edge_attr.clone()                                 # replaced tensor -> new tables
+    assert den._graph(b) is not g2
+
+
+def test_schedule_set_validates_its_arguments(device):
+    from diffusion_ccsp_amd import CcspError, GaussianDiffusion, _lib
+    den, gd = _model(device, T=20)
+    L = _lib.lib()
+    h = gd._handle()
+    ok = np.full(20, 3, dtype=np.int32)
+    assert L.ccsp_schedule_set(h, 20, None, None, ok.ctypes.data, 0) == 0
+    assert L.ccsp_schedule_set(h, 19, None, None, ok.ctypes.data, 0) != 0 and b'timesteps' in L.ccsp_last_error()
+    bad = ok.copy()
+    bad[7] = -1
+    assert L.ccsp_schedule_set(h, 20, None, None, bad.ctypes.data, 0) != 0
+    bad[7] = 10 ** 7
+    assert L.ccsp_schedule_set(h, 20, None, None, bad.ctypes.data, 0) != 0
+    betas = np.full(20, 0.1)
+    betas[3] = 1.5
+    assert L.ccsp_schedule_set(h, 20, betas.ctypes.data, None, None, 2) != 0
+    assert L.ccsp_schedule_set(h, 20, None, None, None, -4) != 0
+    with pytest.raises(ValueError):
+        GaussianDiffusion(den, timesteps=20, EBM='ULA', samples_per_step=torch.ones(19, dtype=torch.int32))
+    with pytest.raises(CcspError):
+        GaussianDiffusion(den, timesteps=20, EBM='ULA', samples_per_step=-1)
+    # two diffusion objects of different lengths on one denoiser: each call re-binds the native model to its own length
+    ga = GaussianDiffusion(den, timesteps=20, EBM='ULA', samples_per_step=2)
+    gb = GaussianDiffusion(den, timesteps=30, EBM='ULA', samples_per_step=1)
+    b = worlds.qualitative_batch(2, 3, seed=1).to_torch()
+    xa = ga.sample(b, seed=2)
+    assert ga.chain_stats()['evals'] == 20 * 3
+    xb = gb.sample(b, seed=2)
+    assert gb.chain_stats()['evals'] == 30 * 2
+    assert torch.equal(ga.sample(b, seed=2), xa) and torch.equal(gb.sample(b, seed=2), xb)

@@ -220,6 +220,64 @@ def test_mala_segments_vs_reference():
     assert (acc[:10] >= 0).all() and (acc[:10] <= 1).all() and acc[:10].mean() > 0.5
 
 
+def mala_timestep_errors(run_step, z, timesteps):
+    """BASELINE config C4's sampler at its hidden width (chain_t256_mala: 12-triangle graphs, H = 256, MALA S = 10, every
+    state of the reference chain recorded together with the reference's own acceptance log, ddpm.py:979-996).  Each
+    listed timestep is run from the reference's recorded state; it must reproduce the next recorded state within 1e-4
+    (relative to the state's magnitude) AND the reference's mean acceptance of that timestep exactly (a mean over
+    N x S binary decisions: any flipped decision shows).  Returns the timesteps where either fails, as
+    (t, rows off, acceptance here, acceptance of the reference).  The chain as a whole is not comparable: one flipped
+    near-tie u ~ exp(.) changes a node's state by O(1) and every later draw with it (the reference's own fp32 and
+    fp64 runs part ways the same way), which is why the fixture records every state."""
+    T = int(z['T'])
+    tol_acc = 0.25 / (z['x'].shape[0] * int(z['S']))
+    bad = []
+    for t in timesteps:
+        k = T - 1 - t
+        x, acc = run_step(z['hist'][k], t)
+        want = z['hist'][k + 1]
+        off = int((np.abs(x - want).max(axis=1) > 1e-4 * (1.0 + np.abs(want).max())).sum())
+        if off or abs(float(acc[t]) - float(z['accept'][t])) > tol_acc:
+            bad.append((int(t), off, float(acc[t]), float(z['accept'][t])))
+    return bad
+
+
+def test_mala_h256_timesteps_vs_reference():
+    z = golden('chain_t256_mala')
+    assert int(z['H']) == 256 and int(z['S']) == 10 and len(z['hist_idx']) == 1001
+    assert int(z['n_rand']) == 1000 * 10 and 0.3 < float(z['accept'].mean()) < 0.9       # a chain that does accept and reject
+    m = oracle_model('diffuse_pairwise', 256, 'weights_diffuse_pairwise_h256_energy.npz', T=1000, S=10, energy=True)
+    g = m.graph(golden_batch(z))
+    ts = list(range(999, -1, -37))                        # 28 of the 1000 timesteps (the GPU test runs them all)
+    bad = mala_timestep_errors(lambda x, t: g.chain('MALA', seed=int(z['seed']), x=x, t_first=t, t_last=t, accept=True), z, ts)
+    assert len(bad) <= 1 and all(b[1] <= 2 for b in bad), bad
+
+
+def test_robot_h256_chain_vs_reference():
+    """BASELINE config C5's mode at its hidden width: 10-object robot_box graphs, H = 256, ULA S = 10"""
+    z = golden('chain_r256_ula')
+    m = oracle_model('robot_box', 256, 'weights_robot_box_h256.npz', T=1000, S=10)
+    g = m.graph(golden_batch(z))
+    x, hist = g.chain('ULA', seed=int(z['seed']), history=True)
+    assert np.abs(x - z['final']).max() < 1e-4
+    for k, idx in enumerate(z['hist_idx']):
+        assert rel_err(hist[idx], z['hist'][k]) < 1e-4, int(idx)
+
+
+def test_single_evaluation_h256_energy_and_robot():
+    z = golden('single_eval_h256')
+    m = oracle_model('diffuse_pairwise', 256, 'weights_diffuse_pairwise_h256_energy.npz', energy=True)
+    g = m.graph(golden_batch(z, 't256e/'))
+    for i, t in enumerate(z['t256e/t']):
+        grad, E = g.energy_grad(z['t256e/poses'][i], int(t))
+        assert abs(E - z['t256e/energy'][i]) <= 2e-5 * (1 + abs(z['t256e/energy'][i]))
+        assert rel_err(grad, z['t256e/grad'][i]) < 5e-5, t
+    m = oracle_model('robot_box', 256, 'weights_robot_box_h256.npz')
+    g = m.graph(golden_batch(z, 'r256/'))
+    for i, t in enumerate(z['r256/t']):
+        assert rel_err(g.denoise(z['r256/poses'][i], int(t)), z['r256/out'][i]) < 2e-5, t
+
+
 def hmc_T20_errors(run_step, z):
     """AnnealedMUHASampler (ddpm.py:1050-1128) at T = 20, where its proposals do get accepted: every timestep is
     run from the reference's recorded state; returns the timesteps whose next state or mean acceptance differ"""
