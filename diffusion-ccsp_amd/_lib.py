@@ -9,7 +9,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 SO = os.path.join(CSRC, 'libccsp_hip.so')
-SOURCES = ['ccsp_hip.hip', 'ccsp_philox.h', 'ccsp_plan.h', 'ccsp_energy_pre.h', 'ccsp_energy.h', 'ccsp_bf16x3.h',
+SOURCES = ['ccsp_hip.hip', 'ccsp_philox.h', 'ccsp_plan.h', 'ccsp_energy_pre.h', 'ccsp_energy.h', 'ccsp_bf16x3.h', 'ccsp_f16x2.h',
            'ccsp_struct.h', 'ccsp_hmc.h', os.path.join('..', '..', 'include', 'ccsp.h')]
 
 SAMPLERS = {False: 0, None: 0, 'NONE': 0, 'ULA': 1, 'ULA+': 2, 'MALA': 3, 'HMC': 4}

@@ -1,0 +1,393 @@
+// fp32-class GEMMs on the f16 matrix cores ("f16x2"): every fp32 operand is scaled by an exact power of two
+// into the fp16 range and split into two fp16 terms  x 2^e = x1 + x2  (11 significand bits each, 22 together),
+// and a product a*b is accumulated in fp32 as the three cross terms of weight >= 2^-11:
+//        a2 b1 + a1 b2 + a1 b1
+// Every fp16 x fp16 product is exact in fp32; the dropped a2 b2 term and the split residuals are <= 2^-22
+// relative -- the accuracy class of a chained fp32 MFMA accumulation (measured 2.4e-7 .. 4.5e-7 of sum|ab|,
+// ccsp_bf16x3.h), so the parity bars are the ones of the fp32 path.  Against the six-product bf16 scheme of
+// ccsp_bf16x3.h this halves the matrix-pipe time and cuts the operand bytes (global, LDS write, LDS read)
+// by a third.
+//
+// Range.  fp16 holds 2^-24 .. 65504 and the reference sampler passes through 1e6 .. 1e19 transients in its
+// first timesteps (tests/golden: chain_q256_T1000_B4), so operands are scaled, always exactly:
+//   * weights: one exponent per weight tensor, chosen at model creation from its largest element;
+//   * pose embeddings (A of the row GEMM): one exponent per node row, from the row's largest element,
+//     computed by the producer (the encoder epilogue of k_node) and stored next to the planes;
+//   * decoder input h = SiLU(U[u0] + U[u1]) (A of the edge kernel): one exponent per (edge, half) row from
+//     the BOUND  max|U[u0]| + max|U[u1]| >= |h|  over that half, where the row maxima are a by-product of
+//     the row GEMM's epilogue (umax).  A bound instead of the exact maximum costs nothing: elements keep all
+//     22 bits down to 2^-18 of the scaled maximum (fp16 normal range), and smaller ones an absolute
+//     precision of 2^-39 of it.
+// The scaled row maximum lies in [2^13, 2^14), K-long sums of products stay below 2^38, and the result is
+// unscaled by the exact inverse power of two in the epilogue (v_ldexp_f32).  Non-finite rows (NaN is data)
+// get exponent 0 and propagate as NaN / Inf.
+//
+// Kernels (hidden_dim 256 only; the small fixtures at hidden_dim 64 stay on ccsp_bf16x3.h):
+//   k_rowgemm_h2<KD, ND>   128 x 128 tiles, 4 waves as 2(M) x 2(N), 64 x 64 per wave (every LDS fragment feeds
+//                          two MFMA tiles: 8 ds_read_b128 per 12 MFMAs, against 9 per 12 at half the flops
+//                          each in k_rowgemm_bf2), two LDS stages of 32 KB (one barrier per K chunk), two
+//                          register sets (operands of chunk c+2 in flight while chunk c is multiplied),
+//                          epilogue through LDS: 16-byte row-contiguous base loads / U stores and the row
+//                          maxima of U for the edge kernel
+//   k_edge_h2<ENERGY>      128 rows = 64 sorted edges x both output halves per workgroup (the decoder weight
+//                          chunk is staged once for both halves), same wave layout and stages; SiLU + scale +
+//                          split of chunk c+1 issued between the MFMA groups of chunk c
+// Included inside the anonymous namespace of ccsp_hip.hip.
+#pragma once
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// (h2_scale_exp / split2h live in ccsp_hip.hip: the node kernel's encoder writes planes too)
+
+// dst[plane][i] = plane-th fp16 term of src[i] * 2^e   (weights, once per model)
+__global__ void k_split2h(long n, const float* __restrict__ src, int e, unsigned short* __restrict__ dst) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned short a, b;
+    split2h(ldexpf(src[i], e), a, b);
+    dst[i] = a; dst[n + i] = b;
+}
+
+// largest |src[i]| as fp32 bits (non-negative floats order like their bit patterns; NaN ranks above Inf, both
+// give exponent 0).  atomicMax is order-independent, so the result is deterministic.
+__global__ void k_absmax_bits(long n, const float* __restrict__ src, unsigned int* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned int v = i < n ? (__float_as_uint(src[i]) & 0x7fffffffu) : 0u;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        const unsigned int o = (unsigned int)__shfl_xor((int)v, s);
+        v = v > o ? v : o;
+    }
+    if ((threadIdx.x & 63) == 0 && v) atomicMax(out, v);
+}
+
+constexpr int H2_BK = 32;                    // K chunk: two MFMA k-steps of 16
+constexpr int H2_PL = 128 * H2_BK;           // fp16 elements per plane of a 128-row operand stage
+constexpr int H2_STAGE = 4 * H2_PL;          // A planes 0, 1 then B planes 0, 1: 32 KB
+// rows are unpadded 64-byte K chunks, the 16-byte piece index XOR-swizzled by (row >> 2) & 3 (rb2_off of
+// ccsp_bf16x3.h: conflict-free ds_read_b128 fragment reads and 16-byte staging writes)
+__device__ __forceinline__ int h2_off(int row, int piece) { return row * H2_BK + ((piece ^ ((row >> 2) & 3)) << 3); }
+
+// one staged K chunk: acc[i][j] += A(rows am0 + 32 i + 0..31) . B(rows bn0 + 32 j + 0..31)^T, three products each
+__device__ __forceinline__ void h2_kstep(const unsigned short* __restrict__ st, int ks, int am0, int bn0, floatx16 (&acc)[2][2]) {
+    const int lane = threadIdx.x & 63;
+    const unsigned short* As = st;
+    const unsigned short* Bs = st + 2 * H2_PL;
+    const int piece = (lane >> 5) + 2 * ks;
+    half8 a[2][2], b[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            a[i][p] = *reinterpret_cast<const half8*>(As + p * H2_PL + h2_off(am0 + 32 * i + (lane & 31), piece));
+            b[i][p] = *reinterpret_cast<const half8*>(Bs + p * H2_PL + h2_off(bn0 + 32 * i + (lane & 31), piece));
+        }
+    // smallest terms first; consecutive MFMAs go to different accumulators
+    constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][PA[q]], b[j][PB[q]], acc[i][j], 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_rowgemm_h2<KD, ND>:  U[row0 + r, col0 + c] = 2^-(ea[r] + ew) * sum_k A[src(r), k] W[ts][col0 + c, k]  + base + tau
+//   A planes [2][n_src][KD] fp16 bits scaled by 2^a_exp[src], rows gathered by urow_node; W planes [2][n_ts][ND][KD]
+//   scaled by 2^w_exp.  umax[row, col0 / 128] = max |U| over the tile's 128 columns (null: not written).
+// ------------------------------------------------------------------------------------------
+template <int KD, int ND>
+__global__ __launch_bounds__(256, 2) void k_rowgemm_h2(const unsigned short* __restrict__ A, size_t a_plane, const int* __restrict__ a_exp,
+                                                       const int* __restrict__ urow_node, const int* __restrict__ tile_row0,
+                                                       const int* __restrict__ tile_nrows, const int* __restrict__ tile_ts,
+                                                       const unsigned short* __restrict__ W, size_t w_plane, size_t w_stride, int w_exp,
+                                                       const float* __restrict__ base, const float* __restrict__ tau_t,
+                                                       float* __restrict__ U, float* __restrict__ umax, StepRef ref, size_t tau_stride) {
+    static_assert(ND % 128 == 0 && KD % H2_BK == 0 && KD / H2_BK >= 3, "shape");
+    constexpr int NCT = ND / 128, NCH = KD / H2_BK;
+    constexpr int C_LD = 160;                                     // epilogue tile [64][160] fp32: conflict-free 16-byte row reads
+    static_assert(64 * C_LD * 4 <= 2 * H2_STAGE * 2, "epilogue tile must fit the stages");
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * H2_STAGE + 256];      // two stages + 128 row exponents
+    int* sE = reinterpret_cast<int*>(smem + 2 * H2_STAGE);
+    if (ref.tab) tau_t += (size_t)ref.tab[*ref.counter].t * tau_stride;      // hipGraph mode: timestep from the device table
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = bid / NCT, ct = bid % NCT;
+    const int row0 = tile_row0[tile], nrows = tile_nrows[tile], ts = tile_ts[tile];
+    const int col0 = ct * 128;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = tid >> 2, lq = tid & 3;                      // staging: rows lrow, lrow + 64, 16-byte piece lq, both planes
+    const unsigned short* a_ptr[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int r = lrow + 64 * i;
+        r = r < nrows ? r : nrows - 1;
+        const int src = urow_node ? urow_node[row0 + r] : row0 + r;
+        a_ptr[i] = A + (size_t)src * KD + lq * 8;
+    }
+    if (tid < 128) {
+        const int r = tid < nrows ? tid : nrows - 1;
+        sE[tid] = a_exp[urow_node ? urow_node[row0 + r] : row0 + r];
+    }
+    const unsigned short* b_ptr = W + (size_t)ts * w_stride + (size_t)(col0 + lrow) * KD + lq * 8;
+    const int st_off = h2_off(lrow, lq);                          // (row + 64 has the same swizzle: + 64 * H2_BK)
+    ushort8 ra[2][4], rb[2][4];                                   // [register set][row half * 2 + plane]
+    auto gload = [&](int c, int set) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                ra[set][i * 2 + p] = *reinterpret_cast<const ushort8*>(a_ptr[i] + (size_t)p * a_plane + c * H2_BK);
+                rb[set][i * 2 + p] = *reinterpret_cast<const ushort8*>(b_ptr + (size_t)i * 64 * KD + (size_t)p * w_plane + c * H2_BK);
+            }
+    };
+    auto lstore = [&](int stage, int set) {
+        unsigned short* As = smem + stage * H2_STAGE;
+        unsigned short* Bs = As + 2 * H2_PL;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                *reinterpret_cast<ushort8*>(As + p * H2_PL + st_off + i * 64 * H2_BK) = ra[set][i * 2 + p];
+                *reinterpret_cast<ushort8*>(Bs + p * H2_PL + st_off + i * 64 * H2_BK) = rb[set][i * 2 + p];
+            }
+    };
+    gload(0, 0);
+    gload(1, 1);
+    // time term + bias of this thread's epilogue columns (slot-0 rows only), in flight during the K loop
+    const int er = tid >> 3, eq = tid & 7;                        // epilogue: rows er, er + 32 of a 64-row pass, columns 4 eq + 32 k
+    float4 tv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        tv[k] = (tau_t && (ts & 1) == 0) ? *reinterpret_cast<const float4*>(tau_t + (size_t)(ts >> 1) * ND + col0 + 4 * eq + 32 * k)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    lstore(0, 0);
+    gload(2, 0);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {                               // fully unrolled: register-set indices are constants
+        // register set (c+1)&1 holds chunk c+1, the other one chunk c+2 (still in flight)
+        if (c + 1 < NCH) lstore((c + 1) & 1, (c + 1) & 1);
+        if (c + 3 < NCH) gload(c + 3, (c + 1) & 1);
+        const unsigned short* st = smem + (c & 1) * H2_STAGE;
+        h2_kstep(st, 0, wm * 64, wn * 64, acc);
+        h2_kstep(st, 1, wm * 64, wn * 64, acc);
+        __syncthreads();
+    }
+    // epilogue through LDS, 64 rows (row tile i of every wave) per pass: the accumulators (one column, 16 rows per lane)
+    // are re-read as rows, so base loads and U stores are 128-byte row segments and the row maximum is a 3-step shuffle
+    float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        // this pass's rows of the tile: Cs row lr = wm' * 32 + rr  <->  tile row wm' * 64 + i * 32 + rr
+        float4 bs[2][4];
+        int trow[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int lr = er + 32 * h;
+            trow[h] = (lr >> 5) * 64 + i * 32 + (lr & 31);
+            const int tr = trow[h] < nrows ? trow[h] : nrows - 1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                bs[h][k] = base ? *reinterpret_cast<const float4*>(base + (size_t)(row0 + tr) * ND + col0 + 4 * eq + 32 * k)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                Cs[(wm * 32 + rr) * C_LD + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int lr = er + 32 * h;
+            if (trow[h] < nrows) {
+                const int e = -(sE[trow[h]] + w_exp);
+                const size_t grow = (size_t)(row0 + trow[h]);
+                float m = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float4 v = *reinterpret_cast<const float4*>(Cs + lr * C_LD + 4 * eq + 32 * k);
+                    float4 o;
+                    o.x = ldexpf(v.x, e) + (bs[h][k].x + tv[k].x);
+                    o.y = ldexpf(v.y, e) + (bs[h][k].y + tv[k].y);
+                    o.z = ldexpf(v.z, e) + (bs[h][k].z + tv[k].z);
+                    o.w = ldexpf(v.w, e) + (bs[h][k].w + tv[k].w);
+                    m = fmaxf(fmaxf(m, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+                    *reinterpret_cast<float4*>(U + grow * ND + col0 + 4 * eq + 32 * k) = o;
+                }
+                if (umax) {                                       // (the 8 lanes of a row take the branch together)
+                    m = fmaxf(m, __shfl_xor(m, 1));
+                    m = fmaxf(m, __shfl_xor(m, 2));
+                    m = fmaxf(m, __shfl_xor(m, 4));
+                    if (eq == 0) umax[grow * NCT + ct] = m;
+                }
+            }
+        }
+        if (i == 0) __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_edge_h2<ENERGY>: the decoder of 64 sorted edges, both output halves (denoise_fn.py:341-371).  Row r < 64 of the
+// tile is (edge e0 + r, half 0), row 64 + r is (edge e0 + r, half 1); A[row, :] = SiLU(U[u0] + U[u1])[half * H : +H]
+// scaled by the row's exponent (bound from umax, see the header) and split in registers; B = planes of
+// pose_decoder.0.weight [H/2, H].  Epilogue: 2^-(e_row + wd_exp) acc + bias -> SiLU -> LDS -> pose_decoder.2 -> CSR
+// slot.  ENERGY as in k_edge<H, true>: -2 (o - pose) to the CSR slot, pre-activations to Q, partial sum of squares.
+// ------------------------------------------------------------------------------------------
+template <bool ENERGY>
+__global__ __launch_bounds__(256, 2) void k_edge_h2(int E_act, int P, const int* __restrict__ e_u0, const int* __restrict__ e_u1,
+                                                    const float* __restrict__ U, const float* __restrict__ umax /*[R][4]*/,
+                                                    const unsigned short* __restrict__ Wd1H /*[2][128][256]*/, int wd_exp,
+                                                    const float* __restrict__ bd1, const float* __restrict__ Wd2,
+                                                    const float* __restrict__ bd2, const int* __restrict__ ent_pos, float* __restrict__ O,
+                                                    EdgeEnergyArgs en, int* __restrict__ counter_inc) {
+    if (counter_inc && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(counter_inc, 1);     // hipGraph mode: next table entry
+    constexpr int H = 256, BN = 128, NCH = H / H2_BK;
+    constexpr int S1_LD = BN + 1;
+    static_assert(64 * S1_LD * 4 <= 2 * H2_STAGE * 2, "epilogue tile must fit the stages");
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * H2_STAGE + 256];
+    int* sE = reinterpret_cast<int*>(smem + 2 * H2_STAGE);
+    const int e0 = xcd_remap(blockIdx.x, gridDim.x) * 64;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = tid >> 3, lq = tid & 7;                        // A producer: rows lr + 32 i (i < 4), fp32 columns 4 lq .. + 3 of the chunk
+    const float* u0_ptr[4];
+    const float* u1_ptr[4];
+    int a_st[4], a_exp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = lr + 32 * i, s = row >> 6;
+        int k = e0 + (row & 63);
+        k = k < E_act ? k : E_act - 1;
+        const int r0 = e_u0[k], r1 = e_u1[k];
+        u0_ptr[i] = U + (size_t)r0 * (2 * H) + s * H + lq * 4;
+        u1_ptr[i] = U + (size_t)r1 * (2 * H) + s * H + lq * 4;
+        const float2 m0 = *reinterpret_cast<const float2*>(umax + (size_t)r0 * 4 + 2 * s);
+        const float2 m1 = *reinterpret_cast<const float2*>(umax + (size_t)r1 * 4 + 2 * s);
+        a_exp[i] = h2_scale_exp(fmaxf(m0.x, m0.y) + fmaxf(m1.x, m1.y));        // |SiLU(z)| <= |z| <= max|U[u0]| + max|U[u1]|
+        if (lq == 0) sE[row] = a_exp[i];
+        a_st[i] = h2_off(row, lq >> 1) + (lq & 1) * 4;
+    }
+    const int brow = tid >> 2, bq = tid & 3;                      // B copy: rows brow, brow + 64, piece bq, both planes
+    const unsigned short* b_ptr = Wd1H + (size_t)brow * H + bq * 8;
+    const int b_st = h2_off(brow, bq);
+    float4 ua[2][4], ub[2][4];                                    // [register set][pass]
+    ushort8 rb[4];
+    auto gload_a = [&](int c, int set) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ua[set][i] = *reinterpret_cast<const float4*>(u0_ptr[i] + c * H2_BK);
+            ub[set][i] = *reinterpret_cast<const float4*>(u1_ptr[i] + c * H2_BK);
+        }
+    };
+    auto gload_b = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                rb[i * 2 + p] = *reinterpret_cast<const ushort8*>(b_ptr + (size_t)p * BN * H + (size_t)i * 64 * H + c * H2_BK);
+    };
+    auto store_a = [&](int stage, int set, int i) {               // SiLU + scale + split of one pass -> the A planes of the stage
+        unsigned short* As = smem + stage * H2_STAGE;
+        const float h[4] = {silu_fast(ua[set][i].x + ub[set][i].x), silu_fast(ua[set][i].y + ub[set][i].y),
+                            silu_fast(ua[set][i].z + ub[set][i].z), silu_fast(ua[set][i].w + ub[set][i].w)};
+        unsigned short p1[4], p2[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split2h(ldexpf(h[e], a_exp[i]), p1[e], p2[e]);
+        unsigned short* d = As + a_st[i];
+        *reinterpret_cast<uint2*>(d) = make_uint2(p1[0] | ((unsigned)p1[1] << 16), p1[2] | ((unsigned)p1[3] << 16));
+        *reinterpret_cast<uint2*>(d + H2_PL) = make_uint2(p2[0] | ((unsigned)p2[1] << 16), p2[2] | ((unsigned)p2[3] << 16));
+    };
+    auto store_b = [&](int stage) {
+        unsigned short* Bs = smem + stage * H2_STAGE + 2 * H2_PL;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                *reinterpret_cast<ushort8*>(Bs + p * H2_PL + b_st + i * 64 * H2_BK) = rb[i * 2 + p];
+    };
+    gload_a(0, 0);
+    gload_b(0);
+    gload_a(1, 1);
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) store_a(0, 0, i);
+    store_b(0);
+    gload_b(1);
+    gload_a(2, 0);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {                               // fully unrolled: the register-set index is a constant
+        const unsigned short* st = smem + (c & 1) * H2_STAGE;
+        const int nx = (c + 1) & 1;                               // next stage, and the register set holding chunk c+1
+        h2_kstep(st, 0, wm * 64, wn * 64, acc);
+        if (c + 1 < NCH) { store_a(nx, nx, 0); store_a(nx, nx, 1); }     // in the shadow of the 12 MFMAs just issued
+        h2_kstep(st, 1, wm * 64, wn * 64, acc);
+        if (c + 1 < NCH) { store_a(nx, nx, 2); store_a(nx, nx, 3); store_b(nx); }
+        if (c + 2 < NCH) gload_b(c + 2);
+        if (c + 3 < NCH) gload_a(c + 3, nx);
+        __syncthreads();
+    }
+    // epilogue, 64 rows (row tile i of every wave: 32 edges x both halves) per pass
+    float* S1 = reinterpret_cast<float*>(smem);
+    float e2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = wn * 64 + j * 32 + (lane & 31);
+            const float bj = bd1[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int row = wm * 64 + i * 32 + rr;                        // tile row: half wm, edge e0 + i * 32 + rr
+                const float q = ldexpf(acc[i][j][r], -(sE[row] + wd_exp)) + bj;
+                S1[(wm * 32 + rr) * S1_LD + col] = silu_fast(q);
+                if constexpr (ENERGY) {
+                    const int k = e0 + i * 32 + rr;
+                    if (en.Q && k < E_act) en.Q[((size_t)2 * k + wm) * BN + col] = q;
+                }
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 64 * P; idx += 256) {
+            const int lrow = idx & 63;                                         // S1 row: half (lrow >> 5), edge e0 + i * 32 + (lrow & 31)
+            const int p = __builtin_amdgcn_readfirstlane(idx >> 6);           // uniform per wave: scalar weight loads
+            const float o = dot4<BN>(S1 + lrow * S1_LD, Wd2 + (size_t)p * BN) + bd2[p];
+            const int k = e0 + i * 32 + (lrow & 31), s = lrow >> 5;
+            if (k < E_act) {
+                if constexpr (ENERGY) {
+                    const int node = s == 0 ? en.e_a[k] : en.e_b[k];
+                    const float d = o - en.xeval[(size_t)node * P + p];
+                    e2 = fmaf(d, d, e2);
+                    O[(size_t)ent_pos[2 * k + s] * P + p] = -2.0f * d;
+                } else {
+                    O[(size_t)ent_pos[2 * k + s] * P + p] = o;                 // straight to the node's CSR slot
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if constexpr (ENERGY) {
+        const float tot = block_sum_256(e2, reinterpret_cast<float*>(smem));
+        if (tid == 0) en.partial[blockIdx.x] = tot;
+    }
+}

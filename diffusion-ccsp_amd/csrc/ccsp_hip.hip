@@ -188,11 +188,29 @@ __device__ __forceinline__ void enc_prefetch(const EncW w, EncPrefetch<H>& pf) {
     __builtin_amdgcn_sched_barrier(0);      // keep these loads at kernel entry (hipcc would sink them to first use)
 }
 
+// f16x2 operands (ccsp_f16x2.h explains the scheme): exponent e with amax * 2^e in [2^13, 2^14), 0 for zero /
+// denormal / Inf / NaN; and the two fp16 terms of an already scaled value
+__device__ __forceinline__ int h2_scale_exp(float amax) {
+    const int be = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+    return (be == 0 || be == 255) ? 0 : 140 - be;
+}
+__device__ __forceinline__ void split2h(float xs, unsigned short& h1, unsigned short& h2) {
+    const _Float16 a = (_Float16)xs;
+    const _Float16 b = (_Float16)(xs - (float)a);
+    h1 = __builtin_bit_cast(unsigned short, a);
+    h2 = __builtin_bit_cast(unsigned short, b);
+}
+
+struct EncOut {
+    float* f32;                 // [N, H] embeddings, or null
+    unsigned short* bf3;        // [3][N][H] bf16 planes (ccsp_bf16x3.h), or null
+    unsigned short* h2;         // [2][N][H] fp16 planes of the row scaled by 2^h2_exp[n] (ccsp_f16x2.h), or null
+    int* h2_exp;                // [N]
+};
+
 template <int H>
 __device__ __forceinline__ void encode_tile_mfma(const EncW w, const EncPrefetch<H>& pf, float (*xs)[8],
-                                                 float (*s1)[H / 2 + 1], int node0, int N, float* __restrict__ out /*[N,H]*/,
-                                                 unsigned short* __restrict__ outS = nullptr /*[3][N][H] bf16 planes or null*/,
-                                                 bool write_f32 = true) {
+                                                 float (*s1)[H / 2 + 1], float (*smax)[NODE_TILE], int node0, int N, const EncOut out) {
     using PFT = EncPrefetch<H>;
     constexpr int TPW = PFT::TPW, KS = PFT::KS, PF = PFT::PF;
     const int tid = threadIdx.x;
@@ -232,23 +250,49 @@ __device__ __forceinline__ void encode_tile_mfma(const EncW w, const EncPrefetch
     // One 16-byte store per tile (and 8 bytes per bf16 plane) instead of four scattered ones: the 2-byte
     // plane stores of the untransposed layout cost 5 % of the whole chain (tools/ab.sh).
     const int n = node0 + (lane & 15);
+    float v[TPW][4];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[j][r] = silu_fast(acc[j][r] + pf.b2[j][r]);
+    int e2 = 0;
+    if (out.h2) {
+        // largest |element| of every node row: in-lane over the lane's 4 TPW columns, the four lanes of the wave that
+        // share the node (lane & 15), then the four waves through LDS (fmaxf skips NaN; an Inf row gets exponent 0)
+        float m = 0.0f;
+#pragma unroll
+        for (int j = 0; j < TPW; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(v[j][r]));
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        if (lane < NODE_TILE) smax[wave][lane] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(smax[0][lane & 15], smax[1][lane & 15]), fmaxf(smax[2][lane & 15], smax[3][lane & 15]));
+        e2 = h2_scale_exp(m);
+        if (n < N && wave == 0 && lane < NODE_TILE) out.h2_exp[n] = e2;
+    }
     if (n < N) {
 #pragma unroll
         for (int j = 0; j < TPW; ++j) {
             const int c0 = wave * 16 * TPW + j * 16 + 4 * (lane >> 4);
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = silu_fast(acc[j][r] + pf.b2[j][r]);
             const size_t o = (size_t)n * H + c0;
-            if (write_f32) *reinterpret_cast<float4*>(out + o) = float4{v[0], v[1], v[2], v[3]};
-            if (outS) {                                       // operand planes of k_rowgemm_bf*, written by the producer
+            const size_t pl = (size_t)N * H;
+            if (out.f32) *reinterpret_cast<float4*>(out.f32 + o) = float4{v[j][0], v[j][1], v[j][2], v[j][3]};
+            if (out.bf3) {                                    // operand planes of k_rowgemm_bf*, written by the producer
                 unsigned short h1[4], h2[4], h3[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) split3(v[r], h1[r], h2[r], h3[r]);
-                const size_t pl = (size_t)N * H;
-                *reinterpret_cast<uint2*>(outS + o) = make_uint2(h1[0] | ((unsigned)h1[1] << 16), h1[2] | ((unsigned)h1[3] << 16));
-                *reinterpret_cast<uint2*>(outS + pl + o) = make_uint2(h2[0] | ((unsigned)h2[1] << 16), h2[2] | ((unsigned)h2[3] << 16));
-                *reinterpret_cast<uint2*>(outS + 2 * pl + o) = make_uint2(h3[0] | ((unsigned)h3[1] << 16), h3[2] | ((unsigned)h3[3] << 16));
+                for (int r = 0; r < 4; ++r) split3(v[j][r], h1[r], h2[r], h3[r]);
+                *reinterpret_cast<uint2*>(out.bf3 + o) = make_uint2(h1[0] | ((unsigned)h1[1] << 16), h1[2] | ((unsigned)h1[3] << 16));
+                *reinterpret_cast<uint2*>(out.bf3 + pl + o) = make_uint2(h2[0] | ((unsigned)h2[1] << 16), h2[2] | ((unsigned)h2[3] << 16));
+                *reinterpret_cast<uint2*>(out.bf3 + 2 * pl + o) = make_uint2(h3[0] | ((unsigned)h3[1] << 16), h3[2] | ((unsigned)h3[3] << 16));
+            }
+            if (out.h2) {                                     // operand planes of k_rowgemm_h2
+                unsigned short h1[4], h2[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) split2h(ldexpf(v[j][r], e2), h1[r], h2[r]);
+                *reinterpret_cast<uint2*>(out.h2 + o) = make_uint2(h1[0] | ((unsigned)h1[1] << 16), h1[2] | ((unsigned)h1[3] << 16));
+                *reinterpret_cast<uint2*>(out.h2 + pl + o) = make_uint2(h2[0] | ((unsigned)h2[1] << 16), h2[2] | ((unsigned)h2[3] << 16));
             }
         }
     }
@@ -699,9 +743,10 @@ struct NodeArgs {
 };
 
 template <int H>
-__global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, float* __restrict__ pemb, unsigned short* __restrict__ pembS, int write_f32) {
+__global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, EncOut eo) {
     __shared__ float xs[NODE_TILE][8];
     __shared__ float s1[NODE_TILE][H / 2 + 1];
+    __shared__ float smax[4][NODE_TILE];
     // the node kernel is a short latency chain on the critical path of every evaluation; when it shares the
     // CUs with the other lane's GEMM kernels its waves should win the issue arbitration
     __builtin_amdgcn_s_setprio(3);
@@ -793,11 +838,12 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, float* __restr
     }
     if (!a.do_encode) return;
     __syncthreads();
-    encode_tile_mfma<H>(w, pf, xs, s1, node0, a.N, pemb, pembS, write_f32 != 0);
+    encode_tile_mfma<H>(w, pf, xs, s1, smax, node0, a.N, eo);
 }
 
 #include "ccsp_energy.h"
 #include "ccsp_bf16x3.h"
+#include "ccsp_f16x2.h"
 #include "ccsp_struct.h"
 #include "ccsp_hmc.h"
 
@@ -852,6 +898,10 @@ struct ccsp_model {
     unsigned short* Wd1S;   // [3][H/2][H]      bf16 planes of pose_decoder.0.weight
     unsigned short* Wd1TS;  // [3][H][H/2]      planes of its transpose (k_edge_bwd_bf)
     unsigned short* WpTS;   // [3][C][2][H][2H] planes of WpT (transpose row GEMM of the energy backward)
+    int f16x2 = 0;          // 1: evaluation GEMMs on the f16 matrix cores with 2-way split, exactly scaled operands (ccsp_f16x2.h; H = 256)
+    unsigned short* WpH = nullptr;    // [2][C][2][2H][H] fp16 planes of Wp * 2^wp_exp
+    unsigned short* Wd1H = nullptr;   // [2][H/2][H]      fp16 planes of pose_decoder.0.weight * 2^wd_exp
+    int wp_exp = 0, wd_exp = 0;
     // StructDiffusion baseline (model_kind 1): transformer weights as given ([out, in] row-major)
     struct SdLayer { float *in_w, *in_b, *out_w, *out_b, *ln1_g, *ln1_b, *fc_w, *fc_b, *proj_w, *proj_b, *ln2_g, *ln2_b; };
     int Wd = 0;            // transformer width: 2H, or 3H with a grasp group
@@ -880,6 +930,9 @@ struct ccsp_graph {
     int *e_type, *e_u0, *e_u1, *e_orig, *urow_node, *tile_row0, *tile_nrows, *tile_ts, *node_ptr, *node_ent, *ent_pos;
     float *base, *U, *O, *pemb, *x, *eps;
     unsigned short* pembS = nullptr;   // [3][N][H] bf16 planes of pemb (bf16x3 mode)
+    unsigned short* pembH = nullptr;   // [2][N][H] fp16 planes of pemb rows scaled by 2^pexp[n] (f16x2 mode)
+    int* pexp = nullptr;               // [N]
+    float* umax = nullptr;             // [R][4] max |U| per row and 128-column tile (k_rowgemm_h2 -> k_edge_h2)
     int *t2_row0 = nullptr, *t2_nrows = nullptr, *t2_ts = nullptr;   // 128-row tiles of k_rowgemm_bf2 (pairs of plan tiles)
     int n_tiles2 = 0;
     int* urow_ts;
@@ -976,6 +1029,19 @@ int launch_eval(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s, bool tabled 
     const float* tau_t = m->tau + (tabled ? 0 : (size_t)t * tau_stride);
     const StepRef ref{tabled ? g->d_tab : nullptr, tabled ? g->d_counter : nullptr};
     int* const cinc = tabled ? g->d_counter : nullptr;
+    if constexpr (H == 256) {
+        if (m->f16x2) {
+            hipLaunchKernelGGL((k_rowgemm_h2<H, 2 * H>), dim3(g->n_tiles2 * (2 * H / 128)), dim3(256), 0, s, g->pembH, (size_t)g->N * H, g->pexp,
+                               g->urow_node, g->t2_row0, g->t2_nrows, g->t2_ts, m->WpH, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H,
+                               m->wp_exp, g->base, tau_t, g->U, g->umax, ref, tau_stride);
+            if (prof) HIP_TRY(hipEventRecord(g->kev[g->kev_used + 1], s));
+            hipLaunchKernelGGL(k_edge_h2<false>, dim3(nblk(p.E_act, 64)), dim3(256), 0, s, p.E_act, m->d.pose_dim, g->e_u0, g->e_u1, g->U, g->umax,
+                               m->Wd1H, m->wd_exp, m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, EdgeEnergyArgs{}, cinc);
+            if (prof) { HIP_TRY(hipEventRecord(g->kev[g->kev_used + 2], s)); g->kev_used += 3; }
+            g->evals++;
+            return 0;
+        }
+    }
     if (m->bf16x3) {
         const long npe = (long)g->N * H;
         if (m->row_tile == 128)
@@ -1028,8 +1094,13 @@ template <int H>
 void launch_node(ccsp_model* m, ccsp_graph* g, const NodeArgs& a, hipStream_t s) {
     // direct-mode bf16x3 evaluations read the planes only; the fp32 embeddings are for the fp32 / energy / transformer paths
     const bool planes = m->bf16x3 && m->d.model_kind == CCSP_MODEL_DIFFUSION_CCSP;
-    hipLaunchKernelGGL(k_node<H>, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a, enc_pose(m), g->pemb,
-                       planes ? g->pembS : (unsigned short*)nullptr, (!planes || m->d.energy_wrapper) ? 1 : 0);
+    const bool h2 = planes && H == 256 && m->f16x2;
+    EncOut eo;
+    eo.f32 = (!planes || m->d.energy_wrapper) ? g->pemb : nullptr;
+    eo.bf3 = (planes && !h2) ? g->pembS : nullptr;
+    eo.h2 = h2 ? g->pembH : nullptr;
+    eo.h2_exp = h2 ? g->pexp : nullptr;
+    hipLaunchKernelGGL(k_node<H>, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a, enc_pose(m), eo);
 }
 
 // ---- StructDiffusion baseline ------------------------------------------------------------------
@@ -1103,7 +1174,14 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     }
     const int nw_u = g->n_tiles * rowgemm_col_tiles<H, 2 * H>();
     const float* tau_t = m->tau + (size_t)t * m->d.n_types * 2 * H;
-    if (m->bf16x3)       // the forward row GEMM is the direct-mode one: same bf16x3 kernel, planes written by k_node
+    bool h2 = false;
+    if constexpr (H == 256) h2 = m->f16x2 != 0;
+    if (h2) {            // the forward row GEMM is the direct-mode one (planes written by k_node)
+        if constexpr (H == 256)
+            hipLaunchKernelGGL((k_rowgemm_h2<H, 2 * H>), dim3(g->n_tiles2 * (2 * H / 128)), dim3(256), 0, s, g->pembH, (size_t)g->N * H, g->pexp,
+                               g->urow_node, g->t2_row0, g->t2_nrows, g->t2_ts, m->WpH, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H,
+                               m->wp_exp, g->base, tau_t, g->U, g->umax, StepRef{nullptr, nullptr}, (size_t)0);
+    } else if (m->bf16x3)
         hipLaunchKernelGGL((k_rowgemm_bf2<H, 2 * H>), dim3(g->n_tiles2 * (2 * H / RB2_TN)), dim3(512), 0, s, g->pembS, (size_t)g->N * H, g->urow_node,
                            g->t2_row0, g->t2_nrows, g->t2_ts, m->WpS, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, g->base, tau_t, g->U,
                            StepRef{nullptr, nullptr}, (size_t)0);
@@ -1114,7 +1192,12 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     int n_part = g->n_edge_blocks;                                                           // one energy partial per workgroup
     bool edge_done = false;
     if constexpr (H == 256) {
-        if (m->bf16x3 && m->edge_kernel == 2) {
+        if (h2) {
+            n_part = nblk(p.E_act, 64);
+            hipLaunchKernelGGL(k_edge_h2<true>, dim3(n_part), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->U, g->umax, m->Wd1H, m->wd_exp, m->pd0_b,
+                               m->pd2_w, m->pd2_b, g->ent_pos, g->O, en, (int*)nullptr);
+            edge_done = true;
+        } else if (m->bf16x3 && m->edge_kernel == 2) {
             n_part = 2 * nblk(p.E_act, 64);
             hipLaunchKernelGGL(k_edge_bf2<true>, dim3(n_part), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->U, m->Wd1S, m->pd0_b, m->pd2_w,
                                m->pd2_b, g->ent_pos, g->O, en, (int*)nullptr);
@@ -1583,6 +1666,11 @@ int graph_build(ccsp_model* m, int N, int E, int F, const float* x, const signed
     TRY(dev_alloc(reg, &g->O, (size_t)2 * p.E_act * P));
     TRY(dev_alloc(reg, &g->pemb, (size_t)N * H));
     TRY(dev_alloc(reg, &g->pembS, (size_t)3 * N * H));
+    if (m->f16x2) {
+        TRY(dev_alloc(reg, &g->pembH, (size_t)2 * N * H));
+        TRY(dev_alloc(reg, &g->pexp, (size_t)N));
+        TRY(dev_alloc(reg, &g->umax, (size_t)p.R * 4));
+    }
     TRY(dev_alloc(reg, &g->x, (size_t)N * P));
     TRY(dev_alloc(reg, &g->eps, (size_t)N * P));
     // chain-constant part: geometry (and grasp) embeddings -> per-row products base[r] (the reference
@@ -1727,7 +1815,13 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     m->lane_min_edges = 6144;
     if (const char* e = getenv("CCSP_LANE_MIN_EDGES")) m->lane_min_edges = atoi(e);
     if (const char* e = getenv("CCSP_LANES")) { const int v = atoi(e); if (v >= 1 && v <= 8) m->lanes = v; }
-    if (const char* e = getenv("CCSP_MMA")) m->bf16x3 = (strcmp(e, "f32") != 0);
+    // CCSP_MMA: f16x2 (default at hidden_dim 256: two-term fp16 operands, three MFMA products per fp32 product),
+    //           bf16x3 (three-term bf16 operands, six products), f32 (v_mfma_f32_32x32x2_f32)
+    m->f16x2 = (H == 256 && d->model_kind == CCSP_MODEL_DIFFUSION_CCSP) ? 1 : 0;
+    if (const char* e = getenv("CCSP_MMA")) {
+        m->bf16x3 = (strcmp(e, "f32") != 0);
+        if (strcmp(e, "f16x2") != 0) m->f16x2 = 0;
+    }
     m->row_tile = 128;
     m->edge_kernel = 2;
     m->graph_mode = 0;
@@ -1851,6 +1945,23 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
         }
         TRY(dev_alloc(reg, &m->Wd1TS, (size_t)3 * nwd));
         hipLaunchKernelGGL(k_split3, dim3(nblk(nwd, 256)), dim3(256), 0, s, nwd, m->pd0_wT, m->Wd1TS);
+        if (m->f16x2) {     // fp16 planes of the same weights, each tensor scaled by one exact power of two (ccsp_f16x2.h)
+            unsigned int* mx = nullptr;
+            unsigned int h_mx[2] = {0u, 0u};
+            TRY(dev_alloc(reg, &mx, 2));
+            HIP_TRY(hipMemsetAsync(mx, 0, 2 * sizeof(unsigned int), s));
+            hipLaunchKernelGGL(k_absmax_bits, dim3(nblk(nwp, 256)), dim3(256), 0, s, nwp, m->Wp, mx);
+            hipLaunchKernelGGL(k_absmax_bits, dim3(nblk(nwd, 256)), dim3(256), 0, s, nwd, m->pd0_w, mx + 1);
+            HIP_TRY(hipMemcpyAsync(h_mx, mx, sizeof(h_mx), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            auto host_exp = [](unsigned int bits) { const int be = (int)((bits >> 23) & 0xffu); return (be == 0 || be == 255) ? 0 : 140 - be; };
+            m->wp_exp = host_exp(h_mx[0]);
+            m->wd_exp = host_exp(h_mx[1]);
+            TRY(dev_alloc(reg, &m->WpH, (size_t)2 * nwp));
+            TRY(dev_alloc(reg, &m->Wd1H, (size_t)2 * nwd));
+            hipLaunchKernelGGL(k_split2h, dim3(nblk(nwp, 256)), dim3(256), 0, s, nwp, m->Wp, m->wp_exp, m->WpH);
+            hipLaunchKernelGGL(k_split2h, dim3(nblk(nwd, 256)), dim3(256), 0, s, nwd, m->pd0_w, m->wd_exp, m->Wd1H);
+        }
     }
 #undef TRY
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
