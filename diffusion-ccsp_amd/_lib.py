@@ -12,6 +12,7 @@ SO = os.path.join(CSRC, 'libccsp_hip.so')
 SOURCES = ['ccsp_hip.hip', 'ccsp_philox.h', 'ccsp_plan.h', 'ccsp_energy_pre.h', 'ccsp_energy.h', 'ccsp_bf16x3.h', 'ccsp_f16x2.h',
            'ccsp_struct.h', 'ccsp_hmc.h', os.path.join('..', '..', 'include', 'ccsp.h')]
 
+K_COUNT = 10          # CCSP_K_COUNT of include/ccsp.h
 SAMPLERS = {False: 0, None: 0, 'NONE': 0, 'ULA': 1, 'ULA+': 2, 'MALA': 3, 'HMC': 4}
 SCHEDULE_KEYS = ['betas', 'alphas_cumprod', 'alphas_cumprod_prev', 'sqrt_recip_alphas_cumprod',
                  'sqrt_recipm1_alphas_cumprod', 'posterior_log_variance_clipped', 'posterior_mean_coef1',
@@ -99,6 +100,7 @@ def lib():
     L.ccsp_chain_run.argtypes = [vp, vp, i32, C.POINTER(Noise), vp, i32, i32, i32, vp, vp, vp]
     L.ccsp_profile_enable.argtypes = [vp, i32]
     L.ccsp_chain_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.ccsp_kernel_stats.argtypes = [vp, i32, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.c_char_p, i32]
     L.ccsp_plan_host.argtypes = [i32, i32, i32] + [vp] * 14
     _lib = L
     return L

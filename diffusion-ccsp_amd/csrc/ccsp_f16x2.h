@@ -62,44 +62,49 @@ __global__ void k_absmax_bits(long n, const float* __restrict__ src, unsigned in
 }
 
 constexpr int H2_BK = 32;                    // K chunk: two MFMA k-steps of 16
-constexpr int H2_PL = 128 * H2_BK;           // fp16 elements per plane of a 128-row operand stage
-constexpr int H2_STAGE = 4 * H2_PL;          // A planes 0, 1 then B planes 0, 1: 32 KB
+constexpr int H2_BPL = 128 * H2_BK;          // fp16 elements per plane of the 128-row B operand stage
 // rows are unpadded 64-byte K chunks, the 16-byte piece index XOR-swizzled by (row >> 2) & 3 (rb2_off of
 // ccsp_bf16x3.h: conflict-free ds_read_b128 fragment reads and 16-byte staging writes)
 __device__ __forceinline__ int h2_off(int row, int piece) { return row * H2_BK + ((piece ^ ((row >> 2) & 3)) << 3); }
 
-// one staged K chunk: acc[i][j] += A(rows am0 + 32 i + 0..31) . B(rows bn0 + 32 j + 0..31)^T, three products each
-__device__ __forceinline__ void h2_kstep(const unsigned short* __restrict__ st, int ks, int am0, int bn0, floatx16 (&acc)[2][2]) {
+// one k-step (K = 16) of a staged chunk: acc[i][j] += A(rows am0 + 32 i + 0..31) . B(rows bn0 + 32 j + 0..31)^T, three
+// products each.  As / Bs: [2 planes][rows][32] fp16 (plane strides apl / H2_BPL).
+template <int MI>
+__device__ __forceinline__ void h2_kstep(const unsigned short* __restrict__ As, int apl, const unsigned short* __restrict__ Bs, int ks,
+                                         int am0, int bn0, floatx16 (&acc)[MI][2]) {
     const int lane = threadIdx.x & 63;
-    const unsigned short* As = st;
-    const unsigned short* Bs = st + 2 * H2_PL;
     const int piece = (lane >> 5) + 2 * ks;
-    half8 a[2][2], b[2][2];
+    half8 a[MI][2], b[2][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int p = 0; p < 2; ++p) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            a[i][p] = *reinterpret_cast<const half8*>(As + p * H2_PL + h2_off(am0 + 32 * i + (lane & 31), piece));
-            b[i][p] = *reinterpret_cast<const half8*>(Bs + p * H2_PL + h2_off(bn0 + 32 * i + (lane & 31), piece));
-        }
+        for (int i = 0; i < MI; ++i) a[i][p] = *reinterpret_cast<const half8*>(As + p * apl + h2_off(am0 + 32 * i + (lane & 31), piece));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j][p] = *reinterpret_cast<const half8*>(Bs + p * H2_BPL + h2_off(bn0 + 32 * j + (lane & 31), piece));
+    }
     // smallest terms first; consecutive MFMAs go to different accumulators
     constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
 #pragma unroll
     for (int q = 0; q < 3; ++q)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][PA[q]], b[j][PB[q]], acc[i][j], 0, 0, 0);
 }
 
 // ------------------------------------------------------------------------------------------
-// k_rowgemm_h2<KD, ND>:  U[row0 + r, col0 + c] = 2^-(ea[r] + ew) * sum_k A[src(r), k] W[ts][col0 + c, k]  + base + tau
+// k_rowgemm_h2<KD, ND, DB>:  U[row0 + r, col0 + c] = 2^-(ea[r] + ew) * sum_k A[src(r), k] W[ts][col0 + c, k]  + base + tau
 //   A planes [2][n_src][KD] fp16 bits scaled by 2^a_exp[src], rows gathered by urow_node; W planes [2][n_ts][ND][KD]
 //   scaled by 2^w_exp.  umax[row, col0 / 128] = max |U| over the tile's 128 columns (null: not written).
+//   The kernel is one latency chain per tile (descriptor -> row indices -> operands -> 8 chunks -> epilogue) and a launch
+//   is as long as the chains it runs one after the other on a CU slot, so the residency is chosen per launch:
+//   DB = true : two LDS stages + two register sets (chunk c+2 in flight), 64.5 KB, 2 workgroups per CU;
+//   DB = false: one stage + one register set, 40.5 KB and <= 168 VGPRs, 3 workgroups per CU -- the whole tile list of a
+//               C2-sized batch (640 tiles) is resident at once instead of running as a full and a 20 %-full round.
 // ------------------------------------------------------------------------------------------
-template <int KD, int ND>
-__global__ __launch_bounds__(256, 2) void k_rowgemm_h2(const unsigned short* __restrict__ A, size_t a_plane, const int* __restrict__ a_exp,
+template <int KD, int ND, bool DB>
+__global__ __launch_bounds__(256, DB ? 2 : 3) void k_rowgemm_h2(const unsigned short* __restrict__ A, size_t a_plane, const int* __restrict__ a_exp,
                                                        const int* __restrict__ urow_node, const int* __restrict__ tile_row0,
                                                        const int* __restrict__ tile_nrows, const int* __restrict__ tile_ts,
                                                        const unsigned short* __restrict__ W, size_t w_plane, size_t w_stride, int w_exp,
@@ -107,10 +112,12 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_h2(const unsigned short* __r
                                                        float* __restrict__ U, float* __restrict__ umax, StepRef ref, size_t tau_stride) {
     static_assert(ND % 128 == 0 && KD % H2_BK == 0 && KD / H2_BK >= 3, "shape");
     constexpr int NCT = ND / 128, NCH = KD / H2_BK;
+    constexpr int APL = 128 * H2_BK, STAGE = 2 * APL + 2 * H2_BPL;        // 32 KB per stage
+    constexpr int NST = DB ? 2 : 1;
     constexpr int C_LD = 160;                                     // epilogue tile [64][160] fp32: conflict-free 16-byte row reads
-    static_assert(64 * C_LD * 4 <= 2 * H2_STAGE * 2, "epilogue tile must fit the stages");
-    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * H2_STAGE + 256];      // two stages + 128 row exponents
-    int* sE = reinterpret_cast<int*>(smem + 2 * H2_STAGE);
+    constexpr int SMEM_US = (NST * STAGE * 2 > 64 * C_LD * 4 ? NST * STAGE : 64 * C_LD * 2);
+    __shared__ __attribute__((aligned(16))) unsigned short smem[SMEM_US + 256];      // stages (epilogue tile on top) + 128 row exponents
+    int* sE = reinterpret_cast<int*>(smem + SMEM_US);
     if (ref.tab) tau_t += (size_t)ref.tab[*ref.counter].t * tau_stride;      // hipGraph mode: timestep from the device table
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tile = bid / NCT, ct = bid % NCT;
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_h2(const unsigned short* __r
     }
     const unsigned short* b_ptr = W + (size_t)ts * w_stride + (size_t)(col0 + lrow) * KD + lq * 8;
     const int st_off = h2_off(lrow, lq);                          // (row + 64 has the same swizzle: + 64 * H2_BK)
-    ushort8 ra[2][4], rb[2][4];                                   // [register set][row half * 2 + plane]
+    ushort8 ra[NST][4], rb[NST][4];                               // [register set][row half * 2 + plane]
     auto gload = [&](int c, int set) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -144,25 +151,16 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_h2(const unsigned short* __r
             }
     };
     auto lstore = [&](int stage, int set) {
-        unsigned short* As = smem + stage * H2_STAGE;
-        unsigned short* Bs = As + 2 * H2_PL;
+        unsigned short* As = smem + stage * STAGE;
+        unsigned short* Bs = As + 2 * APL;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                *reinterpret_cast<ushort8*>(As + p * H2_PL + st_off + i * 64 * H2_BK) = ra[set][i * 2 + p];
-                *reinterpret_cast<ushort8*>(Bs + p * H2_PL + st_off + i * 64 * H2_BK) = rb[set][i * 2 + p];
+                *reinterpret_cast<ushort8*>(As + p * APL + st_off + i * 64 * H2_BK) = ra[set][i * 2 + p];
+                *reinterpret_cast<ushort8*>(Bs + p * H2_BPL + st_off + i * 64 * H2_BK) = rb[set][i * 2 + p];
             }
     };
-    gload(0, 0);
-    gload(1, 1);
-    // time term + bias of this thread's epilogue columns (slot-0 rows only), in flight during the K loop
-    const int er = tid >> 3, eq = tid & 7;                        // epilogue: rows er, er + 32 of a 64-row pass, columns 4 eq + 32 k
-    float4 tv[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        tv[k] = (tau_t && (ts & 1) == 0) ? *reinterpret_cast<const float4*>(tau_t + (size_t)(ts >> 1) * ND + col0 + 4 * eq + 32 * k)
-                                         : make_float4(0.f, 0.f, 0.f, 0.f);
     floatx16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -170,22 +168,44 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_h2(const unsigned short* __r
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    lstore(0, 0);
-    gload(2, 0);
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {                               // fully unrolled: register-set indices are constants
-        // register set (c+1)&1 holds chunk c+1, the other one chunk c+2 (still in flight)
-        if (c + 1 < NCH) lstore((c + 1) & 1, (c + 1) & 1);
-        if (c + 3 < NCH) gload(c + 3, (c + 1) & 1);
-        const unsigned short* st = smem + (c & 1) * H2_STAGE;
-        h2_kstep(st, 0, wm * 64, wn * 64, acc);
-        h2_kstep(st, 1, wm * 64, wn * 64, acc);
+    if constexpr (DB) {
+        gload(0, 0);
+        gload(1, 1);
+        lstore(0, 0);
+        gload(2, 0);
         __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {                           // fully unrolled: register-set indices are constants
+            // register set (c+1)&1 holds chunk c+1, the other one chunk c+2 (still in flight)
+            if (c + 1 < NCH) lstore((c + 1) & 1, (c + 1) & 1);
+            if (c + 3 < NCH) gload(c + 3, (c + 1) & 1);
+            const unsigned short* st = smem + (c & 1) * STAGE;
+            h2_kstep<2>(st, APL, st + 2 * APL, 0, wm * 64, wn * 64, acc);
+            h2_kstep<2>(st, APL, st + 2 * APL, 1, wm * 64, wn * 64, acc);
+            __syncthreads();
+        }
+    } else {
+        gload(0, 0);
+        lstore(0, 0);
+        gload(1, 0);
+        __syncthreads();
+        for (int c = 0; c < NCH; ++c) {
+            h2_kstep<2>(smem, APL, smem + 2 * APL, 0, wm * 64, wn * 64, acc);
+            h2_kstep<2>(smem, APL, smem + 2 * APL, 1, wm * 64, wn * 64, acc);
+            __syncthreads();                                      // every wave is done reading the stage
+            if (c + 1 < NCH) {
+                lstore(0, 0);
+                if (c + 2 < NCH) gload(c + 2, 0);
+                __syncthreads();
+            }
+        }
     }
     // epilogue through LDS, 64 rows (row tile i of every wave) per pass: the accumulators (one column, 16 rows per lane)
     // are re-read as rows, so base loads and U stores are 128-byte row segments and the row maximum is a 3-step shuffle
     float* Cs = reinterpret_cast<float*>(smem);
+    const int er = tid >> 3, eq = tid & 7;                        // rows er, er + 32 of a 64-row pass, columns 4 eq + 32 k
+    const bool has_tau = tau_t && (ts & 1) == 0;                  // time term + bias: slot-0 rows only
+    const float* tau_p = tau_t + (size_t)(ts >> 1) * ND + col0 + 4 * eq;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         // this pass's rows of the tile: Cs row lr = wm' * 32 + rr  <->  tile row wm' * 64 + i * 32 + rr
@@ -210,6 +230,14 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_h2(const unsigned short* __r
             }
         __syncthreads();
 #pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 tv = has_tau ? *reinterpret_cast<const float4*>(tau_p + 32 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                bs[h][k].x += tv.x; bs[h][k].y += tv.y; bs[h][k].z += tv.z; bs[h][k].w += tv.w;
+            }
+        }
+#pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int lr = er + 32 * h;
             if (trow[h] < nrows) {
@@ -220,10 +248,10 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_h2(const unsigned short* __r
                 for (int k = 0; k < 4; ++k) {
                     const float4 v = *reinterpret_cast<const float4*>(Cs + lr * C_LD + 4 * eq + 32 * k);
                     float4 o;
-                    o.x = ldexpf(v.x, e) + (bs[h][k].x + tv[k].x);
-                    o.y = ldexpf(v.y, e) + (bs[h][k].y + tv[k].y);
-                    o.z = ldexpf(v.z, e) + (bs[h][k].z + tv[k].z);
-                    o.w = ldexpf(v.w, e) + (bs[h][k].w + tv[k].w);
+                    o.x = ldexpf(v.x, e) + bs[h][k].x;
+                    o.y = ldexpf(v.y, e) + bs[h][k].y;
+                    o.z = ldexpf(v.z, e) + bs[h][k].z;
+                    o.w = ldexpf(v.w, e) + bs[h][k].w;
                     m = fmaxf(fmaxf(m, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
                     *reinterpret_cast<float4*>(U + grow * ND + col0 + 4 * eq + 32 * k) = o;
                 }
@@ -240,14 +268,18 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_h2(const unsigned short* __r
 }
 
 // ------------------------------------------------------------------------------------------
-// k_edge_h2<ENERGY>: the decoder of 64 sorted edges, both output halves (denoise_fn.py:341-371).  Row r < 64 of the
-// tile is (edge e0 + r, half 0), row 64 + r is (edge e0 + r, half 1); A[row, :] = SiLU(U[u0] + U[u1])[half * H : +H]
-// scaled by the row's exponent (bound from umax, see the header) and split in registers; B = planes of
-// pose_decoder.0.weight [H/2, H].  Epilogue: 2^-(e_row + wd_exp) acc + bias -> SiLU -> LDS -> pose_decoder.2 -> CSR
+// k_edge_h2<ENERGY, MT>: the decoder of 32 MT sorted edges, both output halves (denoise_fn.py:341-371).  With
+// ME = 32 MT, row r < ME of the tile is (edge e0 + r, half 0), row ME + r is (edge e0 + r, half 1);
+// A[row, :] = SiLU(U[u0] + U[u1])[half * H : +H] scaled by the row's exponent (bound from umax, see the header) and split
+// in registers; B = planes of pose_decoder.0.weight [H/2, H] (staged once for both halves).  Waves 2(M) x 2(N): wave row
+// wm is the half, 32 MT x 64 per wave.  Epilogue: 2^-(e_row + wd_exp) acc + bias -> SiLU -> LDS -> pose_decoder.2 -> CSR
 // slot.  ENERGY as in k_edge<H, true>: -2 (o - pose) to the CSR slot, pre-activations to Q, partial sum of squares.
+//   MT = 2: 64 edges, 64.5 KB, 2 workgroups per CU;  MT = 1: 32 edges, 48.3 KB, 3 per CU -- twice the workgroups, each
+//   with half the SiLU / split work per thread: the kernel is one tile's latency chain long, so shorter chains on more
+//   SIMDs win until the tile list no longer fits the CUs at once.
 // ------------------------------------------------------------------------------------------
-template <bool ENERGY>
-__global__ __launch_bounds__(256, 2) void k_edge_h2(int E_act, int P, const int* __restrict__ e_u0, const int* __restrict__ e_u1,
+template <bool ENERGY, int MT>
+__global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void k_edge_h2(int E_act, int P, const int* __restrict__ e_u0, const int* __restrict__ e_u1,
                                                     const float* __restrict__ U, const float* __restrict__ umax /*[R][4]*/,
                                                     const unsigned short* __restrict__ Wd1H /*[2][128][256]*/, int wd_exp,
                                                     const float* __restrict__ bd1, const float* __restrict__ Wd2,
@@ -255,21 +287,24 @@ __global__ __launch_bounds__(256, 2) void k_edge_h2(int E_act, int P, const int*
                                                     EdgeEnergyArgs en, int* __restrict__ counter_inc) {
     if (counter_inc && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(counter_inc, 1);     // hipGraph mode: next table entry
     constexpr int H = 256, BN = 128, NCH = H / H2_BK;
+    constexpr int ME = 32 * MT, ROWS = 2 * ME;                    // edges, tile rows
+    constexpr int APL = ROWS * H2_BK, STAGE = 2 * APL + 2 * H2_BPL;
+    constexpr int NPASS = ROWS / 32;                              // producer passes per chunk: rows lr + 32 i
     constexpr int S1_LD = BN + 1;
-    static_assert(64 * S1_LD * 4 <= 2 * H2_STAGE * 2, "epilogue tile must fit the stages");
-    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * H2_STAGE + 256];
-    int* sE = reinterpret_cast<int*>(smem + 2 * H2_STAGE);
-    const int e0 = xcd_remap(blockIdx.x, gridDim.x) * 64;
+    static_assert(64 * S1_LD * 4 <= 2 * STAGE * 2, "epilogue tile must fit the stages");
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * STAGE + 2 * ROWS];
+    int* sE = reinterpret_cast<int*>(smem + 2 * STAGE);
+    const int e0 = xcd_remap(blockIdx.x, gridDim.x) * ME;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
-    const int lr = tid >> 3, lq = tid & 7;                        // A producer: rows lr + 32 i (i < 4), fp32 columns 4 lq .. + 3 of the chunk
-    const float* u0_ptr[4];
-    const float* u1_ptr[4];
-    int a_st[4], a_exp[4];
+    const int lr = tid >> 3, lq = tid & 7;                        // A producer: rows lr + 32 i, fp32 columns 4 lq .. + 3 of the chunk
+    const float* u0_ptr[NPASS];
+    const float* u1_ptr[NPASS];
+    int a_st[NPASS], a_exp[NPASS];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = lr + 32 * i, s = row >> 6;
-        int k = e0 + (row & 63);
+    for (int i = 0; i < NPASS; ++i) {
+        const int row = lr + 32 * i, s = row / ME;
+        int k = e0 + (row % ME);
         k = k < E_act ? k : E_act - 1;
         const int r0 = e_u0[k], r1 = e_u1[k];
         u0_ptr[i] = U + (size_t)r0 * (2 * H) + s * H + lq * 4;
@@ -283,11 +318,11 @@ __global__ __launch_bounds__(256, 2) void k_edge_h2(int E_act, int P, const int*
     const int brow = tid >> 2, bq = tid & 3;                      // B copy: rows brow, brow + 64, piece bq, both planes
     const unsigned short* b_ptr = Wd1H + (size_t)brow * H + bq * 8;
     const int b_st = h2_off(brow, bq);
-    float4 ua[2][4], ub[2][4];                                    // [register set][pass]
+    float4 ua[2][NPASS], ub[2][NPASS];                            // [register set][pass]
     ushort8 rb[4];
     auto gload_a = [&](int c, int set) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NPASS; ++i) {
             ua[set][i] = *reinterpret_cast<const float4*>(u0_ptr[i] + c * H2_BK);
             ub[set][i] = *reinterpret_cast<const float4*>(u1_ptr[i] + c * H2_BK);
         }
@@ -300,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_h2(int E_act, int P, const int*
                 rb[i * 2 + p] = *reinterpret_cast<const ushort8*>(b_ptr + (size_t)p * BN * H + (size_t)i * 64 * H + c * H2_BK);
     };
     auto store_a = [&](int stage, int set, int i) {               // SiLU + scale + split of one pass -> the A planes of the stage
-        unsigned short* As = smem + stage * H2_STAGE;
+        unsigned short* As = smem + stage * STAGE;
         const float h[4] = {silu_fast(ua[set][i].x + ub[set][i].x), silu_fast(ua[set][i].y + ub[set][i].y),
                             silu_fast(ua[set][i].z + ub[set][i].z), silu_fast(ua[set][i].w + ub[set][i].w)};
         unsigned short p1[4], p2[4];
@@ -308,49 +343,56 @@ __global__ __launch_bounds__(256, 2) void k_edge_h2(int E_act, int P, const int*
         for (int e = 0; e < 4; ++e) split2h(ldexpf(h[e], a_exp[i]), p1[e], p2[e]);
         unsigned short* d = As + a_st[i];
         *reinterpret_cast<uint2*>(d) = make_uint2(p1[0] | ((unsigned)p1[1] << 16), p1[2] | ((unsigned)p1[3] << 16));
-        *reinterpret_cast<uint2*>(d + H2_PL) = make_uint2(p2[0] | ((unsigned)p2[1] << 16), p2[2] | ((unsigned)p2[3] << 16));
+        *reinterpret_cast<uint2*>(d + APL) = make_uint2(p2[0] | ((unsigned)p2[1] << 16), p2[2] | ((unsigned)p2[3] << 16));
     };
     auto store_b = [&](int stage) {
-        unsigned short* Bs = smem + stage * H2_STAGE + 2 * H2_PL;
+        unsigned short* Bs = smem + stage * STAGE + 2 * APL;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int p = 0; p < 2; ++p)
-                *reinterpret_cast<ushort8*>(Bs + p * H2_PL + b_st + i * 64 * H2_BK) = rb[i * 2 + p];
+                *reinterpret_cast<ushort8*>(Bs + p * H2_BPL + b_st + i * 64 * H2_BK) = rb[i * 2 + p];
     };
     gload_a(0, 0);
     gload_b(0);
     gload_a(1, 1);
-    floatx16 acc[2][2];
+    floatx16 acc[MT][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) store_a(0, 0, i);
+    for (int i = 0; i < NPASS; ++i) store_a(0, 0, i);
     store_b(0);
     gload_b(1);
     gload_a(2, 0);
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {                               // fully unrolled: the register-set index is a constant
-        const unsigned short* st = smem + (c & 1) * H2_STAGE;
+        const unsigned short* st = smem + (c & 1) * STAGE;
         const int nx = (c + 1) & 1;                               // next stage, and the register set holding chunk c+1
-        h2_kstep(st, 0, wm * 64, wn * 64, acc);
-        if (c + 1 < NCH) { store_a(nx, nx, 0); store_a(nx, nx, 1); }     // in the shadow of the 12 MFMAs just issued
-        h2_kstep(st, 1, wm * 64, wn * 64, acc);
-        if (c + 1 < NCH) { store_a(nx, nx, 2); store_a(nx, nx, 3); store_b(nx); }
+        h2_kstep<MT>(st, APL, st + 2 * APL, 0, wm * ME, wn * 64, acc);
+        if (c + 1 < NCH) {                                        // in the shadow of the MFMAs just issued
+#pragma unroll
+            for (int i = 0; i < NPASS / 2; ++i) store_a(nx, nx, i);
+        }
+        h2_kstep<MT>(st, APL, st + 2 * APL, 1, wm * ME, wn * 64, acc);
+        if (c + 1 < NCH) {
+#pragma unroll
+            for (int i = NPASS / 2; i < NPASS; ++i) store_a(nx, nx, i);
+            store_b(nx);
+        }
         if (c + 2 < NCH) gload_b(c + 2);
         if (c + 3 < NCH) gload_a(c + 3, nx);
         __syncthreads();
     }
-    // epilogue, 64 rows (row tile i of every wave: 32 edges x both halves) per pass
+    // epilogue, 64 rows per pass (row tile i of every wave: 32 edges x both halves)
     float* S1 = reinterpret_cast<float*>(smem);
     float e2 = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MT; ++i) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = wn * 64 + j * 32 + (lane & 31);
@@ -358,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_h2(int E_act, int P, const int*
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int row = wm * 64 + i * 32 + rr;                        // tile row: half wm, edge e0 + i * 32 + rr
+                const int row = wm * ME + i * 32 + rr;                         // tile row: half wm, edge e0 + i * 32 + rr
                 const float q = ldexpf(acc[i][j][r], -(sE[row] + wd_exp)) + bj;
                 S1[(wm * 32 + rr) * S1_LD + col] = silu_fast(q);
                 if constexpr (ENERGY) {

@@ -902,6 +902,8 @@ struct ccsp_model {
     unsigned short* WpH = nullptr;    // [2][C][2][2H][H] fp16 planes of Wp * 2^wp_exp
     unsigned short* Wd1H = nullptr;   // [2][H/2][H]      fp16 planes of pose_decoder.0.weight * 2^wd_exp
     int wp_exp = 0, wd_exp = 0;
+    int ncu = 256;          // compute units of the device (residency-based kernel selection)
+    int row_db = -1, edge_mt = -1;    // CCSP_ROW_DB / CCSP_EDGE_MT: force a residency variant of the f16x2 kernels (-1: by tile count)
     // StructDiffusion baseline (model_kind 1): transformer weights as given ([out, in] row-major)
     struct SdLayer { float *in_w, *in_b, *out_w, *out_b, *ln1_g, *ln1_b, *fc_w, *fc_b, *proj_w, *proj_b, *ln2_g, *ln2_b; };
     int Wd = 0;            // transformer width: 2H, or 3H with a grasp group
@@ -974,11 +976,25 @@ struct ccsp_graph {
     int64_t evals = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_events = false;
-    std::vector<hipEvent_t> kev;   // (before k_ugemm, between, after k_edge) triples when profiling
+    // profiling (ccsp_profile_enable): one event before every launch of the evaluation / update kernels, tagged with the
+    // kernel about to run (CCSP_K_*), and one closing mark (-1) per evaluation; a kernel's duration is the elapsed time
+    // to the next mark on the same stream (it includes the gap to the next launch)
+    std::vector<hipEvent_t> kev;
+    std::vector<int> kev_id;
     size_t kev_used = 0;
 };
 
 namespace {
+
+const char* const kKernelNames[CCSP_K_COUNT] = {"row GEMM (forward)", "edge decoder (forward)", "node update + pose encoder", "edge decoder backward",
+                                               "row sum of g_z", "row GEMM (transpose)", "node energy backward", "energy sum", "HMC elementwise",
+                                               "StructDiffusion evaluation"};
+
+inline void prof_mark(ccsp_graph* g, hipStream_t s, int id) {
+    if (!g->profile || g->kev_used >= g->kev.size()) return;
+    if (hipEventRecord(g->kev[g->kev_used], s) != hipSuccess) return;
+    g->kev_id[g->kev_used++] = id;
+}
 
 template <typename T>
 int dev_alloc(std::vector<void*>& reg, T** p, size_t n) {
@@ -1016,14 +1032,45 @@ void cosine_betas(int T, std::vector<double>& betas) {   // ddpm.py:152-162
 
 EncW enc_pose(const ccsp_model* m) { return EncW{m->pe0_w, m->pe0_b, m->pe2_wT, m->pe2_b, m->d.pose_dim, m->pe2_wF}; }
 
+// f16x2 kernels (H = 256): the residency variant is chosen so that the whole tile list is resident at once when it can be
+// (ccsp_f16x2.h): row GEMM 2 workgroups per CU with the deep pipeline if the tiles fit, else 3 per CU; edge kernel
+// 32-edge tiles at 3 per CU if they fit, else 64-edge tiles
+void launch_rowgemm_h2(ccsp_model* m, ccsp_graph* g, const float* tau_t, StepRef ref, size_t tau_stride, hipStream_t s) {
+    constexpr int H = 256;
+    const int work = g->n_tiles2 * (2 * H / 128);
+    const bool db = m->row_db >= 0 ? m->row_db != 0 : work <= 2 * m->ncu;
+    if (db)
+        hipLaunchKernelGGL((k_rowgemm_h2<H, 2 * H, true>), dim3(work), dim3(256), 0, s, g->pembH, (size_t)g->N * H, g->pexp, g->urow_node, g->t2_row0,
+                           g->t2_nrows, g->t2_ts, m->WpH, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, m->wp_exp, g->base, tau_t, g->U,
+                           g->umax, ref, tau_stride);
+    else
+        hipLaunchKernelGGL((k_rowgemm_h2<H, 2 * H, false>), dim3(work), dim3(256), 0, s, g->pembH, (size_t)g->N * H, g->pexp, g->urow_node, g->t2_row0,
+                           g->t2_nrows, g->t2_ts, m->WpH, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, m->wp_exp, g->base, tau_t, g->U,
+                           g->umax, ref, tau_stride);
+}
+
+// returns the number of workgroups (= energy partials)
+template <bool ENERGY>
+int launch_edge_h2(ccsp_model* m, ccsp_graph* g, EdgeEnergyArgs en, int* cinc, hipStream_t s) {
+    const int E_act = g->plan.E_act;
+    const int mt = m->edge_mt > 0 ? m->edge_mt : (nblk(E_act, 32) <= 3 * m->ncu ? 1 : 2);
+    const int nwg = nblk(E_act, 32 * mt);
+    if (mt == 1)
+        hipLaunchKernelGGL((k_edge_h2<ENERGY, 1>), dim3(nwg), dim3(256), 0, s, E_act, m->d.pose_dim, g->e_u0, g->e_u1, g->U, g->umax, m->Wd1H, m->wd_exp,
+                           m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, en, cinc);
+    else
+        hipLaunchKernelGGL((k_edge_h2<ENERGY, 2>), dim3(nwg), dim3(256), 0, s, E_act, m->d.pose_dim, g->e_u0, g->e_u1, g->U, g->umax, m->Wd1H, m->wd_exp,
+                           m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, en, cinc);
+    return nwg;
+}
+
 template <int H>
 int launch_eval(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s, bool tabled = false) {
     // U = pose_emb . Wp^T ; O = decoder(...)
     // tabled (hipGraph mode, bf16x3 kernels only): the timestep comes from the device step table, see StepEntry
     const ccsp::Plan& p = g->plan;
     if (p.E_act == 0) return 0;
-    const bool prof = g->profile && g->kev_used + 3 <= g->kev.size();
-    if (prof) HIP_TRY(hipEventRecord(g->kev[g->kev_used], s));
+    prof_mark(g, s, CCSP_K_ROWGEMM);
     const int nw_u = g->n_tiles * rowgemm_col_tiles<H, 2 * H>();
     const size_t tau_stride = (size_t)m->d.n_types * 2 * H;
     const float* tau_t = m->tau + (tabled ? 0 : (size_t)t * tau_stride);
@@ -1031,13 +1078,10 @@ int launch_eval(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s, bool tabled 
     int* const cinc = tabled ? g->d_counter : nullptr;
     if constexpr (H == 256) {
         if (m->f16x2) {
-            hipLaunchKernelGGL((k_rowgemm_h2<H, 2 * H>), dim3(g->n_tiles2 * (2 * H / 128)), dim3(256), 0, s, g->pembH, (size_t)g->N * H, g->pexp,
-                               g->urow_node, g->t2_row0, g->t2_nrows, g->t2_ts, m->WpH, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H,
-                               m->wp_exp, g->base, tau_t, g->U, g->umax, ref, tau_stride);
-            if (prof) HIP_TRY(hipEventRecord(g->kev[g->kev_used + 1], s));
-            hipLaunchKernelGGL(k_edge_h2<false>, dim3(nblk(p.E_act, 64)), dim3(256), 0, s, p.E_act, m->d.pose_dim, g->e_u0, g->e_u1, g->U, g->umax,
-                               m->Wd1H, m->wd_exp, m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, EdgeEnergyArgs{}, cinc);
-            if (prof) { HIP_TRY(hipEventRecord(g->kev[g->kev_used + 2], s)); g->kev_used += 3; }
+            launch_rowgemm_h2(m, g, tau_t, ref, tau_stride, s);
+            prof_mark(g, s, CCSP_K_EDGE);
+            launch_edge_h2<false>(m, g, EdgeEnergyArgs{}, cinc, s);
+            prof_mark(g, s, -1);
             g->evals++;
             return 0;
         }
@@ -1052,13 +1096,13 @@ int launch_eval(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s, bool tabled 
         hipLaunchKernelGGL((k_rowgemm_bf<H, 2 * H>), dim3(nw_u), dim3(256), 0, s, g->pembS, (size_t)npe, g->urow_node, g->tile_row0,
                            g->tile_nrows, g->tile_ts, m->WpS, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, g->base, tau_t, g->U,
                            ref, tau_stride);
-        if (prof) HIP_TRY(hipEventRecord(g->kev[g->kev_used + 1], s));
+        prof_mark(g, s, CCSP_K_EDGE);
         constexpr int BMB = 32 * EdgeBfCfg<H>::WM;
         if constexpr (H == 256) {
             if (m->edge_kernel == 2) {
                 hipLaunchKernelGGL(k_edge_bf2<false>, dim3(2 * nblk(p.E_act, 64)), dim3(256), 0, s, p.E_act, m->d.pose_dim, g->e_u0, g->e_u1, g->U,
                                    m->Wd1S, m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, EdgeEnergyArgs{}, cinc);
-                if (prof) { HIP_TRY(hipEventRecord(g->kev[g->kev_used + 2], s)); g->kev_used += 3; }
+                prof_mark(g, s, -1);
                 g->evals++;
                 return 0;
             }
@@ -1068,13 +1112,13 @@ int launch_eval(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s, bool tabled 
     } else {
     hipLaunchKernelGGL((k_rowgemm<H, 2 * H>), dim3(nw_u < m->max_wgs ? nw_u : m->max_wgs), dim3(256), 0, s, nw_u, g->pemb, g->urow_node, g->tile_row0,
                        g->tile_nrows, g->tile_ts, m->Wp, (size_t)2 * H * H, g->base, tau_t, g->U);
-    if (prof) HIP_TRY(hipEventRecord(g->kev[g->kev_used + 1], s));
+    prof_mark(g, s, CCSP_K_EDGE);
     constexpr int BM = 32 * EdgeCfg<H>::WM;
     const int nw_e = 2 * nblk(p.E_act, BM);
     hipLaunchKernelGGL((k_edge<H, false>), dim3(nw_e), dim3(256), 0, s, p.E_act, m->d.pose_dim, g->e_u0,
                        g->e_u1, g->U, m->pd0_w, m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, EdgeEnergyArgs{});
     }
-    if (prof) { HIP_TRY(hipEventRecord(g->kev[g->kev_used + 2], s)); g->kev_used += 3; }
+    prof_mark(g, s, -1);
     g->evals++;
     return 0;
 }
@@ -1100,7 +1144,9 @@ void launch_node(ccsp_model* m, ccsp_graph* g, const NodeArgs& a, hipStream_t s)
     eo.bf3 = (planes && !h2) ? g->pembS : nullptr;
     eo.h2 = h2 ? g->pembH : nullptr;
     eo.h2_exp = h2 ? g->pexp : nullptr;
+    prof_mark(g, s, CCSP_K_NODE);
     hipLaunchKernelGGL(k_node<H>, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a, enc_pose(m), eo);
+    prof_mark(g, s, -1);
 }
 
 // ---- StructDiffusion baseline ------------------------------------------------------------------
@@ -1118,6 +1164,7 @@ template <int H>
 int launch_eval_sd(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s) {
     if (!g->seq_ready) return fail("StructDiffusion: call ccsp_graph_set_sequences (batch.batch) before evaluating");
     const int M = g->sd_M, Wd = m->Wd, P = m->d.pose_dim;
+    prof_mark(g, s, CCSP_K_SD_EVAL);
     hipLaunchKernelGGL(k_sd_embed, dim3(nblk(M, 4)), dim3(256), 0, s, M, H, Wd, m->d.grasp_dim > 0 ? 1 : 0, g->tok_node, g->tok_pos, g->gemb,
                        g->remb, g->pemb, m->temb + (size_t)t * H, m->sd_pe, m->lnpre_g, m->lnpre_b, g->sdX);
     for (int l = 0; l < SD_LAYERS; ++l) {
@@ -1132,6 +1179,7 @@ int launch_eval_sd(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s) {
     }
     hipLaunchKernelGGL(k_sd_decode<H>, dim3(nblk(g->N, 4)), dim3(256), 0, s, g->N, Wd, P, g->F, g->node_tok, g->sdX, m->lnpost_g, m->lnpost_b,
                        m->pd0_wT, m->pd0_b, m->pd2_w, m->pd2_b, g->xfeat, g->mask, g->eps);
+    prof_mark(g, s, -1);
     g->evals++;
     return 0;
 }
@@ -1174,13 +1222,11 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     }
     const int nw_u = g->n_tiles * rowgemm_col_tiles<H, 2 * H>();
     const float* tau_t = m->tau + (size_t)t * m->d.n_types * 2 * H;
+    prof_mark(g, s, CCSP_K_ROWGEMM);
     bool h2 = false;
     if constexpr (H == 256) h2 = m->f16x2 != 0;
     if (h2) {            // the forward row GEMM is the direct-mode one (planes written by k_node)
-        if constexpr (H == 256)
-            hipLaunchKernelGGL((k_rowgemm_h2<H, 2 * H>), dim3(g->n_tiles2 * (2 * H / 128)), dim3(256), 0, s, g->pembH, (size_t)g->N * H, g->pexp,
-                               g->urow_node, g->t2_row0, g->t2_nrows, g->t2_ts, m->WpH, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H,
-                               m->wp_exp, g->base, tau_t, g->U, g->umax, StepRef{nullptr, nullptr}, (size_t)0);
+        launch_rowgemm_h2(m, g, tau_t, StepRef{nullptr, nullptr}, (size_t)0, s);
     } else if (m->bf16x3)
         hipLaunchKernelGGL((k_rowgemm_bf2<H, 2 * H>), dim3(g->n_tiles2 * (2 * H / RB2_TN)), dim3(512), 0, s, g->pembS, (size_t)g->N * H, g->urow_node,
                            g->t2_row0, g->t2_nrows, g->t2_ts, m->WpS, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, g->base, tau_t, g->U,
@@ -1188,14 +1234,13 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     else
     hipLaunchKernelGGL((k_rowgemm<H, 2 * H>), dim3(nw_u < m->max_wgs ? nw_u : m->max_wgs), dim3(256), 0, s, nw_u, g->pemb, g->urow_node, g->tile_row0,
                        g->tile_nrows, g->tile_ts, m->Wp, (size_t)2 * H * H, g->base, tau_t, g->U);
+    prof_mark(g, s, CCSP_K_EDGE);
     EdgeEnergyArgs en{g->e_a, g->e_b, xeval, with_grad ? g->Q : nullptr, g->partial};
     int n_part = g->n_edge_blocks;                                                           // one energy partial per workgroup
     bool edge_done = false;
     if constexpr (H == 256) {
         if (h2) {
-            n_part = nblk(p.E_act, 64);
-            hipLaunchKernelGGL(k_edge_h2<true>, dim3(n_part), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->U, g->umax, m->Wd1H, m->wd_exp, m->pd0_b,
-                               m->pd2_w, m->pd2_b, g->ent_pos, g->O, en, (int*)nullptr);
+            n_part = launch_edge_h2<true>(m, g, en, (int*)nullptr, s);
             edge_done = true;
         } else if (m->bf16x3 && m->edge_kernel == 2) {
             n_part = 2 * nblk(p.E_act, 64);
@@ -1208,9 +1253,12 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     hipLaunchKernelGGL((k_edge<H, true>), dim3(n_part), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->U, m->pd0_w,
                        m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, en);
     if (!with_grad) {
+        prof_mark(g, s, CCSP_K_ENERGY_SUM);
         hipLaunchKernelGGL(k_energy_sum, dim3(1), dim3(256), 0, s, g->partial, n_part, E_out);
+        prof_mark(g, s, -1);
         return 0;
     }
+    prof_mark(g, s, CCSP_K_EDGE_BWD);
     constexpr int BMB = 32 * BwdCfg<H>::WM, NCTB = H / (32 * BwdCfg<H>::TN * BwdCfg<H>::WN);
     bool bwd_done = false;
     if constexpr (H == 256) {
@@ -1225,10 +1273,12 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
                        g->U, g->O, g->Q, m->pd0_wT, m->pd2_w, g->GZ);
     const bool bf_bwd = H == 256 && m->bf16x3 && m->WpTS != nullptr;      // (the 128-column tiles need H >= 128)
     if (bf_bwd && !g->GZRS && dev_alloc(g->allocs, &g->GZRS, (size_t)3 * p.R * 2 * H)) return 1;
+    prof_mark(g, s, CCSP_K_ROWSUM);
     hipLaunchKernelGGL(k_rowsum, dim3(nblk((long)p.R * (2 * H / 4), 256)), dim3(256), 0, s, p.R, 2 * H, g->row_ptr, g->row_edge, g->GZ, g->GZR,
                        bf_bwd ? g->GZRS : (unsigned short*)nullptr);
     const int* no_map = nullptr;
     const float* nof = nullptr;
+    prof_mark(g, s, CCSP_K_ROWGEMM_T);
     if (bf_bwd) {
         if constexpr (H == 256)
             hipLaunchKernelGGL((k_rowgemm_bf2<2 * H, H>), dim3(g->n_tiles2 * (H / RB2_TN)), dim3(512), 0, s, g->GZRS, (size_t)p.R * 2 * H, no_map,
@@ -1242,8 +1292,10 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     EnergyNodeArgs a{g->N, P, g->node_ptr, g->O, g->nrow_ptr, g->nrow_idx, g->GP, xeval, g->eps, g->partial, n_part, E_out,
                      m->pe0_w, m->pe0_b, m->pe2_w, m->pe2_wT, m->pe2_b};
     static const bool valu_node_energy = getenv("CCSP_NODE_ENERGY_VALU") != nullptr;     // the pre-MFMA kernel, kept for A/B runs
+    prof_mark(g, s, CCSP_K_NODE_ENERGY);
     if (valu_node_energy) hipLaunchKernelGGL(k_node_energy<H>, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(k_node_energy_mfma<H>, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a, (const float*)m->pe2_wF);
+    prof_mark(g, s, -1);
     return 0;
 }
 
@@ -1818,6 +1870,13 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     // CCSP_MMA: f16x2 (default at hidden_dim 256: two-term fp16 operands, three MFMA products per fp32 product),
     //           bf16x3 (three-term bf16 operands, six products), f32 (v_mfma_f32_32x32x2_f32)
     m->f16x2 = (H == 256 && d->model_kind == CCSP_MODEL_DIFFUSION_CCSP) ? 1 : 0;
+    if (const char* e = getenv("CCSP_ROW_DB")) m->row_db = atoi(e) != 0;
+    if (const char* e = getenv("CCSP_EDGE_MT")) m->edge_mt = atoi(e) == 2 ? 2 : 1;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) m->ncu = prop.multiProcessorCount;
+    }
     if (const char* e = getenv("CCSP_MMA")) {
         m->bf16x3 = (strcmp(e, "f32") != 0);
         if (strcmp(e, "f16x2") != 0) m->f16x2 = 0;
@@ -2214,9 +2273,30 @@ int ccsp_profile_enable(ccsp_graph* g, int32_t on) {
     if (!g) return fail("profile_enable: null graph");
     g->profile = on;
     if (on && g->kev.empty()) {
-        g->kev.resize(3 * 1024);
+        g->kev.resize(CCSP_PROFILE_MARKS);
+        g->kev_id.assign(CCSP_PROFILE_MARKS, -1);
         for (auto& e : g->kev) HIP_TRY(hipEventCreate(&e));
     }
+    return 0;
+}
+
+int ccsp_kernel_stats(ccsp_graph* g, int32_t which, int64_t* calls, float* ms_mean, char* name, int32_t name_len) {
+    if (!g) return fail("kernel_stats: null graph");
+    if (which < 0 || which >= CCSP_K_COUNT) return fail("kernel_stats: bad selector %d", which);
+    if (!g->have_events) return fail("kernel_stats: no chain has run on this graph");
+    HIP_TRY(hipEventSynchronize(g->ev1));
+    int64_t n = 0;
+    double acc = 0.0;
+    for (size_t i = 0; i + 1 < g->kev_used; ++i) {
+        if (g->kev_id[i] != which) continue;
+        float v = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&v, g->kev[i], g->kev[i + 1]));
+        acc += v;
+        ++n;
+    }
+    if (calls) *calls = n;
+    if (ms_mean) *ms_mean = n ? (float)(acc / (double)n) : 0.0f;
+    if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s", kKernelNames[which]);
     return 0;
 }
 
@@ -2228,17 +2308,13 @@ int ccsp_chain_stats(ccsp_graph* g, int64_t* evals, float* ms_total, float* ms_u
     HIP_TRY(hipEventElapsedTime(&ms, g->ev0, g->ev1));
     if (evals) *evals = g->evals;
     if (ms_total) *ms_total = ms;
-    float acc_u = 0.0f, acc_e = 0.0f;
-    for (size_t i = 0; i + 2 < g->kev_used; i += 3) {
-        float v = 0.0f;
-        HIP_TRY(hipEventElapsedTime(&v, g->kev[i], g->kev[i + 1]));
-        acc_u += v;
-        HIP_TRY(hipEventElapsedTime(&v, g->kev[i + 1], g->kev[i + 2]));
-        acc_e += v;
+    for (int k = 0; k < 2; ++k) {
+        int64_t n = 0;
+        float mean = 0.0f;
+        if (ccsp_kernel_stats(g, k == 0 ? CCSP_K_ROWGEMM : CCSP_K_EDGE, &n, &mean, nullptr, 0)) return 1;
+        if (k == 0 && ms_ugemm) *ms_ugemm = mean;
+        if (k == 1 && ms_edge) *ms_edge = mean;
     }
-    const float n = (float)(g->kev_used / 3);
-    if (ms_ugemm) *ms_ugemm = g->kev_used ? acc_u / n : 0.0f;
-    if (ms_edge) *ms_edge = g->kev_used ? acc_e / n : 0.0f;
     return 0;
 }
 

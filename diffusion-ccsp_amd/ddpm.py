@@ -236,6 +236,19 @@ class GaussianDiffusion(object):
         _lib.check(_lib.lib().ccsp_chain_stats(g.h, C.byref(ev), C.byref(ms), C.byref(mu), C.byref(me)))
         return dict(evals=ev.value, ms_total=ms.value, ms_ugemm=mu.value, ms_edge=me.value)
 
+    def kernel_stats(self):
+        """per-kernel launch counts and mean durations (ms) of the last PROFILED chain: {label: (calls, ms_mean)}"""
+        g = getattr(self, '_last_graph', None)
+        if g is None:
+            raise _lib.CcspError('no chain has run')
+        out = {}
+        for k in range(_lib.K_COUNT):
+            n, ms, name = C.c_int64(), C.c_float(), C.create_string_buffer(64)
+            _lib.check(_lib.lib().ccsp_kernel_stats(g.h, k, C.byref(n), C.byref(ms), name, 64))
+            if n.value:
+                out[name.value.decode()] = (int(n.value), float(ms.value))
+        return out
+
     def profile(self, batch, on=True):
         """bracket the evaluation kernels of the next chains on this batch with HIP events"""
         g = self._core()._graph(batch)

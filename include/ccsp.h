@@ -155,11 +155,18 @@ int ccsp_chain_run(ccsp_model* model, ccsp_graph* graph, int32_t sampler, const 
 
 /* Kernel-level timing of the most recent ccsp_chain_run on this graph, measured with HIP events
  * on the chain's stream (bench.py's roofline block).  evals = network evaluations executed,
- * ms_total = event time of the whole chain.  After ccsp_profile_enable(graph, 1) the first 1024
- * evaluations of a chain are additionally bracketed launch by launch: ms_ugemm / ms_edge = mean
- * duration of k_ugemm / k_edge (0 when profiling is off).  Synchronises on the chain's end. */
+ * ms_total = event time of the whole chain.  After ccsp_profile_enable(graph, 1) the launches of a chain
+ * are additionally bracketed one by one (ccsp_kernel_stats): ms_ugemm / ms_edge = mean duration of the forward
+ * row GEMM / edge kernel (0 when profiling is off).  Synchronises on the chain's end. */
 int ccsp_profile_enable(ccsp_graph* graph, int32_t on);
 int ccsp_chain_stats(ccsp_graph* graph, int64_t* evals, float* ms_total, float* ms_ugemm, float* ms_edge);
+/* Per-kernel timing of a profiled chain (ccsp_profile_enable): while profiling, an event is recorded before every
+ * launch of the kernels below (the first CCSP_PROFILE_MARKS marks of a chain); which = CCSP_K_*; calls = launches
+ * seen, ms_mean = their mean duration, launch to next mark on the stream; name = a short label (may be NULL). */
+enum { CCSP_K_ROWGEMM = 0, CCSP_K_EDGE = 1, CCSP_K_NODE = 2, CCSP_K_EDGE_BWD = 3, CCSP_K_ROWSUM = 4, CCSP_K_ROWGEMM_T = 5,
+       CCSP_K_NODE_ENERGY = 6, CCSP_K_ENERGY_SUM = 7, CCSP_K_HMC = 8, CCSP_K_SD_EVAL = 9, CCSP_K_COUNT = 10 };
+#define CCSP_PROFILE_MARKS 16384
+int ccsp_kernel_stats(ccsp_graph* graph, int32_t which, int64_t* calls, float* ms_mean, char* name, int32_t name_len);
 
 /* Host-only planning entry (needs no device): the one-time index tables ccsp_graph_create builds
  * from the edge lists -- type-sorted edges, the distinct (type, slot, node) rows, their row tiles
