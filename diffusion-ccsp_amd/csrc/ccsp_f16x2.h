@@ -93,10 +93,96 @@ __device__ __forceinline__ void h2_kstep(const unsigned short* __restrict__ As, 
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][PA[q]], b[j][PB[q]], acc[i][j], 0, 0, 0);
 }
 
+// Epilogue of the row GEMMs, one WAVE at a time and without workgroup barriers: the wave's 64 x 64 accumulators (MFMA
+// layout: one column, 16 rows per lane) go through a wave-private LDS tile [32][H2_CW_LD] (row tile i = 0, 1) and are
+// re-read as rows -- 8 lanes x 16 bytes per row segment -- so the base loads and U stores are 128-byte row segments and
+// the maximum of a row's 64 columns is a 3-step shuffle.  LDS operations of one wave execute in order, so the tile needs
+// no barrier; the base / time-term loads of a row tile are requested before its accumulators are written to LDS.
+// (Measured with s_memtime on k_rowgemm_h3: the same epilogue on workgroup-wide tiles with four __syncthreads and the
+// loads issued pass by pass was 19 k of the kernel's 53 k cycles.)
+//   U[row0 + r, colw + c] = 2^-(sE[r] + w_exp) acc + base + tau;   umax[(row0 + r) * umax_ld + umax_col] = max_c |U|
+constexpr int H2_CW_LD = 68;
+constexpr int H2_CW_SZ = 32 * H2_CW_LD;      // floats per wave
+
+// base (+ time term) values of row tile i of the wave, in the epilogue's row layout; requested ahead of their use
+template <int ND>
+__device__ __forceinline__ void h2_epilogue_prefetch(float4 (&bs)[4][2], int i, int wrow0, int nrows, int row0, int colw,
+                                                     const float* __restrict__ base) {
+    const int lane = threadIdx.x & 63;
+    const int er = lane >> 3, eq = lane & 7;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        const int trow = wrow0 + i * 32 + er + 8 * st;
+        const int tr = trow < nrows ? trow : (nrows - 1 > 0 ? nrows - 1 : 0);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            bs[st][k] = base ? *reinterpret_cast<const float4*>(base + (size_t)(row0 + tr) * ND + colw + 4 * eq + 32 * k)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// bs0: the prefetched base values of row tile 0 (h2_epilogue_prefetch, issued under the last K chunk); tile 1's are
+// requested here before tile 0 is processed
+template <int ND>
+__device__ __forceinline__ void h2_epilogue_wave(const floatx16 (&acc)[2][2], float4 (&bs0)[4][2], float* __restrict__ Cw,
+                                                 int wrow0 /*first tile row of the wave*/, int nrows, int row0,
+                                                 int colw /*first global column of the wave*/, const int* __restrict__ sE, int w_exp,
+                                                 const float* __restrict__ base, const float* __restrict__ tau_row /*or null*/,
+                                                 float* __restrict__ U, float* __restrict__ umax, int umax_ld, int umax_col) {
+    const int lane = threadIdx.x & 63;
+    const int er = lane >> 3, eq = lane & 7;                      // rows er + 8 s (s < 4) of a 32-row tile, columns 4 eq + 32 k (k < 2)
+    float4 tv[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        tv[k] = tau_row ? *reinterpret_cast<const float4*>(tau_row + colw + 4 * eq + 32 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (wrow0 >= nrows) return;                                   // (wave-uniform) nothing of the tile in this wave's rows
+    float4 bs1[4][2];
+    h2_epilogue_prefetch<ND>(bs1, 1, wrow0, nrows, row0, colw, base);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float4 (&bs)[4][2] = i == 0 ? bs0 : bs1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                Cw[rr * H2_CW_LD + j * 32 + (lane & 31)] = acc[i][j][r];
+            }
+        asm volatile("" ::: "memory");                            // (compiler ordering only: the LDS runs one wave's operations in order)
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int trow = wrow0 + i * 32 + er + 8 * st;
+            if (trow < nrows) {
+                const int e = -(sE[trow] + w_exp);
+                const size_t grow = (size_t)(row0 + trow);
+                float m = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const float4 v = *reinterpret_cast<const float4*>(Cw + (er + 8 * st) * H2_CW_LD + 4 * eq + 32 * k);
+                    float4 o;
+                    o.x = ldexpf(v.x, e) + (bs[st][k].x + tv[k].x);
+                    o.y = ldexpf(v.y, e) + (bs[st][k].y + tv[k].y);
+                    o.z = ldexpf(v.z, e) + (bs[st][k].z + tv[k].z);
+                    o.w = ldexpf(v.w, e) + (bs[st][k].w + tv[k].w);
+                    m = fmaxf(fmaxf(m, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+                    *reinterpret_cast<float4*>(U + grow * ND + colw + 4 * eq + 32 * k) = o;
+                }
+                if (umax) {                                       // (the 8 lanes of a row take the branch together)
+                    m = fmaxf(m, __shfl_xor(m, 1));
+                    m = fmaxf(m, __shfl_xor(m, 2));
+                    m = fmaxf(m, __shfl_xor(m, 4));
+                    if (eq == 0) umax[grow * umax_ld + umax_col] = m;
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // k_rowgemm_h2<KD, ND, DB>:  U[row0 + r, col0 + c] = 2^-(ea[r] + ew) * sum_k A[src(r), k] W[ts][col0 + c, k]  + base + tau
 //   A planes [2][n_src][KD] fp16 bits scaled by 2^a_exp[src], rows gathered by urow_node; W planes [2][n_ts][ND][KD]
-//   scaled by 2^w_exp.  umax[row, col0 / 128] = max |U| over the tile's 128 columns (null: not written).
+//   scaled by 2^w_exp.  umax[row, (col0 + 64 wn) / 64] = max |U| over 64 columns (null: not written).
 //   The kernel is one latency chain per tile (descriptor -> row indices -> operands -> 8 chunks -> epilogue) and a launch
 //   is as long as the chains it runs one after the other on a CU slot, so the residency is chosen per launch:
 //   DB = true : two LDS stages + two register sets (chunk c+2 in flight), 64.5 KB, 2 workgroups per CU;
@@ -114,9 +200,8 @@ __global__ __launch_bounds__(256, DB ? 2 : 3) void k_rowgemm_h2(const unsigned s
     constexpr int NCT = ND / 128, NCH = KD / H2_BK;
     constexpr int APL = 128 * H2_BK, STAGE = 2 * APL + 2 * H2_BPL;        // 32 KB per stage
     constexpr int NST = DB ? 2 : 1;
-    constexpr int C_LD = 160;                                     // epilogue tile [64][160] fp32: conflict-free 16-byte row reads
-    constexpr int SMEM_US = (NST * STAGE * 2 > 64 * C_LD * 4 ? NST * STAGE : 64 * C_LD * 2);
-    __shared__ __attribute__((aligned(16))) unsigned short smem[SMEM_US + 256];      // stages (epilogue tile on top) + 128 row exponents
+    constexpr int SMEM_US = (NST * STAGE * 2 > 4 * H2_CW_SZ * 4 ? NST * STAGE : 4 * H2_CW_SZ * 2);
+    __shared__ __attribute__((aligned(16))) unsigned short smem[SMEM_US + 256];      // stages (epilogue tiles on top) + 128 row exponents
     int* sE = reinterpret_cast<int*>(smem + SMEM_US);
     if (ref.tab) tau_t += (size_t)ref.tab[*ref.counter].t * tau_stride;      // hipGraph mode: timestep from the device table
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -168,6 +253,7 @@ __global__ __launch_bounds__(256, DB ? 2 : 3) void k_rowgemm_h2(const unsigned s
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    float4 bs0[4][2];
     if constexpr (DB) {
         gload(0, 0);
         gload(1, 1);
@@ -179,6 +265,7 @@ __global__ __launch_bounds__(256, DB ? 2 : 3) void k_rowgemm_h2(const unsigned s
             // register set (c+1)&1 holds chunk c+1, the other one chunk c+2 (still in flight)
             if (c + 1 < NCH) lstore((c + 1) & 1, (c + 1) & 1);
             if (c + 3 < NCH) gload(c + 3, (c + 1) & 1);
+            if (c == NCH - 1) h2_epilogue_prefetch<ND>(bs0, 0, wm * 64, nrows, row0, col0 + wn * 64, base);
             const unsigned short* st = smem + (c & 1) * STAGE;
             h2_kstep<2>(st, APL, st + 2 * APL, 0, wm * 64, wn * 64, acc);
             h2_kstep<2>(st, APL, st + 2 * APL, 1, wm * 64, wn * 64, acc);
@@ -190,6 +277,7 @@ __global__ __launch_bounds__(256, DB ? 2 : 3) void k_rowgemm_h2(const unsigned s
         gload(1, 0);
         __syncthreads();
         for (int c = 0; c < NCH; ++c) {
+            if (c == NCH - 1) h2_epilogue_prefetch<ND>(bs0, 0, wm * 64, nrows, row0, col0 + wn * 64, base);
             h2_kstep<2>(smem, APL, smem + 2 * APL, 0, wm * 64, wn * 64, acc);
             h2_kstep<2>(smem, APL, smem + 2 * APL, 1, wm * 64, wn * 64, acc);
             __syncthreads();                                      // every wave is done reading the stage
@@ -200,71 +288,111 @@ __global__ __launch_bounds__(256, DB ? 2 : 3) void k_rowgemm_h2(const unsigned s
             }
         }
     }
-    // epilogue through LDS, 64 rows (row tile i of every wave) per pass: the accumulators (one column, 16 rows per lane)
-    // are re-read as rows, so base loads and U stores are 128-byte row segments and the row maximum is a 3-step shuffle
-    float* Cs = reinterpret_cast<float*>(smem);
-    const int er = tid >> 3, eq = tid & 7;                        // rows er, er + 32 of a 64-row pass, columns 4 eq + 32 k
-    const bool has_tau = tau_t && (ts & 1) == 0;                  // time term + bias: slot-0 rows only
-    const float* tau_p = tau_t + (size_t)(ts >> 1) * ND + col0 + 4 * eq;
+    // (every wave is past the last barrier: the stages are free for the wave-private epilogue tiles)
+    h2_epilogue_wave<ND>(acc, bs0, reinterpret_cast<float*>(smem) + wave * H2_CW_SZ, wm * 64, nrows, row0, col0 + wn * 64, sE, w_exp, base,
+                         (tau_t && (ts & 1) == 0) ? tau_t + (size_t)(ts >> 1) * ND : nullptr, U, umax, 2 * NCT, 2 * ct + wn);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_rowgemm_h3<KD, ND>: the same product on 384 x 128 super-tiles, one 12-wave workgroup per CU.
+//   Measured on the 128 x 128 kernel above (tools/abl_run.sh variants, C2 batch): dropping the operand loads, the
+//   base / U traffic or the MFMAs each removes only 10 - 20 % of its 29 us -- per CU the matrix pipe (7.7 us), the LDS
+//   (8 us: three workgroups each stage their own copy of the weight chunk) and the vector-memory path (750 KB per CU)
+//   are about equally loaded and the 3 x 8 barrier phases serialise them.  Here three row units share ONE staged weight
+//   chunk: per CU a third less operand traffic (L2 -> CU and LDS writes), LDS fragment reads at a third of the MFMA
+//   time, and two LDS stages of 64 KB so that the copy of chunk c+1 and the loads of chunk c+2 run under the 72 MFMAs
+//   per SIMD of chunk c.  12 waves as 6(M) x 2(N), 64 x 64 per wave; waves whose rows are all beyond the tile's
+//   nrows skip the MFMAs.  Epilogue per 64-row wave pair through its own 20 KB LDS region, as in k_rowgemm_h2.
+// ------------------------------------------------------------------------------------------
+constexpr int H3_TM = 384;
+
+template <int KD, int ND>
+__global__ __launch_bounds__(768, 3) void k_rowgemm_h3(const unsigned short* __restrict__ A, size_t a_plane, const int* __restrict__ a_exp,
+                                                       const int* __restrict__ urow_node, const int* __restrict__ tile_row0,
+                                                       const int* __restrict__ tile_nrows, const int* __restrict__ tile_ts,
+                                                       const unsigned short* __restrict__ W, size_t w_plane, size_t w_stride, int w_exp,
+                                                       const float* __restrict__ base, const float* __restrict__ tau_t,
+                                                       float* __restrict__ U, float* __restrict__ umax, StepRef ref, size_t tau_stride) {
+    static_assert(ND % 128 == 0 && KD % H2_BK == 0 && KD / H2_BK >= 3, "shape");
+    constexpr int NCT = ND / 128, NCH = KD / H2_BK;
+    constexpr int APL = H3_TM * H2_BK, STAGE = 2 * APL + 2 * H2_BPL;     // 64 KB per stage
+    static_assert(12 * H2_CW_SZ * 4 <= 2 * STAGE * 2, "epilogue tiles must fit the stages");
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * STAGE + 2 * H3_TM];      // two stages + 384 row exponents
+    int* sE = reinterpret_cast<int*>(smem + 2 * STAGE);
+    if (ref.tab) tau_t += (size_t)ref.tab[*ref.counter].t * tau_stride;      // hipGraph mode: timestep from the device table
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = bid / NCT, ct = bid % NCT;
+    const int row0 = tile_row0[tile], nrows = tile_nrows[tile], ts = tile_ts[tile];
+    const int col0 = ct * 128;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = tid >> 2, lq = tid & 3;                      // staging: A rows lrow, lrow + 192; B row lrow (tid < 512); piece lq, both planes
+    const unsigned short* a_ptr[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        // this pass's rows of the tile: Cs row lr = wm' * 32 + rr  <->  tile row wm' * 64 + i * 32 + rr
-        float4 bs[2][4];
-        int trow[2];
+        int r = lrow + 192 * i;
+        r = r < nrows ? r : nrows - 1;
+        const int src = urow_node ? urow_node[row0 + r] : row0 + r;
+        a_ptr[i] = A + (size_t)src * KD + lq * 8;
+    }
+    if (tid < H3_TM) {
+        const int r = tid < nrows ? tid : nrows - 1;
+        sE[tid] = a_exp[urow_node ? urow_node[row0 + r] : row0 + r];
+    }
+    const bool does_b = tid < 512;
+    const unsigned short* b_ptr = W + (size_t)ts * w_stride + (size_t)(col0 + (does_b ? lrow : 0)) * KD + lq * 8;
+    const int st_a0 = h2_off(lrow, lq), st_a1 = h2_off(lrow + 192, lq), st_b = h2_off(does_b ? lrow : 0, lq);
+    ushort8 ra[4], rb[2];                                         // [row half * 2 + plane], [plane]
+    auto gload = [&](int c) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int lr = er + 32 * h;
-            trow[h] = (lr >> 5) * 64 + i * 32 + (lr & 31);
-            const int tr = trow[h] < nrows ? trow[h] : nrows - 1;
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                bs[h][k] = base ? *reinterpret_cast<const float4*>(base + (size_t)(row0 + tr) * ND + col0 + 4 * eq + 32 * k)
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int p = 0; p < 2; ++p) ra[i * 2 + p] = *reinterpret_cast<const ushort8*>(a_ptr[i] + (size_t)p * a_plane + c * H2_BK);
+        if (does_b) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) rb[p] = *reinterpret_cast<const ushort8*>(b_ptr + (size_t)p * w_plane + c * H2_BK);
         }
+    };
+    auto lstore = [&](int stage) {
+        unsigned short* As = smem + stage * STAGE;
+        unsigned short* Bs = As + 2 * APL;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            *reinterpret_cast<ushort8*>(As + p * APL + st_a0) = ra[p];
+            *reinterpret_cast<ushort8*>(As + p * APL + st_a1) = ra[2 + p];
+        }
+        if (does_b) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) *reinterpret_cast<ushort8*>(Bs + p * H2_BPL + st_b) = rb[p];
+        }
+    };
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                Cs[(wm * 32 + rr) * C_LD + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
-            }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const bool live = wm * 64 < nrows;                            // (wave-uniform) this wave's 64 rows hold at least one row of the tile
+    float4 bs0[4][2];
+    gload(0);
+    lstore(0);
+    gload(1);
+    __syncthreads();
+    for (int c = 0; c < NCH; ++c) {
+        // the registers hold chunk c+1: behind the first 12 MFMAs of this chunk it is copied to the other stage and chunk
+        // c+2 requested, so that the copy and the loads run under the matrix pipe
+        const unsigned short* st = smem + (c & 1) * STAGE;
+        if (live) h2_kstep<2>(st, APL, st + 2 * APL, 0, wm * 64, wn * 64, acc);
+        if (c + 1 < NCH) lstore((c + 1) & 1);
+        if (c + 2 < NCH) gload(c + 2);
+        if (c == NCH - 1) h2_epilogue_prefetch<ND>(bs0, 0, wm * 64, nrows, row0, col0 + wn * 64, base);
+        if (live) h2_kstep<2>(st, APL, st + 2 * APL, 1, wm * 64, wn * 64, acc);
         __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float4 tv = has_tau ? *reinterpret_cast<const float4*>(tau_p + 32 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                bs[h][k].x += tv.x; bs[h][k].y += tv.y; bs[h][k].z += tv.z; bs[h][k].w += tv.w;
-            }
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int lr = er + 32 * h;
-            if (trow[h] < nrows) {
-                const int e = -(sE[trow[h]] + w_exp);
-                const size_t grow = (size_t)(row0 + trow[h]);
-                float m = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float4 v = *reinterpret_cast<const float4*>(Cs + lr * C_LD + 4 * eq + 32 * k);
-                    float4 o;
-                    o.x = ldexpf(v.x, e) + bs[h][k].x;
-                    o.y = ldexpf(v.y, e) + bs[h][k].y;
-                    o.z = ldexpf(v.z, e) + bs[h][k].z;
-                    o.w = ldexpf(v.w, e) + bs[h][k].w;
-                    m = fmaxf(fmaxf(m, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
-                    *reinterpret_cast<float4*>(U + grow * ND + col0 + 4 * eq + 32 * k) = o;
-                }
-                if (umax) {                                       // (the 8 lanes of a row take the branch together)
-                    m = fmaxf(m, __shfl_xor(m, 1));
-                    m = fmaxf(m, __shfl_xor(m, 2));
-                    m = fmaxf(m, __shfl_xor(m, 4));
-                    if (eq == 0) umax[grow * NCT + ct] = m;
-                }
-            }
-        }
-        if (i == 0) __syncthreads();
     }
+    // (every wave is past the last barrier: the stages are free for the wave-private epilogue tiles)
+    h2_epilogue_wave<ND>(acc, bs0, reinterpret_cast<float*>(smem) + wave * H2_CW_SZ, wm * 64, nrows, row0, col0 + wn * 64, sE, w_exp, base,
+                         (tau_t && (ts & 1) == 0) ? tau_t + (size_t)(ts >> 1) * ND : nullptr, U, umax, 2 * NCT, 2 * ct + wn);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -280,7 +408,7 @@ __global__ __launch_bounds__(256, DB ? 2 : 3) void k_rowgemm_h2(const unsigned s
 // ------------------------------------------------------------------------------------------
 template <bool ENERGY, int MT>
 __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void k_edge_h2(int E_act, int P, const int* __restrict__ e_u0, const int* __restrict__ e_u1,
-                                                    const float* __restrict__ U, const float* __restrict__ umax /*[R][4]*/,
+                                                    const float* __restrict__ U, const float* __restrict__ umax /*[R][8]*/,
                                                     const unsigned short* __restrict__ Wd1H /*[2][128][256]*/, int wd_exp,
                                                     const float* __restrict__ bd1, const float* __restrict__ Wd2,
                                                     const float* __restrict__ bd2, const int* __restrict__ ent_pos, float* __restrict__ O,
@@ -309,9 +437,10 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void k_edge_h2(int E_act, int
         const int r0 = e_u0[k], r1 = e_u1[k];
         u0_ptr[i] = U + (size_t)r0 * (2 * H) + s * H + lq * 4;
         u1_ptr[i] = U + (size_t)r1 * (2 * H) + s * H + lq * 4;
-        const float2 m0 = *reinterpret_cast<const float2*>(umax + (size_t)r0 * 4 + 2 * s);
-        const float2 m1 = *reinterpret_cast<const float2*>(umax + (size_t)r1 * 4 + 2 * s);
-        a_exp[i] = h2_scale_exp(fmaxf(m0.x, m0.y) + fmaxf(m1.x, m1.y));        // |SiLU(z)| <= |z| <= max|U[u0]| + max|U[u1]|
+        const float4 m0 = *reinterpret_cast<const float4*>(umax + (size_t)r0 * 8 + 4 * s);
+        const float4 m1 = *reinterpret_cast<const float4*>(umax + (size_t)r1 * 8 + 4 * s);
+        // |SiLU(z)| <= |z| <= max|U[u0]| + max|U[u1]| over the half's four 64-column pieces
+        a_exp[i] = h2_scale_exp(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)) + fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w)));
         if (lq == 0) sE[row] = a_exp[i];
         a_st[i] = h2_off(row, lq >> 1) + (lq & 1) * 4;
     }

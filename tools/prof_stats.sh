@@ -11,7 +11,7 @@ i=0
 for cfg in "$@"; do
   i=$((i+1))
   rm -rf /tmp/st_$i
-  env $cfg timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/st_$i --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/stats_$i.log 2>&1
+  env $cfg timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/st_$i --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline $BENCH_ARGS > $OUT/stats_$i.log 2>&1
   f=$(find /tmp/st_$i -name "*kernel_stats.csv" | head -1)
   cp "$f" $OUT/stats_$i.csv
   echo "== $cfg" >> $OUT/stats.txt
