@@ -185,12 +185,17 @@ __device__ __forceinline__ void h2_epilogue_wave(const floatx16 (&acc)[2][2], fl
 //   scaled by 2^w_exp.  umax[row, (col0 + 64 wn) / 64] = max |U| over 64 columns (null: not written).
 //   The kernel is one latency chain per tile (descriptor -> row indices -> operands -> 8 chunks -> epilogue) and a launch
 //   is as long as the chains it runs one after the other on a CU slot, so the residency is chosen per launch:
-//   DB = true : two LDS stages + two register sets (chunk c+2 in flight), 64.5 KB, 2 workgroups per CU;
-//   DB = false: one stage + one register set, 40.5 KB and <= 168 VGPRs, 3 workgroups per CU -- the whole tile list of a
-//               C2-sized batch (640 tiles) is resident at once instead of running as a full and a 20 %-full round.
+//   MODE 0: one stage + one register set, 33 KB and <= 168 VGPRs, 3 workgroups per CU -- the whole tile list of a
+//           C2-sized batch (640 tiles) is resident at once instead of running as a full and a 20 %-full round;
+//   MODE 1: two LDS stages + two register sets (chunk c+2 in flight), 64.5 KB, 2 workgroups per CU;
+//   MODE 2: two LDS stages filled by direct-to-LDS loads (global_load_lds_dwordx4: no staging registers and no
+//           ds_write -- the 16-byte stores were half of the kernel's LDS-instruction cycles).  A wave-instruction
+//           writes 64 lanes x 16 bytes = sixteen consecutive 64-byte rows of one plane, lane-linear, so the XOR
+//           swizzle of the stage is applied on the SOURCE side: the lane in physical slot s of row r fetches logical
+//           piece s ^ ((r >> 2) & 3).
 // ------------------------------------------------------------------------------------------
-template <int KD, int ND, bool DB>
-__global__ __launch_bounds__(256, DB ? 2 : 3) void k_rowgemm_h2(const unsigned short* __restrict__ A, size_t a_plane, const int* __restrict__ a_exp,
+template <int KD, int ND, int MODE>
+__global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void k_rowgemm_h2(const unsigned short* __restrict__ A, size_t a_plane, const int* __restrict__ a_exp,
                                                        const int* __restrict__ urow_node, const int* __restrict__ tile_row0,
                                                        const int* __restrict__ tile_nrows, const int* __restrict__ tile_ts,
                                                        const unsigned short* __restrict__ W, size_t w_plane, size_t w_stride, int w_exp,
@@ -199,7 +204,9 @@ __global__ __launch_bounds__(256, DB ? 2 : 3) void k_rowgemm_h2(const unsigned s
     static_assert(ND % 128 == 0 && KD % H2_BK == 0 && KD / H2_BK >= 3, "shape");
     constexpr int NCT = ND / 128, NCH = KD / H2_BK;
     constexpr int APL = 128 * H2_BK, STAGE = 2 * APL + 2 * H2_BPL;        // 32 KB per stage
-    constexpr int NST = DB ? 2 : 1;
+    constexpr bool DB = MODE == 1;
+    constexpr int NST = MODE == 0 ? 1 : 2;                        // LDS stages
+    constexpr int NRS = MODE == 1 ? 2 : 1;                        // register sets (MODE 2 uses none)
     constexpr int SMEM_US = (NST * STAGE * 2 > 4 * H2_CW_SZ * 4 ? NST * STAGE : 4 * H2_CW_SZ * 2);
     __shared__ __attribute__((aligned(16))) unsigned short smem[SMEM_US + 256];      // stages (epilogue tiles on top) + 128 row exponents
     int* sE = reinterpret_cast<int*>(smem + SMEM_US);
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(256, DB ? 2 : 3) void k_rowgemm_h2(const unsigned s
     }
     const unsigned short* b_ptr = W + (size_t)ts * w_stride + (size_t)(col0 + lrow) * KD + lq * 8;
     const int st_off = h2_off(lrow, lq);                          // (row + 64 has the same swizzle: + 64 * H2_BK)
-    ushort8 ra[NST][4], rb[NST][4];                               // [register set][row half * 2 + plane]
+    ushort8 ra[NRS][4], rb[NRS][4];                               // [register set][row half * 2 + plane]
     auto gload = [&](int c, int set) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -254,7 +261,44 @@ __global__ __launch_bounds__(256, DB ? 2 : 3) void k_rowgemm_h2(const unsigned s
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     float4 bs0[4][2];
-    if constexpr (DB) {
+    if constexpr (MODE == 2) {
+        // wave w fills 1 KB blocks 4 w .. 4 w + 3 of the A planes and of the B planes: block = (plane, sixteen rows)
+        using gptr = const __attribute__((address_space(1))) void*;
+        using lptr = __attribute__((address_space(3))) void*;
+        const unsigned short* ga[4];
+        const unsigned short* gb[4];
+        int lo[4];                                                // wave-uniform stage offset of the block (fp16 elements)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int blk = 4 * wave + j, plane = blk >> 3, rb16 = blk & 7;
+            const int row = rb16 * 16 + (lane >> 2);
+            const int piece = (lane & 3) ^ ((row >> 2) & 3);
+            const int r = row < nrows ? row : nrows - 1;
+            const int src = urow_node ? urow_node[row0 + r] : row0 + r;
+            ga[j] = A + (size_t)plane * a_plane + (size_t)src * KD + piece * 8;
+            gb[j] = W + (size_t)plane * w_plane + (size_t)ts * w_stride + (size_t)(col0 + row) * KD + piece * 8;
+            lo[j] = __builtin_amdgcn_readfirstlane(plane * APL + rb16 * 16 * H2_BK);
+        }
+        auto glds = [&](int c, int stage) {
+            unsigned short* st = smem + stage * STAGE;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                __builtin_amdgcn_global_load_lds((gptr)(ga[j] + c * H2_BK), (lptr)(st + lo[j]), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr)(gb[j] + c * H2_BK), (lptr)(st + 2 * APL + lo[j]), 16, 0, 0);
+            }
+        };
+        glds(0, 0);
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (c + 1 < NCH) glds(c + 1, (c + 1) & 1);
+            if (c == NCH - 1) h2_epilogue_prefetch<ND>(bs0, 0, wm * 64, nrows, row0, col0 + wn * 64, base);
+            const unsigned short* st = smem + (c & 1) * STAGE;
+            h2_kstep<2>(st, APL, st + 2 * APL, 0, wm * 64, wn * 64, acc);
+            h2_kstep<2>(st, APL, st + 2 * APL, 1, wm * 64, wn * 64, acc);
+            __syncthreads();                                      // (drains the LDS-DMA of chunk c+1 as well)
+        }
+    } else if constexpr (DB) {
         gload(0, 0);
         gload(1, 1);
         lstore(0, 0);
@@ -287,108 +331,6 @@ __global__ __launch_bounds__(256, DB ? 2 : 3) void k_rowgemm_h2(const unsigned s
                 __syncthreads();
             }
         }
-    }
-    // (every wave is past the last barrier: the stages are free for the wave-private epilogue tiles)
-    h2_epilogue_wave<ND>(acc, bs0, reinterpret_cast<float*>(smem) + wave * H2_CW_SZ, wm * 64, nrows, row0, col0 + wn * 64, sE, w_exp, base,
-                         (tau_t && (ts & 1) == 0) ? tau_t + (size_t)(ts >> 1) * ND : nullptr, U, umax, 2 * NCT, 2 * ct + wn);
-}
-
-// ------------------------------------------------------------------------------------------
-// k_rowgemm_h3<KD, ND>: the same product on 384 x 128 super-tiles, one 12-wave workgroup per CU.
-//   Measured on the 128 x 128 kernel above (tools/abl_run.sh variants, C2 batch): dropping the operand loads, the
-//   base / U traffic or the MFMAs each removes only 10 - 20 % of its 29 us -- per CU the matrix pipe (7.7 us), the LDS
-//   (8 us: three workgroups each stage their own copy of the weight chunk) and the vector-memory path (750 KB per CU)
-//   are about equally loaded and the 3 x 8 barrier phases serialise them.  Here three row units share ONE staged weight
-//   chunk: per CU a third less operand traffic (L2 -> CU and LDS writes), LDS fragment reads at a third of the MFMA
-//   time, and two LDS stages of 64 KB so that the copy of chunk c+1 and the loads of chunk c+2 run under the 72 MFMAs
-//   per SIMD of chunk c.  12 waves as 6(M) x 2(N), 64 x 64 per wave; waves whose rows are all beyond the tile's
-//   nrows skip the MFMAs.  Epilogue per 64-row wave pair through its own 20 KB LDS region, as in k_rowgemm_h2.
-// ------------------------------------------------------------------------------------------
-constexpr int H3_TM = 384;
-
-template <int KD, int ND>
-__global__ __launch_bounds__(768, 3) void k_rowgemm_h3(const unsigned short* __restrict__ A, size_t a_plane, const int* __restrict__ a_exp,
-                                                       const int* __restrict__ urow_node, const int* __restrict__ tile_row0,
-                                                       const int* __restrict__ tile_nrows, const int* __restrict__ tile_ts,
-                                                       const unsigned short* __restrict__ W, size_t w_plane, size_t w_stride, int w_exp,
-                                                       const float* __restrict__ base, const float* __restrict__ tau_t,
-                                                       float* __restrict__ U, float* __restrict__ umax, StepRef ref, size_t tau_stride) {
-    static_assert(ND % 128 == 0 && KD % H2_BK == 0 && KD / H2_BK >= 3, "shape");
-    constexpr int NCT = ND / 128, NCH = KD / H2_BK;
-    constexpr int APL = H3_TM * H2_BK, STAGE = 2 * APL + 2 * H2_BPL;     // 64 KB per stage
-    static_assert(12 * H2_CW_SZ * 4 <= 2 * STAGE * 2, "epilogue tiles must fit the stages");
-    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * STAGE + 2 * H3_TM];      // two stages + 384 row exponents
-    int* sE = reinterpret_cast<int*>(smem + 2 * STAGE);
-    if (ref.tab) tau_t += (size_t)ref.tab[*ref.counter].t * tau_stride;      // hipGraph mode: timestep from the device table
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile = bid / NCT, ct = bid % NCT;
-    const int row0 = tile_row0[tile], nrows = tile_nrows[tile], ts = tile_ts[tile];
-    const int col0 = ct * 128;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int lrow = tid >> 2, lq = tid & 3;                      // staging: A rows lrow, lrow + 192; B row lrow (tid < 512); piece lq, both planes
-    const unsigned short* a_ptr[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int r = lrow + 192 * i;
-        r = r < nrows ? r : nrows - 1;
-        const int src = urow_node ? urow_node[row0 + r] : row0 + r;
-        a_ptr[i] = A + (size_t)src * KD + lq * 8;
-    }
-    if (tid < H3_TM) {
-        const int r = tid < nrows ? tid : nrows - 1;
-        sE[tid] = a_exp[urow_node ? urow_node[row0 + r] : row0 + r];
-    }
-    const bool does_b = tid < 512;
-    const unsigned short* b_ptr = W + (size_t)ts * w_stride + (size_t)(col0 + (does_b ? lrow : 0)) * KD + lq * 8;
-    const int st_a0 = h2_off(lrow, lq), st_a1 = h2_off(lrow + 192, lq), st_b = h2_off(does_b ? lrow : 0, lq);
-    ushort8 ra[4], rb[2];                                         // [row half * 2 + plane], [plane]
-    auto gload = [&](int c) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int p = 0; p < 2; ++p) ra[i * 2 + p] = *reinterpret_cast<const ushort8*>(a_ptr[i] + (size_t)p * a_plane + c * H2_BK);
-        if (does_b) {
-#pragma unroll
-            for (int p = 0; p < 2; ++p) rb[p] = *reinterpret_cast<const ushort8*>(b_ptr + (size_t)p * w_plane + c * H2_BK);
-        }
-    };
-    auto lstore = [&](int stage) {
-        unsigned short* As = smem + stage * STAGE;
-        unsigned short* Bs = As + 2 * APL;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            *reinterpret_cast<ushort8*>(As + p * APL + st_a0) = ra[p];
-            *reinterpret_cast<ushort8*>(As + p * APL + st_a1) = ra[2 + p];
-        }
-        if (does_b) {
-#pragma unroll
-            for (int p = 0; p < 2; ++p) *reinterpret_cast<ushort8*>(Bs + p * H2_BPL + st_b) = rb[p];
-        }
-    };
-    floatx16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    const bool live = wm * 64 < nrows;                            // (wave-uniform) this wave's 64 rows hold at least one row of the tile
-    float4 bs0[4][2];
-    gload(0);
-    lstore(0);
-    gload(1);
-    __syncthreads();
-    for (int c = 0; c < NCH; ++c) {
-        // the registers hold chunk c+1: behind the first 12 MFMAs of this chunk it is copied to the other stage and chunk
-        // c+2 requested, so that the copy and the loads run under the matrix pipe
-        const unsigned short* st = smem + (c & 1) * STAGE;
-        if (live) h2_kstep<2>(st, APL, st + 2 * APL, 0, wm * 64, wn * 64, acc);
-        if (c + 1 < NCH) lstore((c + 1) & 1);
-        if (c + 2 < NCH) gload(c + 2);
-        if (c == NCH - 1) h2_epilogue_prefetch<ND>(bs0, 0, wm * 64, nrows, row0, col0 + wn * 64, base);
-        if (live) h2_kstep<2>(st, APL, st + 2 * APL, 1, wm * 64, wn * 64, acc);
-        __syncthreads();
     }
     // (every wave is past the last barrier: the stages are free for the wave-private epilogue tiles)
     h2_epilogue_wave<ND>(acc, bs0, reinterpret_cast<float*>(smem) + wave * H2_CW_SZ, wm * 64, nrows, row0, col0 + wn * 64, sE, w_exp, base,

@@ -903,8 +903,7 @@ struct ccsp_model {
     unsigned short* Wd1H = nullptr;   // [2][H/2][H]      fp16 planes of pose_decoder.0.weight * 2^wd_exp
     int wp_exp = 0, wd_exp = 0;
     int ncu = 256;          // compute units of the device (residency-based kernel selection)
-    int row_kernel = 3;     // CCSP_ROW_KERNEL: 3 = k_rowgemm_h3 (384-row super-tiles, default), 2 = k_rowgemm_h2 (128-row tiles)
-    int row_db = -1, edge_mt = -1;    // CCSP_ROW_DB / CCSP_EDGE_MT: force a residency variant of the f16x2 kernels (-1: by tile count)
+    int row_mode = -1, edge_mt = -1;  // CCSP_ROW_MODE / CCSP_EDGE_MT: force a variant of the f16x2 kernels (-1: by tile count)
     // StructDiffusion baseline (model_kind 1): transformer weights as given ([out, in] row-major)
     struct SdLayer { float *in_w, *in_b, *out_w, *out_b, *ln1_g, *ln1_b, *fc_w, *fc_b, *proj_w, *proj_b, *ln2_g, *ln2_b; };
     int Wd = 0;            // transformer width: 2H, or 3H with a grasp group
@@ -938,9 +937,6 @@ struct ccsp_graph {
     float* umax = nullptr;             // [R][8] max |U| per row and 64-column piece (k_rowgemm_h2 / _h3 -> k_edge_h2)
     int *t2_row0 = nullptr, *t2_nrows = nullptr, *t2_ts = nullptr;   // 128-row tiles of k_rowgemm_bf2 (pairs of plan tiles)
     int n_tiles2 = 0;
-    int *t3_row0 = nullptr, *t3_nrows = nullptr, *t3_ts = nullptr;   // 384-row super-tiles of k_rowgemm_h3 (up to six plan tiles)
-    int n_tiles3 = 0;
-    std::vector<int> h_t3;
     int* urow_ts;
     // energy mode (allocated on first use)
     bool energy_ready = false;
@@ -1037,24 +1033,22 @@ void cosine_betas(int T, std::vector<double>& betas) {   // ddpm.py:152-162
 EncW enc_pose(const ccsp_model* m) { return EncW{m->pe0_w, m->pe0_b, m->pe2_wT, m->pe2_b, m->d.pose_dim, m->pe2_wF}; }
 
 // f16x2 kernels (H = 256): the residency variant is chosen so that the whole tile list is resident at once when it can be
-// (ccsp_f16x2.h): row GEMM 2 workgroups per CU with the deep pipeline if the tiles fit, else 3 per CU; edge kernel
+// (ccsp_f16x2.h): row GEMM 2 workgroups per CU with direct-to-LDS staging if the tiles fit, else 3 per CU; edge kernel
 // 32-edge tiles at 3 per CU if they fit, else 64-edge tiles
 void launch_rowgemm_h2(ccsp_model* m, ccsp_graph* g, const float* tau_t, StepRef ref, size_t tau_stride, hipStream_t s) {
     constexpr int H = 256;
-    if (m->row_kernel == 3) {
-        hipLaunchKernelGGL((k_rowgemm_h3<H, 2 * H>), dim3(g->n_tiles3 * (2 * H / 128)), dim3(768), 0, s, g->pembH, (size_t)g->N * H, g->pexp, g->urow_node,
-                           g->t3_row0, g->t3_nrows, g->t3_ts, m->WpH, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, m->wp_exp, g->base, tau_t,
-                           g->U, g->umax, ref, tau_stride);
-        return;
-    }
     const int work = g->n_tiles2 * (2 * H / 128);
-    const bool db = m->row_db >= 0 ? m->row_db != 0 : work <= 2 * m->ncu;
-    if (db)
-        hipLaunchKernelGGL((k_rowgemm_h2<H, 2 * H, true>), dim3(work), dim3(256), 0, s, g->pembH, (size_t)g->N * H, g->pexp, g->urow_node, g->t2_row0,
+    const int mode = m->row_mode >= 0 ? m->row_mode : (work <= 2 * m->ncu ? 2 : 0);
+    if (mode == 2)
+        hipLaunchKernelGGL((k_rowgemm_h2<H, 2 * H, 2>), dim3(work), dim3(256), 0, s, g->pembH, (size_t)g->N * H, g->pexp, g->urow_node, g->t2_row0,
+                           g->t2_nrows, g->t2_ts, m->WpH, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, m->wp_exp, g->base, tau_t, g->U,
+                           g->umax, ref, tau_stride);
+    else if (mode == 1)
+        hipLaunchKernelGGL((k_rowgemm_h2<H, 2 * H, 1>), dim3(work), dim3(256), 0, s, g->pembH, (size_t)g->N * H, g->pexp, g->urow_node, g->t2_row0,
                            g->t2_nrows, g->t2_ts, m->WpH, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, m->wp_exp, g->base, tau_t, g->U,
                            g->umax, ref, tau_stride);
     else
-        hipLaunchKernelGGL((k_rowgemm_h2<H, 2 * H, false>), dim3(work), dim3(256), 0, s, g->pembH, (size_t)g->N * H, g->pexp, g->urow_node, g->t2_row0,
+        hipLaunchKernelGGL((k_rowgemm_h2<H, 2 * H, 0>), dim3(work), dim3(256), 0, s, g->pembH, (size_t)g->N * H, g->pexp, g->urow_node, g->t2_row0,
                            g->t2_nrows, g->t2_ts, m->WpH, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, m->wp_exp, g->base, tau_t, g->U,
                            g->umax, ref, tau_stride);
 }
@@ -1723,26 +1717,6 @@ int graph_build(ccsp_model* m, int N, int E, int F, const float* x, const signed
         TRY(dev_upload(reg, &t2, g->h_t2, s));
         g->t2_row0 = t2; g->t2_nrows = t2 + g->n_tiles2; g->t2_ts = t2 + 2 * g->n_tiles2;
     }
-    if (m->f16x2) {   // 384-row super-tiles: runs of consecutive 64-row plan tiles of one (type, slot) group, up to six at a time
-        std::vector<int> r0, nr, tsv;
-        for (size_t i = 0; i < p.tile_row0.size();) {
-            size_t j = i;
-            int rows = 0;
-            while (j < p.tile_row0.size() && p.tile_ts[j] == p.tile_ts[i] && p.tile_row0[j] == p.tile_row0[i] + rows && rows + p.tile_nrows[j] <= 384) {
-                rows += p.tile_nrows[j];
-                ++j;
-            }
-            r0.push_back(p.tile_row0[i]); nr.push_back(rows); tsv.push_back(p.tile_ts[i]);
-            i = j;
-        }
-        g->n_tiles3 = (int)r0.size();
-        g->h_t3.assign(r0.begin(), r0.end());
-        g->h_t3.insert(g->h_t3.end(), nr.begin(), nr.end());
-        g->h_t3.insert(g->h_t3.end(), tsv.begin(), tsv.end());
-        int* t3 = nullptr;
-        TRY(dev_upload(reg, &t3, g->h_t3, s));
-        g->t3_row0 = t3; g->t3_nrows = t3 + g->n_tiles3; g->t3_ts = t3 + 2 * g->n_tiles3;
-    }
     TRY(dev_alloc(reg, &g->base, (size_t)p.R * 2 * H));
     TRY(dev_alloc(reg, &g->U, (size_t)p.R * 2 * H));
     TRY(dev_alloc(reg, &g->O, (size_t)2 * p.E_act * P));
@@ -1900,8 +1874,7 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     // CCSP_MMA: f16x2 (default at hidden_dim 256: two-term fp16 operands, three MFMA products per fp32 product),
     //           bf16x3 (three-term bf16 operands, six products), f32 (v_mfma_f32_32x32x2_f32)
     m->f16x2 = (H == 256 && d->model_kind == CCSP_MODEL_DIFFUSION_CCSP) ? 1 : 0;
-    if (const char* e = getenv("CCSP_ROW_KERNEL")) m->row_kernel = atoi(e) == 2 ? 2 : 3;
-    if (const char* e = getenv("CCSP_ROW_DB")) m->row_db = atoi(e) != 0;
+    if (const char* e = getenv("CCSP_ROW_MODE")) { const int v = atoi(e); if (v >= 0 && v <= 2) m->row_mode = v; }
     if (const char* e = getenv("CCSP_EDGE_MT")) m->edge_mt = atoi(e) == 2 ? 2 : 1;
     {
         int dev = 0;
