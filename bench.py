@@ -1,22 +1,31 @@
 #!/usr/bin/env python
-"""bench.py -- solved-samples/sec of the Diffusion-CCSP reverse-diffusion sampler on MI355X.
+"""bench.py -- samples/sec (and solved samples/sec) of the Diffusion-CCSP reverse-diffusion sampler on MI355X.
 
-Workload (BASELINE.json configs[1] "C2"; configs[2] "C3" = the same shard on every GPU):
-RandomSplitQualitativeWorld, 8 objects per graph, T=1000, ULA with 10 Langevin steps per timestep,
-256 graphs per GPU, hidden_dim 256, fp32 -- 11 000 network evaluations per chain.
+Workloads (BASELINE.json configs; hyper-parameters are the reference defaults, train_utils.py:86-89: hidden_dim 256,
+samples_per_step 10, step_sizes '2*self.betas'), one per-GPU shard each, synthetic graphs:
 
-A "step" is one whole `GaussianDiffusion.sample(batch)` call: graph upload/planning + the full
-reverse chain of the rank's 256 graphs (+ the gather of final poses when N > 1).  Inputs (the
-collated batch tensors and the weights) are resident in HBM before the timed region.
+  --config c2 (default; c3 = the same shard on every GPU)
+        RandomSplitQualitativeWorld, 8 objects, T=1000 ULA, 256 graphs per GPU -- 11 000 network evaluations per chain
+  --config c4   TriangularRandomSplitWorld, 12 objects, T=1000 MALA (energy mode), 256 graphs per GPU (1024 over 4 GPUs;
+                each shard is its own reference batch: replica semantics)
+  --config c5   3D panda-box packing (robot_box), 10 objects, T=1000 ULA, 64 graphs per GPU (512 over 8 GPUs)
 
-    python bench.py --gpus 1 --steps 3 --warmup 1
+A "step" is one whole `GaussianDiffusion.sample(batch)` call: graph upload / planning + the full reverse chain of the
+rank's graphs (+ the gather of final poses when N > 1).  Inputs (the collated batch tensors and the weights) are resident
+in HBM before the timed region.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1 [--config c2|c4|c5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  Extra blocks: "roofline" (the evaluation kernels timed with HIP
-events on the chain's stream in a separate profiled pass, priced against the fp32 MFMA peak with the
-ALGORITHMIC flops of SURVEY.md 8d) and "cpu_baseline" (the cost-faithful PyTorch-CPU port of the
-reference sampler, oracle/torch_proxy.py, timed on this box's host cores on a bounded sample).
+Rank 0 prints ONE JSON line.  Extra blocks:
+  "roofline"      every kernel of the chain timed launch by launch with HIP events on the chain's own stream in a separate
+                  profiled pass (ccsp_kernel_stats); the dominant kernel priced as EXECUTED matrix-pipe flops / its mean
+                  duration / the dense peak of the pipe that runs them (frac <= 1).  The reference formulation's
+                  ALGORITHMIC flops over the same time are reported beside it, not as the fraction: the
+                  row factorisation executes 3.7x fewer flops than the reference's per-edge products.
+  "cpu_baseline"  the cost-faithful PyTorch-CPU port of the reference sampler (oracle/torch_proxy.py) timed on this box's
+                  host cores on a bounded sample.
 """
 import argparse
 import json
@@ -30,16 +39,36 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md (dense f32 matrix peak)
-PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 matrix peak (same guide; never the 2:1-sparsity figure)
-GRAPHS_PER_GPU = 256
-N_OBJECTS = 8
+# dense matrix-pipe peaks, /opt/skills/guides/MI355X_MICROARCH.md (never the 2:1-sparsity figures)
+PEAKS = {'f16': 2500.0, 'bf16': 2500.0, 'f32': 157.3}
 HIDDEN = 256
 T_STEPS = 1000
 S_LANGEVIN = 10
 
+CONFIGS = {
+    'c2': dict(mode='qualitative', n_types=13, n_objects=8, graphs=256, EBM='ULA', energy=False, batch='qualitative_batch',
+               weights=('weights/qualitative_h256_trained.npz', 'tests/golden/weights_qualitative_h256.npz'),
+               label='C2: RandomSplitQualitativeWorld 8 objects, T=1000 ULA S=10'),
+    'c4': dict(mode='diffuse_pairwise', n_types=2, n_objects=12, graphs=256, EBM='MALA', energy=True, batch='triangular_batch',
+               weights=('tests/golden/weights_diffuse_pairwise_h256_energy.npz',),
+               label='C4: TriangularRandomSplitWorld 12 objects, T=1000 MALA S=10 (energy mode)'),
+    'c5': dict(mode='robot_box', n_types=2, n_objects=10, graphs=64, EBM='ULA', energy=False, batch='robot_box_batch',
+               weights=('tests/golden/weights_robot_box_h256.npz',),
+               label='C5: 3D panda-box packing (robot_box) 10 objects, T=1000 ULA S=10'),
+}
+WEIGHT_NOTES = {
+    'weights/qualitative_h256_trained.npz': '12 000 steps on one MI355X by tools/train_gpu.py with the reference recipe (p_losses l2, one t per batch, '
+                                            'Adam 5e-4, batch 128) on worlds of 2-8 objects from this package\'s generator',
+    'tests/golden/weights_qualitative_h256.npz': 'parity fixture: 2000 CPU steps of the reference loss (oracle/ref_train.py)',
+    'tests/golden/weights_diffuse_pairwise_h256_energy.npz': 'parity fixture: 1200 CPU steps of the reference loss in energy mode (oracle/ref_train.py); the weights '
+                                                             'the reference-generated C4 goldens were made with',
+    'tests/golden/weights_robot_box_h256.npz': 'parity fixture: 2000 CPU steps of the reference loss (oracle/ref_train.py) on synthetic robot_box graphs',
+}
+
 
 def load_weights(path):
+    """npz with reference state_dict key names; type-MLP matrices may be stored int8 + one fp32 scale per output row
+    ('::q8' / '::scale'): the DEQUANTISED values are the weights (the reference goldens were generated from exactly these)"""
     z = np.load(path)
     out = {}
     for k in z.files:
@@ -50,20 +79,54 @@ def load_weights(path):
     return out
 
 
-def algorithmic_flops(n_nodes, n_edges, H=HIDDEN, P=4, kin_mult=5):
-    """reference dense formulation, 2 flop per multiply-add, per network evaluation"""
+def weights_storage(path):
+    z = np.load(path)
+    return 'int8 per-row-scaled type-MLP matrices (dequantised values are the weights), fp32 elsewhere' if any(k.endswith('::q8') for k in z.files) else 'fp32'
+
+
+def algorithmic_flops(n_nodes, n_edges, H, P, grasp):
+    """SURVEY.md 8(d): reference dense formulation, 2 flop per multiply-add, per network evaluation (direct mode;
+    energy mode = 2x: forward + input gradient)"""
+    kin = (6 if grasp else 5) * H
     f_node = 2 * (P * H // 2 + (H // 2) * H)
-    f_edge = 2 * (kin_mult * H * 2 * H) + 2 * 2 * (H * H // 2 + (H // 2) * P)
+    f_edge = 2 * (kin * 2 * H) + 2 * 2 * (H * H // 2 + (H // 2) * P)
     return n_nodes * f_node + n_edges * f_edge, f_node, f_edge
 
 
-def pmc_traffic(bf):
-    """fabric-side bytes per launch pair from the committed rocprofv3 --pmc passes (profiles/*pmc_summary*: FETCH_SIZE and
-    WRITE_SIZE are KiB per dispatch; FETCH_SIZE doubled per MI355X_MICROARCH.md, HBM section: 16-B/lane reads are tallied at
-    half their bytes on gfx950).  Infinity-Cache hits are included in these counters, so this is an upper bound on HBM bytes.
-    None when the summary for the active kernel pair is not in the tree."""
-    path = os.path.join(ROOT, 'profiles', 'r01b_pmc_summary_bf16x3.txt' if bf else 'r01_pmc_summary_v2_eval_kernels.txt')
-    names = ('k_rowgemm_bf', 'k_edge_bf') if bf else ('k_ugemm', 'k_edge<')
+def executed_work(label, N, E, R, H, mma):
+    """(fp32-equivalent flops, matrix-pipe products per fp32 product, pipe) of one launch of the kernel behind a
+    ccsp_kernel_stats label -- what the kernels EXECUTE after the row factorisation; None for non-matrix kernels"""
+    prod = {'f16x2': (3, 'f16'), 'bf16x3': (6, 'bf16'), 'f32': (1, 'f32')}[mma]
+    table = {
+        'row GEMM (forward)': (2.0 * R * (2 * H) * H,) + prod,
+        'edge decoder (forward)': (2.0 * (2 * E) * (H // 2) * H,) + prod,
+        'node update + pose encoder': (2.0 * N * H * (H // 2), 1, 'f32'),
+        # energy-mode backward kernels run on the bf16x3 scheme unless CCSP_MMA=f32
+        'edge decoder backward': (2.0 * (2 * E) * H * (H // 2),) + ((1, 'f32') if mma == 'f32' else (6, 'bf16')),
+        'row GEMM (transpose)': (2.0 * R * H * (2 * H),) + ((1, 'f32') if mma == 'f32' else (6, 'bf16')),
+        'node energy backward': (2.0 * 2 * N * H * (H // 2), 1, 'f32'),
+    }
+    return table.get(label)
+
+
+KERNEL_SYMBOLS = {      # label -> kernel symbol prefix by GEMM mode (for the PMC traffic lookup and the report)
+    'row GEMM (forward)': {'f16x2': 'k_rowgemm_h2', 'bf16x3': 'k_rowgemm_bf2', 'f32': 'k_rowgemm<256, 512>'},
+    'edge decoder (forward)': {'f16x2': 'k_edge_h2', 'bf16x3': 'k_edge_bf2', 'f32': 'k_edge<256'},
+    'node update + pose encoder': {m: 'k_node<256>' for m in ('f16x2', 'bf16x3', 'f32')},
+    'edge decoder backward': {'f16x2': 'k_edge_bwd_bf', 'bf16x3': 'k_edge_bwd_bf', 'f32': 'k_edge_bwd<256>'},
+    'row GEMM (transpose)': {'f16x2': 'k_rowgemm_bf2<512, 256>', 'bf16x3': 'k_rowgemm_bf2<512, 256>', 'f32': 'k_rowgemm<512, 256>'},
+    'node energy backward': {m: 'k_node_energy_mfma' for m in ('f16x2', 'bf16x3', 'f32')},
+    'row sum of g_z': {m: 'k_rowsum' for m in ('f16x2', 'bf16x3', 'f32')},
+    'energy sum': {m: 'k_energy_sum' for m in ('f16x2', 'bf16x3', 'f32')},
+}
+
+
+def pmc_traffic(config, symbol):
+    """fabric-side bytes per launch of `symbol` from THIS round's rocprofv3 --pmc passes (profiles/r02_pmc_<config>.txt,
+    made by tools/pmc_run.sh: separate passes, FETCH_SIZE and WRITE_SIZE in KiB per dispatch; FETCH_SIZE doubled per
+    MI355X_MICROARCH.md, HBM section: 16-B/lane reads are tallied at half their bytes on gfx950).  Infinity-Cache hits are
+    included in these counters, so this is an upper bound on HBM bytes.  None when the summary does not hold the kernel."""
+    path = os.path.join(ROOT, 'profiles', 'r02_pmc_%s.txt' % config)
     try:
         cur, got = None, {}
         for line in open(path):
@@ -71,11 +134,11 @@ def pmc_traffic(bf):
                 cur = line.strip()
                 continue
             f = line.split()
-            if f[0] in ('FETCH_SIZE', 'WRITE_SIZE') and any(cur.startswith(n) for n in names):
-                got[(cur, f[0])] = float(f[2])
-        if len(got) != 4:
+            if f and f[0] in ('FETCH_SIZE', 'WRITE_SIZE') and cur is not None and cur.startswith(symbol):
+                got[f[0]] = float(f[2])
+        if len(got) != 2:
             return None
-        return sum(v * 1024.0 * (2.0 if k[1] == 'FETCH_SIZE' else 1.0) for k, v in got.items())
+        return got['FETCH_SIZE'] * 1024.0 * 2.0 + got['WRITE_SIZE'] * 1024.0
     except OSError:
         return None
 
@@ -85,11 +148,17 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--graphs-per-gpu', type=int, default=GRAPHS_PER_GPU)
+    ap.add_argument('--config', default='c2', choices=sorted(CONFIGS) + ['c3'])
+    ap.add_argument('--graphs-per-gpu', type=int, default=0, help='override the configuration\'s per-GPU shard size')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-evaluate', action='store_true', help='skip the Trainer.evaluate-style solved accounting (c2 only)')
     ap.add_argument('--force-dist', action='store_true', help='initialise RCCL even for one rank (exercises the N>1 code path)')
+    ap.add_argument('--mala-global-batch', action='store_true',
+                    help='c4 with N > 1: couple the shards through the reference\'s batch-scalar energies (2-float all_reduce per inner step)')
     args = ap.parse_args()
+    cname = 'c2' if args.config == 'c3' else args.config
+    cfg = CONFIGS[cname]
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -107,23 +176,27 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
-    from diffusion_ccsp_amd import ConstraintDiffuser, GaussianDiffusion, device_info, sharding, worlds
-    B = args.graphs_per_gpu
+    from diffusion_ccsp_amd import (ComposedEBMDenoiseFn, ConstraintDiffuser, GaussianDiffusion, device_info, sharding, worlds)
+    from diffusion_ccsp_amd import _lib
+    B = args.graphs_per_gpu or cfg['graphs']
+    mode, energy = cfg['mode'], cfg['energy']
+    dims = worlds.MODE_DIMS[mode]
+    P, grasp = dims[-1][0], len(dims) == 3
     # independent shards: rank r owns graphs [r*B, (r+1)*B) of the global batch (seed 5 + rank)
-    batch_np = worlds.qualitative_batch(B, N_OBJECTS, seed=5 + rank)
+    batch_np = getattr(worlds, cfg['batch'])(B, cfg['n_objects'], seed=5 + rank)
     n_nodes, n_edges = batch_np.x.shape[0], batch_np.edge_index.shape[1]
-    dims = worlds.MODE_DIMS['qualitative']
 
-    # weights: rank 0 reads the fixture, every other rank receives them over RCCL (xGMI)
-    # weights: the checkpoint trained on an MI355X with tools/train_gpu.py (the reference's recipe; the reference's own
-    # checkpoints are not in its tree) when it is in the tree, else the parity fixture
-    trained = os.path.join(ROOT, 'weights', 'qualitative_h%d_trained.npz' % HIDDEN)
-    wpath = trained if os.path.isfile(trained) else os.path.join(ROOT, 'tests', 'golden', 'weights_qualitative_h%d.npz' % HIDDEN)
-    den = ConstraintDiffuser(dims=dims, hidden_dim=HIDDEN, input_mode='qualitative', EBM='ULA', device=dev, verbose=False)
+    # weights: rank 0 reads the file, every other rank receives them over RCCL (xGMI)
+    wrel = next(w for w in cfg['weights'] if os.path.isfile(os.path.join(ROOT, w)))
+    wpath = os.path.join(ROOT, wrel)
+    den = ConstraintDiffuser(dims=dims, hidden_dim=HIDDEN, input_mode=mode, EBM=cfg['EBM'], energy_wrapper=energy, device=dev, verbose=False)
     sd = load_weights(wpath) if rank == 0 else None
     sd = sharding.broadcast_state_dict(sd, den.shapes(), dev, dist)
     den.load_state_dict(sd)
-    gd = GaussianDiffusion(den, timesteps=T_STEPS, EBM='ULA', samples_per_step=S_LANGEVIN)
+    fn = ComposedEBMDenoiseFn(den) if energy else den
+    gd = GaussianDiffusion(fn, timesteps=T_STEPS, EBM=cfg['EBM'], samples_per_step=S_LANGEVIN)
+    if args.mala_global_batch and dist is not None and cfg['EBM'] == 'MALA':
+        sharding.enable_global_batch_energy(gd, dist)
     base = batch_np.to_torch(dev)
 
     def one_step(k):
@@ -153,73 +226,106 @@ def main():
         elapsed = float(t.item())
     finite = bool(torch.isfinite(x).all().item())
     nan_graphs = len(set(batch_np.batch[(~torch.isfinite(x).all(dim=1)).cpu().numpy()].tolist()))
-    # "solved?" check of the last batch (diffusion-ccsp_amd/checker.py); outside the timed region
-    from diffusion_ccsp_amd import checker
-    solved = checker.solved_mask(x.detach().cpu().numpy(), batch_np)
-    n_solved = torch.tensor([int(solved.sum()), int(solved.size)], device=dev, dtype=torch.int64)
-    if dist is not None:
-        dist.all_reduce(n_solved)
-    solved_fraction = float(n_solved[0].item()) / max(1, int(n_solved[1].item()))
     samples = world * B * args.steps
     value = samples / elapsed
+    evals_per_chain = T_STEPS * (1 + (2 if cfg['EBM'] == 'MALA' else 1) * S_LANGEVIN)
 
     rec = {
-        'metric': 'solved samples/sec, T=1000 ULA, RandomSplitQualitativeWorld 8-obj',
+        'metric': 'samples/sec (all chains; solved_samples_per_s counts the solved ones), T=1000 %s, %s' % (cfg['EBM'], cfg['label'].split(':')[1].split(',')[0].strip() + ' %d-obj' % cfg['n_objects']),
         'value': value, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'C2: RandomSplitQualitativeWorld 8 objects, T=1000 ULA S=10, %d graphs per GPU, hidden_dim %d'
-                               % (B, HIDDEN),
-                   'graphs_per_gpu': B, 'nodes_per_gpu': n_nodes, 'edges_per_gpu': n_edges,
-                   'evaluations_per_chain': T_STEPS * (1 + S_LANGEVIN),
-                   'parallelism': 'independent graph shards x%d, RCCL weight broadcast + final gather only' % world,
-                   'weights': ('weights/qualitative_h256_trained.npz: 12 000 steps on one MI355X by tools/train_gpu.py with the reference recipe '
-                               '(p_losses l2, one t per batch, Adam 5e-4, batch 128) on worlds of 2-8 objects from this package\'s generator'
-                               if wpath == trained else
-                               'parity fixture tests/golden/weights_qualitative_h256.npz (2000 CPU steps of the reference loss)'),
-                   'solved_fraction': solved_fraction, 'solved_samples_per_s': value * solved_fraction,
-                   'solved_note': 'fraction of the last batch (one try per graph, no rejection) passing the collision + qualitative-'
-                                  'constraint check of diffusion-ccsp_amd/checker.py; value counts all samples, solved_samples_per_s the solved ones',
-                   'outputs_finite': finite, 'graphs_with_nonfinite_poses': nan_graphs,
-                   'nonfinite_note': 'the reference sampler itself overflows fp32 in its first timesteps on some graphs (ULA step 2*beta with beta -> 0.999; '
-                                     'Trainer.evaluate skips such graphs, ddpm.py:644); the CPU oracle reproduces the same rows, see DESIGN.md'},
+        'config': {'workload': '%s, %d graphs per GPU, hidden_dim %d' % (cfg['label'], B, HIDDEN),
+                   'name': args.config, 'graphs_per_gpu': B, 'nodes_per_gpu': n_nodes, 'edges_per_gpu': n_edges,
+                   'evaluations_per_chain': evals_per_chain,
+                   'parallelism': 'independent graph shards x%d, RCCL weight broadcast + final gather only' % world +
+                                  (' + MALA global-batch energies (2-float all_reduce per inner step)' if args.mala_global_batch and dist is not None and cfg['EBM'] == 'MALA' else ''),
+                   'gemm_mode': os.environ.get('CCSP_MMA', 'f16x2'),
+                   'weights': wrel, 'weights_storage': weights_storage(wpath), 'weights_note': WEIGHT_NOTES.get(wrel, ''),
+                   'outputs_finite': finite, 'graphs_with_nonfinite_poses': nan_graphs},
     }
 
+    if cname == 'c2':
+        # "solved?" check (diffusion-ccsp_amd/checker.py); outside the timed region
+        from diffusion_ccsp_amd import checker, evaluate
+        solved = checker.solved_mask(x.detach().cpu().numpy(), batch_np)
+        n_solved = torch.tensor([int(solved.sum()), int(solved.size)], device=dev, dtype=torch.int64)
+        if dist is not None:
+            dist.all_reduce(n_solved)
+        solved_fraction = float(n_solved[0].item()) / max(1, int(n_solved[1].item()))
+        rec['solved_fraction'] = solved_fraction
+        rec['solved_samples_per_s'] = value * solved_fraction
+        rec['config']['solved_note'] = ('solved_fraction = share of the last timed batch (one try per graph, no rejection) passing the collision + '
+                                        'qualitative-constraint check of diffusion-ccsp_amd/checker.py; the reference sampler itself overflows fp32 in its '
+                                        'first timesteps on some graphs (ULA step 2*beta with beta -> 0.999; Trainer.evaluate skips them, ddpm.py:644), see DESIGN.md section 7')
+        if rank == 0 and not args.no_evaluate:
+            # the reference's own accounting (Trainer.evaluate, ddpm.py:591-603,823-836): tries=(3, 0), top-1 / top-3
+            import tempfile
+            rng = np.random.default_rng(11)
+            sets = {}
+            for n_obj in (3, 8):
+                gs = []
+                for _ in range(100):
+                    wd = worlds.sample_qualitative_world(rng, n_obj)
+                    gs.append(worlds.encode_qualitative(wd['nodes'], wd['constraints']))
+                sets[n_obj] = gs
+            with tempfile.TemporaryDirectory() as td:
+                log = evaluate.Evaluator(gd, sets, td).evaluate(0, tries=(3, 0), run_all=True, seed=500)
+            rec['evaluate'] = {'pattern': 'Trainer.evaluate: test sets of 100 graphs, tries=(3, 0), batch size 100 (ddpm.py:591-603)',
+                               'sets': {k: {'success_rate': v['success_rate'], 'success_rate_top3': v['success_rate_top3'],
+                                            'sampling_s_per_graph': float(np.mean([s[2] for s in v['sampling_time']]))} for k, v in log.items()}}
+
     if rank == 0 and not args.no_roofline:
-        # separate profiled pass: HIP events around every k_ugemm / k_edge launch of the first 1024
-        # evaluations of one more chain, recorded on the stream the kernels run on
+        # separate profiled pass: a HIP event before every launch of one more chain, on the stream the kernels run on
         b = base.clone()
         gd.profile(b, True)
         gd.sample(b, seed=77)
         st = gd.chain_stats()
-        plan = __import__('diffusion_ccsp_amd')._lib.plan_host(n_nodes, 13, batch_np.edge_index, batch_np.edge_attr)
-        f_eval, f_node, f_edge = algorithmic_flops(n_nodes, plan['E_act'])
-        ms_eval = st['ms_ugemm'] + st['ms_edge']
-        exec_flops = 2.0 * plan['R'] * 2 * HIDDEN * HIDDEN + plan['E_act'] * 2 * 2 * (HIDDEN * HIDDEN // 2 + HIDDEN // 2 * 4) + n_nodes * f_node
-        ach = f_eval / (ms_eval * 1e-3) / 1e12 if ms_eval > 0 else None
-        bf = os.environ.get('CCSP_MMA', 'bf16x3') != 'f32'      # library default: fp32-accurate GEMMs as 6 bf16 MFMA products
-        gemm_flops = exec_flops - n_nodes * f_node               # the two evaluation kernels (the encoder runs in k_node)
-        exec_tf = gemm_flops / (ms_eval * 1e-3) / 1e12 if ms_eval > 0 else None
-        if bf:
-            pipe = {'instruction': 'v_mfma_f32_32x32x16_bf16 x6 per fp32 product (bf16x3 split operands)',
-                    'issued_tflops': 6.0 * exec_tf if exec_tf else None, 'pipe_peak_tflops': PEAK_BF16_MFMA_TFLOPS,
-                    'utilisation': (6.0 * exec_tf / PEAK_BF16_MFMA_TFLOPS) if exec_tf else None}
-        else:
-            pipe = {'instruction': 'v_mfma_f32_32x32x2_f32', 'issued_tflops': exec_tf, 'pipe_peak_tflops': PEAK_FP32_MFMA_TFLOPS,
-                    'utilisation': (exec_tf / PEAK_FP32_MFMA_TFLOPS) if exec_tf else None}
+        ks = gd.kernel_stats()
+        plan = _lib.plan_host(n_nodes, cfg['n_types'], batch_np.edge_index, batch_np.edge_attr)
+        R, E_act = plan['R'], plan['E_act']
+        mma = os.environ.get('CCSP_MMA', 'f16x2')
+        f_eval, f_node, f_edge = algorithmic_flops(n_nodes, E_act, HIDDEN, P, grasp)
+        kernels = []
+        for label, (calls, ms) in ks.items():
+            w = executed_work(label, n_nodes, E_act, R, HIDDEN, mma)
+            sym = KERNEL_SYMBOLS.get(label, {}).get(mma, '')
+            ent = {'kernel': label, 'symbol': sym, 'calls_timed': calls, 'us_mean': 1e3 * ms}
+            if w is not None:
+                flops, prods, pipe = w
+                ent.update({'executed_flops_fp32_equiv': flops, 'products_per_fp32_product': prods, 'pipe': pipe,
+                            'pipe_tflops': prods * flops / (ms * 1e-3) / 1e12, 'pipe_peak_tflops': PEAKS[pipe],
+                            'frac': prods * flops / (ms * 1e-3) / 1e12 / PEAKS[pipe]})
+            tr = pmc_traffic(args.config if args.config != 'c3' else 'c2', sym) if sym else None
+            if tr is not None:
+                ent['fabric_bytes_per_launch'] = tr
+            kernels.append(ent)
+        timed = sum(k['us_mean'] * k['calls_timed'] for k in kernels)
+        for k in kernels:
+            k['share_of_timed'] = k['us_mean'] * k['calls_timed'] / timed if timed else None
+        dom = max((k for k in kernels if 'frac' in k), key=lambda k: k['us_mean'] * k['calls_timed'])
+        # evaluations seen by the profiler = launches of the forward row GEMM
+        n_eval_timed = ks.get('row GEMM (forward)', (0, 0.0))[0]
+        us_eval = timed / n_eval_timed if n_eval_timed else None
         rec['roofline'] = {
-            'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': (ach / PEAK_FP32_MFMA_TFLOPS) if ach else None, 'traffic': pmc_traffic(bf),
-            'kernel': ('k_rowgemm_bf<256,512> + k_edge_bf<256>' if bf else 'k_rowgemm<256,512> + k_edge<256,false>') +
-                      ' (the two GEMM launches of one network evaluation)',
-            'note': 'achieved = ALGORITHMIC fp32 flops of the reference formulation / measured time, against the fp32 MFMA peak (the '
-                    'dtype of the arithmetic); the row factorisation executes 3.7x fewer flops, so frac > 1 is expected -- read '
-                    'matrix_pipe.utilisation for how busy the hardware is',
-            'algorithmic_flops_per_launch_pair': f_eval, 'flops_per_node': f_node, 'flops_per_edge': f_edge,
-            'ms_k_ugemm': st['ms_ugemm'], 'ms_k_edge': st['ms_edge'],
-            'executed_flops_per_launch_pair': gemm_flops, 'executed_tflops': exec_tf, 'matrix_pipe': pipe,
+            'bound': 'mfma', 'achieved': dom['pipe_tflops'], 'peak': dom['pipe_peak_tflops'], 'unit': 'TFLOP/s', 'frac': dom['frac'],
+            'traffic': dom.get('fabric_bytes_per_launch'),
+            'kernel': '%s: %s' % (dom['kernel'], dom['symbol']),
+            'note': 'achieved = flops the dominant kernel EXECUTES on the %s matrix pipe (%d MFMA products per fp32 product after the row '
+                    'factorisation) / its mean launch duration (HIP events on the chain stream, launch to next mark); peak = dense %s peak' %
+                    (dom['pipe'], dom['products_per_fp32_product'], dom['pipe']),
+            'frac_fp32_equiv': dom['executed_flops_fp32_equiv'] / (dom['us_mean'] * 1e-6) / 1e12 / PEAKS['f32'],
+            'kernels': kernels,
+            'us_per_evaluation_timed': us_eval,
+            'algorithmic': {'flops_per_evaluation': f_eval * (2 if energy else 1), 'flops_per_node': f_node, 'flops_per_edge': f_edge,
+                            'note': 'SURVEY.md 8(d): the reference\'s dense per-edge formulation (energy mode: forward + input gradient = 2x); '
+                                    'algorithmic_tflops = that / the timed evaluation, NOT a utilisation: the kernels execute %.2fx fewer flops'
+                                    % (f_eval / max(1.0, sum(k.get('executed_flops_fp32_equiv', 0.0) for k in kernels if k['kernel'] in
+                                                             ('row GEMM (forward)', 'edge decoder (forward)', 'node update + pose encoder')))),
+                            'algorithmic_tflops': (f_eval * (2 if energy else 1) / (us_eval * 1e-6) / 1e12) if us_eval else None,
+                            'whole_chain_algorithmic_tflops': f_eval * (2 if energy else 1) * st['evals'] / (st['ms_total'] * 1e-3) / 1e12 / (2 if energy else 1)},
             'chain_ms_event': st['ms_total'], 'chain_evals': st['evals'],
-            'whole_chain_algorithmic_tflops': f_eval * st['evals'] / (st['ms_total'] * 1e-3) / 1e12,
+            'profile_note': 'the profiled chain runs as one lane with an event per launch; its ms is not the timed value above',
         }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -227,8 +333,8 @@ def main():
         import torch_proxy                              # the checker / baseline port, never the product path
         cpu_batch = batch_np.to_torch('cpu')
         cpu_batch.num_graphs = B
-        r = torch_proxy.time_baseline(load_weights(wpath), dims, HIDDEN, 13, cpu_batch, T=T_STEPS, S=S_LANGEVIN,
-                                      n_timesteps=3, budget_s=25.0)
+        r = torch_proxy.time_baseline(load_weights(wpath), dims, HIDDEN, cfg['n_types'], cpu_batch, T=T_STEPS, S=S_LANGEVIN,
+                                      n_timesteps=3, budget_s=25.0, sampler=cfg['EBM'])
         rec['cpu_baseline'] = {'value': r['samples_per_s'], 'unit': 'samples/s', 'cores': r['cores'], 'kind': 'port',
                                'sample': r['sample'], 'sec_per_timestep': r['sec_per_timestep'],
                                'sec_per_eval_by_threads': r['sec_per_eval_by_threads'],
@@ -240,6 +346,8 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         sys.stderr.flush()
+        if 'solved_samples_per_s' in rec:
+            print('solved %.2f samples/s (%.1f %% of %.1f samples/s)' % (rec['solved_samples_per_s'], 100 * rec['solved_fraction'], value), file=sys.stderr)
         print(json.dumps(rec), flush=True)      # the one JSON line, after RCCL's own banner output
 
 

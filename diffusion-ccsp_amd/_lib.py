@@ -31,6 +31,9 @@ class CcspError(RuntimeError):
     pass
 
 
+ENERGY_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)      # (ctx, device float[2], stream) -> 0 / error
+
+
 class ModelDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'hidden_dim', 'pose_dim', 'pose_begin', 'geom_dim', 'grasp_dim', 'grasp_begin', 'n_types',
@@ -100,6 +103,7 @@ def lib():
     L.ccsp_chain_run.argtypes = [vp, vp, i32, C.POINTER(Noise), vp, i32, i32, i32, vp, vp, vp]
     L.ccsp_profile_enable.argtypes = [vp, i32]
     L.ccsp_chain_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.ccsp_model_set_energy_hook.argtypes = [vp, vp, vp]
     L.ccsp_kernel_stats.argtypes = [vp, i32, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.c_char_p, i32]
     L.ccsp_plan_host.argtypes = [i32, i32, i32] + [vp] * 14
     _lib = L

@@ -903,6 +903,8 @@ struct ccsp_model {
     unsigned short* Wd1H = nullptr;   // [2][H/2][H]      fp16 planes of pose_decoder.0.weight * 2^wd_exp
     int wp_exp = 0, wd_exp = 0;
     int ncu = 256;          // compute units of the device (residency-based kernel selection)
+    ccsp_energy_hook energy_hook = nullptr;   // MALA global-batch mode (ccsp_model_set_energy_hook)
+    void* energy_hook_ctx = nullptr;
     int row_mode = -1, edge_mt = -1;  // CCSP_ROW_MODE / CCSP_EDGE_MT: force a variant of the f16x2 kernels (-1: by tile count)
     // StructDiffusion baseline (model_kind 1): transformer weights as given ([out, in] row-major)
     struct SdLayer { float *in_w, *in_b, *out_w, *out_b, *ln1_g, *ln1_b, *fc_w, *fc_b, *proj_w, *proj_b, *ln2_g, *ln2_b; };
@@ -1481,6 +1483,9 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
                 a.step = STEP_MALA_PROPOSE;
                 launch_node<H>(m, g, a, s);                                   // x_hat, and its pose embedding
                 if (launch_eval_energy<H>(m, g, t, g->xhat, false, E_hat, s)) return 1;
+                // global-batch mode: E(x), E(x_hat) of this shard -> sums over all shards (the reference's energies are
+                // one scalar for the WHOLE batch, ddpm.py:1026-1038); the hook enqueues the reduction on the chain's stream
+                if (m->energy_hook && m->energy_hook(m->energy_hook_ctx, g->Escal, (void*)s)) return fail("chain_run: the energy hook failed");
                 NodeArgs b = node_args(m, g);
                 b.src = 1; b.eps_buf = g->eps; b.do_encode = 1; b.xhat = g->xhat; b.step = STEP_MALA_ACCEPT;
                 b.E_x = E_x; b.E_hat = E_hat; b.acc_count = g->acc_count + t;
@@ -2045,6 +2050,13 @@ void ccsp_model_destroy(ccsp_model* m) {
     if (m->capture_stream) (void)hipStreamDestroy(m->capture_stream);
     for (void* p : m->allocs) (void)hipFree(p);
     delete m;
+}
+
+int ccsp_model_set_energy_hook(ccsp_model* m, ccsp_energy_hook hook, void* ctx) {
+    if (!m) return fail("model_set_energy_hook: null model");
+    m->energy_hook = hook;
+    m->energy_hook_ctx = ctx;
+    return 0;
 }
 
 int ccsp_time_embedding(ccsp_model* m, int32_t t, float* out, void* stream) {

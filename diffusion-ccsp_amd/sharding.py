@@ -11,6 +11,12 @@ GPU.  The only communication is
 both through ``torch.distributed`` (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU
 tests).  Noise parity across shardings comes from the counter-based stream being indexed by the
 *global* node row (noise.py): a shard passes ``row_offset`` = index of its first node.
+
+MALA is the exception: the reference's accept test uses ONE energy for the whole batch
+(``logp_x`` / ``logp_x_hat`` of shape [1], ddpm.py:1026-1038), so the shards of a batch are coupled.
+Two modes: *replica semantics* (default; each shard is its own reference batch, no communication),
+and *global-batch* (``enable_global_batch_energy``): one all-reduce of 2 floats per MALA inner step
+(T x S = 10 000 per chain) makes the sharded run the reference's run at the full batch size.
 """
 import numpy as np
 import torch
@@ -101,3 +107,39 @@ def sample_sharded(sample_fn, batch, dist=None, seed=0):
         s, _ = shard_batch(batch, r, world)
         sizes.append(int(s.x.shape[0]))
     return gather_poses(x, dist, sizes)
+
+
+class _DevicePair(object):
+    """zero-copy torch view of the library's device float[2] {E(x), E(x_hat)}"""
+
+    def __init__(self, ptr):
+        self.__cuda_array_interface__ = {'shape': (2,), 'typestr': '<f4', 'data': (int(ptr), False), 'version': 2}
+
+
+def enable_global_batch_energy(gd, dist):
+    """MALA global-batch mode on the HIP path (ccsp_model_set_energy_hook): every inner step's shard energies are summed
+    over the ranks of `dist` on the chain's stream before the accept test -- ``ncclAllReduce(sum, 2 floats)`` over
+    RCCL/xGMI.  Call again after the denoiser's weights are reloaded (the native model is re-created).  ``dist=None``
+    removes the hook.  The per-timestep acceptance rates a rank reads back remain those of its own shard."""
+    from . import _lib
+    core = gd._core()
+    h = gd._handle()
+    if dist is None:
+        _lib.check(_lib.lib().ccsp_model_set_energy_hook(h, None, None))
+        core._energy_hook = None
+        return
+    views = {}
+
+    def hook(ctx, ptr, stream):
+        try:
+            t = views.get(ptr)
+            if t is None:
+                t = views[ptr] = torch.as_tensor(_DevicePair(ptr), device=core.device)
+            dist.all_reduce(t)              # on the current stream = the stream the chain is enqueued on
+            return 0
+        except Exception:                   # noqa: never let an exception cross the C boundary
+            return 1
+    cb = _lib.ENERGY_HOOK(hook)
+    core._energy_hook = (cb, views)         # keep the trampoline alive as long as the model
+    import ctypes as C
+    _lib.check(_lib.lib().ccsp_model_set_energy_hook(h, C.cast(cb, C.c_void_p), None))

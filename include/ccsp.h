@@ -153,6 +153,15 @@ int ccsp_chain_run(ccsp_model* model, ccsp_graph* graph, int32_t sampler, const 
                    float* x, int32_t init, int32_t t_first, int32_t t_last, float* history,
                    float* accept, void* stream);
 
+/* MALA across shards.  The reference's accept test uses ONE energy for the whole batch
+ * (logp_x, logp_x_hat of shape [1], ddpm.py:1026-1038), so a batch cut into per-GPU shards only reproduces the
+ * unsharded chain if the shards' energies are summed.  With a hook installed, every MALA inner step calls
+ * hook(ctx, pair, stream) between the energy evaluation at the proposal and the accept step: pair = DEVICE float[2]
+ * {E(x), E(x_hat)} of this shard; the hook replaces both by their sums over all shards with work enqueued on `stream`
+ * (e.g. an RCCL all_reduce) and returns 0.  NULL removes the hook (replica semantics: each shard is its own batch). */
+typedef int (*ccsp_energy_hook)(void* ctx, float* pair, void* stream);
+int ccsp_model_set_energy_hook(ccsp_model* model, ccsp_energy_hook hook, void* ctx);
+
 /* Kernel-level timing of the most recent ccsp_chain_run on this graph, measured with HIP events
  * on the chain's stream (bench.py's roofline block).  evals = network evaluations executed,
  * ms_total = event time of the whole chain.  After ccsp_profile_enable(graph, 1) the launches of a chain

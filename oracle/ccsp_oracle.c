@@ -39,6 +39,8 @@ struct ccspo_model {
     float *betas, *ac, *acp, *sqrt_recip_ac, *sqrt_recipm1_ac, *post_lv, *post_var, *coef1, *coef2, *kappa, *step;
     int32_t* sps;
     real* temb;               /* [T,H] lazily filled */
+    ccspo_energy_hook energy_hook;   /* MALA global-batch mode: shard energies -> batch energies (NULL: replica semantics) */
+    void* energy_hook_ctx;
     uint8_t* temb_ok;
 };
 
@@ -591,11 +593,13 @@ static void denoise_real(ccspo_model* m, const ccspo_graph* g, eval_ws* ws, int 
 }
 
 /* energy mode: E = sum |o - pose|^2 and dE/dposes (denoise_fn.py:373-375,518-519,539-548) */
-static void energy_real(ccspo_model* m, const ccspo_graph* g, eval_ws* ws, int t, real* grad, real* energy) {
+/* The batch energy is accumulated in double (per-edge terms in `real`) and rounded once: the sum then does not
+ * depend on how a batch is cut into shards beyond 1e-16 (ccspo_model_set_energy_hook). */
+static void energy_real_d(ccspo_model* m, const ccspo_graph* g, eval_ws* ws, int t, real* grad, real* energy, double* energy_d) {
     int H = m->d.hidden_dim, P = m->d.pose_dim, N = g->N, h2 = H / 2;
     real* gpemb = (real*)xcalloc((size_t)N * H, sizeof(real));
     eval_forward(m, g, ws, t, 1, gpemb);
-    real E = 0;
+    double E = 0;
     memset(grad, 0, sizeof(real) * (size_t)N * P);
     for (int k = 0; k < g->n_active; ++k) {
         int e = g->order[k];
@@ -607,7 +611,7 @@ static void energy_real(ccspo_model* m, const ccspo_graph* g, eval_ws* ws, int t
                 Ee += dlt * dlt;
                 grad[(size_t)nd[s] * P + p] += (real)(-2) * dlt;            /* direct term */
             }
-        E += Ee;
+        E += (double)Ee;
     }
     for (int n = 0; n < N; ++n) {                                           /* through the pose encoder */
         real gy2[2048], gs1[1024];
@@ -617,8 +621,13 @@ static void energy_real(ccspo_model* m, const ccspo_graph* g, eval_ws* ws, int t
         for (int k = 0; k < h2; ++k) gs1[k] *= silu_grad(ws->y1[(size_t)n * h2 + k]);
         lin_bwd_in(&m->pe0, gs1, grad + (size_t)n * P, 0, P);
     }
-    *energy = E;
+    *energy = (real)E;
+    if (energy_d) *energy_d = E;
     free(gpemb);
+}
+
+static void energy_real(ccspo_model* m, const ccspo_graph* g, eval_ws* ws, int t, real* grad, real* energy) {
+    energy_real_d(m, g, ws, t, grad, energy, NULL);
 }
 
 static int check_t(const ccspo_model* m, int t) { return t >= 0 && t < m->d.timesteps; }
@@ -632,6 +641,13 @@ int ccspo_denoise(ccspo_model* m, ccspo_graph* g, const float* poses_in, int32_t
     denoise_real(m, g, &ws, t, o);
     for (size_t i = 0; i < (size_t)g->N * P; ++i) out[i] = (float)o[i];
     free(o); ws_free(&ws);
+    return 0;
+}
+
+int ccspo_model_set_energy_hook(ccspo_model* m, ccspo_energy_hook hook, void* ctx) {
+    if (!m) FAIL("model_set_energy_hook: null model");
+    m->energy_hook = hook;
+    m->energy_hook_ctx = ctx;
     return 0;
 }
 
@@ -856,7 +872,8 @@ int ccspo_chain_run(ccspo_model* m, ccspo_graph* g, int32_t sampler, const ccspo
         for (int s = 0; s < S; ++s) {
             memcpy(ws.poses, x, sizeof(real) * NP);
             real Ex = 0;
-            if (d->energy_wrapper) energy_real(m, g, &ws, t, eps, &Ex); else denoise_real(m, g, &ws, t, eps);
+            double pair[2] = {0, 0};                                         /* E(x), E(x_hat) in double for the shard hook */
+            if (d->energy_wrapper) energy_real_d(m, g, &ws, t, eps, &Ex, &pair[0]); else denoise_real(m, g, &ws, t, eps);
             if ((rc = noise_normal(nz, call0[t] + 1 + (uint64_t)s, N, P, z))) goto done;
             if (sampler != CCSPO_SAMPLER_MALA) {
                 /* AnnealedULASampler.sample_step (ddpm.py:956-966): x + grad*ss + noise*std */
@@ -874,7 +891,12 @@ int ccspo_chain_run(ccspo_model* m, ccspo_graph* g, int32_t sampler, const ccspo
                 /* energy_function re-evaluates the model at x and x_hat (ddpm.py:285-289, :1026-1027) */
                 real Ehat = 0;
                 memcpy(ws.poses, xhat, sizeof(real) * NP);
-                energy_real(m, g, &ws, t, scratch, &Ehat);
+                energy_real_d(m, g, &ws, t, scratch, &Ehat, &pair[1]);
+                if (m->energy_hook) {                                         /* shards -> the whole batch's energies */
+                    if (m->energy_hook(m->energy_hook_ctx, pair)) { rc = 1; snprintf(g_err, sizeof(g_err), "chain_run: the energy hook failed"); goto done; }
+                    Ex = (real)pair[0];
+                    Ehat = (real)pair[1];
+                }
                 real logp_x = (-Ex) * kappa, logp_xhat = (-Ehat) * kappa;     /* one scalar for the whole batch */
                 if ((rc = noise_uniform(nz, ucall0[t] + (uint64_t)s, N, u))) goto done;
                 real var = std * std, log_scale = r_log(std);

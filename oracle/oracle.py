@@ -141,6 +141,25 @@ class OracleModel(object):
         self._check(self.L.ccspo_schedule_set(self.h, None if b is None else _ptr(b), None if s is None else _ptr(s),
                                               None if sp is None else _ptr(sp), default))
 
+    def set_energy_hook(self, fn):
+        """MALA global-batch mode: fn(pair: float64 numpy view of length 2) sums the shard's {E(x), E(x_hat)} over all
+        shards in place (e.g. a torch.distributed all_reduce); None removes it"""
+        HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double))
+        self.L.ccspo_model_set_energy_hook.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        if fn is None:
+            self._hook = None
+            self._check(self.L.ccspo_model_set_energy_hook(self.h, None, None))
+            return
+
+        def trampoline(ctx, pair):
+            try:
+                fn(np.ctypeslib.as_array(pair, shape=(2,)))
+                return 0
+            except Exception:           # noqa: never let an exception cross the C boundary
+                return 1
+        self._hook = HOOK(trampoline)
+        self._check(self.L.ccspo_model_set_energy_hook(self.h, C.cast(self._hook, C.c_void_p), None))
+
     def schedule(self):
         out = {}
         for i, k in enumerate(SCHEDULE_KEYS):

@@ -27,7 +27,8 @@ def _lin(x, w, b):
 
 class ProxyDiffuser(object):
     def __init__(self, weights, dims, hidden_dim, n_types, normalize=True):
-        self.W = {k: torch.as_tensor(np.asarray(v), dtype=torch.float32) for k, v in weights.items()}
+        # parameters like the reference module's (requires_grad): in energy mode autograd then records the same graph
+        self.W = {k: torch.as_tensor(np.asarray(v), dtype=torch.float32).clone().requires_grad_(True) for k, v in weights.items()}
         self.dims, self.H, self.C, self.normalize = dims, hidden_dim, n_types, normalize
         self.grasp = len(dims) == 3
         self.P = dims[-1][0]
@@ -46,7 +47,16 @@ class ProxyDiffuser(object):
         h = F.mish(_lin(emb, self.W['time_mlp.1.weight'], self.W['time_mlp.1.bias']))
         return _lin(h, self.W['time_mlp.3.weight'], self.W['time_mlp.3.bias'])
 
-    def __call__(self, poses_in, batch, t):
+    def energy_grad(self, poses_in, batch, t):
+        """energy mode (ComposedEBMDenoiseFn, denoise_fn.py:57-83,373-375,539-548): E = sum over (edge, slot) |o - pose|^2 and
+        dE/dposes through autograd, like the reference (every call is a forward AND a backward pass)"""
+        with torch.enable_grad():
+            poses = poses_in.detach().clone().requires_grad_(True)
+            energy = self.__call__(poses, batch, t, energy=True)
+            grad = torch.autograd.grad(energy, poses)[0]
+        return grad.detach(), energy.detach()
+
+    def __call__(self, poses_in, batch, t, energy=False):
         H, P = self.H, self.P
         x = batch.x.clone()
         geoms_emb = self._mlp2('geom_encoder', x[:, :self.dims[0][2]])
@@ -55,13 +65,15 @@ class ProxyDiffuser(object):
         edge_index = batch.edge_index.T
         out = torch.zeros_like(poses_in)
         cnt = torch.zeros_like(poses_in[:, 0])
+        total_energy = 0
         for i in range(self.C):
             edges = torch.where(batch.edge_attr == i)[0]
             edges = edges.detach().cpu().numpy()
             if edges.shape[0] == 0:
                 continue
             args = torch.stack([edge_index[edges][:, 0], edge_index[edges][:, 1]], dim=1)
-            temb = self.time_mlp(t.expand(edges.shape[0]))
+            # [E_i, 1] rows through the time MLP as a 3-D batch, then [:, 0] -- the shape the reference feeds (denoise_fn.py:328)
+            temb = self.time_mlp(t.unsqueeze(0).expand(edges.shape[0], *t.shape))[:, 0]
             parts = [geoms_emb[args].reshape(len(edges), -1), poses_emb[args].reshape(len(edges), -1), temb]
             if self.grasp:
                 parts = [grasp_emb[args[:, 0]]] + parts
@@ -69,10 +81,15 @@ class ProxyDiffuser(object):
             h = F.silu(_lin(inputs, self.W['mlps.%d.0.weight' % i], self.W['mlps.%d.0.bias' % i]))
             h = torch.stack([h[:, :H], h[:, H:]], dim=1)
             o = self._mlp2('pose_decoder', h, last_act=False)
+            if energy:
+                total_energy = total_energy + ((o - poses_in[args]) ** 2).sum()
+                continue
             flat = args.reshape(-1)
             o = o.reshape(-1, P)
             out.scatter_add_(0, flat.unsqueeze(-1).expand(o.shape), o)
             cnt += torch.bincount(flat, minlength=out.shape[0])
+        if energy:
+            return total_energy
         if self.normalize:
             out /= torch.sqrt(cnt.unsqueeze(-1))
         m = batch.mask.bool()
@@ -114,6 +131,33 @@ def timestep(model, sch, batch, x, t, S, noise_fn):
     return x
 
 
+def mala_timestep(model, sch, batch, x, t, S, noise_fn, uniform_fn):
+    """one timestep of the MALA chain on an energy-mode model: ancestral step with epsilon = dE/dposes, then S inner steps of
+    AnnealedMALASampler.sample_step (ddpm.py:1013-1047) -- the gradient at x plus the energy function at x and at the proposal,
+    each a forward + backward pass as in the reference (energy_function -> neg_logp_unnorm -> model.forward(tag='EBM'))"""
+    tt = torch.full((1,), t, dtype=torch.long)
+    eps, _ = model.energy_grad(x, batch, tt)
+    x0 = sch['a'][t] * x - sch['b'][t] * eps
+    mean = sch['c1'][t] * x0 + sch['c2'][t] * x
+    x = mean + (0 if t == 0 else 1) * (0.5 * sch['lv'][t]).exp() * noise_fn()
+    ss = 2 * sch['betas'][t]
+    std = (2 * ss) ** .5
+    for _ in range(S):
+        g, _ = model.energy_grad(x, batch, tt)
+        grad = -g * sch['kappa'][t]
+        mu = x + grad * ss
+        x_hat = mu + noise_fn() * std
+        logp_x = -model.energy_grad(x, batch, tt)[1] * sch['kappa'][t]
+        logp_x_hat = -model.energy_grad(x_hat, batch, tt)[1] * sch['kappa'][t]
+        dist = torch.distributions.Normal(mu, torch.ones_like(x) * std)
+        logp_accept = logp_x_hat - logp_x + dist.log_prob(x).sum(1) - dist.log_prob(x_hat).sum(1)
+        accept = (uniform_fn() < torch.exp(logp_accept)).float()
+        x = accept[:, None] * x_hat + (1 - accept[:, None]) * x
+    m = batch.mask.bool()
+    x[m] = batch.x[:, model.dims[-1][1]:model.dims[-1][2]][m]
+    return x
+
+
 @torch.no_grad()
 def sample(model, batch, T, S, noise_fn):
     sch = cosine_schedule(T)
@@ -127,7 +171,7 @@ def sample(model, batch, T, S, noise_fn):
 
 
 def time_baseline(weights, dims, hidden_dim, n_types, batch, T=1000, S=10, n_timesteps=3, budget_s=25.0,
-                  thread_candidates=(8, 16, 32, 64)):
+                  thread_candidates=(8, 16, 32, 64), sampler='ULA'):
     """times full timesteps (1+S evaluations each) of the proxy on the host cores and extrapolates x T.
     PyTorch-CPU does not scale to every core of a large host on these small matrices (128 threads were
     4x slower than 8 on the GPU box), so one timestep is timed per candidate thread count first and the
@@ -138,25 +182,33 @@ def time_baseline(weights, dims, hidden_dim, n_types, batch, T=1000, S=10, n_tim
     g = torch.Generator().manual_seed(0)
     N, P = batch.x.shape[0], dims[-1][0]
     noise_fn = lambda: torch.randn((N, P), generator=g)  # noqa: E731
+    uniform_fn = lambda: torch.rand((N,), generator=g)  # noqa: E731
+    mala = sampler == 'MALA'
+    if mala:
+        step = lambda xx, t, s: mala_timestep(model, sch, batch, xx, t, s, noise_fn, uniform_fn)  # noqa: E731
+        evals = lambda s: 1 + 3 * s  # noqa: E731  (forward + backward each)
+    else:
+        step = lambda xx, t, s: timestep(model, sch, batch, xx, t, s, noise_fn)  # noqa: E731
+        evals = lambda s: 1 + s  # noqa: E731
     x = 0.5 * noise_fn()
     max_threads = torch.get_num_threads()
     cands = sorted(set(min(c, max_threads) for c in thread_candidates))
-    timestep(model, sch, batch, x, T // 2, 1, noise_fn)          # warm-up (allocator, threads)
+    step(x, T // 2, 0 if mala else 1)                             # warm-up (allocator, threads)
     t_all = time.time()
     trial = {}
     for c in cands:
         torch.set_num_threads(c)
-        timestep(model, sch, batch, x, T // 2, 0, noise_fn)
+        step(x, T // 2, 0)
         t0 = time.time()
-        timestep(model, sch, batch, x, T // 2, 2, noise_fn)      # 3 evaluations
-        trial[c] = (time.time() - t0) / 3.0
+        step(x, T // 2, 1 if mala else 2)                         # 4 (MALA) / 3 evaluations
+        trial[c] = (time.time() - t0) / (4.0 if mala else 3.0)
         if time.time() - t_all > budget_s * 0.5:
             break
     best = min(trial, key=trial.get)
     torch.set_num_threads(best)
     done, t0 = 0, time.time()
     for k in range(n_timesteps):
-        x = timestep(model, sch, batch, x, T - 1 - k, S, noise_fn)
+        x = step(x, T - 1 - k, S)
         done += 1
         if time.time() - t_all > budget_s:
             break
@@ -165,5 +217,6 @@ def time_baseline(weights, dims, hidden_dim, n_types, batch, T=1000, S=10, n_tim
     n_graphs = int(batch.num_graphs) if hasattr(batch, 'num_graphs') else 1
     return dict(samples_per_s=n_graphs / (dt * T), sec_per_timestep=dt, cores=best,
                 sec_per_eval_by_threads={int(k): float(v) for k, v in trial.items()},
-                sample='%d full timesteps (%d network evaluations) of the %d-graph batch at %d threads (best of %s), '
-                       'extrapolated x%d/%d' % (done, done * (1 + S), n_graphs, best, list(trial.keys()), T, done))
+                sample='%d full %s timesteps (%d network evaluations%s) of the %d-graph batch at %d threads (best of %s), '
+                       'extrapolated x%d/%d' % (done, sampler, done * evals(S), ', forward + backward each' if mala else '', n_graphs, best,
+                                                list(trial.keys()), T, done))

@@ -101,3 +101,36 @@ def test_schedule_set_validates_its_arguments(device):
     xb = gb.sample(b, seed=2)
     assert gb.chain_stats()['evals'] == 30 * 2
     assert torch.equal(ga.sample(b, seed=2), xa) and torch.equal(gb.sample(b, seed=2), xb)
+
+
+def test_mala_energy_hook_is_called_on_the_chain_stream(device):
+    """MALA global-batch mode (ccsp_model_set_energy_hook through sharding.enable_global_batch_energy): with a one-rank
+    'reduction' the chain is bit-equal to the hook-free run; a reduction that changes the energies changes the accept
+    decisions; removing the hook restores the first result"""
+    from diffusion_ccsp_amd import ComposedEBMDenoiseFn, ConstraintDiffuser, GaussianDiffusion, sharding
+    den = ConstraintDiffuser(dims=worlds.MODE_DIMS['diffuse_pairwise'], hidden_dim=64, input_mode='diffuse_pairwise', EBM='MALA',
+                             energy_wrapper=True, device=device, verbose=False)
+    den.load_state_dict(weights('weights_diffuse_pairwise_h64_energy.npz'))
+    gd = GaussianDiffusion(ComposedEBMDenoiseFn(den), timesteps=1000, EBM='MALA', samples_per_step=3)
+    b = worlds.triangular_batch(3, 6, seed=19).to_torch()
+    x0 = torch.zeros(b.x.shape[0], 4)
+
+    class OneRank(object):
+        def __init__(self, scale):
+            self.scale, self.calls = scale, 0
+
+        def all_reduce(self, t):
+            assert t.is_cuda and t.shape == (2,)
+            t.mul_(self.scale)
+            self.calls += 1
+    base = gd.p_sample_segment(b, x0, 400, 393, seed=5).cpu().numpy()
+    one = OneRank(1.0)
+    sharding.enable_global_batch_energy(gd, one)
+    same = gd.p_sample_segment(b, x0, 400, 393, seed=5).cpu().numpy()
+    assert one.calls == 8 * 3 and np.array_equal(same, base)
+    big = OneRank(64.0)
+    sharding.enable_global_batch_energy(gd, big)
+    other = gd.p_sample_segment(b, x0, 400, 393, seed=5).cpu().numpy()
+    assert big.calls == 8 * 3 and not np.array_equal(other, base)
+    sharding.enable_global_batch_energy(gd, None)
+    assert np.array_equal(gd.p_sample_segment(b, x0, 400, 393, seed=5).cpu().numpy(), base)

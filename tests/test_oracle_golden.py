@@ -339,6 +339,18 @@ def test_torch_proxy_matches_reference():
             with torch.no_grad():
                 got = model(torch.from_numpy(z[tag + '/poses'][i]), b, torch.tensor([int(t)])).numpy()
             assert rel_err(got, z[tag + '/out'][i]) < 1e-5
+    # energy mode (the C4 leg of bench.py's cpu_baseline): autograd gradient and energy vs the reference's
+    model = torch_proxy.ProxyDiffuser(weights('weights_diffuse_pairwise_h64_energy.npz'), worlds.MODE_DIMS['diffuse_pairwise'], 64, 2)
+    b = golden_batch(z, 't64e/')
+    for i, t in enumerate(z['t64e/t'][:3]):
+        grad, E = model.energy_grad(torch.from_numpy(z['t64e/poses'][i]), b, torch.tensor([int(t)]))
+        assert rel_err(grad.numpy(), z['t64e/grad'][i]) < 1e-5 and abs(float(E) - z['t64e/energy'][i]) <= 1e-5 * (1 + abs(z['t64e/energy'][i]))
+    # and one MALA timestep runs (cost model of the baseline: 1 + 3 S forward+backward passes)
+    sch = torch_proxy.cosine_schedule(1000)
+    g = torch.Generator().manual_seed(0)
+    N = b.x.shape[0]
+    x = torch_proxy.mala_timestep(model, sch, b, torch.zeros(N, 4), 300, 2, lambda: torch.randn((N, 4), generator=g), lambda: torch.rand((N,), generator=g))
+    assert torch.isfinite(x).all()
 
 
 def test_timestep_restart_equals_full_chain():

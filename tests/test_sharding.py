@@ -77,3 +77,83 @@ def test_world_size_2_gloo_matches_unsharded():
     for rank, same, x in got:
         assert same, 'broadcast weights differ on rank %d' % rank
         assert np.array_equal(x, want), rank
+
+
+# ---------------------------------------------------------------- MALA: the batch-scalar energies couple the shards
+
+def _mala_model():
+    return oracle_model('diffuse_pairwise', 64, 'weights_diffuse_pairwise_h64_energy.npz', T=1000, S=3, energy=True)
+
+
+def _mala_batch():
+    return worlds.triangular_batch(3, 6, seed=19)             # 3 graphs -> shards of 2 + 1
+
+
+def _mala_start():
+    b = _mala_batch()
+    x0 = (np.random.default_rng(4).standard_normal((b.x.shape[0], 4)) * 0.3).astype(np.float32)
+    m = b.mask.astype(bool)
+    x0[m] = b.x[m][:, 3:7]
+    return x0
+
+
+def _mala_worker(rank, world, port, q, global_batch):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    m = _mala_model()
+    calls = [0]
+    if global_batch:
+        def hook(pair):                                       # {E(x), E(x_hat)} of this shard -> of the whole batch
+            t = torch.from_numpy(pair)
+            dist.all_reduce(t)
+            calls[0] += 1
+        m.set_energy_hook(hook)
+
+    x0 = _mala_start()
+
+    def fn(sub, seed, row_offset):
+        xs = x0[row_offset:row_offset + sub.x.shape[0]]
+        return torch.from_numpy(m.graph(sub.to_torch()).chain('MALA', seed=seed, row_offset=row_offset, x=xs, t_first=300, t_last=293))
+    x = sharding.sample_sharded(fn, _mala_batch(), dist, seed=23)
+    q.put((rank, x.numpy(), calls[0]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_mala(global_batch):
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_mala_worker, args=(r, world, port, q, global_batch)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return got
+
+
+def test_mala_global_batch_world_size_2_matches_unsharded():
+    """with the shards' energies summed before every accept test (one 2-float all_reduce per MALA inner step)
+    the sharded chain IS the reference's chain at the full batch size: bit-equal to the unsharded oracle run.  Without the
+    hook each shard is its own reference batch (replica semantics): a different, equally valid, chain."""
+    batch = _mala_batch()
+    x0 = _mala_start()
+    want, acc = _mala_model().graph(batch.to_torch()).chain('MALA', seed=23, x=x0, t_first=300, t_last=293, accept=True)
+    assert 0.05 < acc[293:301].mean() < 0.95                  # timesteps where proposals are both accepted and rejected
+    got = _run_mala(True)
+    for rank, x, calls in got:
+        assert calls == 8 * 3, calls                          # one reduction per inner step of the 8 timesteps
+        assert np.array_equal(x, want), rank
+    replica = _run_mala(False)
+    assert np.array_equal(replica[0][1], replica[1][1]) and not np.array_equal(replica[0][1], want)
+    # replica semantics = every shard run as a batch of its own
+    parts = []
+    for r in range(2):
+        sub, r0 = sharding.shard_batch(batch, r, 2)
+        parts.append(_mala_model().graph(sub.to_torch()).chain('MALA', seed=23, row_offset=r0, x=x0[r0:r0 + sub.x.shape[0]], t_first=300, t_last=293))
+    assert np.array_equal(replica[0][1], np.concatenate(parts))

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/abl_*; for so in "" $(ls $R/tools/abl_*.so 2>/dev/null); do
   tag=$(basename "${so:-default}" .so)
-  CCSP_SO=$so timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/abl_$tag --output-format csv -- python $R/tools/profile_eval.py 100 > /dev/null 2>&1
+  CCSP_SO=$so timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/abl_$tag --output-format csv -- python $R/tools/profile_eval.py ${EVALS:-100} ${GRAPHS:-256} > /dev/null 2>&1
   f=$(find /tmp/abl_$tag -name "*kernel_stats.csv" | head -1)
   echo "== $tag"
   python - "$f" <<'PY'
