@@ -346,6 +346,11 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         sys.stderr.flush()
+        try:                                     # RCCL prints its version banner through C stdio: flush it out BEFORE the JSON line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:                        # noqa
+            pass
         if 'solved_samples_per_s' in rec:
             print('solved %.2f samples/s (%.1f %% of %.1f samples/s)' % (rec['solved_samples_per_s'], 100 * rec['solved_fraction'], value), file=sys.stderr)
         print(json.dumps(rec), flush=True)      # the one JSON line, after RCCL's own banner output

@@ -93,6 +93,9 @@ def lib():
     L.ccsp_schedule_set.argtypes = [vp, i32, vp, vp, vp, i32]
     L.ccsp_schedule_get.argtypes = [vp, i32, vp]
     L.ccsp_time_embedding.argtypes = [vp, i32, vp, vp]
+    L.ccsp_encode.argtypes = [vp, i32, i32, vp, vp, vp]
+    L.ccsp_time_mlp.argtypes = [vp, i32, vp, vp, vp]
+    L.ccsp_process_constraint.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
     L.ccsp_graph_create.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, C.POINTER(vp)]
     L.ccsp_graph_destroy.argtypes = [vp]
     L.ccsp_graph_set_sequences.argtypes = [vp, vp, vp, vp]

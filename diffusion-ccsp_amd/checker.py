@@ -14,9 +14,11 @@ calls ``check_constraints_satisfied`` (envs/worlds.py:734-764): a sample is solv
 Restated here without trimesh / python-fcl:
   * the labeller is worlds.qualitative_constraints (pinned against the reference by golden vectors);
   * FCL is not importable in the build container, so box-box collision is a separating-axis test on the
-    oriented footprints (all bodies span the same z range).  **Parity of exactly-touching boxes is
-    unpinned** (FCL's contact tolerance is unknown); strictly overlapping / strictly apart agree by
-    geometry.
+    oriented footprints (all bodies span the same z range).  Strictly overlapping / strictly apart boxes agree
+    with any exact box-box query by geometry.  **At exact contact the two may differ**: here projections that
+    overlap by <= 1e-9 count as touching = not colliding, FCL may report a contact at zero distance; this can
+    only matter for poses that lie exactly on a boundary -- a measure-zero set for sampled poses, and the
+    generator's scenes keep > 1e-4 clearance (tests/test_checker.py::test_touching_and_near_touching_boxes).
 
 Reference quirk kept: the feature columns are stored [w, l, x, y, cs, sn] but unpacked as
 ``w, l, x, y, sn, cs`` (data_utils.py:246), so the yaw used downstream is atan2(col4, col5).

@@ -99,7 +99,7 @@ __global__ void k_sinusoid(int T, int H, float* __restrict__ e) {
 
 // y[r, o] = act(b[o] + sum_k x[r,k] W[o,k]); one thread per output (set-up only, not hot)
 __global__ void k_linear_rows(int R, int K, int O, const float* __restrict__ x, int ldx, const float* __restrict__ W, int ldw,
-                              const float* __restrict__ b, int act /*0 none, 1 mish*/, float* __restrict__ y, int ldy) {
+                              const float* __restrict__ b, int act /*0 none, 1 mish, 2 silu*/, float* __restrict__ y, int ldy) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)R * O) return;
     const int r = (int)(idx / O), o = (int)(idx % O);
@@ -109,7 +109,40 @@ __global__ void k_linear_rows(int R, int K, int O, const float* __restrict__ x, 
     for (int k = 0; k < K; ++k) acc = fmaf(xr[k], wr[k], acc);
     acc += b ? b[o] : 0.0f;
     if (act == 1) acc = mish_f(acc);
+    if (act == 2) acc = silu_f(acc);
     y[(size_t)r * ldy + o] = acc;
+}
+
+// SinusoidalPosEmb for arbitrary (float) t values: e[r, :] like k_sinusoid (operator API, not hot)
+__global__ void k_sinusoid_values(int R, int H, const float* __restrict__ tv, float* __restrict__ e) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = H / 2;
+    if (idx >= R * half) return;
+    const int r = idx / half, k = idx % half;
+    const float c = (float)(-(log(10000.0) / (double)(half - 1)));
+    const float a = tv[r] * expf((float)k * c);
+    e[(size_t)r * H + k] = sinf(a);
+    e[(size_t)r * H + half + k] = cosf(a);
+}
+
+// type MLP of ONE constraint type on caller-supplied embeddings (ConstraintDiffuser._process_constraint, denoise_fn.py:341-356):
+// h[r, o] = SiLU(b[o] + [grasp_a | geom_a geom_b | pose_a pose_b | time] . W[o, :]) from the per-segment weight slices
+__global__ void k_type_mlp_rows(int R, int H, const float* __restrict__ gr /*[R,H] or null*/, const float* __restrict__ ge /*[R,2,H]*/,
+                                const float* __restrict__ pe /*[R,2,H]*/, const float* __restrict__ te /*[R,H]*/,
+                                const float* __restrict__ Wr, const float* __restrict__ Wg0, const float* __restrict__ Wg1,
+                                const float* __restrict__ Wp0, const float* __restrict__ Wp1, const float* __restrict__ Wt,
+                                const float* __restrict__ bias, float* __restrict__ h /*[R,2H]*/) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)R * 2 * H) return;
+    const int r = (int)(idx / (2 * H)), o = (int)(idx % (2 * H));
+    float acc = 0.0f;                                     // segments in the order of the concatenated input
+    if (gr) for (int k = 0; k < H; ++k) acc = fmaf(gr[(size_t)r * H + k], Wr[(size_t)o * H + k], acc);
+    for (int k = 0; k < H; ++k) acc = fmaf(ge[((size_t)r * 2) * H + k], Wg0[(size_t)o * H + k], acc);
+    for (int k = 0; k < H; ++k) acc = fmaf(ge[((size_t)r * 2 + 1) * H + k], Wg1[(size_t)o * H + k], acc);
+    for (int k = 0; k < H; ++k) acc = fmaf(pe[((size_t)r * 2) * H + k], Wp0[(size_t)o * H + k], acc);
+    for (int k = 0; k < H; ++k) acc = fmaf(pe[((size_t)r * 2 + 1) * H + k], Wp1[(size_t)o * H + k], acc);
+    for (int k = 0; k < H; ++k) acc = fmaf(te[(size_t)r * H + k], Wt[(size_t)o * H + k], acc);
+    h[idx] = silu_f(acc + bias[o]);
 }
 
 // dst[r, c] = src[r, col0 + c]  (weight re-layout)
@@ -912,6 +945,9 @@ struct ccsp_model {
     float *lnpre_g = nullptr, *lnpre_b = nullptr, *lnpost_g = nullptr, *lnpost_b = nullptr;
     float* sd_pe = nullptr;   // [8][Wd] positional-encoding rows (transformer.py:22-28)
     SdLayer sd[4];
+    float *tm1_w = nullptr, *tm1_b = nullptr, *tm3_w = nullptr, *tm3_b = nullptr;   // time_mlp.{1,3} copies (operator API: float t)
+    float* Wt = nullptr;    // [C][2H][H]  time slices of the type MLPs, and their biases bt [C][2H] (operator API)
+    float* bt = nullptr;
     float* temb;   // [T][H]
     float* tau;    // [T][C][2H]      W_t . temb(t) + b_i
     std::vector<float> betas, ac, acp, sqrt_recip_ac, sqrt_recipm1_ac, post_lv, post_var, coef1, coef2, kappa, step;
@@ -1931,9 +1967,9 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     hipLaunchKernelGGL(k_transpose, dim3(nblk((long)(H / 2) * H, 256)), dim3(256), 0, s, H / 2, H, params[k], m->pd0_wT);
     TRY(dup(&m->pd0_w, (size_t)(H / 2) * H)); TRY(dup(&m->pd0_b, H / 2));
     TRY(dup(&m->pd2_w, (size_t)P * (H / 2))); TRY(dup(&m->pd2_b, P));
-    const float* tm1_w = params[k]; const float* tm1_b = params[k + 1];
-    const float* tm3_w = params[k + 2]; const float* tm3_b = params[k + 3];
-    k += 4;
+    TRY(dup(&m->tm1_w, (size_t)4 * H * H)); TRY(dup(&m->tm1_b, (size_t)4 * H));
+    TRY(dup(&m->tm3_w, (size_t)4 * H * H)); TRY(dup(&m->tm3_b, H));
+    const float *tm1_w = m->tm1_w, *tm1_b = m->tm1_b, *tm3_w = m->tm3_w, *tm3_b = m->tm3_b;
     // time embedding table temb[T,H] = time_mlp(t)  (denoise_fn.py:259-264)
     float *sinus = nullptr, *hid = nullptr;
     TRY(dev_alloc(reg, &sinus, (size_t)T * H));
@@ -1985,6 +2021,8 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     if (grasp) { TRY(dev_alloc(reg, &m->Wr, (size_t)C * 2 * WS)); HIP_TRY(hipMemsetAsync(m->Wr, 0, (size_t)C * 2 * WS * sizeof(float), s)); }
     TRY(dev_alloc(reg, &m->WpT, (size_t)C * 2 * WS));
     TRY(dev_alloc(reg, &m->tau, (size_t)T * C * 2 * H));
+    TRY(dev_alloc(reg, &m->Wt, (size_t)C * WS));
+    TRY(dev_alloc(reg, &m->bt, (size_t)C * 2 * H));
     const int off = grasp ? H : 0;
     for (int i = 0; i < C; ++i) {
         const float* Wi = params[k + 2 * i];
@@ -1995,6 +2033,8 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
         hipLaunchKernelGGL(k_copy_cols, dim3(gridc), dim3(256), 0, s, 2 * H, H, Wi, m->K_in, off + H, m->Wg + (size_t)(2 * i + 1) * WS, H);
         hipLaunchKernelGGL(k_copy_cols, dim3(gridc), dim3(256), 0, s, 2 * H, H, Wi, m->K_in, off + 2 * H, m->Wp + (size_t)(2 * i) * WS, H);
         hipLaunchKernelGGL(k_copy_cols, dim3(gridc), dim3(256), 0, s, 2 * H, H, Wi, m->K_in, off + 3 * H, m->Wp + (size_t)(2 * i + 1) * WS, H);
+        hipLaunchKernelGGL(k_copy_cols, dim3(gridc), dim3(256), 0, s, 2 * H, H, Wi, m->K_in, off + 4 * H, m->Wt + (size_t)i * WS, H);
+        HIP_TRY(hipMemcpyAsync(m->bt + (size_t)i * 2 * H, bi, (size_t)2 * H * sizeof(float), hipMemcpyDeviceToDevice, s));
         for (int sl = 0; sl < 2; ++sl)      // WpT[i, sl] [H, 2H] = Wp[i, sl]^T
             hipLaunchKernelGGL(k_transpose, dim3(gridc), dim3(256), 0, s, 2 * H, H, m->Wp + (size_t)(2 * i + sl) * WS, m->WpT + (size_t)(2 * i + sl) * WS);
         // tau[t, i, :] = Wi[:, time cols] . temb[t] + b_i
@@ -2063,6 +2103,68 @@ int ccsp_time_embedding(ccsp_model* m, int32_t t, float* out, void* stream) {
     if (!m || !out) return fail("time_embedding: null argument");
     if (t < 0 || t >= m->d.timesteps) return fail("time_embedding: t=%d out of range", t);
     HIP_TRY(hipMemcpyAsync(out, m->temb + (size_t)t * m->d.hidden_dim, sizeof(float) * m->d.hidden_dim, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+// ---- operator-level entry points (visualize_energy.py:402-450 calls the denoiser's sub-modules on its own tensors)
+int ccsp_encode(ccsp_model* m, int32_t which, int32_t n, const float* in, float* out, void* stream) {
+    if (!m || !in || !out) return fail("encode: null argument");
+    if (n < 1) return fail("encode: n=%d", n);
+    const ccsp_model_desc& d = m->d;
+    EncW w;
+    if (which == CCSP_ENC_GEOM) w = EncW{m->ge0_w, m->ge0_b, m->ge2_wT, m->ge2_b, d.geom_dim, nullptr};
+    else if (which == CCSP_ENC_POSE) w = EncW{m->pe0_w, m->pe0_b, m->pe2_wT, m->pe2_b, d.pose_dim, nullptr};
+    else if (which == CCSP_ENC_GRASP) {
+        if (d.grasp_dim <= 0) return fail("encode: the model has no grasp encoder");
+        w = EncW{m->gr0_w, m->gr0_b, m->gr2_wT, m->gr2_b, d.grasp_dim, nullptr};
+    } else return fail("encode: unknown encoder %d", which);
+    hipStream_t s = (hipStream_t)stream;
+    if (d.hidden_dim == 256) hipLaunchKernelGGL(k_encode<256>, dim3(nblk(n, NODE_TILE)), dim3(256), 0, s, n, in, w.in_dim, 0, w, out);
+    else hipLaunchKernelGGL(k_encode<64>, dim3(nblk(n, NODE_TILE)), dim3(256), 0, s, n, in, w.in_dim, 0, w, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ccsp_time_mlp(ccsp_model* m, int32_t n, const float* t_values, float* out, void* stream) {
+    if (!m || !t_values || !out) return fail("time_mlp: null argument");
+    if (n < 1) return fail("time_mlp: n=%d", n);
+    const int H = m->d.hidden_dim;
+    hipStream_t s = (hipStream_t)stream;
+    float *sinus = nullptr, *hid = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&sinus, (size_t)n * H * sizeof(float), s));
+    HIP_TRY(hipMallocAsync((void**)&hid, (size_t)n * 4 * H * sizeof(float), s));
+    hipLaunchKernelGGL(k_sinusoid_values, dim3(nblk((long)n * (H / 2), 256)), dim3(256), 0, s, n, H, t_values, sinus);
+    hipLaunchKernelGGL(k_linear_rows, dim3(nblk((long)n * 4 * H, 256)), dim3(256), 0, s, n, H, 4 * H, sinus, H, m->tm1_w, H, m->tm1_b, 1, hid, 4 * H);
+    hipLaunchKernelGGL(k_linear_rows, dim3(nblk((long)n * H, 256)), dim3(256), 0, s, n, 4 * H, H, hid, 4 * H, m->tm3_w, 4 * H, m->tm3_b, 0, out, H);
+    HIP_TRY(hipFreeAsync(sinus, s));
+    HIP_TRY(hipFreeAsync(hid, s));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ccsp_process_constraint(ccsp_model* m, int32_t type, int32_t n, const float* geoms_emb, const float* poses_emb, const float* time_emb,
+                            const float* grasp_emb, float* out, void* stream) {
+    if (!m || !geoms_emb || !poses_emb || !time_emb || !out) return fail("process_constraint: null argument");
+    const ccsp_model_desc& d = m->d;
+    if (d.model_kind != CCSP_MODEL_DIFFUSION_CCSP) return fail("process_constraint: StructDiffusion has no per-constraint MLPs");
+    if (type < 0 || type >= d.n_types) return fail("process_constraint: constraint type %d out of range", type);
+    if (n < 1) return fail("process_constraint: n=%d", n);
+    if ((d.grasp_dim > 0) != (grasp_emb != nullptr)) return fail("process_constraint: grasp_emb must be given exactly for 'robot' models");
+    const int H = d.hidden_dim, P = d.pose_dim;
+    const size_t WS = (size_t)2 * H * H;
+    hipStream_t s = (hipStream_t)stream;
+    float *h = nullptr, *q = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&h, (size_t)n * 2 * H * sizeof(float), s));
+    HIP_TRY(hipMallocAsync((void**)&q, (size_t)n * 2 * (H / 2) * sizeof(float), s));
+    hipLaunchKernelGGL(k_type_mlp_rows, dim3(nblk((long)n * 2 * H, 256)), dim3(256), 0, s, n, H, grasp_emb, geoms_emb, poses_emb, time_emb,
+                       m->Wr ? m->Wr + (size_t)(2 * type) * WS : (const float*)nullptr, m->Wg + (size_t)(2 * type) * WS, m->Wg + (size_t)(2 * type + 1) * WS,
+                       m->Wp + (size_t)(2 * type) * WS, m->Wp + (size_t)(2 * type + 1) * WS, m->Wt + (size_t)type * WS, m->bt + (size_t)type * 2 * H, h);
+    // pose_decoder on both halves: h [n, 2H] read as [2n, H]  (denoise_fn.py:357-366)
+    hipLaunchKernelGGL(k_linear_rows, dim3(nblk((long)2 * n * (H / 2), 256)), dim3(256), 0, s, 2 * n, H, H / 2, h, H, m->pd0_w, H, m->pd0_b, 2, q, H / 2);
+    hipLaunchKernelGGL(k_linear_rows, dim3(nblk((long)2 * n * P, 256)), dim3(256), 0, s, 2 * n, H / 2, P, q, H / 2, m->pd2_w, H / 2, m->pd2_b, 0, out, P);
+    HIP_TRY(hipFreeAsync(h, s));
+    HIP_TRY(hipFreeAsync(q, s));
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 

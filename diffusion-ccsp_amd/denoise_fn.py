@@ -296,12 +296,53 @@ class ConstraintDiffuser(object):
 
     # ---- the reference's call surface ---------------------------------------------------
     def time_mlp(self, t):
-        """time embedding rows for integer timesteps t [n] -> [n, H] (denoise_fn.py:259-264)"""
-        L = _lib.lib()
-        ts = [int(v) for v in torch.as_tensor(t).reshape(-1).tolist()]
-        out = torch.empty((len(ts), self.hidden_dim), device=self.device, dtype=torch.float32)
-        for i, tv in enumerate(ts):
-            _lib.check(L.ccsp_time_embedding(self._handle(), tv, _ptr(out[i]), _stream_ptr(self.device)))
+        """time embedding rows for timestep values t [n] (integer or float, as visualize_energy.py:409 passes them) -> [n, H]
+        (SinusoidalPosEmb + the time MLP, denoise_fn.py:38-50,259-264)"""
+        tv = torch.as_tensor(t).detach().to(self.device, torch.float32).reshape(-1).contiguous()
+        out = torch.empty((tv.shape[0], self.hidden_dim), device=self.device, dtype=torch.float32)
+        _lib.check(_lib.lib().ccsp_time_mlp(self._handle(), tv.shape[0], _ptr(tv), _ptr(out), _stream_ptr(self.device)))
+        return out
+
+    def _encode(self, which, x, in_dim):
+        x = torch.as_tensor(x).detach().to(self.device, torch.float32)
+        if x.shape[-1] != in_dim:
+            raise ValueError('encoder input has %d columns, expected %d' % (x.shape[-1], in_dim))
+        flat = x.reshape(-1, in_dim).contiguous()
+        out = torch.empty((flat.shape[0], self.hidden_dim), device=self.device, dtype=torch.float32)
+        if flat.shape[0]:
+            _lib.check(_lib.lib().ccsp_encode(self._handle(), which, flat.shape[0], _ptr(flat), _ptr(out), _stream_ptr(self.device)))
+        return out.reshape(tuple(x.shape[:-1]) + (self.hidden_dim,))
+
+    # the denoiser's sub-modules as callables on the caller's own tensors, any leading shape (visualize_energy.py:402-450)
+    def geom_encoder(self, x):
+        """denoise_fn.geom_encoder (denoise_fn.py:227-236): [..., dims[0][0]] -> [..., H]"""
+        return self._encode(0, x, self.dims[0][0])
+
+    def pose_encoder(self, x):
+        """denoise_fn.pose_encoder (denoise_fn.py:241-250): [..., P] -> [..., H]"""
+        return self._encode(1, x, self.dims[-1][0])
+
+    def grasp_encoder(self, x):
+        if not self._grasp:
+            raise AttributeError("grasp_encoder exists for 'robot' input modes only")
+        return self._encode(2, x, self.dims[1][0])
+
+    def _process_constraint(self, i, input_dict):
+        """ConstraintDiffuser._process_constraint (denoise_fn.py:341-371): the type-i MLP on [geoms_emb | poses_emb |
+        time_embedding] (+ grasp_emb first for 'robot' modes) and the pose decoder on both output halves -> [b, 2, P]"""
+        ge = input_dict['geoms_emb'].detach().to(self.device, torch.float32).contiguous()
+        pe = input_dict['poses_emb'].detach().to(self.device, torch.float32).contiguous()
+        te = input_dict['time_embedding'].detach().to(self.device, torch.float32).contiguous()
+        b, H = ge.shape[0], self.hidden_dim
+        if tuple(ge.shape) != (b, 2, H) or tuple(pe.shape) != (b, 2, H) or tuple(te.shape) != (b, H):
+            raise ValueError('_process_constraint: geoms_emb / poses_emb must be [b, 2, %d] and time_embedding [b, %d]' % (H, H))
+        gr = None
+        if self._grasp:
+            gr = input_dict['grasp_emb'].detach().to(self.device, torch.float32).contiguous()
+        out = torch.empty((b, 2, self.dims[-1][0]), device=self.device, dtype=torch.float32)
+        if b:
+            _lib.check(_lib.lib().ccsp_process_constraint(self._handle(), int(i), b, _ptr(ge), _ptr(pe), _ptr(te),
+                                                          None if gr is None else _ptr(gr), _ptr(out), _stream_ptr(self.device)))
         return out
 
     def edge_outputs(self, poses_in, batch, t):

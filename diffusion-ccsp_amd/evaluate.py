@@ -142,18 +142,22 @@ class Evaluator(object):
                         with open(json_name, 'w') as f:
                             json.dump(log, f)
                 if m == 0 and count != 0:
-                    self._summarize(key, success_list, n_total, succeeded, success_rounds, log)
+                    self._summarize(key, success_list, n_total, succeeded, success_rounds, log, final=True)
             with open(json_name, 'w') as f:
                 json.dump(log, f)
             if not run_all and percentage == 0:          # ddpm.py:797-800: stop at the first test set nothing solves
                 break
         return log
 
-    def _summarize(self, key, success_list, count, succeeded, success_rounds, log):
-        """summarize_success_rate (ddpm.py:823-836)"""
+    def _summarize(self, key, success_list, count, succeeded, success_rounds, log, final=False):
+        """summarize_success_rate (ddpm.py:823-843): top-1 = share of graphs solved at try 0, top-k ('success_rate_top3') = share
+        solved at any try, average sampling time per graph from the model's sample_loop_time window; the closing call of a
+        test set (send_wandb=True in the reference) also empties that window (:837)"""
         top1 = round(len([s for s in success_rounds.values() if s == 0]) / count, 3)
         topk = round(len(succeeded) / count, 3)
         times = getattr(self.model, 'sample_loop_time', None) or [0.0]
         log.setdefault(key, {})
         log[key].update({'success': [list(s) for s in success_list], 'success_rate': top1, 'success_rate_top3': topk,
                          'model_ave_sample_time': sum(times) / len(times) / count})
+        if final and hasattr(self.model, 'sample_loop_time'):
+            self.model.sample_loop_time = []

@@ -1,7 +1,7 @@
 """Raw graph -> the sampler's input contract, without torch_geometric.
 
-Restates ``data_transform_cn_diffuse_batch`` (reference networks/data_transforms.py:26-200) and the
-stability json->graph encoder (:272-303).  A raw graph is what the reference's world generators save
+Restates ``data_transform_cn_diffuse_batch`` (reference networks/data_transforms.py:26-200), the
+stability json->graph encoder (:272-303) and the robot (TableToBoxWorld) json->graph encoder (:203-269).  A raw graph is what the reference's world generators save
 (envs/worlds.py:247-358): ``x`` rows ``[type, features...]`` and ``edge_index`` entries
 ``(constraint name, arg1, arg2)``.  The output is the dict consumed by ``worlds.collate``:
 x [n, F] fp32 normalised (geometry columns then pose columns), edge_index [2, E] int64, edge_attr [E]
@@ -95,4 +95,50 @@ def stability_raw_graph(container, placements, supports, input_mode='stability_f
         for j in range(i + 1, n):
             if ('supportedby', i, j) not in edges and ('supportedby', j, i) not in edges:
                 edges.append(('cfree', i, j))
+    return np.asarray(rows, dtype=np.float64), edges
+
+
+GRASP_SIDES = ("x+", "x-", "y+", "y-", "z+")
+
+
+def yaw_from_quat(q):
+    """yaw (rotation about z) of a quaternion (x, y, z, w) -- the third component of pybullet's getEulerFromQuaternion,
+    which the reference reaches through pybullet_planning.euler_from_quat (data_transforms.py:236)"""
+    x, y, z, w = [float(v) for v in q]
+    return float(np.arctan2(2.0 * (w * z + x * y), 1.0 - 2.0 * (y * y + z * z)))
+
+
+def robot_raw_graph(container, placements, scene_id=0, qualitative_constraints=()):
+    """``robot_data_json_to_pt`` (:203-269): tray dimensions / pose + grasped objects -> (raw_x [n, 29] rows
+    [type | w/w0, l/l0, h/h0, w0, l0, h0, x0, y0 | mobility_id, scale | one-hot grasp side (5) | grasp_id | x, y, z, sn, cs |
+    pick pose (7)], raw_edges 'gin' i -> 0 and 'gfree' j -> i for j > i).  Objects carry their ``grasp_side``
+    ([(side, sign)], envs/data_utils.py:675-678); looking it up from a grasp quaternion needs the absent
+    packing_models submodule (data_utils.py:686-693) and is not restated."""
+    w0, l0 = [float(v) for v in container['tray_dim'][:2]]
+    x0, y0, z0 = [float(v) for v in container['tray_pose']]
+    h0 = 0.25
+    rows = [[0] + [1, 1, 0, w0, l0, h0, x0, y0, 0, 0] + [0] * 6 + [0] * 5 + [0] * 7]
+    for obj in placements:
+        w, l, h = obj['extent']
+        if 'place_pose' in obj:
+            x, y, z = obj['place_pose'][0]
+            x = (x - x0) / w0 * 2
+            y = (y - y0) / l0 * 2
+            z = z / h0
+            yaw = yaw_from_quat(obj['place_pose'][1])
+            mobility_id = int(obj['name'].split('_')[1])
+        else:
+            x, y, z, yaw = 0, 0, 0, 0
+            mobility_id = scene_id
+        sides = {k: 0 for k in GRASP_SIDES}
+        sides.update({k[0]: abs(k[1]) for k in obj['grasp_side']})
+        pick_pose = list(obj['pick_pose'][0]) + list(obj['pick_pose'][1])
+        rows.append([1] + [w / w0, l / l0, h / h0, w0, l0, h0, x0, y0, mobility_id, obj['scale']] + list(sides.values())
+                    + [obj['grasp_id']] + [x, y, z, np.sin(yaw), np.cos(yaw)] + pick_pose)
+    n = len(rows)
+    edges = [('gin', i, 0) for i in range(1, n)]
+    for i in range(1, n):
+        for j in range(i + 1, n):
+            edges.append(('gfree', j, i))
+    edges += [tuple(c) for c in qualitative_constraints]
     return np.asarray(rows, dtype=np.float64), edges

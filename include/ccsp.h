@@ -114,6 +114,21 @@ int ccsp_schedule_get(const ccsp_model* model, int32_t which, float* out_host);
  * reads denoise_fn.time_mlp) */
 int ccsp_time_embedding(ccsp_model* model, int32_t t, float* out, void* stream);
 
+/* Operator-level entry points: visualize_energy.py:402-450 calls the denoiser's sub-modules on tensors of its own
+ * (a grid of poses for one constraint type).  All arrays DEVICE fp32 row-major; not on the sampling path.
+ *   ccsp_encode              denoise_fn.geom_encoder / .pose_encoder / .grasp_encoder (denoise_fn.py:227-250):
+ *                            in [n, dims[group][0]] -> out [n, H]
+ *   ccsp_time_mlp            denoise_fn.time_mlp on arbitrary (float) timestep values (denoise_fn.py:38-50,259-264):
+ *                            t_values [n] -> out [n, H]
+ *   ccsp_process_constraint  ConstraintDiffuser._process_constraint(type, input_dict) (denoise_fn.py:341-371):
+ *                            geoms_emb [n, 2, H], poses_emb [n, 2, H], time_emb [n, H], grasp_emb [n, H] ('robot'
+ *                            models only, else NULL) -> out [n, 2, P], the decoded pose pair of every row */
+enum { CCSP_ENC_GEOM = 0, CCSP_ENC_POSE = 1, CCSP_ENC_GRASP = 2 };
+int ccsp_encode(ccsp_model* model, int32_t which, int32_t n, const float* in, float* out, void* stream);
+int ccsp_time_mlp(ccsp_model* model, int32_t n, const float* t_values, float* out, void* stream);
+int ccsp_process_constraint(ccsp_model* model, int32_t type, int32_t n, const float* geoms_emb, const float* poses_emb,
+                            const float* time_emb, const float* grasp_emb, float* out, void* stream);
+
 /* Replaces the per-evaluation graph handling of ConstraintDiffuser.forward
  * (denoise_fn.py:313-339,466-485,508): one-time type sort of the edges, node->edge CSR in the
  * reference's accumulation order, geometry/grasp embeddings and the chain-constant part of every

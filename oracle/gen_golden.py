@@ -102,12 +102,13 @@ def batch_arrays(b):
                 edge_attr=b.edge_attr.numpy().astype(np.float32), mask=b.mask.numpy().astype(np.int8))
 
 
+GRASP_KEYS = ['x+', 'x-', 'y+', 'y-', 'z+']
 HIST_IDX = [0, 1, 2, 3, 4, 5, 10, 50, 100, 200, 300, 400, 500, 600, 700, 800, 900, 950, 990, 998, 999, 1000]
 
 
 def run_chain(name, mode, H, wfile, batch, EBM, T=1000, S=10, seed=7, energy=False, dtype=torch.float32,
               model_name='Diffusion-CCSP', ebm_per_steps=1, full_hist=False):
-    W = oracle_mod.load_weights(os.path.join(GOLD, wfile))
+    W = oracle_mod.load_weights(os.path.join(ROOT, wfile) if os.sep in wfile else os.path.join(GOLD, wfile))
     model, gd = build_reference(mode, H, W, energy=energy, EBM=EBM, T=T, S=S, dtype=dtype, model_name=model_name,
                                 ebm_per_steps=ebm_per_steps)
     b = batch.clone()
@@ -166,6 +167,74 @@ def gen_schedule():
         rec['T%d/step_sizes' % T] = gd.step_sizes.numpy()
     np.savez_compressed(os.path.join(GOLD, 'schedule.npz'), **rec)
     print('schedule.npz')
+
+
+def gen_operators():
+    """the denoiser's sub-modules called the way visualize_energy.py:402-450 calls them: geom_encoder, pose_encoder,
+    time_mlp on a FLOAT timestep, _process_constraint(i, input_dict) on a grid of pose pairs (+ the grasp branch)"""
+    rec = {}
+    rng = np.random.default_rng(55)
+    for tag, mode, wfile in (('q64', 'qualitative', 'weights_qualitative_h64.npz'), ('r64', 'robot_box', 'weights_robot_box_h64.npz'),
+                             ('q256', 'qualitative', 'weights_qualitative_h256.npz')):
+        W = oracle_mod.load_weights(os.path.join(GOLD, wfile))
+        H = int(wfile.split('_h')[1].split('.')[0])
+        model, _ = build_reference(mode, H, W)
+        dims = worlds.MODE_DIMS[mode]
+        n = 12
+        geoms_in = rng.uniform(0.05, 0.9, (2, dims[0][0])).astype(np.float32)
+        poses_in = rng.uniform(-1, 1, (n, 2, dims[-1][0])).astype(np.float32)
+        tval = np.asarray([417.25], dtype=np.float32)
+        with torch.no_grad():
+            ge = model.geom_encoder(torch.from_numpy(geoms_in))
+            te = model.time_mlp(torch.from_numpy(tval))
+            pe = model.pose_encoder(torch.from_numpy(poses_in))
+            d = {'args': None, 'geoms_emb': ge[None].repeat(n, 1, 1), 'poses_emb': pe, 'time_embedding': te.repeat(n, 1)}
+            if 'robot' in mode:
+                grasp_in = np.eye(5, dtype=np.float32)[rng.integers(0, 5, n)]
+                d['grasp_emb'] = model.grasp_encoder(torch.from_numpy(grasp_in))
+                rec[tag + '/grasp_in'] = grasp_in
+                rec[tag + '/grasp_emb'] = d['grasp_emb'].numpy()
+            outs = np.stack([model._process_constraint(i, d).numpy() for i in range(len(model.mlps))])
+        rec.update({tag + '/geoms_in': geoms_in, tag + '/poses_in': poses_in, tag + '/t': tval, tag + '/geoms_emb': ge.numpy(),
+                    tag + '/poses_emb': pe.numpy(), tag + '/time_emb': te.numpy(), tag + '/outputs': outs})
+    np.savez_compressed(os.path.join(GOLD, 'operators.npz'), **rec)
+    print('operators.npz')
+
+
+def gen_evaluate_summary():
+    """Trainer.summarize_success_rate (ddpm.py:823-843) -- the success accounting and the log record of Trainer.evaluate --
+    called on scripted bookkeeping states through the reference's own method (wandb stubbed, use_wandb False)"""
+    import json
+    import types
+    sys.modules.setdefault('wandb', types.ModuleType('wandb'))
+    rng = np.random.default_rng(17)
+    cases = []
+    for c in range(12):
+        count = int(rng.integers(3, 40))
+        tries = int(rng.integers(1, 6))
+        success_list, success_rounds, succeeded = [], {}, []
+        for j in range(count):
+            for k in range(tries):
+                if j in success_rounds and rng.random() < 0.5:
+                    continue                                    # (first-loader graphs are not re-checked once solved; later loaders may)
+                if rng.random() < 0.25:
+                    success_list.append((j, k))
+                    if j not in success_rounds:
+                        succeeded.append(j)
+                        success_rounds[j] = k
+        times = [float(v) for v in rng.uniform(0.2, 3.0, int(rng.integers(1, 11)))]
+        fake = types.SimpleNamespace(model=types.SimpleNamespace(sample_loop_time=list(times)), use_wandb=False)
+        log = {}
+        final = bool(c % 2)
+        with contextlib.redirect_stdout(io.StringIO()):
+            ddpm.Trainer.summarize_success_rate(fake, count, list(success_list), count, list(succeeded), dict(success_rounds), log,
+                                                tries=tries, send_wandb=final)
+        cases.append(dict(i=count, count=count, tries=tries, success_list=success_list, succeeded=succeeded,
+                          success_rounds={str(k): v for k, v in success_rounds.items()}, sample_loop_time=times, final=final,
+                          expected=json.loads(json.dumps(log[count])), sample_loop_time_after=list(fake.model.sample_loop_time)))
+    with open(os.path.join(GOLD, 'evaluate_summary.json'), 'w') as f:
+        json.dump(cases, f)
+    print('evaluate_summary.json')
 
 
 def gen_labeller():
@@ -236,6 +305,40 @@ def gen_pre_transform():
     rec['stab/ref_raw_x'] = sd.x.numpy()
     rec['stab/ref_raw_edges'] = np.asarray([[worlds.STABILITY_CONSTRAINTS.index(e[0]), e[1], e[2]] for e in sd.edge_index], dtype=np.int64)
     run('stab', sd.x.numpy().astype(np.float64), sd.edge_index, 'stability_flat')
+    # robot json -> raw graph by robot_data_json_to_pt (:203-269).  pybullet_planning is absent: the stub supplies only
+    # euler_from_quat (pybullet's standard x, y, z, w -> roll, pitch, yaw), and the fixture's place poses are pure yaw
+    # rotations, for which every convention-consistent extraction returns the same yaw
+    import types
+
+    def euler_from_quat(q):
+        x, y, z, w = q
+        return (float(np.arctan2(2 * (w * x + y * z), 1 - 2 * (x * x + y * y))), float(np.arcsin(np.clip(2 * (w * y - z * x), -1, 1))),
+                float(np.arctan2(2 * (w * z + x * y), 1 - 2 * (y * y + z * z))))
+    sys.modules['pybullet_planning'] = types.SimpleNamespace(euler_from_quat=euler_from_quat)
+    rcont = dict(tray_dim=[0.42, 0.55, 0.1], tray_pose=[0.5, -0.2, 0.3])
+    rplace = []
+    for k in range(5):
+        yaw = float(rng.uniform(-3, 3))
+        rplace.append(dict(name='Bottle_%d' % (3000 + k), extent=rng.uniform(0.04, 0.2, 3).tolist(), scale=float(rng.uniform(0.5, 1.5)),
+                           grasp_id=int(rng.integers(0, 12)), grasp_side=[[GRASP_KEYS[int(rng.integers(0, 5))], int(rng.choice([-1, 1]))]],
+                           place_pose=[(rng.uniform(-0.15, 0.15, 3) + [0.5, -0.2, 0.1]).tolist(), [0.0, 0.0, float(np.sin(yaw / 2)), float(np.cos(yaw / 2))]],
+                           pick_pose=[rng.uniform(-1, 1, 3).tolist(), rng.uniform(-1, 1, 4).tolist()]))
+    rplace.append(dict(name='x', extent=[0.1, 0.1, 0.1], scale=1.0, grasp_id=2, grasp_side=[['z+', 1]],
+                       pick_pose=[[0.1, 0.2, 0.3], [0, 0, 0, 1]]))       # no place_pose: zeros and mobility_id = scene_id
+    rd = dt.robot_data_json_to_pt(dict(container=rcont, placements=rplace, stats=dict(scene_id=77)), 'x')
+    rec['robotjson/tray_dim'] = np.asarray(rcont['tray_dim'])
+    rec['robotjson/tray_pose'] = np.asarray(rcont['tray_pose'])
+    rec['robotjson/extent'] = np.asarray([p['extent'] for p in rplace])
+    rec['robotjson/scale'] = np.asarray([p['scale'] for p in rplace])
+    rec['robotjson/grasp_id'] = np.asarray([p['grasp_id'] for p in rplace], dtype=np.int64)
+    rec['robotjson/grasp_side'] = np.asarray([[GRASP_KEYS.index(p['grasp_side'][0][0]), p['grasp_side'][0][1]] for p in rplace], dtype=np.int64)
+    rec['robotjson/place_pos'] = np.asarray([p['place_pose'][0] for p in rplace[:5]])
+    rec['robotjson/place_quat'] = np.asarray([p['place_pose'][1] for p in rplace[:5]])
+    rec['robotjson/mobility'] = np.asarray([3000 + k for k in range(5)], dtype=np.int64)
+    rec['robotjson/pick_pose'] = np.asarray([p['pick_pose'][0] + p['pick_pose'][1] for p in rplace], dtype=np.float64)
+    rec['robotjson/ref_raw_x'] = rd.x.numpy()
+    rec['robotjson/ref_raw_edges'] = np.asarray([[worlds.ROBOT_CONSTRAINTS.index(e[0]), e[1], e[2]] for e in rd.edge_index], dtype=np.int64)
+    run('robotjson', rd.x.numpy().astype(np.float64), rd.edge_index, 'robot_box')
     # robot rows (29 columns): geometry 8 + the rest, world_dims from the container row
     rob = worlds.robot_box_batch(1, 4, seed=3)
     raw = np.concatenate([np.asarray([[0]] + [[1]] * 4, dtype=np.float64), rob.x.astype(np.float64)], axis=1)
@@ -478,6 +581,10 @@ def gen_chains(which):
                                              worlds.triangular_batch(4, 12, seed=44).to_torch(), 'MALA', S=10, energy=True, full_hist=True),
         'chain_r256_ula': lambda: run_chain('chain_r256_ula', 'robot_box', 256, 'weights_robot_box_h256.npz',
                                             worlds.robot_box_batch(3, 10, seed=45).to_torch(), 'ULA', S=10),
+        # bench.py's C2 weights on 8-object graphs: what the REFERENCE sampler does with them (finite rows, non-finite rows,
+        # final poses for the solved check) -- the HIP path must show the same rows and the same solved mask
+        'chain_q256_bench_B16': lambda: run_chain('chain_q256_bench_B16', 'qualitative', 256, 'weights/qualitative_h256_trained.npz',
+                                                  worlds.qualitative_batch(16, 8, seed=19).to_torch(), 'ULA'),
         'chain_q64_T1000_B4_f64': lambda: run_chain('chain_q64_T1000_B4_f64', 'qualitative', 64, 'weights_qualitative_h64.npz',
                                                     worlds.qualitative_batch(4, 8, seed=31).to_torch(), 'ULA', dtype=torch.float64),
     }
@@ -500,6 +607,10 @@ if __name__ == '__main__':
     os.makedirs(GOLD, exist_ok=True)
     if not which or 'schedule' in which:
         gen_schedule()
+    if not which or 'operators' in which:
+        gen_operators()
+    if not which or 'evaluate_summary' in which:
+        gen_evaluate_summary()
     if not which or 'labeller' in which:
         gen_labeller()
     if not which or 'single_eval' in which:

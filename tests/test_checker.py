@@ -60,3 +60,49 @@ def test_missing_constraint_is_reported():
     fake = ('center-in', 1, 0) if ('center-in', 1, 0) not in given else ('left-in', 1, 0)
     missing = checker.evaluate_graph(feats, (3.0, 2.0), given + [fake])
     assert missing == [fake] or missing == []  # ('left-in' may hold by chance; 'center-in' cannot be both)
+
+
+def test_touching_and_near_touching_boxes():
+    """The SAT test stands in for FCL's box-box query (envs/collisions.py:58-130), whose behaviour at exact contact is not
+    pinned (python-fcl is not importable here).  Convention of this build: boxes whose projections overlap by <= 1e-9 on
+    some axis are 'touching' = NOT colliding.  These properties fix the convention and its consistency: the decision flips
+    exactly at contact (+-1e-6 either side), is symmetric in its arguments, and is invariant under a common rigid motion."""
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        w1, l1, w2, l2 = rng.uniform(0.1, 1.0, 4)
+        yaw = rng.uniform(-np.pi, np.pi)
+        c, s = np.cos(yaw), np.sin(yaw)
+        a = (0.0, 0.0, w1, l1, yaw)
+        # second box of the same orientation pushed along a's local x axis: contact at a centre distance of (w1 + w2) / 2
+        d0 = (w1 + w2) / 2
+        for delta, want in ((1e-6, False), (0.0, False), (-1e-6, True)):
+            d = d0 + delta
+            b = (c * d, s * d, w2, l2, yaw)
+            assert checker.rects_overlap(a, b) is want, (delta, a, b)
+            assert checker.rects_overlap(b, a) is want
+            # common rigid motion: rotate both by phi about the origin and translate
+            phi, tx, ty = rng.uniform(-np.pi, np.pi), rng.uniform(-2, 2), rng.uniform(-2, 2)
+            cp, sp = np.cos(phi), np.sin(phi)
+            mv = lambda r: (cp * r[0] - sp * r[1] + tx, sp * r[0] + cp * r[1] + ty, r[2], r[3], r[4] + phi)  # noqa: E731
+            if delta != 0.0:                      # (exact contact is not representable after the motion's rounding)
+                assert checker.rects_overlap(mv(a), mv(b)) is want
+        # corner-to-edge contact of a box turned by 45 degrees: contact at distance w1 / 2 + half diagonal of the square
+        sq = rng.uniform(0.1, 0.8)
+        d0 = w1 / 2 + sq / np.sqrt(2)
+        assert not checker.rects_overlap((0.0, 0.0, w1, l1, 0.0), (d0 + 1e-6, 0.0, sq, sq, np.pi / 4))
+        assert checker.rects_overlap((0.0, 0.0, w1, l1, 0.0), (d0 - 1e-6, 0.0, sq, sq, np.pi / 4))
+    # tiles against the tray walls: a tile whose edge lies exactly on the inner wall face does not collide, 1e-6 further does
+    w, l = 3.0, 2.0
+    tile = lambda x: [(x, 0.0, 0.4, 0.4, 0.0)]  # noqa: E731
+    assert checker.collisions(tile(w / 2 - 0.2), (w, l)) == []
+    assert checker.collisions(tile(w / 2 - 0.2 + 1e-6), (w, l)) == [('east', 'tile_0')]
+    assert checker.collisions(tile(-w / 2 + 0.2 - 1e-6), (w, l)) == [('west', 'tile_0')]
+    # the generator's own scenes keep a positive clearance between tiles (paddings), so no ground truth sits on the boundary
+    b = worlds.qualitative_batch(10, 8, seed=21)
+    for j in range(10):
+        nodes = np.nonzero(np.asarray(b.batch) == j)[0]
+        feats = np.concatenate([b.x[nodes, :2], b.x[nodes, 2:6]], axis=1)
+        tiles = checker.reconstruct(feats, (3.0, 2.0))
+        shrunk = [(t[0], t[1], t[2] - 1e-4, t[3] - 1e-4, t[4]) for t in tiles]
+        grown = [(t[0], t[1], t[2] + 1e-4, t[3] + 1e-4, t[4]) for t in tiles]
+        assert checker.collisions(shrunk, (3.0, 2.0)) == [] and checker.collisions(grown, (3.0, 2.0)) == []

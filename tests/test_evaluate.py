@@ -63,6 +63,27 @@ def test_accounting_and_log_schema(tmp_path):
     assert log3['3']['eval_tries'] == 2 and len(log3['3']['sampling_time']) == 1 + 2 * 2
 
 
+def test_summary_matches_the_reference_method(tmp_path):
+    """tests/golden/evaluate_summary.json: the reference's own Trainer.summarize_success_rate (ddpm.py:823-843) run on scripted
+    bookkeeping states by oracle/gen_golden.py -- top-1 / top-k rounding, the per-graph sampling time, the record's keys, and
+    the emptied sample_loop_time window after the closing call of a test set"""
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'evaluate_summary.json')))
+    assert len(cases) >= 10
+
+    class M(object):
+        pass
+    for c in cases:
+        m = M()
+        m.sample_loop_time = list(c['sample_loop_time'])
+        ev = evaluate.Evaluator(m, {}, str(tmp_path), device='cpu')
+        log = {}
+        ev._summarize(str(c['i']), [tuple(s) for s in c['success_list']], c['count'], list(c['succeeded']),
+                      {int(k): v for k, v in c['success_rounds'].items()}, log, final=c['final'])
+        got = json.loads(json.dumps(log[str(c['i'])]))
+        assert got == c['expected'], (got, c['expected'])
+        assert m.sample_loop_time == c['sample_loop_time_after']
+
+
 @pytest.mark.gpu
 def test_real_sampler_and_checkpoint_roundtrip(device, tmp_path):
     gd = evaluate.create_sampler('qualitative', hidden_dim=64, timesteps=100, EBM='ULA', samples_per_step=2, device=device)

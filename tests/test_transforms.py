@@ -34,6 +34,30 @@ def test_stability_json_encoder_matches_reference():
     assert edges == want
 
 
+def test_robot_json_encoder_matches_reference():
+    """robot_data_json_to_pt (data_transforms.py:203-269): tray + grasped objects -> the 29-column raw rows and the
+    'gin' / 'gfree' edges, then through pre_transform to the 28-column sampler input"""
+    z = golden('pre_transform')
+    keys = transforms.GRASP_SIDES
+    placements = []
+    for k in range(len(z['robotjson/scale'])):
+        p = dict(name='Bottle_%d' % (int(z['robotjson/mobility'][k]) if k < 5 else 0), extent=z['robotjson/extent'][k].tolist(),
+                 scale=float(z['robotjson/scale'][k]), grasp_id=int(z['robotjson/grasp_id'][k]),
+                 grasp_side=[[keys[int(z['robotjson/grasp_side'][k][0])], int(z['robotjson/grasp_side'][k][1])]],
+                 pick_pose=[z['robotjson/pick_pose'][k][:3].tolist(), z['robotjson/pick_pose'][k][3:].tolist()])
+        if k < 5:
+            p['place_pose'] = [z['robotjson/place_pos'][k].tolist(), z['robotjson/place_quat'][k].tolist()]
+        placements.append(p)
+    raw_x, edges = transforms.robot_raw_graph(dict(tray_dim=z['robotjson/tray_dim'].tolist(), tray_pose=z['robotjson/tray_pose'].tolist()),
+                                              placements, scene_id=77)
+    assert raw_x.shape == (7, 29)
+    assert np.array_equal(raw_x.astype(np.float32), z['robotjson/ref_raw_x'])
+    want = [(worlds.ROBOT_CONSTRAINTS[int(t)], int(a), int(b)) for t, a, b in z['robotjson/ref_raw_edges']]
+    assert edges == want and len(edges) == 6 + 15
+    out = transforms.pre_transform(raw_x.astype(np.float32), edges, 'robot_box')
+    assert np.array_equal(out['x'], z['robotjson/x']) and np.array_equal(out['edge_index'], z['robotjson/edge_index'])
+
+
 def test_encode_qualitative_is_the_same_function():
     rng = np.random.default_rng(0)
     wd = worlds.sample_qualitative_world(rng, 5)

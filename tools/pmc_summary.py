@@ -5,7 +5,7 @@ import sys
 from collections import defaultdict
 
 acc = defaultdict(lambda: defaultdict(list))
-files = glob.glob(sys.argv[1] + '/**/*counter_collection.csv', recursive=True)
+files = [f for f in glob.glob(sys.argv[1] + '/**/*counter_collection.csv', recursive=True) if len(sys.argv) < 3 or sys.argv[2] in f]
 if files:
     print('columns:', open(files[0]).readline().strip())
 for f in files:
@@ -13,7 +13,7 @@ for f in files:
         name = row['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
         acc[name][row['Counter_Name']].append(float(row['Counter_Value']))
 for name in sorted(acc):
-    if not any(k in name for k in ('k_ugemm', 'k_rowgemm', 'k_edge', 'k_node', 'k_split', 'k_sd_', 'k_fused')):
+    if not any(k in name for k in ('k_ugemm', 'k_rowgemm', 'k_edge', 'k_node', 'k_rowsum', 'k_energy', 'k_sd_')):
         continue
     print(name)
     for c in sorted(acc[name]):

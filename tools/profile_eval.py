@@ -1,27 +1,31 @@
-"""profiling helper (not part of the product path): repeats single network evaluations of the C2
-batch so that rocprofv3 --pmc passes see the hot kernels in isolation.
-usage: python tools/profile_eval.py [n_evals] [graphs]"""
+"""profiling helper (not part of the product path): repeats single network evaluations of a BASELINE configuration's
+per-GPU batch so that rocprofv3 --pmc passes see the hot kernels in isolation (energy-mode configurations: gradient
+evaluations, i.e. all six energy kernels).
+usage: python tools/profile_eval.py [n_evals] [graphs] [c2|c4|c5]"""
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import numpy as np
 import torch
-from bench import load_weights
+from bench import CONFIGS, load_weights
 from diffusion_ccsp_amd import ConstraintDiffuser, worlds, _lib
 if os.environ.get('CCSP_SO'):          # ablation builds (tools only)
     _lib.SO = os.environ['CCSP_SO']
     _lib._stale = lambda: False
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+cfg = CONFIGS[sys.argv[3] if len(sys.argv) > 3 else 'c2']
+B = int(sys.argv[2]) if len(sys.argv) > 2 and int(sys.argv[2]) > 0 else cfg['graphs']
 dev = torch.device('cuda:0')
-den = ConstraintDiffuser(dims=worlds.MODE_DIMS['qualitative'], hidden_dim=256, input_mode='qualitative', device=dev, verbose=False)
-den.load_state_dict(load_weights(os.path.join(ROOT, 'tests', 'golden', 'weights_qualitative_h256.npz')))
-batch = worlds.qualitative_batch(B, 8, seed=5).to_torch(dev)
-x = (torch.randn(batch.x.shape[0], 4) * 0.7).to(dev)
+dims = worlds.MODE_DIMS[cfg['mode']]
+den = ConstraintDiffuser(dims=dims, hidden_dim=256, input_mode=cfg['mode'], EBM=cfg['EBM'], energy_wrapper=cfg['energy'], device=dev, verbose=False)
+wrel = next(w for w in reversed(cfg['weights']) if os.path.isfile(os.path.join(ROOT, w)))
+den.load_state_dict(load_weights(os.path.join(ROOT, wrel)))
+batch = getattr(worlds, cfg['batch'])(B, cfg['n_objects'], seed=5).to_torch(dev)
+x = (torch.randn(batch.x.shape[0], dims[-1][0]) * 0.7).to(dev)
 for i in range(n):
-    out = den(x, batch, torch.tensor([500 - i]), eval=True)
+    out = den(x, batch, torch.tensor([500 - i]), eval=True, tag='EBM')
+    out = out[0] if isinstance(out, tuple) else out
 torch.cuda.synchronize()
 print('ok', float(out.abs().max()))
