@@ -7,16 +7,15 @@ __device__ __forceinline__ float silu_grad_fast(float v) {       // d/dv [v sigm
     return sg * (1.0f + v * (1.0f - sg));
 }
 
-// deterministic block sum of one float per thread (256 threads); result valid in thread 0
-__device__ __forceinline__ float block_sum_256(float v, float* red /*[256] LDS*/) {
-    const int tid = threadIdx.x;
-    red[tid] = v;
-    __syncthreads();
+// deterministic block sum of one float per thread (256 threads), every thread gets the result: a butterfly of wavefront
+// shuffles inside each of the four waves (fixed order), then the four wave sums through LDS -- two barriers instead of the nine
+// of an LDS tree.  `red` needs 4 floats and may be reused right after the call.
+__device__ __forceinline__ float block_sum_256(float v, float* red /*[>= 4] LDS*/) {
 #pragma unroll
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) red[tid] += red[tid + s];
-        __syncthreads();
-    }
-    return red[0];
+    for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return tot;
 }
-

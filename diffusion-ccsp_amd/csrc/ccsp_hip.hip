@@ -765,6 +765,8 @@ struct NodeArgs {
     float* xhat;            // MALA proposal buffer [N,P]
     const float* E_x;       // MALA: batch energy at x and at the proposal (device scalars)
     const float* E_hat;
+    const float* E_hat_partial;   // MALA accept: if non-null, E(x_hat) is the sum of these per-workgroup partials of the edge
+    int n_hat_partial;            // kernel (same order as k_energy_sum) and E_hat is not read: one launch less per inner step
     int* acc_count;         // MALA: accepted-node counter of this timestep
     // schedule scalars of this timestep
     float a_t, b_t, c1, c2, sigma, kappa, ss, std_;
@@ -796,6 +798,16 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, EncOut eo) {
     const int tid = threadIdx.x;
     EncPrefetch<H> pf;
     if (a.do_encode) enc_prefetch<H>(w, pf);
+    float e_hat = 0.0f;
+    if (a.step == STEP_MALA_ACCEPT) {                           // (uniform: kernel argument)
+        if (a.E_hat_partial) {
+            float v = 0.0f;
+            for (int i = tid; i < a.n_hat_partial; i += 256) v += a.E_hat_partial[i];
+            e_hat = block_sum_256(v, &smax[0][0]);
+        } else {
+            e_hat = a.E_hat[0];
+        }
+    }
     if (tid < NODE_TILE * 8) {
         const int nl = tid / 8, p = tid % 8;
         const int n = node0 + nl;
@@ -846,7 +858,7 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, EncOut eo) {
                         lrev += -(dr * dr) / (2.0f * var) - log_scale - lc;
                         lfwd += -(df * df) / (2.0f * var) - log_scale - lc;
                     }
-                    const float logp_x = (-a.E_x[0]) * a.kappa, logp_h = (-a.E_hat[0]) * a.kappa;
+                    const float logp_x = (-a.E_x[0]) * a.kappa, logp_h = (-e_hat) * a.kappa;
                     const float la = logp_h - logp_x + lrev - lfwd;
                     float u;
                     if (a.noise.mode == CCSP_NOISE_INJECTED) u = a.noise.uniform[n];
@@ -987,6 +999,7 @@ struct ccsp_graph {
     std::vector<int> h_denom;      // host copy kept alive for the async upload
     std::vector<int> h_t2;         // (row0 | nrows | ts) of the 128-row tiles, kept alive for the async upload
     int n_edge_blocks = 0;
+    int n_part_last = 0;           // energy partials written by the most recent edge kernel
     std::vector<void*> allocs;
     // concurrent lanes: the batch cut into independent sub-batches (children), each a complete graph
     // object with its own stream, whose chains are enqueued interleaved (see ccsp_chain_run)
@@ -1252,13 +1265,14 @@ int energy_prepare(ccsp_model* m, ccsp_graph* g, hipStream_t s) {
 
 // one energy-mode evaluation at `xeval` (pose embeddings of xeval must already be in g->pemb).
 // with_grad: dE/dposes -> g->eps and E -> E_out;  otherwise only E -> E_out.
+// E_out == nullptr (energy-only evaluations): leave the per-workgroup partials in g->partial / g->n_part_last for the consumer
 template <int H>
 int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, bool with_grad, float* E_out, hipStream_t s) {
     const ccsp::Plan& p = g->plan;
     const int P = m->d.pose_dim;
     g->evals++;
     if (p.E_act == 0) {
-        HIP_TRY(hipMemsetAsync(E_out, 0, sizeof(float), s));
+        if (E_out) HIP_TRY(hipMemsetAsync(E_out, 0, sizeof(float), s));
         if (with_grad) HIP_TRY(hipMemsetAsync(g->eps, 0, (size_t)g->N * P * sizeof(float), s));
         return 0;
     }
@@ -1294,9 +1308,12 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     if (!edge_done)
     hipLaunchKernelGGL((k_edge<H, true>), dim3(n_part), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->U, m->pd0_w,
                        m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, en);
+    g->n_part_last = n_part;
     if (!with_grad) {
-        prof_mark(g, s, CCSP_K_ENERGY_SUM);
-        hipLaunchKernelGGL(k_energy_sum, dim3(1), dim3(256), 0, s, g->partial, n_part, E_out);
+        if (E_out) {
+            prof_mark(g, s, CCSP_K_ENERGY_SUM);
+            hipLaunchKernelGGL(k_energy_sum, dim3(1), dim3(256), 0, s, g->partial, n_part, E_out);
+        }
         prof_mark(g, s, -1);
         return 0;
     }
@@ -1518,13 +1535,16 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
                 }
                 a.step = STEP_MALA_PROPOSE;
                 launch_node<H>(m, g, a, s);                                   // x_hat, and its pose embedding
-                if (launch_eval_energy<H>(m, g, t, g->xhat, false, E_hat, s)) return 1;
+                // without a shard hook the accept kernel sums the proposal's energy partials itself (no k_energy_sum launch)
+                const bool fold_sum = m->energy_hook == nullptr && g->plan.E_act > 0;
+                if (launch_eval_energy<H>(m, g, t, g->xhat, false, fold_sum ? (float*)nullptr : E_hat, s)) return 1;
                 // global-batch mode: E(x), E(x_hat) of this shard -> sums over all shards (the reference's energies are
                 // one scalar for the WHOLE batch, ddpm.py:1026-1038); the hook enqueues the reduction on the chain's stream
                 if (m->energy_hook && m->energy_hook(m->energy_hook_ctx, g->Escal, (void*)s)) return fail("chain_run: the energy hook failed");
                 NodeArgs b = node_args(m, g);
                 b.src = 1; b.eps_buf = g->eps; b.do_encode = 1; b.xhat = g->xhat; b.step = STEP_MALA_ACCEPT;
                 b.E_x = E_x; b.E_hat = E_hat; b.acc_count = g->acc_count + t;
+                if (fold_sum) { b.E_hat_partial = g->partial; b.n_hat_partial = g->n_part_last; }
                 b.reset_mask = (e == S);
                 b.hist = e == S ? hist_at(L, T - t) : nullptr;
                 sched(b, t);
