@@ -130,30 +130,54 @@ __global__ __launch_bounds__(256) void k_edge_bwd(int E_act, int P, const int* _
     }
 }
 
-// GZR[r, :] = sum over the sorted edges sharing U row r (ascending) of GZ[k, :]; optionally also as the three bf16
-// planes [3][R][W2] that k_rowgemm_bf2<2H, H> (the transpose row GEMM on the bf16 pipe) reads
-__global__ void k_rowsum(int R, int W2, const int* __restrict__ row_ptr, const int* __restrict__ row_edge,
-                         const float* __restrict__ GZ, float* __restrict__ GZR, unsigned short* __restrict__ GZRS) {
+// GZR[r, :] = sum over the sorted edges sharing U row r (ascending) of GZ[k, :], written in ONE of three forms for the
+// transpose row GEMM that consumes it: fp32 (GZR), three bf16 planes [3][R][W2] (GZRS, k_rowgemm_bf2<2H, H>), or two fp16
+// planes of the row scaled by 2^gexp[r] (GZRH, k_rowgemm_h2<2H, H>; W2 = 512: a row is the 128 threads of a wave pair, its
+// maximum two shuffle butterflies and one LDS exchange)
+__global__ __launch_bounds__(256) void k_rowsum(int R, int W2, const int* __restrict__ row_ptr, const int* __restrict__ row_edge,
+                                                const float* __restrict__ GZ, float* __restrict__ GZR, unsigned short* __restrict__ GZRS,
+                                                unsigned short* __restrict__ GZRH, int* __restrict__ gexp) {
+    __shared__ float wmax[4];
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int W4 = W2 / 4;
-    if (idx >= (long)R * W4) return;
-    const int r = (int)(idx / W4), c = (int)(idx % W4) * 4;
+    const bool live = idx < (long)R * W4;
+    const int r = live ? (int)(idx / W4) : 0, c = live ? (int)(idx % W4) * 4 : 0;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int q = row_ptr[r]; q < row_ptr[r + 1]; ++q) {
-        const float4 v = *reinterpret_cast<const float4*>(GZ + (size_t)row_edge[q] * W2 + c);
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-    if (GZRS) {
+    if (live)
+        for (int q = row_ptr[r]; q < row_ptr[r + 1]; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(GZ + (size_t)row_edge[q] * W2 + c);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    const size_t o = (size_t)r * W2 + c, pl = (size_t)R * W2;
+    if (GZRH) {                                                   // (uniform: kernel argument; W4 == 128)
+        float m = fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w)));
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) m = fmaxf(m, __shfl_xor(m, sft));
+        const int wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) wmax[wave] = m;
+        __syncthreads();
+        const int e = h2_scale_exp(fmaxf(wmax[wave & ~1], wmax[wave | 1]));
+        if (live) {
+            if ((threadIdx.x & 127) == 0) gexp[r] = e;
+            const float h[4] = {acc.x, acc.y, acc.z, acc.w};
+            unsigned short p1[4], p2[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) split2h(ldexpf(h[k], e), p1[k], p2[k]);
+            *reinterpret_cast<uint2*>(GZRH + o) = make_uint2(p1[0] | ((unsigned)p1[1] << 16), p1[2] | ((unsigned)p1[3] << 16));
+            *reinterpret_cast<uint2*>(GZRH + pl + o) = make_uint2(p2[0] | ((unsigned)p2[1] << 16), p2[2] | ((unsigned)p2[3] << 16));
+        }
+    } else if (!live) {
+        return;
+    } else if (GZRS) {
         const float h[4] = {acc.x, acc.y, acc.z, acc.w};
         unsigned short p1[4], p2[4], p3[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) split3(h[e], p1[e], p2[e], p3[e]);
-        const size_t o = (size_t)r * W2 + c, pl = (size_t)R * W2;
         *reinterpret_cast<uint2*>(GZRS + o) = make_uint2(p1[0] | ((unsigned)p1[1] << 16), p1[2] | ((unsigned)p1[3] << 16));
         *reinterpret_cast<uint2*>(GZRS + pl + o) = make_uint2(p2[0] | ((unsigned)p2[1] << 16), p2[2] | ((unsigned)p2[3] << 16));
         *reinterpret_cast<uint2*>(GZRS + 2 * pl + o) = make_uint2(p3[0] | ((unsigned)p3[1] << 16), p3[2] | ((unsigned)p3[3] << 16));
     } else {
-        *reinterpret_cast<float4*>(GZR + (size_t)r * W2 + c) = acc;
+        *reinterpret_cast<float4*>(GZR + o) = acc;
     }
 }
 

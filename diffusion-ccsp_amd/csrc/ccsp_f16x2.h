@@ -504,3 +504,148 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void k_edge_h2(int E_act, int
         if (tid == 0) en.partial[blockIdx.x] = tot;
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// k_edge_bwd_h2: the decoder backward of the energy mode (k_edge_bwd_bf of ccsp_bf16x3.h) on the f16 pipe.
+// Rows = (sorted edge, slot s); K = H/2 = 128 decoder hidden units; N = 128 of the H columns per workgroup.
+// A[row, j] = (sum_p go[p] Wd2[p, j]) * SiLU'(q[row, j]), go = 2 d = -O_csr, built on the VALU for chunk c+1 between the
+// MFMA groups of chunk c.  Row exponent from the bound |A| <= 1.1 * max|Wd2| * sum_p |go[p]|  (|SiLU'| < 1.1): every thread
+// of a row has its go values, so the exponent costs nothing.  B = fp16 planes of Wd1^T [H, H/2] (same exponent as Wd1).
+// Epilogue: GZ[k, s H + n] = 2^-(e_row + wd_exp) acc * SiLU'(U[u0] + U[u1])[s H + n], through LDS as row segments.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_edge_bwd_h2(int E_act, int P, const int* __restrict__ e_u0, const int* __restrict__ e_u1,
+                                                        const int* __restrict__ ent_pos, const float* __restrict__ U,
+                                                        const float* __restrict__ Ocsr, const float* __restrict__ Q /*[2E,128]*/,
+                                                        const unsigned short* __restrict__ Wd1TH /*[2][256][128]*/, int wd_exp, float wd2_absmax,
+                                                        const float* __restrict__ Wd2 /*[P,128]*/, float* __restrict__ GZ) {
+    constexpr int H = 256, KD = 128, BM = 64, BN = 128, NCH = KD / H2_BK;
+    constexpr int APL = BM * H2_BK, STAGE = 2 * APL + 2 * H2_BPL;             // 8 KB of A planes + 16 KB of B planes per stage
+    constexpr int C_LD = BN + 4;
+    static_assert(2 * STAGE * 2 >= BM * C_LD * 4, "epilogue tile must fit the stages");
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * STAGE];
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int ct = bid & 1, s = (bid >> 1) & 1, e0 = (bid >> 2) * BM;
+    const int n0 = ct * BN;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = tid >> 3, lq = tid & 7;
+    float go[2][8];
+    const float* q_ptr[2];
+    int a_st[2], a_exp[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int k = e0 + lr + 32 * i;
+        k = k < E_act ? k : E_act - 1;
+        const size_t row = (size_t)2 * k + s;
+        const float* o = Ocsr + (size_t)ent_pos[row] * P;
+        float sum = 0.0f;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            go[i][p] = p < P ? -o[p] : 0.0f;                       // 2 d = -(-2 d)
+            sum += fabsf(go[i][p]);
+        }
+        a_exp[i] = h2_scale_exp(1.1f * wd2_absmax * sum);
+        q_ptr[i] = Q + row * KD + lq * 4;
+        a_st[i] = h2_off(lr + 32 * i, lq >> 1) + (lq & 1) * 4;
+    }
+    const int brow = tid >> 2, bq = tid & 3;
+    const unsigned short* b_ptr = Wd1TH + (size_t)(n0 + brow) * KD + bq * 8;
+    const int b_st = h2_off(brow, bq);
+    float4 rq[2][2];                                              // [register set][pass]: decoder pre-activations
+    ushort8 rb[4];
+    auto gload_a = [&](int c, int set) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) rq[set][i] = *reinterpret_cast<const float4*>(q_ptr[i] + c * H2_BK);
+    };
+    auto gload_b = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                rb[i * 2 + p] = *reinterpret_cast<const ushort8*>(b_ptr + (size_t)p * H * KD + (size_t)i * 64 * KD + c * H2_BK);
+    };
+    auto store_a = [&](int stage, int c, int set, int i) {
+        unsigned short* As = smem + stage * STAGE;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            if (p < P) {
+                const float4 w2 = *reinterpret_cast<const float4*>(Wd2 + (size_t)p * KD + c * H2_BK + lq * 4);
+                g.x = fmaf(go[i][p], w2.x, g.x); g.y = fmaf(go[i][p], w2.y, g.y);
+                g.z = fmaf(go[i][p], w2.z, g.z); g.w = fmaf(go[i][p], w2.w, g.w);
+            }
+        }
+        const float4 q = rq[set][i];
+        const float h[4] = {g.x * silu_grad_fast(q.x), g.y * silu_grad_fast(q.y), g.z * silu_grad_fast(q.z), g.w * silu_grad_fast(q.w)};
+        unsigned short p1[4], p2[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split2h(ldexpf(h[e], a_exp[i]), p1[e], p2[e]);
+        unsigned short* d = As + a_st[i];
+        *reinterpret_cast<uint2*>(d) = make_uint2(p1[0] | ((unsigned)p1[1] << 16), p1[2] | ((unsigned)p1[3] << 16));
+        *reinterpret_cast<uint2*>(d + APL) = make_uint2(p2[0] | ((unsigned)p2[1] << 16), p2[2] | ((unsigned)p2[3] << 16));
+    };
+    auto store_b = [&](int stage) {
+        unsigned short* Bs = smem + stage * STAGE + 2 * APL;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                *reinterpret_cast<ushort8*>(Bs + p * H2_BPL + b_st + i * 64 * H2_BK) = rb[i * 2 + p];
+    };
+    gload_a(0, 0);
+    gload_b(0);
+    gload_a(1, 1);
+    floatx16 acc[1][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.0f;
+    store_a(0, 0, 0, 0);
+    store_a(0, 0, 0, 1);
+    store_b(0);
+    gload_b(1);
+    gload_a(2, 0);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const unsigned short* st = smem + (c & 1) * STAGE;
+        const int nx = (c + 1) & 1;
+        h2_kstep<1>(st, APL, st + 2 * APL, 0, wm * 32, wn * 64, acc);
+        if (c + 1 < NCH) store_a(nx, c + 1, nx, 0);
+        h2_kstep<1>(st, APL, st + 2 * APL, 1, wm * 32, wn * 64, acc);
+        if (c + 1 < NCH) { store_a(nx, c + 1, nx, 1); store_b(nx); }
+        if (c + 2 < NCH) gload_b(c + 2);
+        if (c + 3 < NCH) gload_a(c + 3, nx);
+        __syncthreads();
+    }
+    // epilogue through LDS: the accumulators are re-read as rows of float4, so the U gathers and the GZ stores are 128-byte row
+    // segments; the thread that produced a row's A values reads it back, so its exponent is in a register
+    float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            Cs[row * C_LD + wn * 64 + j * 32 + (lane & 31)] = acc[0][j][r];
+        }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = lr + 32 * i;
+        const int k = e0 + row;
+        if (k >= E_act) continue;
+        const int e = -(a_exp[i] + wd_exp);
+        const float* u0 = U + (size_t)e_u0[k] * (2 * H) + s * H + n0;
+        const float* u1 = U + (size_t)e_u1[k] * (2 * H) + s * H + n0;
+        float* gz = GZ + (size_t)k * (2 * H) + s * H + n0;
+#pragma unroll
+        for (int mcol = 0; mcol < 4; ++mcol) {
+            const int c = lq * 4 + 32 * mcol;
+            const float4 a = *reinterpret_cast<const float4*>(u0 + c);
+            const float4 b = *reinterpret_cast<const float4*>(u1 + c);
+            const float4 v = *reinterpret_cast<const float4*>(Cs + row * C_LD + c);
+            *reinterpret_cast<float4*>(gz + c) = make_float4(ldexpf(v.x, e) * silu_grad_fast(a.x + b.x), ldexpf(v.y, e) * silu_grad_fast(a.y + b.y),
+                                                             ldexpf(v.z, e) * silu_grad_fast(a.z + b.z), ldexpf(v.w, e) * silu_grad_fast(a.w + b.w));
+        }
+    }
+}

@@ -947,6 +947,10 @@ struct ccsp_model {
     unsigned short* WpH = nullptr;    // [2][C][2][2H][H] fp16 planes of Wp * 2^wp_exp
     unsigned short* Wd1H = nullptr;   // [2][H/2][H]      fp16 planes of pose_decoder.0.weight * 2^wd_exp
     int wp_exp = 0, wd_exp = 0;
+    unsigned short* WpTH = nullptr;   // [2][C][2][H][2H] fp16 planes of WpT * 2^wp_exp (energy backward; energy_wrapper models only)
+    unsigned short* Wd1TH = nullptr;  // [2][H][H/2]      fp16 planes of pose_decoder.0.weight^T * 2^wd_exp
+    float wd2_absmax = 0.0f;          // max |pose_decoder.2.weight| (row-exponent bound of k_edge_bwd_h2)
+    int energy_bwd_h2 = 1;            // CCSP_ENERGY_BWD=bf16x3 keeps the backward GEMMs on the six-product bf16 kernels
     int ncu = 256;          // compute units of the device (residency-based kernel selection)
     ccsp_energy_hook energy_hook = nullptr;   // MALA global-batch mode (ccsp_model_set_energy_hook)
     void* energy_hook_ctx = nullptr;
@@ -993,6 +997,8 @@ struct ccsp_graph {
     int *e_a = nullptr, *e_b = nullptr, *row_ptr = nullptr, *row_edge = nullptr, *nrow_ptr = nullptr, *nrow_idx = nullptr;
     int *tileb_row0 = nullptr, *tileb_nrows = nullptr, *tileb_ts = nullptr;
     unsigned short* GZRS = nullptr;    // [3][R][2H] bf16 planes of GZR (energy backward on the bf16 pipe)
+    unsigned short* GZRH = nullptr;    // [2][R][2H] fp16 planes of GZR rows scaled by 2^gexp[r] (energy backward on the f16 pipe)
+    int* gexp = nullptr;               // [R]
     float *Q = nullptr, *GZ = nullptr, *GZR = nullptr, *GP = nullptr, *xhat = nullptr, *partial = nullptr, *Escal = nullptr;
     int *acc_count = nullptr, *acc_denom = nullptr;
     float *hmc_vk = nullptr, *hmc_vp = nullptr, *hmc_vl = nullptr;   // HMC momenta (allocated on first use)
@@ -1320,8 +1326,13 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     prof_mark(g, s, CCSP_K_EDGE_BWD);
     constexpr int BMB = 32 * BwdCfg<H>::WM, NCTB = H / (32 * BwdCfg<H>::TN * BwdCfg<H>::WN);
     bool bwd_done = false;
+    const bool h2_bwd = h2 && m->WpTH != nullptr && m->energy_bwd_h2;      // backward GEMMs on the f16x2 scheme as well
     if constexpr (H == 256) {
-        if (m->bf16x3 && m->edge_kernel == 2) {
+        if (h2_bwd) {
+            hipLaunchKernelGGL(k_edge_bwd_h2, dim3(nblk(p.E_act, 64) * 4), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->ent_pos, g->U, g->O, g->Q,
+                               m->Wd1TH, m->wd_exp, m->wd2_absmax, m->pd2_w, g->GZ);
+            bwd_done = true;
+        } else if (m->bf16x3 && m->edge_kernel == 2) {
             hipLaunchKernelGGL(k_edge_bwd_bf, dim3(nblk(p.E_act, 64) * 4), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->ent_pos, g->U, g->O, g->Q,
                                m->Wd1TS, m->pd2_w, g->GZ);
             bwd_done = true;
@@ -1330,15 +1341,28 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     if (!bwd_done)
     hipLaunchKernelGGL(k_edge_bwd<H>, dim3(nblk(p.E_act, BMB) * 2 * NCTB), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->ent_pos,
                        g->U, g->O, g->Q, m->pd0_wT, m->pd2_w, g->GZ);
-    const bool bf_bwd = H == 256 && m->bf16x3 && m->WpTS != nullptr;      // (the 128-column tiles need H >= 128)
+    const bool bf_bwd = !h2_bwd && H == 256 && m->bf16x3 && m->WpTS != nullptr;      // (the 128-column tiles need H >= 128)
     if (bf_bwd && !g->GZRS && dev_alloc(g->allocs, &g->GZRS, (size_t)3 * p.R * 2 * H)) return 1;
+    if (h2_bwd && !g->GZRH && (dev_alloc(g->allocs, &g->GZRH, (size_t)2 * p.R * 2 * H) || dev_alloc(g->allocs, &g->gexp, (size_t)p.R))) return 1;
     prof_mark(g, s, CCSP_K_ROWSUM);
     hipLaunchKernelGGL(k_rowsum, dim3(nblk((long)p.R * (2 * H / 4), 256)), dim3(256), 0, s, p.R, 2 * H, g->row_ptr, g->row_edge, g->GZ, g->GZR,
-                       bf_bwd ? g->GZRS : (unsigned short*)nullptr);
+                       bf_bwd ? g->GZRS : (unsigned short*)nullptr, h2_bwd ? g->GZRH : (unsigned short*)nullptr, g->gexp);
     const int* no_map = nullptr;
     const float* nof = nullptr;
     prof_mark(g, s, CCSP_K_ROWGEMM_T);
-    if (bf_bwd) {
+    if (h2_bwd) {
+        if constexpr (H == 256) {       // g_p[row] = g_z[row] . Wp[type, slot]: the forward kernel with K = 2H, N = H, identity rows, no base
+            const int work = g->n_tiles2 * (H / 128);
+            const int mode = m->row_mode >= 0 ? m->row_mode : (work <= 2 * m->ncu ? 2 : 0);
+            float* nou = nullptr;
+#define CCSP_ROWGEMM_T(MODE)                                                                                                                        \
+            hipLaunchKernelGGL((k_rowgemm_h2<2 * H, H, MODE>), dim3(work), dim3(256), 0, s, g->GZRH, (size_t)p.R * 2 * H, g->gexp, no_map, g->t2_row0,  \
+                               g->t2_nrows, g->t2_ts, m->WpTH, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, m->wp_exp, nof, nof, g->GP, nou,   \
+                               StepRef{nullptr, nullptr}, (size_t)0)
+            if (mode == 2) CCSP_ROWGEMM_T(2); else if (mode == 1) CCSP_ROWGEMM_T(1); else CCSP_ROWGEMM_T(0);
+#undef CCSP_ROWGEMM_T
+        }
+    } else if (bf_bwd) {
         if constexpr (H == 256)
             hipLaunchKernelGGL((k_rowgemm_bf2<2 * H, H>), dim3(g->n_tiles2 * (H / RB2_TN)), dim3(512), 0, s, g->GZRS, (size_t)p.R * 2 * H, no_map,
                                g->t2_row0, g->t2_nrows, g->t2_ts, m->WpTS, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, nof, nof, g->GP,
@@ -2075,13 +2099,15 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
         hipLaunchKernelGGL(k_split3, dim3(nblk(nwd, 256)), dim3(256), 0, s, nwd, m->pd0_wT, m->Wd1TS);
         if (m->f16x2) {     // fp16 planes of the same weights, each tensor scaled by one exact power of two (ccsp_f16x2.h)
             unsigned int* mx = nullptr;
-            unsigned int h_mx[2] = {0u, 0u};
-            TRY(dev_alloc(reg, &mx, 2));
-            HIP_TRY(hipMemsetAsync(mx, 0, 2 * sizeof(unsigned int), s));
+            unsigned int h_mx[3] = {0u, 0u, 0u};
+            TRY(dev_alloc(reg, &mx, 3));
+            HIP_TRY(hipMemsetAsync(mx, 0, 3 * sizeof(unsigned int), s));
             hipLaunchKernelGGL(k_absmax_bits, dim3(nblk(nwp, 256)), dim3(256), 0, s, nwp, m->Wp, mx);
             hipLaunchKernelGGL(k_absmax_bits, dim3(nblk(nwd, 256)), dim3(256), 0, s, nwd, m->pd0_w, mx + 1);
+            hipLaunchKernelGGL(k_absmax_bits, dim3(nblk((long)P * (H / 2), 256)), dim3(256), 0, s, (long)P * (H / 2), m->pd2_w, mx + 2);
             HIP_TRY(hipMemcpyAsync(h_mx, mx, sizeof(h_mx), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
+            memcpy(&m->wd2_absmax, &h_mx[2], sizeof(float));
             auto host_exp = [](unsigned int bits) { const int be = (int)((bits >> 23) & 0xffu); return (be == 0 || be == 255) ? 0 : 140 - be; };
             m->wp_exp = host_exp(h_mx[0]);
             m->wd_exp = host_exp(h_mx[1]);
@@ -2089,6 +2115,13 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
             TRY(dev_alloc(reg, &m->Wd1H, (size_t)2 * nwd));
             hipLaunchKernelGGL(k_split2h, dim3(nblk(nwp, 256)), dim3(256), 0, s, nwp, m->Wp, m->wp_exp, m->WpH);
             hipLaunchKernelGGL(k_split2h, dim3(nblk(nwd, 256)), dim3(256), 0, s, nwd, m->pd0_w, m->wd_exp, m->Wd1H);
+            if (d->energy_wrapper) {    // the backward GEMMs' weights: the same tensors transposed, the same exponents
+                if (const char* e = getenv("CCSP_ENERGY_BWD")) m->energy_bwd_h2 = strcmp(e, "bf16x3") != 0;
+                TRY(dev_alloc(reg, &m->WpTH, (size_t)2 * nwp));
+                TRY(dev_alloc(reg, &m->Wd1TH, (size_t)2 * nwd));
+                hipLaunchKernelGGL(k_split2h, dim3(nblk(nwp, 256)), dim3(256), 0, s, nwp, m->WpT, m->wp_exp, m->WpTH);
+                hipLaunchKernelGGL(k_split2h, dim3(nblk(nwd, 256)), dim3(256), 0, s, nwd, m->pd0_wT, m->wd_exp, m->Wd1TH);
+            }
         }
     }
 #undef TRY

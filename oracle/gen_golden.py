@@ -585,6 +585,10 @@ def gen_chains(which):
         # final poses for the solved check) -- the HIP path must show the same rows and the same solved mask
         'chain_q256_bench_B16': lambda: run_chain('chain_q256_bench_B16', 'qualitative', 256, 'weights/qualitative_h256_trained.npz',
                                                   worlds.qualitative_batch(16, 8, seed=19).to_torch(), 'ULA'),
+        # a longer-trained checkpoint of the same recipe (50 000 steps): the REFERENCE sampler overflows fp32 on most 8-object
+        # graphs with it -- the better the network fits, the larger the transient of the first timesteps
+        'chain_q256_50k_B16': lambda: run_chain('chain_q256_50k_B16', 'qualitative', 256, 'weights/qualitative_h256_50k.npz',
+                                                worlds.qualitative_batch(16, 8, seed=19).to_torch(), 'ULA'),
         'chain_q64_T1000_B4_f64': lambda: run_chain('chain_q64_T1000_B4_f64', 'qualitative', 64, 'weights_qualitative_h64.npz',
                                                     worlds.qualitative_batch(4, 8, seed=31).to_torch(), 'ULA', dtype=torch.float64),
     }
