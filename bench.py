@@ -93,28 +93,41 @@ def algorithmic_flops(n_nodes, n_edges, H, P, grasp):
     return n_nodes * f_node + n_edges * f_edge, f_node, f_edge
 
 
+def backward_mode(mma):
+    """GEMM scheme of the energy-mode backward kernels (ccsp_hip.hip reads CCSP_ENERGY_BWD at model creation)"""
+    if mma == 'f16x2' and os.environ.get('CCSP_ENERGY_BWD', '') == 'bf16x3':
+        return 'bf16x3'
+    return mma
+
+
+def kernel_symbol(label, mma):
+    row = KERNEL_SYMBOLS.get(label, {})
+    return row.get(backward_mode(mma) if label in ('edge decoder backward', 'row GEMM (transpose)') else mma, '')
+
+
 def executed_work(label, N, E, R, H, mma):
     """(fp32-equivalent flops, matrix-pipe products per fp32 product, pipe) of one launch of the kernel behind a
     ccsp_kernel_stats label -- what the kernels EXECUTE after the row factorisation; None for non-matrix kernels"""
     prod = {'f16x2': (3, 'f16'), 'bf16x3': (6, 'bf16'), 'f32': (1, 'f32')}[mma]
+    bwd = {'f16x2': (3, 'f16'), 'bf16x3': (6, 'bf16'), 'f32': (1, 'f32')}[backward_mode(mma)]
     table = {
         'row GEMM (forward)': (2.0 * R * (2 * H) * H,) + prod,
         'edge decoder (forward)': (2.0 * (2 * E) * (H // 2) * H,) + prod,
         'node update + pose encoder': (2.0 * N * H * (H // 2), 1, 'f32'),
-        # energy-mode backward kernels run on the bf16x3 scheme unless CCSP_MMA=f32
-        'edge decoder backward': (2.0 * (2 * E) * H * (H // 2),) + ((1, 'f32') if mma == 'f32' else (6, 'bf16')),
-        'row GEMM (transpose)': (2.0 * R * H * (2 * H),) + ((1, 'f32') if mma == 'f32' else (6, 'bf16')),
+        # energy-mode backward kernels: same scheme as the forward ones unless CCSP_ENERGY_BWD=bf16x3
+        'edge decoder backward': (2.0 * (2 * E) * H * (H // 2),) + bwd,
+        'row GEMM (transpose)': (2.0 * R * H * (2 * H),) + bwd,
         'node energy backward': (2.0 * 2 * N * H * (H // 2), 1, 'f32'),
     }
     return table.get(label)
 
 
 KERNEL_SYMBOLS = {      # label -> kernel symbol prefix by GEMM mode (for the PMC traffic lookup and the report)
-    'row GEMM (forward)': {'f16x2': 'k_rowgemm_h2', 'bf16x3': 'k_rowgemm_bf2', 'f32': 'k_rowgemm<256, 512>'},
+    'row GEMM (forward)': {'f16x2': 'k_rowgemm_h2<256, 512', 'bf16x3': 'k_rowgemm_bf2<256, 512', 'f32': 'k_rowgemm<256, 512>'},
     'edge decoder (forward)': {'f16x2': 'k_edge_h2', 'bf16x3': 'k_edge_bf2', 'f32': 'k_edge<256'},
     'node update + pose encoder': {m: 'k_node<256>' for m in ('f16x2', 'bf16x3', 'f32')},
-    'edge decoder backward': {'f16x2': 'k_edge_bwd_bf', 'bf16x3': 'k_edge_bwd_bf', 'f32': 'k_edge_bwd<256>'},
-    'row GEMM (transpose)': {'f16x2': 'k_rowgemm_bf2<512, 256>', 'bf16x3': 'k_rowgemm_bf2<512, 256>', 'f32': 'k_rowgemm<512, 256>'},
+    'edge decoder backward': {'f16x2': 'k_edge_bwd_h2', 'bf16x3': 'k_edge_bwd_bf', 'f32': 'k_edge_bwd<256>'},
+    'row GEMM (transpose)': {'f16x2': 'k_rowgemm_h2<512, 256', 'bf16x3': 'k_rowgemm_bf2<512, 256>', 'f32': 'k_rowgemm<512, 256>'},
     'node energy backward': {m: 'k_node_energy_mfma' for m in ('f16x2', 'bf16x3', 'f32')},
     'row sum of g_z': {m: 'k_rowsum' for m in ('f16x2', 'bf16x3', 'f32')},
     'energy sum': {m: 'k_energy_sum' for m in ('f16x2', 'bf16x3', 'f32')},
@@ -289,7 +302,7 @@ def main():
         kernels = []
         for label, (calls, ms) in ks.items():
             w = executed_work(label, n_nodes, E_act, R, HIDDEN, mma)
-            sym = KERNEL_SYMBOLS.get(label, {}).get(mma, '')
+            sym = kernel_symbol(label, mma)
             ent = {'kernel': label, 'symbol': sym, 'calls_timed': calls, 'us_mean': 1e3 * ms}
             if w is not None:
                 flops, prods, pipe = w

@@ -23,15 +23,22 @@
 // get exponent 0 and propagate as NaN / Inf.
 //
 // Kernels (hidden_dim 256 only; the small fixtures at hidden_dim 64 stay on ccsp_bf16x3.h):
-//   k_rowgemm_h2<KD, ND>   128 x 128 tiles, 4 waves as 2(M) x 2(N), 64 x 64 per wave (every LDS fragment feeds
-//                          two MFMA tiles: 8 ds_read_b128 per 12 MFMAs, against 9 per 12 at half the flops
-//                          each in k_rowgemm_bf2), two LDS stages of 32 KB (one barrier per K chunk), two
-//                          register sets (operands of chunk c+2 in flight while chunk c is multiplied),
-//                          epilogue through LDS: 16-byte row-contiguous base loads / U stores and the row
-//                          maxima of U for the edge kernel
-//   k_edge_h2<ENERGY>      128 rows = 64 sorted edges x both output halves per workgroup (the decoder weight
-//                          chunk is staged once for both halves), same wave layout and stages; SiLU + scale +
-//                          split of chunk c+1 issued between the MFMA groups of chunk c
+//   k_rowgemm_h2<KD, ND, MODE>   128 x 128 tiles, 4 waves as 2(M) x 2(N), 64 x 64 per wave (every LDS fragment
+//                          feeds two MFMA tiles: 8 ds_read_b128 per 12 MFMAs, against 9 per 12 at half the
+//                          flops each in k_rowgemm_bf2); epilogue per wave through a wave-private LDS tile:
+//                          16-byte row-contiguous base loads / U stores and the row maxima of U for the edge
+//                          kernel.  MODE picks the staging by residency (launch_rowgemm_h2): 0 = one 16 KB
+//                          stage and one register set, 3 workgroups per CU (tile lists longer than 2 per CU);
+//                          1 = two stages, two register sets (chunk c+2 in flight while c is multiplied);
+//                          2 = two stages filled by global_load_lds_dwordx4, swizzle applied to the source
+//                          address.  <256, 512> is the forward GEMM, <512, 256> the energy mode's transpose GEMM
+//   k_edge_h2<ENERGY, MT>  MT = 2: 128 rows = 64 sorted edges x both output halves per workgroup (the decoder
+//                          weight chunk is staged once for both halves); MT = 1: 32 edges, 3 workgroups per CU
+//                          (default whenever all tiles then fit in one round).  SiLU + scale + split of chunk
+//                          c+1 issued between the MFMA groups of chunk c
+//   k_edge_bwd_h2          energy mode: g_h = g_o Wd2 (VALU), g_q = g_h SiLU'(q), g_z = (g_q Wd1) SiLU'(z) with the
+//                          GEMM on the same three products; the row exponent comes from the bound
+//                          1.1 * max|Wd2| * sum|g_o| >= |g_h|
 // Included inside the anonymous namespace of ccsp_hip.hip.
 #pragma once
 
