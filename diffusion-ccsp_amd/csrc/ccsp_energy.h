@@ -130,45 +130,21 @@ __global__ __launch_bounds__(256) void k_edge_bwd(int E_act, int P, const int* _
     }
 }
 
-// GZR[r, :] = sum over the sorted edges sharing U row r (ascending) of GZ[k, :], written in ONE of three forms for the
-// transpose row GEMM that consumes it: fp32 (GZR), three bf16 planes [3][R][W2] (GZRS, k_rowgemm_bf2<2H, H>), or two fp16
-// planes of the row scaled by 2^gexp[r] (GZRH, k_rowgemm_h2<2H, H>; W2 = 512: a row is the 128 threads of a wave pair, its
-// maximum two shuffle butterflies and one LDS exchange)
+// GZR[r, :] = sum over the sorted edges sharing U row r (ascending) of GZ[k, :], written in the form the transpose row GEMM
+// consumes: fp32 (GZR), or three bf16 planes [3][R][W2] (GZRS, k_rowgemm_bf2<2H, H>); the f16x2 form is k_rowsum_h2 below
 __global__ __launch_bounds__(256) void k_rowsum(int R, int W2, const int* __restrict__ row_ptr, const int* __restrict__ row_edge,
-                                                const float* __restrict__ GZ, float* __restrict__ GZR, unsigned short* __restrict__ GZRS,
-                                                unsigned short* __restrict__ GZRH, int* __restrict__ gexp) {
-    __shared__ float wmax[4];
+                                                const float* __restrict__ GZ, float* __restrict__ GZR, unsigned short* __restrict__ GZRS) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int W4 = W2 / 4;
-    const bool live = idx < (long)R * W4;
-    const int r = live ? (int)(idx / W4) : 0, c = live ? (int)(idx % W4) * 4 : 0;
+    if (idx >= (long)R * W4) return;
+    const int r = (int)(idx / W4), c = (int)(idx % W4) * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (live)
-        for (int q = row_ptr[r]; q < row_ptr[r + 1]; ++q) {
-            const float4 v = *reinterpret_cast<const float4*>(GZ + (size_t)row_edge[q] * W2 + c);
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-        }
+    for (int q = row_ptr[r]; q < row_ptr[r + 1]; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(GZ + (size_t)row_edge[q] * W2 + c);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
     const size_t o = (size_t)r * W2 + c, pl = (size_t)R * W2;
-    if (GZRH) {                                                   // (uniform: kernel argument; W4 == 128)
-        float m = fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w)));
-#pragma unroll
-        for (int sft = 32; sft > 0; sft >>= 1) m = fmaxf(m, __shfl_xor(m, sft));
-        const int wave = threadIdx.x >> 6;
-        if ((threadIdx.x & 63) == 0) wmax[wave] = m;
-        __syncthreads();
-        const int e = h2_scale_exp(fmaxf(wmax[wave & ~1], wmax[wave | 1]));
-        if (live) {
-            if ((threadIdx.x & 127) == 0) gexp[r] = e;
-            const float h[4] = {acc.x, acc.y, acc.z, acc.w};
-            unsigned short p1[4], p2[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) split2h(ldexpf(h[k], e), p1[k], p2[k]);
-            *reinterpret_cast<uint2*>(GZRH + o) = make_uint2(p1[0] | ((unsigned)p1[1] << 16), p1[2] | ((unsigned)p1[3] << 16));
-            *reinterpret_cast<uint2*>(GZRH + pl + o) = make_uint2(p2[0] | ((unsigned)p2[1] << 16), p2[2] | ((unsigned)p2[3] << 16));
-        }
-    } else if (!live) {
-        return;
-    } else if (GZRS) {
+    if (GZRS) {
         const float h[4] = {acc.x, acc.y, acc.z, acc.w};
         unsigned short p1[4], p2[4], p3[4];
 #pragma unroll
@@ -179,6 +155,51 @@ __global__ __launch_bounds__(256) void k_rowsum(int R, int W2, const int* __rest
     } else {
         *reinterpret_cast<float4*>(GZR + o) = acc;
     }
+}
+
+// the f16x2 form of k_rowsum at hidden_dim 256 (W2 = 512): one wavefront per U row, two float4 column groups per lane, so the
+// row maximum is one shuffle butterfly (no LDS, no barrier) and a row's edge indices are fetched four at a time ahead of the
+// GZ rows they address (the sum keeps the ascending edge order)
+__global__ __launch_bounds__(256) void k_rowsum_h2(int R, const int* __restrict__ row_ptr, const int* __restrict__ row_edge,
+                                                   const float* __restrict__ GZ, unsigned short* __restrict__ GZRH, int* __restrict__ gexp) {
+    constexpr int W2 = 512;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= R) return;                                           // (wave-uniform)
+    const int q0 = row_ptr[r], q1 = row_ptr[r + 1];
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    for (int q = q0; q < q1; q += 4) {
+        int ek[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ek[i] = row_edge[q + i < q1 ? q + i : q1 - 1];
+        float4 v0[4], v1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float* g = GZ + (size_t)ek[i] * W2 + lane * 4;
+            v0[i] = *reinterpret_cast<const float4*>(g);
+            v1[i] = *reinterpret_cast<const float4*>(g + 256);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (q + i < q1) {
+                a0.x += v0[i].x; a0.y += v0[i].y; a0.z += v0[i].z; a0.w += v0[i].w;
+                a1.x += v1[i].x; a1.y += v1[i].y; a1.z += v1[i].z; a1.w += v1[i].w;
+            }
+    }
+    float m = fmaxf(fmaxf(fmaxf(fabsf(a0.x), fabsf(a0.y)), fmaxf(fabsf(a0.z), fabsf(a0.w))),
+                    fmaxf(fmaxf(fabsf(a1.x), fabsf(a1.y)), fmaxf(fabsf(a1.z), fabsf(a1.w))));
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) m = fmaxf(m, __shfl_xor(m, sft));
+    const int e = h2_scale_exp(m);
+    if (lane == 0) gexp[r] = e;
+    const size_t o = (size_t)r * W2 + lane * 4, pl = (size_t)R * W2;
+    const float h[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    unsigned short p1[8], p2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) split2h(ldexpf(h[k], e), p1[k], p2[k]);
+    *reinterpret_cast<uint2*>(GZRH + o) = make_uint2(p1[0] | ((unsigned)p1[1] << 16), p1[2] | ((unsigned)p1[3] << 16));
+    *reinterpret_cast<uint2*>(GZRH + o + 256) = make_uint2(p1[4] | ((unsigned)p1[5] << 16), p1[6] | ((unsigned)p1[7] << 16));
+    *reinterpret_cast<uint2*>(GZRH + pl + o) = make_uint2(p2[0] | ((unsigned)p2[1] << 16), p2[2] | ((unsigned)p2[3] << 16));
+    *reinterpret_cast<uint2*>(GZRH + pl + o + 256) = make_uint2(p2[4] | ((unsigned)p2[5] << 16), p2[6] | ((unsigned)p2[7] << 16));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -311,14 +332,39 @@ __global__ __launch_bounds__(256) void k_node_energy_mfma(EnergyNodeArgs a, cons
     constexpr int KC = H / 2, TPW = H / 64, KS = H / 8;          // forward: K = H/2 in steps of 4, TPW column tiles per wave
     constexpr int BT = KC / 16;                                   // backward: 16-wide tiles of the H/2 hidden units
     constexpr int BTW = BT >= 4 ? BT / 4 : 1;                     // ... per wave
+    constexpr int PF = KS >= 16 ? 8 : KS / 2;                     // forward fragments requested at kernel entry
     __shared__ float xs[NODE_TILE][8];
     __shared__ float dir[NODE_TILE][8];
     __shared__ float y1[NODE_TILE][KC + 4];                       // pre-activation, later g_y1
     __shared__ float s1[NODE_TILE][KC + 1];
     __shared__ float gy2[NODE_TILE][H + 4];
+    __shared__ float w0s[KC][9];                                  // pose_encoder.0.weight, columns >= P are 0 (stride 9: conflict-free)
     __shared__ float red[256];
     const int node0 = blockIdx.x * NODE_TILE;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nl = lane & 15, n = node0 + nl;
+    // The kernel is a latency chain on 200-odd workgroups (CSR ranges -> rows -> two dependent small GEMMs), so every load
+    // that does not depend on the chain is requested here, in the order it will be consumed: first-layer weights, the
+    // node's U-row range, the first forward fragments.
+    float w0r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i;                            // KC * 8 = 4 * 256 at H = 256
+        const int j = idx >> 3, d = idx & 7;
+        w0r[i] = (idx < KC * 8 && d < a.P) ? a.W0[j * a.P + d] : 0.0f;
+    }
+    const int rb = n < a.N ? a.nrow_ptr[n] : 0, re = n < a.N ? a.nrow_ptr[n + 1] : 0;
+    const float* wf = W2F + ((size_t)wave * KS * 64 + lane) * TPW;
+    float wpf[PF][TPW];
+#pragma unroll
+    for (int ks = 0; ks < PF; ++ks)
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) wpf[ks][q] = wf[(size_t)ks * 64 * TPW + q];
+    float4 bj[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) bj[j] = *reinterpret_cast<const float4*>(a.b2 + wave * 16 * TPW + j * 16 + 4 * (lane >> 4));
+    const float b0j = a.b0[tid % KC];
+    __builtin_amdgcn_sched_barrier(0);
     if (blockIdx.x == 0 && a.E_out) {            // uniform branch: whole block participates
         float v = 0.0f;
         for (int i = tid; i < a.n_partial; i += 256) v += a.partial[i];
@@ -327,67 +373,106 @@ __global__ __launch_bounds__(256) void k_node_energy_mfma(EnergyNodeArgs a, cons
         __syncthreads();
     }
     if (tid < NODE_TILE * 8) {
-        const int nl = tid / 8, p = tid % 8, n = node0 + nl;
+        const int nl1 = tid / 8, p = tid % 8, n1 = node0 + nl1;
         float xv = 0.0f, dv = 0.0f;
-        if (n < a.N && p < a.P) {
-            xv = a.x[(size_t)n * a.P + p];
-            const int beg = a.node_ptr[n], end = a.node_ptr[n + 1];
+        if (n1 < a.N && p < a.P) {
+            xv = a.x[(size_t)n1 * a.P + p];
+            const int beg = a.node_ptr[n1], end = a.node_ptr[n1 + 1];
             const float* op = a.Ocsr + (size_t)beg * a.P + p;
 #pragma unroll 8
             for (int q = 0; q < end - beg; ++q) dv += op[(size_t)q * a.P];
         }
-        xs[nl][p] = xv;
-        dir[nl][p] = dv;
+        xs[nl1][p] = xv;
+        dir[nl1][p] = dv;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i;
+        if (idx < KC * 8) w0s[idx >> 3][idx & 7] = w0r[i];
+    }
+    // sum of the node's GP rows (ascending row order), independent of the pose: in flight under the first layer
+    float4 gp[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) gp[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+        const int c00 = wave * 16 * TPW + 4 * (lane >> 4);
+        for (int q = rb; q < re; ++q) {
+            const float* row = a.GP + (size_t)a.nrow_idx[q] * H + c00;
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+                const float4 v = *reinterpret_cast<const float4*>(row + j * 16);
+                gp[j].x += v.x; gp[j].y += v.y; gp[j].z += v.z; gp[j].w += v.w;
+            }
+        }
     }
     __syncthreads();
-    for (int idx = tid; idx < NODE_TILE * KC; idx += 256) {
-        const int n = idx / KC, j = idx % KC;
-        float acc = 0.0f;
-        for (int d = 0; d < a.P; ++d) acc = fmaf(xs[n][d], a.W0[j * a.P + d], acc);
-        acc += a.b0[j];
-        y1[n][j] = acc;
-        s1[n][j] = silu_fast(acc);
+    {
+        const int j = tid % KC;
+#pragma unroll
+        for (int i = 0; i < NODE_TILE * KC / 256; ++i) {
+            const int nn = tid / KC + i * (256 / KC);
+            float acc = 0.0f;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) acc = fmaf(xs[nn][d], w0s[j][d], acc);      // xs / w0s columns >= P are 0
+            acc += b0j;
+            y1[nn][j] = acc;
+            s1[nn][j] = silu_fast(acc);
+        }
     }
     __syncthreads();
-    const int nl = lane & 15, n = node0 + nl;
     {   // y2^T tiles = W2 . s1^T; g_y2 = (sum of the node's GP rows) * SiLU'(y2)
         floatx4 acc[TPW];
 #pragma unroll
         for (int j = 0; j < TPW; ++j) acc[j] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
-        const float* wf = W2F + ((size_t)wave * KS * 64 + lane) * TPW;
         const float* bp = &s1[nl][lane >> 4];
-#pragma unroll 8
+        float rest[KS - PF][TPW];                                 // the remaining fragments, requested before the first MFMA
+#pragma unroll
+        for (int ks = PF; ks < KS; ++ks)
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) rest[ks - PF][q] = wf[(size_t)ks * 64 * TPW + q];
+#pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const float b = bp[ks * 4];
 #pragma unroll
-            for (int j = 0; j < TPW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[(size_t)ks * 64 * TPW + j], b, acc[j], 0, 0, 0);
+            for (int j = 0; j < TPW; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ks < PF ? wpf[ks][j] : rest[ks - PF][j], b, acc[j], 0, 0, 0);
         }
-        const int rb = n < a.N ? a.nrow_ptr[n] : 0, re = n < a.N ? a.nrow_ptr[n + 1] : 0;
 #pragma unroll
         for (int j = 0; j < TPW; ++j) {
             const int c0 = wave * 16 * TPW + j * 16 + 4 * (lane >> 4);
-            float4 gp = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int q = rb; q < re; ++q) {
-                const float4 v = *reinterpret_cast<const float4*>(a.GP + (size_t)a.nrow_idx[q] * H + c0);
-                gp.x += v.x; gp.y += v.y; gp.z += v.z; gp.w += v.w;
-            }
-            const float4 bj = *reinterpret_cast<const float4*>(a.b2 + c0);
-            *reinterpret_cast<float4*>(&gy2[nl][c0]) = make_float4(gp.x * silu_grad_fast(acc[j][0] + bj.x), gp.y * silu_grad_fast(acc[j][1] + bj.y),
-                                                                    gp.z * silu_grad_fast(acc[j][2] + bj.z), gp.w * silu_grad_fast(acc[j][3] + bj.w));
+            *reinterpret_cast<float4*>(&gy2[nl][c0]) =
+                make_float4(gp[j].x * silu_grad_fast(acc[j][0] + bj[j].x), gp[j].y * silu_grad_fast(acc[j][1] + bj[j].y),
+                            gp[j].z * silu_grad_fast(acc[j][2] + bj[j].z), gp[j].w * silu_grad_fast(acc[j][3] + bj[j].w));
         }
     }
+    // backward weights: A[i = hidden unit][c] = W2[c][i]; half of them requested ahead of the barrier
+    constexpr int KB = H / 4, KBH = KB / 2;
+    const float* ap = a.W2 + (size_t)(lane >> 4) * KC + wave * 16 * BTW + (lane & 15);
+    float wb0[KBH][BTW];
+    if (wave < BT) {
+#pragma unroll
+        for (int ks = 0; ks < KBH; ++ks)
+#pragma unroll
+            for (int t = 0; t < BTW; ++t) wb0[ks][t] = ap[(size_t)ks * 4 * KC + t * 16];
+    }
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     if (wave < BT) {   // g_s1^T tiles = W2^T . g_y2^T  (contraction over the H outputs);  g_y1 = g_s1 * SiLU'(y1)
         floatx4 acc[BTW];
 #pragma unroll
         for (int t = 0; t < BTW; ++t) acc[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
         const float* bp = &gy2[nl][lane >> 4];
-        const float* ap = a.W2 + (size_t)(lane >> 4) * KC + wave * 16 * BTW + (lane & 15);     // A[i = hidden unit][c] = W2[c][i]
-#pragma unroll 8
-        for (int ks = 0; ks < H / 4; ++ks) {
+        float wb1[KB - KBH][BTW];
+#pragma unroll
+        for (int ks = KBH; ks < KB; ++ks)
+#pragma unroll
+            for (int t = 0; t < BTW; ++t) wb1[ks - KBH][t] = ap[(size_t)ks * 4 * KC + t * 16];
+#pragma unroll
+        for (int ks = 0; ks < KB; ++ks) {
             const float b = bp[ks * 4];
 #pragma unroll
-            for (int t = 0; t < BTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[(size_t)ks * 4 * KC + t * 16], b, acc[t], 0, 0, 0);
+            for (int t = 0; t < BTW; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ks < KBH ? wb0[ks][t] : wb1[ks - KBH][t], b, acc[t], 0, 0, 0);
         }
 #pragma unroll
         for (int t = 0; t < BTW; ++t) {
@@ -399,13 +484,16 @@ __global__ __launch_bounds__(256) void k_node_energy_mfma(EnergyNodeArgs a, cons
         }
     }
     __syncthreads();
-    if (tid < NODE_TILE * 8) {
-        const int nl2 = tid / 8, p = tid % 8, n2 = node0 + nl2;
-        if (n2 < a.N && p < a.P) {
-            float gx = 0.0f;
-            for (int k = 0; k < KC; ++k) gx = fmaf(y1[nl2][k], a.W0[k * a.P + p], gx);
-            a.grad[(size_t)n2 * a.P + p] = dir[nl2][p] + gx;
-        }
+    {   // grad = direct term + W0^T g_y1: two threads per (node, component), each half of the hidden units in ascending order
+        const int half = tid >> 7, t7 = tid & 127;
+        const int nl2 = t7 / 8, p = t7 % 8;
+        float gx = 0.0f;
+#pragma unroll 16
+        for (int k = half * (KC / 2); k < (half + 1) * (KC / 2); ++k) gx = fmaf(y1[nl2][k], w0s[k][p], gx);
+        if (half == 1) red[t7] = gx;
+        __syncthreads();
+        const int n2 = node0 + nl2;
+        if (half == 0 && n2 < a.N && p < a.P) a.grad[(size_t)n2 * a.P + p] = dir[nl2][p] + (gx + red[t7]);
     }
 }
 

@@ -1345,8 +1345,11 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     if (bf_bwd && !g->GZRS && dev_alloc(g->allocs, &g->GZRS, (size_t)3 * p.R * 2 * H)) return 1;
     if (h2_bwd && !g->GZRH && (dev_alloc(g->allocs, &g->GZRH, (size_t)2 * p.R * 2 * H) || dev_alloc(g->allocs, &g->gexp, (size_t)p.R))) return 1;
     prof_mark(g, s, CCSP_K_ROWSUM);
+    if (h2_bwd)
+        hipLaunchKernelGGL(k_rowsum_h2, dim3(nblk(p.R, 4)), dim3(256), 0, s, p.R, g->row_ptr, g->row_edge, g->GZ, g->GZRH, g->gexp);
+    else
     hipLaunchKernelGGL(k_rowsum, dim3(nblk((long)p.R * (2 * H / 4), 256)), dim3(256), 0, s, p.R, 2 * H, g->row_ptr, g->row_edge, g->GZ, g->GZR,
-                       bf_bwd ? g->GZRS : (unsigned short*)nullptr, h2_bwd ? g->GZRH : (unsigned short*)nullptr, g->gexp);
+                       bf_bwd ? g->GZRS : (unsigned short*)nullptr);
     const int* no_map = nullptr;
     const float* nof = nullptr;
     prof_mark(g, s, CCSP_K_ROWGEMM_T);

@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 for rep in 1 2; do
   for cfg in "$@"; do
-    v=$(env $cfg python $R/bench.py --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | python -c "import json,sys; print('%.1f' % json.loads(sys.stdin.read())['value'])")
+    v=$(env $cfg python $R/bench.py $BENCH_ARGS --no-cpu-baseline --no-roofline --no-evaluate 2>/dev/null | tail -1 | python -c "import json,sys; print('%.1f' % json.loads(sys.stdin.read())['value'])")
     echo "$cfg: $v"
   done
 done
