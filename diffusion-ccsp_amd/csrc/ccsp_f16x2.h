@@ -538,20 +538,16 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_h2(int E_act, int P, const 
     const int lr = tid >> 3, lq = tid & 7;
     float go[2][8];
     const float* q_ptr[2];
-    int a_st[2], a_exp[2];
+    int a_st[2], a_exp[2], o_pos[2], ku0[2], ku1[2];
+    // index loads first: everything below hangs off them (CSR slot -> go -> row exponent; U rows of the epilogue)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         int k = e0 + lr + 32 * i;
         k = k < E_act ? k : E_act - 1;
         const size_t row = (size_t)2 * k + s;
-        const float* o = Ocsr + (size_t)ent_pos[row] * P;
-        float sum = 0.0f;
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            go[i][p] = p < P ? -o[p] : 0.0f;                       // 2 d = -(-2 d)
-            sum += fabsf(go[i][p]);
-        }
-        a_exp[i] = h2_scale_exp(1.1f * wd2_absmax * sum);
+        o_pos[i] = ent_pos[row];
+        ku0[i] = e_u0[k];
+        ku1[i] = e_u1[k];
         q_ptr[i] = Q + row * KD + lq * 4;
         a_st[i] = h2_off(lr + 32 * i, lq >> 1) + (lq & 1) * 4;
     }
@@ -602,6 +598,17 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_h2(int E_act, int P, const 
     gload_a(0, 0);
     gload_b(0);
     gload_a(1, 1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float* o = Ocsr + (size_t)o_pos[i] * P;
+        float sum = 0.0f;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            go[i][p] = p < P ? -o[p] : 0.0f;                       // 2 d = -(-2 d)
+            sum += fabsf(go[i][p]);
+        }
+        a_exp[i] = h2_scale_exp(1.1f * wd2_absmax * sum);
+    }
     floatx16 acc[1][2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -628,6 +635,19 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_h2(int E_act, int P, const 
     // epilogue through LDS: the accumulators are re-read as rows of float4, so the U gathers and the GZ stores are 128-byte row
     // segments; the thread that produced a row's A values reads it back, so its exponent is in a register
     float* Cs = reinterpret_cast<float*>(smem);
+    // the U rows are requested before the accumulators go through LDS
+    float4 ua[2][4], ub[2][4];
+    auto uload = [&](int i) {
+        const float* u0 = U + (size_t)ku0[i] * (2 * H) + s * H + n0 + lq * 4;
+        const float* u1 = U + (size_t)ku1[i] * (2 * H) + s * H + n0 + lq * 4;
+#pragma unroll
+        for (int mcol = 0; mcol < 4; ++mcol) {
+            ua[i][mcol] = *reinterpret_cast<const float4*>(u0 + 32 * mcol);
+            ub[i][mcol] = *reinterpret_cast<const float4*>(u1 + 32 * mcol);
+        }
+    };
+    uload(0);
+    uload(1);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -640,19 +660,19 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_h2(int E_act, int P, const 
     for (int i = 0; i < 2; ++i) {
         const int row = lr + 32 * i;
         const int k = e0 + row;
-        if (k >= E_act) continue;
         const int e = -(a_exp[i] + wd_exp);
-        const float* u0 = U + (size_t)e_u0[k] * (2 * H) + s * H + n0;
-        const float* u1 = U + (size_t)e_u1[k] * (2 * H) + s * H + n0;
-        float* gz = GZ + (size_t)k * (2 * H) + s * H + n0;
+        float4 g[4];
 #pragma unroll
         for (int mcol = 0; mcol < 4; ++mcol) {
-            const int c = lq * 4 + 32 * mcol;
-            const float4 a = *reinterpret_cast<const float4*>(u0 + c);
-            const float4 b = *reinterpret_cast<const float4*>(u1 + c);
-            const float4 v = *reinterpret_cast<const float4*>(Cs + row * C_LD + c);
-            *reinterpret_cast<float4*>(gz + c) = make_float4(ldexpf(v.x, e) * silu_grad_fast(a.x + b.x), ldexpf(v.y, e) * silu_grad_fast(a.y + b.y),
-                                                             ldexpf(v.z, e) * silu_grad_fast(a.z + b.z), ldexpf(v.w, e) * silu_grad_fast(a.w + b.w));
+            const float4 a = ua[i][mcol], b = ub[i][mcol];
+            const float4 v = *reinterpret_cast<const float4*>(Cs + row * C_LD + lq * 4 + 32 * mcol);
+            g[mcol] = make_float4(ldexpf(v.x, e) * silu_grad_fast(a.x + b.x), ldexpf(v.y, e) * silu_grad_fast(a.y + b.y),
+                                  ldexpf(v.z, e) * silu_grad_fast(a.z + b.z), ldexpf(v.w, e) * silu_grad_fast(a.w + b.w));
+        }
+        if (k < E_act) {
+            float* gz = GZ + (size_t)k * (2 * H) + s * H + n0 + lq * 4;
+#pragma unroll
+            for (int mcol = 0; mcol < 4; ++mcol) *reinterpret_cast<float4*>(gz + 32 * mcol) = g[mcol];
         }
     }
 }
