@@ -130,8 +130,8 @@ __device__ __forceinline__ void h2_epilogue_prefetch(float4 (&bs)[4][2], int i, 
 
 // bs0: the prefetched base values of row tile 0 (h2_epilogue_prefetch, issued under the last K chunk); tile 1's are
 // requested here before tile 0 is processed
-template <int ND>
-__device__ __forceinline__ void h2_epilogue_wave(const floatx16 (&acc)[2][2], float4 (&bs0)[4][2], float* __restrict__ Cw,
+template <int ND, int MI>
+__device__ __forceinline__ void h2_epilogue_wave(const floatx16 (&acc)[MI][2], float4 (&bs0)[4][2], float* __restrict__ Cw,
                                                  int wrow0 /*first tile row of the wave*/, int nrows, int row0,
                                                  int colw /*first global column of the wave*/, const int* __restrict__ sE, int w_exp,
                                                  const float* __restrict__ base, const float* __restrict__ tau_row /*or null*/,
@@ -144,9 +144,9 @@ __device__ __forceinline__ void h2_epilogue_wave(const floatx16 (&acc)[2][2], fl
         tv[k] = tau_row ? *reinterpret_cast<const float4*>(tau_row + colw + 4 * eq + 32 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
     if (wrow0 >= nrows) return;                                   // (wave-uniform) nothing of the tile in this wave's rows
     float4 bs1[4][2];
-    h2_epilogue_prefetch<ND>(bs1, 1, wrow0, nrows, row0, colw, base);
+    if constexpr (MI == 2) h2_epilogue_prefetch<ND>(bs1, 1, wrow0, nrows, row0, colw, base);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MI; ++i) {
         float4 (&bs)[4][2] = i == 0 ? bs0 : bs1;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -186,6 +186,15 @@ __device__ __forceinline__ void h2_epilogue_wave(const floatx16 (&acc)[2][2], fl
     }
 }
 
+// s_waitcnt vmcnt(n) lgkmcnt(0) with n known after unrolling (the immediate must be a literal)
+__device__ __forceinline__ void h2_wait_vm_lgkm0(int n) {
+    if (n >= 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+    else if (n >= 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+    else if (n >= 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else if (n >= 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
 // ------------------------------------------------------------------------------------------
 // k_rowgemm_h2<KD, ND, DB>:  U[row0 + r, col0 + c] = 2^-(ea[r] + ew) * sum_k A[src(r), k] W[ts][col0 + c, k]  + base + tau
 //   A planes [2][n_src][KD] fp16 bits scaled by 2^a_exp[src], rows gathered by urow_node; W planes [2][n_ts][ND][KD]
@@ -202,7 +211,7 @@ __device__ __forceinline__ void h2_epilogue_wave(const floatx16 (&acc)[2][2], fl
 //           piece s ^ ((r >> 2) & 3).
 // ------------------------------------------------------------------------------------------
 template <int KD, int ND, int MODE>
-__global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void k_rowgemm_h2(const unsigned short* __restrict__ A, size_t a_plane, const int* __restrict__ a_exp,
+__global__ __launch_bounds__(256, MODE == 0 ? 3 : (MODE == 3 ? 1 : 2)) void k_rowgemm_h2(const unsigned short* __restrict__ A, size_t a_plane, const int* __restrict__ a_exp,
                                                        const int* __restrict__ urow_node, const int* __restrict__ tile_row0,
                                                        const int* __restrict__ tile_nrows, const int* __restrict__ tile_ts,
                                                        const unsigned short* __restrict__ W, size_t w_plane, size_t w_stride, int w_exp,
@@ -210,10 +219,11 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void k_rowgemm_h2(const uns
                                                        float* __restrict__ U, float* __restrict__ umax, StepRef ref, size_t tau_stride) {
     static_assert(ND % 128 == 0 && KD % H2_BK == 0 && KD / H2_BK >= 3, "shape");
     constexpr int NCT = ND / 128, NCH = KD / H2_BK;
-    constexpr int APL = 128 * H2_BK, STAGE = 2 * APL + 2 * H2_BPL;        // 32 KB per stage
+    constexpr int MI = MODE == 4 ? 1 : 2, TM = 64 * MI;           // 32-row MFMA tiles per wave, rows per workgroup tile
+    constexpr int APL = TM * H2_BK, STAGE = 2 * APL + 2 * H2_BPL;         // 32 KB per stage (24 KB for 64-row tiles)
     constexpr bool DB = MODE == 1;
-    constexpr int NST = MODE == 0 ? 1 : 2;                        // LDS stages
-    constexpr int NRS = MODE == 1 ? 2 : 1;                        // register sets (MODE 2 uses none)
+    constexpr int NST = MODE == 0 ? 1 : (MODE == 3 ? 4 : (MODE == 4 ? 3 : 2));      // LDS stages
+    constexpr int NRS = MODE == 1 ? 2 : 1;                        // register sets (MODE 2 and 3 use none)
     constexpr int SMEM_US = (NST * STAGE * 2 > 4 * H2_CW_SZ * 4 ? NST * STAGE : 4 * H2_CW_SZ * 2);
     __shared__ __attribute__((aligned(16))) unsigned short smem[SMEM_US + 256];      // stages (epilogue tiles on top) + 128 row exponents
     int* sE = reinterpret_cast<int*>(smem + SMEM_US);
@@ -225,15 +235,17 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void k_rowgemm_h2(const uns
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const int lrow = tid >> 2, lq = tid & 3;                      // staging: rows lrow, lrow + 64, 16-byte piece lq, both planes
-    const unsigned short* a_ptr[2];
+    const unsigned short* a_ptr[2] = {nullptr, nullptr};          // (register staging: MODE 0 and 1 only)
+    if constexpr (MODE < 2) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int r = lrow + 64 * i;
-        r = r < nrows ? r : nrows - 1;
-        const int src = urow_node ? urow_node[row0 + r] : row0 + r;
-        a_ptr[i] = A + (size_t)src * KD + lq * 8;
+        for (int i = 0; i < 2; ++i) {
+            int r = lrow + 64 * i;
+            r = r < nrows ? r : nrows - 1;
+            const int src = urow_node ? urow_node[row0 + r] : row0 + r;
+            a_ptr[i] = A + (size_t)src * KD + lq * 8;
+        }
     }
-    if (tid < 128) {
+    if (tid < TM) {
         const int r = tid < nrows ? tid : nrows - 1;
         sE[tid] = a_exp[urow_node ? urow_node[row0 + r] : row0 + r];
     }
@@ -260,50 +272,87 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void k_rowgemm_h2(const uns
                 *reinterpret_cast<ushort8*>(Bs + p * H2_BPL + st_off + i * 64 * H2_BK) = rb[set][i * 2 + p];
             }
     };
-    floatx16 acc[2][2];
+    floatx16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     float4 bs0[4][2];
-    if constexpr (MODE == 2) {
-        // wave w fills 1 KB blocks 4 w .. 4 w + 3 of the A planes and of the B planes: block = (plane, sixteen rows)
+    const int wr0 = wm * 32 * MI;                                 // first tile row of the wave
+    if constexpr (MODE >= 2) {
+        // a wave-instruction fills one 1 KB block = (plane, sixteen rows); wave w owns blocks NA w .. NA w + NA - 1 of the A
+        // planes (2 x TM / 16 blocks) and 4 w .. 4 w + 3 of the B planes
         using gptr = const __attribute__((address_space(1))) void*;
         using lptr = __attribute__((address_space(3))) void*;
-        const unsigned short* ga[4];
+        constexpr int NA = TM / 32, ARB = TM / 16;
+        const unsigned short* ga[NA];
         const unsigned short* gb[4];
-        int lo[4];                                                // wave-uniform stage offset of the block (fp16 elements)
+        int loa[NA], lob[4];                                      // wave-uniform stage offsets of the blocks (fp16 elements)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int blk = 4 * wave + j, plane = blk >> 3, rb16 = blk & 7;
+        for (int j = 0; j < NA; ++j) {
+            const int blk = NA * wave + j, plane = blk / ARB, rb16 = blk % ARB;
             const int row = rb16 * 16 + (lane >> 2);
             const int piece = (lane & 3) ^ ((row >> 2) & 3);
             const int r = row < nrows ? row : nrows - 1;
             const int src = urow_node ? urow_node[row0 + r] : row0 + r;
             ga[j] = A + (size_t)plane * a_plane + (size_t)src * KD + piece * 8;
+            loa[j] = __builtin_amdgcn_readfirstlane(plane * APL + rb16 * 16 * H2_BK);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int blk = 4 * wave + j, plane = blk >> 3, rb16 = blk & 7;
+            const int row = rb16 * 16 + (lane >> 2);
+            const int piece = (lane & 3) ^ ((row >> 2) & 3);
             gb[j] = W + (size_t)plane * w_plane + (size_t)ts * w_stride + (size_t)(col0 + row) * KD + piece * 8;
-            lo[j] = __builtin_amdgcn_readfirstlane(plane * APL + rb16 * 16 * H2_BK);
+            lob[j] = __builtin_amdgcn_readfirstlane(plane * H2_BPL + rb16 * 16 * H2_BK);
         }
         auto glds = [&](int c, int stage) {
             unsigned short* st = smem + stage * STAGE;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                __builtin_amdgcn_global_load_lds((gptr)(ga[j] + c * H2_BK), (lptr)(st + lo[j]), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gptr)(gb[j] + c * H2_BK), (lptr)(st + 2 * APL + lo[j]), 16, 0, 0);
-            }
+            for (int j = 0; j < NA; ++j) __builtin_amdgcn_global_load_lds((gptr)(ga[j] + c * H2_BK), (lptr)(st + loa[j]), 16, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds((gptr)(gb[j] + c * H2_BK), (lptr)(st + 2 * APL + lob[j]), 16, 0, 0);
         };
+        if constexpr (MODE >= 3) {
+            // Low-latency forms for short tile lists (small batches: the kernel is one dependent chain, not a throughput
+            // problem): a ring of NST stages with NST - 1 chunks of operands in flight and COUNTED waits -- s_waitcnt vmcnt(n)
+            // lets the loads of the younger chunks stay outstanding while chunk c is multiplied (vector-memory loads retire
+            // in order).  The barriers are bare s_barrier: __syncthreads() carries a fence that drains every load.  `base` of
+            // the first row tile is requested before anything else (older than the ring's loads, so it has landed first).
+            //   MODE 3: 128-row tiles, four stages;  MODE 4: 64-row tiles (32 x 64 per wave), three stages, 72 KB -- a quarter of
+            //   the MFMA and epilogue work per wave and twice the workgroups, for tile lists that leave most CUs empty.
+            constexpr int NL = NA + 4, D = NST - 1;               // loads per chunk and thread; chunks requested ahead
+            h2_epilogue_prefetch<ND>(bs0, 0, wr0, nrows, row0, col0 + wn * 64, base);
+#pragma unroll
+            for (int c = 0; c < D; ++c) glds(c, c);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                // (lgkmcnt(0): this wave's LDS reads of the stage about to be refilled have returned)
+                h2_wait_vm_lgkm0((NCH - 1 - c < D - 1 ? NCH - 1 - c : D - 1) * NL);
+                __builtin_amdgcn_s_barrier();                         // chunk c has landed for every wave; stage (c-1) % NST is free
+                __builtin_amdgcn_sched_barrier(0);
+                if (c + D < NCH) glds(c + D, (c + D) % NST);
+                const unsigned short* st = smem + (c % NST) * STAGE;
+                h2_kstep<MI>(st, APL, st + 2 * APL, 0, wr0, wn * 64, acc);
+                h2_kstep<MI>(st, APL, st + 2 * APL, 1, wr0, wn * 64, acc);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                             // every wave is done reading the stages
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
         glds(0, 0);
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             if (c + 1 < NCH) glds(c + 1, (c + 1) & 1);
-            if (c == NCH - 1) h2_epilogue_prefetch<ND>(bs0, 0, wm * 64, nrows, row0, col0 + wn * 64, base);
+            if (c == NCH - 1) h2_epilogue_prefetch<ND>(bs0, 0, wr0, nrows, row0, col0 + wn * 64, base);
             const unsigned short* st = smem + (c & 1) * STAGE;
-            h2_kstep<2>(st, APL, st + 2 * APL, 0, wm * 64, wn * 64, acc);
-            h2_kstep<2>(st, APL, st + 2 * APL, 1, wm * 64, wn * 64, acc);
+            h2_kstep<MI>(st, APL, st + 2 * APL, 0, wr0, wn * 64, acc);
+            h2_kstep<MI>(st, APL, st + 2 * APL, 1, wr0, wn * 64, acc);
             __syncthreads();                                      // (drains the LDS-DMA of chunk c+1 as well)
+        }
         }
     } else if constexpr (DB) {
         gload(0, 0);
@@ -316,10 +365,10 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void k_rowgemm_h2(const uns
             // register set (c+1)&1 holds chunk c+1, the other one chunk c+2 (still in flight)
             if (c + 1 < NCH) lstore((c + 1) & 1, (c + 1) & 1);
             if (c + 3 < NCH) gload(c + 3, (c + 1) & 1);
-            if (c == NCH - 1) h2_epilogue_prefetch<ND>(bs0, 0, wm * 64, nrows, row0, col0 + wn * 64, base);
+            if (c == NCH - 1) h2_epilogue_prefetch<ND>(bs0, 0, wr0, nrows, row0, col0 + wn * 64, base);
             const unsigned short* st = smem + (c & 1) * STAGE;
-            h2_kstep<2>(st, APL, st + 2 * APL, 0, wm * 64, wn * 64, acc);
-            h2_kstep<2>(st, APL, st + 2 * APL, 1, wm * 64, wn * 64, acc);
+            h2_kstep<MI>(st, APL, st + 2 * APL, 0, wr0, wn * 64, acc);
+            h2_kstep<MI>(st, APL, st + 2 * APL, 1, wr0, wn * 64, acc);
             __syncthreads();
         }
     } else {
@@ -328,9 +377,9 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void k_rowgemm_h2(const uns
         gload(1, 0);
         __syncthreads();
         for (int c = 0; c < NCH; ++c) {
-            if (c == NCH - 1) h2_epilogue_prefetch<ND>(bs0, 0, wm * 64, nrows, row0, col0 + wn * 64, base);
-            h2_kstep<2>(smem, APL, smem + 2 * APL, 0, wm * 64, wn * 64, acc);
-            h2_kstep<2>(smem, APL, smem + 2 * APL, 1, wm * 64, wn * 64, acc);
+            if (c == NCH - 1) h2_epilogue_prefetch<ND>(bs0, 0, wr0, nrows, row0, col0 + wn * 64, base);
+            h2_kstep<MI>(smem, APL, smem + 2 * APL, 0, wr0, wn * 64, acc);
+            h2_kstep<MI>(smem, APL, smem + 2 * APL, 1, wr0, wn * 64, acc);
             __syncthreads();                                      // every wave is done reading the stage
             if (c + 1 < NCH) {
                 lstore(0, 0);
@@ -340,7 +389,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void k_rowgemm_h2(const uns
         }
     }
     // (every wave is past the last barrier: the stages are free for the wave-private epilogue tiles)
-    h2_epilogue_wave<ND>(acc, bs0, reinterpret_cast<float*>(smem) + wave * H2_CW_SZ, wm * 64, nrows, row0, col0 + wn * 64, sE, w_exp, base,
+    h2_epilogue_wave<ND, MI>(acc, bs0, reinterpret_cast<float*>(smem) + wave * H2_CW_SZ, wr0, nrows, row0, col0 + wn * 64, sE, w_exp, base,
                          (tau_t && (ts & 1) == 0) ? tau_t + (size_t)(ts >> 1) * ND : nullptr, U, umax, 2 * NCT, 2 * ct + wn);
 }
 
@@ -355,7 +404,34 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void k_rowgemm_h2(const uns
 //   with half the SiLU / split work per thread: the kernel is one tile's latency chain long, so shorter chains on more
 //   SIMDs win until the tile list no longer fits the CUs at once.
 // ------------------------------------------------------------------------------------------
-template <bool ENERGY, int MT>
+// second decoder layer of a 64-row S1 tile (o[row, p] = sum_j S1[row, j] Wd2[p, j], 128 hidden units): wave w multiplies hidden
+// units 32 w .. 32 w + 31 of all 64 rows (lane = row: conflict-free LDS reads at the odd row stride, weights wave-uniform ->
+// scalar loads) and leaves its P partial sums in RED[w][p][row]; the caller adds the four partials in a fixed order.  32 LDS
+// reads per lane instead of the 128 of a whole dot product per (row, p) item: 2.3 k cycles shorter per workgroup, which is what
+// counts when the grid is a single round (k_edge_h2<., ., 1>, small batches: C5 +3.5 %); with several workgroups per CU in flight
+// the extra barrier costs more than the reads (C2 -1 %), so large grids keep the one-pass form.  PP > 0: pose_dim at compile time.
+template <int PP>
+__device__ __forceinline__ void h2_decoder_l2(const float* __restrict__ S1, int s1_ld, const float* __restrict__ Wd2, int P, float* __restrict__ RED,
+                                              int wave, int lane) {
+    const int kq = __builtin_amdgcn_readfirstlane(wave) * 32;
+    float part[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) part[p] = 0.0f;
+    const float* srow = S1 + lane * s1_ld + kq;
+    const float* w = Wd2 + kq;
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+        const float sv = srow[k];
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+            if (PP > 0 ? p < PP : p < P) part[p] = fmaf(sv, w[p * 128 + k], part[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+        if (PP > 0 ? p < PP : p < P) RED[(wave * 8 + p) * 64 + lane] = part[p];
+}
+
+template <bool ENERGY, int MT, int L2>
 __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void k_edge_h2(int E_act, int P, const int* __restrict__ e_u0, const int* __restrict__ e_u1,
                                                     const float* __restrict__ U, const float* __restrict__ umax /*[R][8]*/,
                                                     const unsigned short* __restrict__ Wd1H /*[2][128][256]*/, int wd_exp,
@@ -368,7 +444,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void k_edge_h2(int E_act, int
     constexpr int APL = ROWS * H2_BK, STAGE = 2 * APL + 2 * H2_BPL;
     constexpr int NPASS = ROWS / 32;                              // producer passes per chunk: rows lr + 32 i
     constexpr int S1_LD = BN + 1;
-    static_assert(64 * S1_LD * 4 <= 2 * STAGE * 2, "epilogue tile must fit the stages");
+    static_assert((64 * S1_LD + 4 * 8 * 64) * 4 <= 2 * STAGE * 2, "epilogue tile and the layer-2 partials must fit the stages");
     __shared__ __attribute__((aligned(16))) unsigned short smem[2 * STAGE + 2 * ROWS];
     int* sE = reinterpret_cast<int*>(smem + 2 * STAGE);
     const int e0 = xcd_remap(blockIdx.x, gridDim.x) * ME;
@@ -468,6 +544,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void k_edge_h2(int E_act, int
     }
     // epilogue, 64 rows per pass (row tile i of every wave: 32 edges x both halves)
     float* S1 = reinterpret_cast<float*>(smem);
+    float* RED = S1 + 64 * S1_LD;
     float e2 = 0.0f;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -488,10 +565,24 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void k_edge_h2(int E_act, int
             }
         }
         __syncthreads();
+        if constexpr (L2 == 1) {                                               // (see h2_decoder_l2)
+            if (P == 4) h2_decoder_l2<4>(S1, S1_LD, Wd2, P, RED, wave, lane);
+            else if (P == 5) h2_decoder_l2<5>(S1, S1_LD, Wd2, P, RED, wave, lane);
+            else h2_decoder_l2<0>(S1, S1_LD, Wd2, P, RED, wave, lane);
+            __syncthreads();
+        }
         for (int idx = tid; idx < 64 * P; idx += 256) {
             const int lrow = idx & 63;                                         // S1 row: half (lrow >> 5), edge e0 + i * 32 + (lrow & 31)
-            const int p = __builtin_amdgcn_readfirstlane(idx >> 6);           // uniform per wave: scalar weight loads
-            const float o = dot4<BN>(S1 + lrow * S1_LD, Wd2 + (size_t)p * BN) + bd2[p];
+            float o;
+            if constexpr (L2 == 1) {
+                const int p = idx >> 6;
+                const float* rp = RED + p * 64 + lrow;
+                o = ((rp[0] + rp[8 * 64]) + (rp[16 * 64] + rp[24 * 64])) + bd2[p];
+            } else {
+                const int p = __builtin_amdgcn_readfirstlane(idx >> 6);       // uniform per wave: scalar weight loads
+                o = dot4<BN>(S1 + lrow * S1_LD, Wd2 + (size_t)p * BN) + bd2[p];
+            }
+            const int p = idx >> 6;
             const int k = e0 + i * 32 + (lrow & 31), s = lrow >> 5;
             if (k < E_act) {
                 if constexpr (ENERGY) {

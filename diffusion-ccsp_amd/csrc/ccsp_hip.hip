@@ -1092,22 +1092,27 @@ EncW enc_pose(const ccsp_model* m) { return EncW{m->pe0_w, m->pe0_b, m->pe2_wT, 
 // f16x2 kernels (H = 256): the residency variant is chosen so that the whole tile list is resident at once when it can be
 // (ccsp_f16x2.h): row GEMM 2 workgroups per CU with direct-to-LDS staging if the tiles fit, else 3 per CU; edge kernel
 // 32-edge tiles at 3 per CU if they fit, else 64-edge tiles
+// variant of k_rowgemm_h2 for a launch of `nct` column tiles per row tile (ccsp_f16x2.h): 64-row tiles on a ring of LDS stages
+// when even those leave room on the CUs (short tile lists are latency chains), else 128-row tiles at 2 workgroups per CU
+// with direct-to-LDS staging if they fit, else 3 per CU
+int rowgemm_h2_mode(const ccsp_model* m, const ccsp_graph* g, int nct) {
+    if (m->row_mode >= 0) return m->row_mode;
+    if (g->n_tiles * nct <= 2 * m->ncu) return 4;
+    return g->n_tiles2 * nct <= 2 * m->ncu ? 2 : 0;
+}
+
 void launch_rowgemm_h2(ccsp_model* m, ccsp_graph* g, const float* tau_t, StepRef ref, size_t tau_stride, hipStream_t s) {
     constexpr int H = 256;
-    const int work = g->n_tiles2 * (2 * H / 128);
-    const int mode = m->row_mode >= 0 ? m->row_mode : (work <= 2 * m->ncu ? 2 : 0);
-    if (mode == 2)
-        hipLaunchKernelGGL((k_rowgemm_h2<H, 2 * H, 2>), dim3(work), dim3(256), 0, s, g->pembH, (size_t)g->N * H, g->pexp, g->urow_node, g->t2_row0,
-                           g->t2_nrows, g->t2_ts, m->WpH, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, m->wp_exp, g->base, tau_t, g->U,
-                           g->umax, ref, tau_stride);
-    else if (mode == 1)
-        hipLaunchKernelGGL((k_rowgemm_h2<H, 2 * H, 1>), dim3(work), dim3(256), 0, s, g->pembH, (size_t)g->N * H, g->pexp, g->urow_node, g->t2_row0,
-                           g->t2_nrows, g->t2_ts, m->WpH, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, m->wp_exp, g->base, tau_t, g->U,
-                           g->umax, ref, tau_stride);
-    else
-        hipLaunchKernelGGL((k_rowgemm_h2<H, 2 * H, 0>), dim3(work), dim3(256), 0, s, g->pembH, (size_t)g->N * H, g->pexp, g->urow_node, g->t2_row0,
-                           g->t2_nrows, g->t2_ts, m->WpH, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, m->wp_exp, g->base, tau_t, g->U,
-                           g->umax, ref, tau_stride);
+    const int mode = rowgemm_h2_mode(m, g, 2 * H / 128);
+    const bool small = mode == 4;                       // 64-row plan tiles instead of their 128-row pairs
+    const int work = (small ? g->n_tiles : g->n_tiles2) * (2 * H / 128);
+#define CCSP_ROWGEMM_F(MODE)                                                                                                                          \
+    hipLaunchKernelGGL((k_rowgemm_h2<H, 2 * H, MODE>), dim3(work), dim3(256), 0, s, g->pembH, (size_t)g->N * H, g->pexp, g->urow_node,                  \
+                       small ? g->tile_row0 : g->t2_row0, small ? g->tile_nrows : g->t2_nrows, small ? g->tile_ts : g->t2_ts, m->WpH,                   \
+                       (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, m->wp_exp, g->base, tau_t, g->U, g->umax, ref, tau_stride)
+    if (mode == 4) CCSP_ROWGEMM_F(4); else if (mode == 3) CCSP_ROWGEMM_F(3); else if (mode == 2) CCSP_ROWGEMM_F(2);
+    else if (mode == 1) CCSP_ROWGEMM_F(1); else CCSP_ROWGEMM_F(0);
+#undef CCSP_ROWGEMM_F
 }
 
 // returns the number of workgroups (= energy partials)
@@ -1116,12 +1121,13 @@ int launch_edge_h2(ccsp_model* m, ccsp_graph* g, EdgeEnergyArgs en, int* cinc, h
     const int E_act = g->plan.E_act;
     const int mt = m->edge_mt > 0 ? m->edge_mt : (nblk(E_act, 32) <= 3 * m->ncu ? 1 : 2);
     const int nwg = nblk(E_act, 32 * mt);
-    if (mt == 1)
-        hipLaunchKernelGGL((k_edge_h2<ENERGY, 1>), dim3(nwg), dim3(256), 0, s, E_act, m->d.pose_dim, g->e_u0, g->e_u1, g->U, g->umax, m->Wd1H, m->wd_exp,
-                           m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, en, cinc);
-    else
-        hipLaunchKernelGGL((k_edge_h2<ENERGY, 2>), dim3(nwg), dim3(256), 0, s, E_act, m->d.pose_dim, g->e_u0, g->e_u1, g->U, g->umax, m->Wd1H, m->wd_exp,
-                           m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, en, cinc);
+#define CCSP_EDGE_F(MT, L2)                                                                                                                          \
+    hipLaunchKernelGGL((k_edge_h2<ENERGY, MT, L2>), dim3(nwg), dim3(256), 0, s, E_act, m->d.pose_dim, g->e_u0, g->e_u1, g->U, g->umax, m->Wd1H, m->wd_exp, \
+                       m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, en, cinc)
+    if (mt == 1 && nwg <= m->ncu) CCSP_EDGE_F(1, 1);          // a single round of workgroups: the short-latency second layer
+    else if (mt == 1) CCSP_EDGE_F(1, 0);
+    else CCSP_EDGE_F(2, 0);
+#undef CCSP_EDGE_F
     return nwg;
 }
 
@@ -1355,14 +1361,17 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     prof_mark(g, s, CCSP_K_ROWGEMM_T);
     if (h2_bwd) {
         if constexpr (H == 256) {       // g_p[row] = g_z[row] . Wp[type, slot]: the forward kernel with K = 2H, N = H, identity rows, no base
-            const int work = g->n_tiles2 * (H / 128);
-            const int mode = m->row_mode >= 0 ? m->row_mode : (work <= 2 * m->ncu ? 2 : 0);
+            const int mode = rowgemm_h2_mode(m, g, H / 128);
+            const bool small = mode == 4;
+            const int work = (small ? g->n_tiles : g->n_tiles2) * (H / 128);
             float* nou = nullptr;
 #define CCSP_ROWGEMM_T(MODE)                                                                                                                        \
-            hipLaunchKernelGGL((k_rowgemm_h2<2 * H, H, MODE>), dim3(work), dim3(256), 0, s, g->GZRH, (size_t)p.R * 2 * H, g->gexp, no_map, g->t2_row0,  \
-                               g->t2_nrows, g->t2_ts, m->WpTH, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, m->wp_exp, nof, nof, g->GP, nou,   \
-                               StepRef{nullptr, nullptr}, (size_t)0)
-            if (mode == 2) CCSP_ROWGEMM_T(2); else if (mode == 1) CCSP_ROWGEMM_T(1); else CCSP_ROWGEMM_T(0);
+            hipLaunchKernelGGL((k_rowgemm_h2<2 * H, H, MODE>), dim3(work), dim3(256), 0, s, g->GZRH, (size_t)p.R * 2 * H, g->gexp, no_map,              \
+                               small ? g->tile_row0 : g->t2_row0, small ? g->tile_nrows : g->t2_nrows, small ? g->tile_ts : g->t2_ts, m->WpTH,          \
+                               (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, m->wp_exp, nof, nof, g->GP, nou, StepRef{nullptr, nullptr},     \
+                               (size_t)0)
+            if (mode == 4) CCSP_ROWGEMM_T(4); else if (mode == 3) CCSP_ROWGEMM_T(3); else if (mode == 2) CCSP_ROWGEMM_T(2);
+            else if (mode == 1) CCSP_ROWGEMM_T(1); else CCSP_ROWGEMM_T(0);
 #undef CCSP_ROWGEMM_T
         }
     } else if (bf_bwd) {
@@ -1962,7 +1971,7 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     // CCSP_MMA: f16x2 (default at hidden_dim 256: two-term fp16 operands, three MFMA products per fp32 product),
     //           bf16x3 (three-term bf16 operands, six products), f32 (v_mfma_f32_32x32x2_f32)
     m->f16x2 = (H == 256 && d->model_kind == CCSP_MODEL_DIFFUSION_CCSP) ? 1 : 0;
-    if (const char* e = getenv("CCSP_ROW_MODE")) { const int v = atoi(e); if (v >= 0 && v <= 2) m->row_mode = v; }
+    if (const char* e = getenv("CCSP_ROW_MODE")) { const int v = atoi(e); if (v >= 0 && v <= 4) m->row_mode = v; }
     if (const char* e = getenv("CCSP_EDGE_MT")) m->edge_mt = atoi(e) == 2 ? 2 : 1;
     {
         int dev = 0;
