@@ -1093,11 +1093,12 @@ EncW enc_pose(const ccsp_model* m) { return EncW{m->pe0_w, m->pe0_b, m->pe2_wT, 
 // (ccsp_f16x2.h): row GEMM 2 workgroups per CU with direct-to-LDS staging if the tiles fit, else 3 per CU; edge kernel
 // 32-edge tiles at 3 per CU if they fit, else 64-edge tiles
 // variant of k_rowgemm_h2 for a launch of `nct` column tiles per row tile (ccsp_f16x2.h): 64-row tiles on a ring of LDS stages
-// when even those leave room on the CUs (short tile lists are latency chains), else 128-row tiles at 2 workgroups per CU
-// with direct-to-LDS staging if they fit, else 3 per CU
+// when even those are at most one workgroup per CU (short tile lists are latency chains: C5 +12 %; with more work than that
+// the 128-row forms win, C4 -1 % and C2 -4 % if forced), else 128-row tiles at 2 workgroups per CU with direct-to-LDS
+// staging if they fit, else 3 per CU
 int rowgemm_h2_mode(const ccsp_model* m, const ccsp_graph* g, int nct) {
     if (m->row_mode >= 0) return m->row_mode;
-    if (g->n_tiles * nct <= 2 * m->ncu) return 4;
+    if (g->n_tiles * nct <= m->ncu) return 4;
     return g->n_tiles2 * nct <= 2 * m->ncu ? 2 : 0;
 }
 
