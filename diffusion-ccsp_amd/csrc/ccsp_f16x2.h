@@ -42,7 +42,7 @@
 // Included inside the anonymous namespace of ccsp_hip.hip.
 #pragma once
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+// (half8 is declared in ccsp_hip.hip: the node kernel's encoder uses it too)
 
 // (h2_scale_exp / split2h live in ccsp_hip.hip: the node kernel's encoder writes planes too)
 

@@ -172,9 +172,13 @@ struct EncW {
     const float* b2;   // [H]
     int in_dim;
     const float* W2F;  // layer-2 weight in v_mfma_f32_16x16x4_f32 B-fragment order (k_pack_enc_frag), or null
+    const unsigned short* W2H;   // the same weight * 2^w2_exp as two fp16 planes in v_mfma_f32_16x16x32_f16 fragment order, or null
+    int w2_exp;
+    float c1, c2;                // |layer-1 pre-activation| <= c1 * max|x| + c2  (largest absolute row sum of W0, largest |b0|)
 };
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 // W2 [H, H/2] (nn.Linear weight) -> B fragments of 16x16x4: for wave w (H/4 columns), k-step ks,
 // lane l, column tile j:  W2F[((w*KS + ks)*64 + l)*TPW + j] = W2[w*16*TPW + j*16 + (l&15)][ks*4 + (l>>4)]
@@ -241,53 +245,15 @@ struct EncOut {
     int* h2_exp;                // [N]
 };
 
+// Epilogue of the MFMA pose encoders.  The weight fragment is the A operand, so the product comes out transposed: C/D layout
+// of 16x16 is col = lane & 15 -> the node, row = (lane >> 4) * 4 + reg -> four CONSECUTIVE output columns per lane
+// (v[tile][reg]).  One 16-byte store per tile (and 8 bytes per 2-byte plane) instead of four scattered ones: the 2-byte
+// plane stores of the untransposed layout cost 5 % of the whole chain (tools/ab.sh).
 template <int H>
-__device__ __forceinline__ void encode_tile_mfma(const EncW w, const EncPrefetch<H>& pf, float (*xs)[8],
-                                                 float (*s1)[H / 2 + 1], float (*smax)[NODE_TILE], int node0, int N, const EncOut out) {
-    using PFT = EncPrefetch<H>;
-    constexpr int TPW = PFT::TPW, KS = PFT::KS, PF = PFT::PF;
-    const int tid = threadIdx.x;
-    {
-        const int j = tid % (H / 2);
-#pragma unroll
-        for (int i = 0; i < H / 32; ++i) {
-            const int n = tid / (H / 2) + i * (512 / H);
-            float acc = 0.0f;
-#pragma unroll
-            for (int d = 0; d < 8; ++d) acc = fmaf(xs[n][d], pf.w0[d], acc);     // xs columns >= in_dim are 0
-            s1[n][j] = silu_fast(acc + pf.b0);
-        }
-    }
-    __syncthreads();
-    const int wave = tid >> 6, lane = tid & 63;
-    floatx4 acc[TPW];
-#pragma unroll
-    for (int j = 0; j < TPW; ++j) acc[j] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
-    const float* wf = w.W2F + ((size_t)wave * KS * 64 + lane) * TPW;
-    const float* ap = &s1[lane & 15][lane >> 4];
-    // the remaining fragments are requested before the first MFMA is issued
-    float rest[KS - PF][TPW];
-#pragma unroll
-    for (int ks = PF; ks < KS; ++ks)
-#pragma unroll
-        for (int q = 0; q < TPW; ++q) rest[ks - PF][q] = wf[(size_t)ks * 64 * TPW + q];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const float a = ap[ks * 4];
-#pragma unroll
-        for (int j = 0; j < TPW; ++j)
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ks < PF ? pf.wf[ks][j] : rest[ks - PF][j], a, acc[j], 0, 0, 0);
-    }
-    // The weight fragment is the A operand, so the product comes out transposed: C/D layout of 16x16 is
-    // col = lane & 15 -> the node, row = (lane >> 4) * 4 + reg -> four CONSECUTIVE output columns per lane.
-    // One 16-byte store per tile (and 8 bytes per bf16 plane) instead of four scattered ones: the 2-byte
-    // plane stores of the untransposed layout cost 5 % of the whole chain (tools/ab.sh).
+__device__ __forceinline__ void enc_store_tile(const float (&v)[H / 64][4], float (*smax)[NODE_TILE], int node0, int N, const EncOut out) {
+    constexpr int TPW = H / 64;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n = node0 + (lane & 15);
-    float v[TPW][4];
-#pragma unroll
-    for (int j = 0; j < TPW; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[j][r] = silu_fast(acc[j][r] + pf.b2[j][r]);
     int e2 = 0;
     if (out.h2) {
         // largest |element| of every node row: in-lane over the lane's 4 TPW columns, the four lanes of the wave that
@@ -329,6 +295,155 @@ __device__ __forceinline__ void encode_tile_mfma(const EncW w, const EncPrefetch
             }
         }
     }
+}
+
+template <int H>
+__device__ __forceinline__ void encode_tile_mfma(const EncW w, const EncPrefetch<H>& pf, float (*xs)[8],
+                                                 float (*s1)[H / 2 + 1], float (*smax)[NODE_TILE], int node0, int N, const EncOut out) {
+    using PFT = EncPrefetch<H>;
+    constexpr int TPW = PFT::TPW, KS = PFT::KS, PF = PFT::PF;
+    const int tid = threadIdx.x;
+    {
+        const int j = tid % (H / 2);
+#pragma unroll
+        for (int i = 0; i < H / 32; ++i) {
+            const int n = tid / (H / 2) + i * (512 / H);
+            float acc = 0.0f;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) acc = fmaf(xs[n][d], pf.w0[d], acc);     // xs columns >= in_dim are 0
+            s1[n][j] = silu_fast(acc + pf.b0);
+        }
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    floatx4 acc[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) acc[j] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+    const float* wf = w.W2F + ((size_t)wave * KS * 64 + lane) * TPW;
+    const float* ap = &s1[lane & 15][lane >> 4];
+    // the remaining fragments are requested before the first MFMA is issued
+    float rest[KS - PF][TPW];
+#pragma unroll
+    for (int ks = PF; ks < KS; ++ks)
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) rest[ks - PF][q] = wf[(size_t)ks * 64 * TPW + q];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const float a = ap[ks * 4];
+#pragma unroll
+        for (int j = 0; j < TPW; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ks < PF ? pf.wf[ks][j] : rest[ks - PF][j], a, acc[j], 0, 0, 0);
+    }
+    float v[TPW][4];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[j][r] = silu_fast(acc[j][r] + pf.b2[j][r]);
+    enc_store_tile<H>(v, smax, node0, N, out);
+}
+
+// ---- the pose encoder's second layer on the f16 matrix pipe (hidden_dim 256, f16x2 mode; scheme of ccsp_f16x2.h) ----
+// 16 nodes x 256 x 128 is 4096 cycles of v_mfma_f32_16x16x4_f32 per wave and 768 of v_mfma_f32_16x16x32_f16 with three
+// products -- on a kernel that is one latency chain.  Operands: the weight * 2^w2_exp as two fp16 planes in A-fragment order
+// (k_pack_enc_frag_h2); the layer-1 activations s1 = SiLU(y1) of a node scaled by 2^e with e from the BOUND
+// |s1| <= |y1| <= c1 max|x| + c2 (no reduction over the row needed; a loose bound costs nothing, see ccsp_f16x2.h).
+//   W2H[plane][(((w * 4 + ks) * 4 + j) * 64 + l) * 8 + e8] = term of W2[w*64 + j*16 + (l & 15)][ks*32 + 8 (l >> 4) + e8] * 2^e
+__global__ void k_pack_enc_frag_h2(const float* __restrict__ W2 /*[256,128]*/, int e, unsigned short* __restrict__ W2H) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 256 * 128) return;
+    const int e8 = idx & 7, l = (idx >> 3) & 63, j = (idx >> 9) & 3, ks = (idx >> 11) & 3, w = idx >> 13;
+    const int col = w * 64 + j * 16 + (l & 15), k = ks * 32 + 8 * (l >> 4) + e8;
+    unsigned short a, b;
+    split2h(ldexpf(W2[col * 128 + k], e), a, b);
+    W2H[idx] = a;
+    W2H[256 * 128 + idx] = b;
+}
+
+constexpr int ENC_H2_LD = 136;      // fp16 row stride of the s1 planes: 272 bytes, 16-byte fragment reads of 16 rows hit all banks once
+
+struct EncPrefetchH {
+    float w0[8], b0;
+    half8 wa[2][4];                 // k-step 0 of the layer-2 fragments: [plane][tile]
+    float b2[4][4];
+};
+
+__device__ __forceinline__ void enc_prefetch_h2(const EncW w, EncPrefetchH& pf) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int j = tid % 128;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) pf.w0[d] = d < w.in_dim ? w.W0[j * w.in_dim + d] : 0.0f;
+    pf.b0 = w.b0[j];
+    const half8* wh = reinterpret_cast<const half8*>(w.W2H) + (size_t)wave * 16 * 64 + lane;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pf.wa[p][q] = wh[(size_t)p * 4096 + q * 64];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pf.b2[q][r] = w.b2[wave * 64 + q * 16 + 4 * (lane >> 4) + r];
+    __builtin_amdgcn_sched_barrier(0);      // keep these loads at kernel entry (hipcc would sink them to first use)
+}
+
+// s1h: [2][NODE_TILE][ENC_H2_LD] fp16 bits in LDS; sexp: [NODE_TILE].  All 256 threads participate.
+__device__ __forceinline__ void encode_tile_h2(const EncW w, const EncPrefetchH& pf, float (*xs)[8], unsigned short* s1h, int* sexp,
+                                               float (*smax)[NODE_TILE], int node0, int N, const EncOut out) {
+    constexpr int H = 256, LD = ENC_H2_LD;
+    const int tid = threadIdx.x;
+    {
+        const int j = tid % 128;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int n = tid / 128 + 2 * i;
+            float acc = 0.0f, amax = 0.0f;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                const float xv = xs[n][d];                      // columns >= in_dim are 0
+                acc = fmaf(xv, pf.w0[d], acc);
+                amax = fmaxf(amax, fabsf(xv));
+            }
+            // (a NaN pose gives amax 0 -- fmaxf skips it -- hence a finite exponent; the NaN itself travels in the fp16 terms)
+            const int e = h2_scale_exp(fmaf(w.c1, amax, w.c2));
+            unsigned short h1, h2;
+            split2h(ldexpf(silu_fast(acc + pf.b0), e), h1, h2);
+            s1h[n * LD + j] = h1;
+            s1h[(NODE_TILE + n) * LD + j] = h2;
+            if (j == 0) sexp[n] = e;
+        }
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    floatx4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+    const half8* wh = reinterpret_cast<const half8*>(w.W2H) + (size_t)wave * 16 * 64 + lane;
+    half8 rest[3][2][4];                                         // k-steps 1..3, requested before the first MFMA
+#pragma unroll
+    for (int ks = 1; ks < 4; ++ks)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rest[ks - 1][p][q] = wh[(size_t)p * 4096 + (ks * 4 + q) * 64];
+    const unsigned short* bp = s1h + (lane & 15) * LD + 8 * (lane >> 4);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const half8 b1 = *reinterpret_cast<const half8*>(bp + ks * 32);
+        const half8 b2 = *reinterpret_cast<const half8*>(bp + NODE_TILE * LD + ks * 32);
+        // smallest terms first; consecutive MFMAs go to different accumulators
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ks == 0 ? pf.wa[1][j] : rest[ks - 1][1][j], b1, acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ks == 0 ? pf.wa[0][j] : rest[ks - 1][0][j], b2, acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ks == 0 ? pf.wa[0][j] : rest[ks - 1][0][j], b1, acc[j], 0, 0, 0);
+    }
+    const int eu = -(sexp[lane & 15] + w.w2_exp);
+    float v[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[j][r] = silu_fast(ldexpf(acc[j][r], eu) + pf.b2[j][r]);
+    enc_store_tile<H>(v, smax, node0, N, out);
 }
 
 // xs: [NODE_TILE][8] in LDS; s1: [NODE_TILE][H/2] in LDS.  All 256 threads participate.
@@ -777,11 +892,14 @@ struct NodeArgs {
     const ChainHeader* hdr;
 };
 
-template <int H>
+template <int H, bool ENCH /*second encoder layer on the f16 pipe (encode_tile_h2)*/>
 __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, EncOut eo) {
+    static_assert(!ENCH || H == 256, "the f16 encoder is written for hidden_dim 256");
+    constexpr int S1_FLOATS = ENCH ? (2 * NODE_TILE * ENC_H2_LD) / 2 : NODE_TILE * (H / 2 + 1);
     __shared__ float xs[NODE_TILE][8];
-    __shared__ float s1[NODE_TILE][H / 2 + 1];
+    __shared__ __attribute__((aligned(16))) float s1raw[S1_FLOATS];      // layer-1 activations: fp32 rows, or two fp16 planes
     __shared__ float smax[4][NODE_TILE];
+    __shared__ int sexp[NODE_TILE];
     // the node kernel is a short latency chain on the critical path of every evaluation; when it shares the
     // CUs with the other lane's GEMM kernels its waves should win the issue arbitration
     __builtin_amdgcn_s_setprio(3);
@@ -797,7 +915,11 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, EncOut eo) {
     const int node0 = blockIdx.x * NODE_TILE;
     const int tid = threadIdx.x;
     EncPrefetch<H> pf;
-    if (a.do_encode) enc_prefetch<H>(w, pf);
+    EncPrefetchH pfh;
+    if (a.do_encode) {
+        if constexpr (ENCH) enc_prefetch_h2(w, pfh);
+        else enc_prefetch<H>(w, pf);
+    }
     float e_hat = 0.0f;
     if (a.step == STEP_MALA_ACCEPT) {                           // (uniform: kernel argument)
         if (a.E_hat_partial) {
@@ -820,8 +942,15 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, EncOut eo) {
                 const int beg = a.node_ptr[n], end = a.node_ptr[n + 1];
                 float acc = 0.0f;
                 const float* op = a.O + (size_t)beg * a.P + p;
-#pragma unroll 8
-                for (int q = 0; q < end - beg; ++q) acc += op[(size_t)q * a.P];
+                // sixteen entries per round trip (a node of an 8-object graph has up to ~20), summed in CSR order; the
+                // padding terms are +0.0f and change nothing
+                for (int q0 = 0; q0 < end - beg; q0 += 16) {
+                    float v[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) v[j] = q0 + j < end - beg ? op[(size_t)(q0 + j) * a.P] : 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) acc += v[j];
+                }
                 if (a.normalize) acc = acc / sqrtf((float)(end - beg));        // 0/0 -> NaN like the reference
                 eps = masked ? a.xfeat[(size_t)n * a.F + a.F - a.P + p] : acc; // out[mask] = x[:, -P:][mask]
             } else if (a.src == 1) {
@@ -883,7 +1012,8 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, EncOut eo) {
     }
     if (!a.do_encode) return;
     __syncthreads();
-    encode_tile_mfma<H>(w, pf, xs, s1, smax, node0, a.N, eo);
+    if constexpr (ENCH) encode_tile_h2(w, pfh, xs, reinterpret_cast<unsigned short*>(s1raw), sexp, smax, node0, a.N, eo);
+    else encode_tile_mfma<H>(w, pf, xs, reinterpret_cast<float (*)[H / 2 + 1]>(s1raw), smax, node0, a.N, eo);
 }
 
 #include "ccsp_energy.h"
@@ -950,6 +1080,9 @@ struct ccsp_model {
     unsigned short* WpTH = nullptr;   // [2][C][2][H][2H] fp16 planes of WpT * 2^wp_exp (energy backward; energy_wrapper models only)
     unsigned short* Wd1TH = nullptr;  // [2][H][H/2]      fp16 planes of pose_decoder.0.weight^T * 2^wd_exp
     float wd2_absmax = 0.0f;          // max |pose_decoder.2.weight| (row-exponent bound of k_edge_bwd_h2)
+    unsigned short* pe2_wH = nullptr; // pose_encoder.2.weight * 2^pe2_exp, fp16 planes in fragment order (k_pack_enc_frag_h2); CCSP_ENC=f32 leaves it null
+    int pe2_exp = 0;
+    float pe0_c1 = 0.0f, pe0_c2 = 0.0f;   // bound of the pose encoder's layer-1 pre-activation: c1 max|x| + c2
     int energy_bwd_h2 = 1;            // CCSP_ENERGY_BWD=bf16x3 keeps the backward GEMMs on the six-product bf16 kernels
     int ncu = 256;          // compute units of the device (residency-based kernel selection)
     ccsp_energy_hook energy_hook = nullptr;   // MALA global-batch mode (ccsp_model_set_energy_hook)
@@ -1087,7 +1220,7 @@ void cosine_betas(int T, std::vector<double>& betas) {   // ddpm.py:152-162
     }
 }
 
-EncW enc_pose(const ccsp_model* m) { return EncW{m->pe0_w, m->pe0_b, m->pe2_wT, m->pe2_b, m->d.pose_dim, m->pe2_wF}; }
+EncW enc_pose(const ccsp_model* m) { return EncW{m->pe0_w, m->pe0_b, m->pe2_wT, m->pe2_b, m->d.pose_dim, m->pe2_wF, m->pe2_wH, m->pe2_exp, m->pe0_c1, m->pe0_c2}; }
 
 // f16x2 kernels (H = 256): the residency variant is chosen so that the whole tile list is resident at once when it can be
 // (ccsp_f16x2.h): row GEMM 2 workgroups per CU with direct-to-LDS staging if the tiles fit, else 3 per CU; edge kernel
@@ -1213,7 +1346,12 @@ void launch_node(ccsp_model* m, ccsp_graph* g, const NodeArgs& a, hipStream_t s)
     eo.h2 = h2 ? g->pembH : nullptr;
     eo.h2_exp = h2 ? g->pexp : nullptr;
     prof_mark(g, s, CCSP_K_NODE);
-    hipLaunchKernelGGL(k_node<H>, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a, enc_pose(m), eo);
+    bool ench = false;
+    if constexpr (H == 256) ench = m->pe2_wH != nullptr;
+    if constexpr (H == 256) {
+        if (ench) hipLaunchKernelGGL((k_node<H, true>), dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a, enc_pose(m), eo);
+    }
+    if (!ench) hipLaunchKernelGGL((k_node<H, false>), dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a, enc_pose(m), eo);
     prof_mark(g, s, -1);
 }
 
@@ -2112,9 +2250,13 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
         hipLaunchKernelGGL(k_split3, dim3(nblk(nwd, 256)), dim3(256), 0, s, nwd, m->pd0_wT, m->Wd1TS);
         if (m->f16x2) {     // fp16 planes of the same weights, each tensor scaled by one exact power of two (ccsp_f16x2.h)
             unsigned int* mx = nullptr;
-            unsigned int h_mx[3] = {0u, 0u, 0u};
-            TRY(dev_alloc(reg, &mx, 3));
-            HIP_TRY(hipMemsetAsync(mx, 0, 3 * sizeof(unsigned int), s));
+            unsigned int h_mx[4] = {0u, 0u, 0u, 0u};
+            TRY(dev_alloc(reg, &mx, 4));
+            HIP_TRY(hipMemsetAsync(mx, 0, 4 * sizeof(unsigned int), s));
+            hipLaunchKernelGGL(k_absmax_bits, dim3(nblk((long)H * (H / 2), 256)), dim3(256), 0, s, (long)H * (H / 2), m->pe2_w, mx + 3);
+            std::vector<float> h_w0((size_t)(H / 2) * P), h_b0(H / 2);
+            HIP_TRY(hipMemcpyAsync(h_w0.data(), m->pe0_w, h_w0.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(h_b0.data(), m->pe0_b, h_b0.size() * sizeof(float), hipMemcpyDeviceToHost, s));
             hipLaunchKernelGGL(k_absmax_bits, dim3(nblk(nwp, 256)), dim3(256), 0, s, nwp, m->Wp, mx);
             hipLaunchKernelGGL(k_absmax_bits, dim3(nblk(nwd, 256)), dim3(256), 0, s, nwd, m->pd0_w, mx + 1);
             hipLaunchKernelGGL(k_absmax_bits, dim3(nblk((long)P * (H / 2), 256)), dim3(256), 0, s, (long)P * (H / 2), m->pd2_w, mx + 2);
@@ -2124,6 +2266,23 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
             auto host_exp = [](unsigned int bits) { const int be = (int)((bits >> 23) & 0xffu); return (be == 0 || be == 255) ? 0 : 140 - be; };
             m->wp_exp = host_exp(h_mx[0]);
             m->wd_exp = host_exp(h_mx[1]);
+            {   // pose encoder on the f16 pipe (encode_tile_h2): layer-2 planes, and the layer-1 bound |W0 x + b0| <= c1 max|x| + c2
+                const char* enc = getenv("CCSP_ENC");
+                bool finite = true;
+                for (int j = 0; j < H / 2; ++j) {
+                    float rs = 0.0f;
+                    for (int dd = 0; dd < P; ++dd) rs += fabsf(h_w0[(size_t)j * P + dd]);
+                    finite = finite && std::isfinite(rs) && std::isfinite(h_b0[j]);
+                    m->pe0_c1 = fmaxf(m->pe0_c1, rs);
+                    m->pe0_c2 = fmaxf(m->pe0_c2, fabsf(h_b0[j]));
+                }
+                m->pe0_c1 *= 1.0001f; m->pe0_c2 *= 1.0001f;            // (fp32 rounding of the bound itself)
+                if (finite && !(enc && strcmp(enc, "f32") == 0)) {
+                    m->pe2_exp = host_exp(h_mx[3]);
+                    TRY(dev_alloc(reg, &m->pe2_wH, (size_t)2 * H * (H / 2)));
+                    hipLaunchKernelGGL(k_pack_enc_frag_h2, dim3(nblk((long)H * (H / 2), 256)), dim3(256), 0, s, m->pe2_w, m->pe2_exp, m->pe2_wH);
+                }
+            }
             TRY(dev_alloc(reg, &m->WpH, (size_t)2 * nwp));
             TRY(dev_alloc(reg, &m->Wd1H, (size_t)2 * nwd));
             hipLaunchKernelGGL(k_split2h, dim3(nblk(nwp, 256)), dim3(256), 0, s, nwp, m->Wp, m->wp_exp, m->WpH);
