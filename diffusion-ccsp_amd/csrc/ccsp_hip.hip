@@ -363,7 +363,7 @@ constexpr int ENC_H2_LD = 136;      // fp16 row stride of the s1 planes: 272 byt
 
 struct EncPrefetchH {
     float w0[8], b0;
-    half8 wa[2][4];                 // k-step 0 of the layer-2 fragments: [plane][tile]
+    half8 wa[4][2][4];              // the layer-2 fragments of the wave: [k-step][plane][tile], 128 VGPRs
     float b2[4][4];
 };
 
@@ -375,9 +375,11 @@ __device__ __forceinline__ void enc_prefetch_h2(const EncW w, EncPrefetchH& pf) 
     pf.b0 = w.b0[j];
     const half8* wh = reinterpret_cast<const half8*>(w.W2H) + (size_t)wave * 16 * 64 + lane;
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+    for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) pf.wa[p][q] = wh[(size_t)p * 4096 + q * 64];
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pf.wa[ks][p][q] = wh[(size_t)p * 4096 + (ks * 4 + q) * 64];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -385,7 +387,8 @@ __device__ __forceinline__ void enc_prefetch_h2(const EncW w, EncPrefetchH& pf) 
     __builtin_amdgcn_sched_barrier(0);      // keep these loads at kernel entry (hipcc would sink them to first use)
 }
 
-// s1h: [2][NODE_TILE][ENC_H2_LD] fp16 bits in LDS; sexp: [NODE_TILE].  All 256 threads participate.
+// s1h: [2][NODE_TILE][ENC_H2_LD] fp16 bits in LDS; sexp: [NODE_TILE] row exponents (enc_row_exp, written with xs).  All 256
+// threads participate.
 __device__ __forceinline__ void encode_tile_h2(const EncW w, const EncPrefetchH& pf, float (*xs)[8], unsigned short* s1h, int* sexp,
                                                float (*smax)[NODE_TILE], int node0, int N, const EncOut out) {
     constexpr int H = 256, LD = ENC_H2_LD;
@@ -395,20 +398,13 @@ __device__ __forceinline__ void encode_tile_h2(const EncW w, const EncPrefetchH&
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int n = tid / 128 + 2 * i;
-            float acc = 0.0f, amax = 0.0f;
+            float acc = 0.0f;
 #pragma unroll
-            for (int d = 0; d < 8; ++d) {
-                const float xv = xs[n][d];                      // columns >= in_dim are 0
-                acc = fmaf(xv, pf.w0[d], acc);
-                amax = fmaxf(amax, fabsf(xv));
-            }
-            // (a NaN pose gives amax 0 -- fmaxf skips it -- hence a finite exponent; the NaN itself travels in the fp16 terms)
-            const int e = h2_scale_exp(fmaf(w.c1, amax, w.c2));
+            for (int d = 0; d < 8; ++d) acc = fmaf(xs[n][d], pf.w0[d], acc);        // columns >= in_dim are 0
             unsigned short h1, h2;
-            split2h(ldexpf(silu_fast(acc + pf.b0), e), h1, h2);
+            split2h(ldexpf(silu_fast(acc + pf.b0), sexp[n]), h1, h2);
             s1h[n * LD + j] = h1;
             s1h[(NODE_TILE + n) * LD + j] = h2;
-            if (j == 0) sexp[n] = e;
         }
     }
     __syncthreads();
@@ -416,14 +412,6 @@ __device__ __forceinline__ void encode_tile_h2(const EncW w, const EncPrefetchH&
     floatx4 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
-    const half8* wh = reinterpret_cast<const half8*>(w.W2H) + (size_t)wave * 16 * 64 + lane;
-    half8 rest[3][2][4];                                         // k-steps 1..3, requested before the first MFMA
-#pragma unroll
-    for (int ks = 1; ks < 4; ++ks)
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) rest[ks - 1][p][q] = wh[(size_t)p * 4096 + (ks * 4 + q) * 64];
     const unsigned short* bp = s1h + (lane & 15) * LD + 8 * (lane >> 4);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -431,11 +419,11 @@ __device__ __forceinline__ void encode_tile_h2(const EncW w, const EncPrefetchH&
         const half8 b2 = *reinterpret_cast<const half8*>(bp + NODE_TILE * LD + ks * 32);
         // smallest terms first; consecutive MFMAs go to different accumulators
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ks == 0 ? pf.wa[1][j] : rest[ks - 1][1][j], b1, acc[j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf.wa[ks][1][j], b1, acc[j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ks == 0 ? pf.wa[0][j] : rest[ks - 1][0][j], b2, acc[j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf.wa[ks][0][j], b2, acc[j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ks == 0 ? pf.wa[0][j] : rest[ks - 1][0][j], b1, acc[j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf.wa[ks][0][j], b1, acc[j], 0, 0, 0);
     }
     const int eu = -(sexp[lane & 15] + w.w2_exp);
     float v[4][4];
@@ -914,6 +902,24 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, EncOut eo) {
     }
     const int node0 = blockIdx.x * NODE_TILE;
     const int tid = threadIdx.x;
+    // The chain of this kernel is CSR range -> edge outputs -> update -> encoder.  Vector-memory loads return in order, so
+    // the chain's loads are issued FIRST and the encoder's weights (160 VGPRs of them in the f16 form) behind them: they are
+    // in flight under the update and never in front of a load the update waits for.
+    int csr_beg = 0, csr_cnt = 0;
+    float csr_v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) csr_v[j] = 0.0f;
+    if (a.src == 0 && tid < NODE_TILE * 8) {
+        const int n = node0 + tid / 8, p = tid % 8;
+        if (n < a.N && p < a.P) {
+            csr_beg = a.node_ptr[n];
+            csr_cnt = a.node_ptr[n + 1] - csr_beg;
+            const float* op = a.O + (size_t)csr_beg * a.P + p;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) csr_v[j] = j < csr_cnt ? op[(size_t)j * a.P] : 0.0f;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     EncPrefetch<H> pf;
     EncPrefetchH pfh;
     if (a.do_encode) {
@@ -939,19 +945,20 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, EncOut eo) {
             const bool masked = a.mask[n] != 0;
             float eps = 0.0f;
             if (a.src == 0) {
-                const int beg = a.node_ptr[n], end = a.node_ptr[n + 1];
-                float acc = 0.0f;
-                const float* op = a.O + (size_t)beg * a.P + p;
                 // sixteen entries per round trip (a node of an 8-object graph has up to ~20), summed in CSR order; the
-                // padding terms are +0.0f and change nothing
-                for (int q0 = 0; q0 < end - beg; q0 += 16) {
+                // padding terms are +0.0f and change nothing.  The first sixteen were requested at kernel entry.
+                float acc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc += csr_v[j];
+                const float* op = a.O + (size_t)csr_beg * a.P + p;
+                for (int q0 = 16; q0 < csr_cnt; q0 += 16) {
                     float v[16];
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) v[j] = q0 + j < end - beg ? op[(size_t)(q0 + j) * a.P] : 0.0f;
+                    for (int j = 0; j < 16; ++j) v[j] = q0 + j < csr_cnt ? op[(size_t)(q0 + j) * a.P] : 0.0f;
 #pragma unroll
                     for (int j = 0; j < 16; ++j) acc += v[j];
                 }
-                if (a.normalize) acc = acc / sqrtf((float)(end - beg));        // 0/0 -> NaN like the reference
+                if (a.normalize) acc = acc / sqrtf((float)csr_cnt);            // 0/0 -> NaN like the reference
                 eps = masked ? a.xfeat[(size_t)n * a.F + a.F - a.P + p] : acc; // out[mask] = x[:, -P:][mask]
             } else if (a.src == 1) {
                 eps = a.eps_buf[i];
@@ -1009,6 +1016,13 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, EncOut eo) {
             xnew = xv;
         }
         xs[nl][p] = xnew;
+        if constexpr (ENCH) {        // row exponent of the encoder's layer-1 activations from the bound c1 max|x| + c2 (encode_tile_h2)
+            float amax = fabsf(xnew);                           // (fmaxf skips a NaN pose: finite exponent, the NaN travels in the fp16 terms)
+            amax = fmaxf(amax, __shfl_xor(amax, 1));
+            amax = fmaxf(amax, __shfl_xor(amax, 2));
+            amax = fmaxf(amax, __shfl_xor(amax, 4));
+            if (p == 0) sexp[nl] = h2_scale_exp(fmaf(w.c1, amax, w.c2));
+        }
     }
     if (!a.do_encode) return;
     __syncthreads();

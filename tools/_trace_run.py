@@ -26,7 +26,7 @@ t = buf.reshape(3, 64, 32).astype(np.int64)
 names = {0: ['entry', 'index setup'] + ['chunk %d landed' % c for c in range(8)] + ['K loop done', '-', 'epilogue done'],
          1: ['entry', 'indices+umax', 'stage 0 built'] + ['chunk %d done' % c for c in range(8)] + ['S1 written', 'layer-2 partials', 'O stored'],
          2: ['entry', 'CSR sum + update', 'layer 1', 'layer 2 MFMA', 'row max', 'planes stored']}
-for kern, title in ((0, 'k_rowgemm_h2 MODE 3'), (1, 'k_edge_h2'), (2, 'k_node')):
+for kern, title in ((0, 'k_rowgemm_h2 ring'), (1, 'k_edge_h2'), (2, 'k_node')):
     tk = t[kern]
     live = tk[:, 0] > 0
     tk = tk[live]
