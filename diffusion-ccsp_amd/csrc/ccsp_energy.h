@@ -497,6 +497,270 @@ __global__ __launch_bounds__(256) void k_node_energy_mfma(EnergyNodeArgs a, cons
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_node_energy_h2: k_node_energy_mfma at hidden_dim 256 with both 16 x 256 x 128 products on the f16 matrix pipe (three products
+// of two-term fp16 operands, ccsp_f16x2.h; 2 x 768 cycles of v_mfma_f32_16x16x32_f16 per wave instead of 2 x 4096 of
+// v_mfma_f32_16x16x4_f32).  Operand scaling: the weight by one exponent (planes packed by k_pack_enc_frag_h2 for the forward
+// product, k_pack_enc_frag_h2t for W2^T); the layer-1 activations per node by the bound c1 max|x| + c2 (as in encode_tile_h2);
+// g_y2 per node by its exact row maximum (shuffles + one LDS exchange).  Loads are issued in the order of the dependent chains
+// (vector-memory loads return in order): U-row ranges and CSR ranges, row indices and edge outputs, GP rows, then the weights.
+//   W2TH[plane][(((w * 8 + ks) * 2 + t) * 64 + l) * 8 + e8] = term of W2[ks*32 + 8 (l >> 4) + e8][w*32 + t*16 + (l & 15)] * 2^e
+// ------------------------------------------------------------------------------------------
+__global__ void k_pack_enc_frag_h2t(const float* __restrict__ W2 /*[256,128]*/, int e, unsigned short* __restrict__ W2TH) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 256 * 128) return;
+    const int e8 = idx & 7, l = (idx >> 3) & 63, t = (idx >> 9) & 1, ks = (idx >> 10) & 7, w = idx >> 13;
+    const int cc = ks * 32 + 8 * (l >> 4) + e8, i = w * 32 + t * 16 + (l & 15);
+    unsigned short a, b;
+    split2h(ldexpf(W2[cc * 128 + i], e), a, b);
+    W2TH[idx] = a;
+    W2TH[256 * 128 + idx] = b;
+}
+
+__global__ __launch_bounds__(256) void k_node_energy_h2(EnergyNodeArgs a, EncW w, const unsigned short* __restrict__ W2TH) {
+    constexpr int H = 256, KC = 128, LD1 = ENC_H2_LD, LD2 = H + 8;       // fp16 row strides: 16-byte fragment reads hit all banks once
+    __shared__ float xs[NODE_TILE][8];
+    __shared__ float dir[NODE_TILE][8];
+    __shared__ float y1[NODE_TILE][KC + 4];                       // pre-activation, later g_y1
+    __shared__ __attribute__((aligned(16))) unsigned short s1h[2 * NODE_TILE * LD1];
+    __shared__ __attribute__((aligned(16))) unsigned short g2h[2 * NODE_TILE * LD2];
+    __shared__ float w0s[KC][9];                                  // pose_encoder.0.weight, columns >= P are 0 (stride 9: conflict-free)
+    __shared__ float red[256];
+    __shared__ float smax[4][NODE_TILE];
+    __shared__ int sexp[NODE_TILE];
+    const int node0 = blockIdx.x * NODE_TILE;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nl = lane & 15, n = node0 + nl;
+    // ---- chain heads
+    const int rb = n < a.N ? a.nrow_ptr[n] : 0, re = n < a.N ? a.nrow_ptr[n + 1] : 0;
+    int beg = 0, cnt = 0;
+    float xv = 0.0f;
+    const int nl1 = tid / 8, p1 = tid % 8, n1 = node0 + nl1;
+    const bool upd = tid < NODE_TILE * 8 && n1 < a.N && p1 < a.P;
+    if (upd) {
+        beg = a.node_ptr[n1];
+        cnt = a.node_ptr[n1 + 1] - beg;
+        xv = a.x[(size_t)n1 * a.P + p1];
+    }
+    // ---- second links: the first four U rows of the lane's node, the first sixteen CSR entries
+    const int c00 = wave * 64 + 4 * (lane >> 4);
+    int id0[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) id0[i] = rb < re ? a.nrow_idx[rb + i < re ? rb + i : re - 1] : 0;
+    float ov[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) ov[j] = 0.0f;
+    if (upd) {
+        const float* op = a.Ocsr + (size_t)beg * a.P + p1;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) ov[j] = j < cnt ? op[(size_t)j * a.P] : 0.0f;
+    }
+    float4 gv[4][4];
+    if (rb < re) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gv[i][j] = *reinterpret_cast<const float4*>(a.GP + (size_t)id0[i] * H + c00 + j * 16);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- the weights, behind the chains
+    float w0r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i;                            // KC * 8 = 4 * 256
+        const int j = idx >> 3, d = idx & 7;
+        w0r[i] = d < a.P ? a.W0[j * a.P + d] : 0.0f;
+    }
+    float w0t[8];                                                 // layer-1 row of this thread's hidden unit
+    {
+        const int j = tid % KC;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) w0t[d] = d < a.P ? a.W0[j * a.P + d] : 0.0f;
+    }
+    const float b0j = a.b0[tid % KC];
+    const half8* wh = reinterpret_cast<const half8*>(w.W2H) + (size_t)wave * 16 * 64 + lane;
+    half8 wa[4][2][4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wa[ks][pp][q] = wh[(size_t)pp * 4096 + (ks * 4 + q) * 64];
+    float4 bj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bj[j] = *reinterpret_cast<const float4*>(a.b2 + c00 + j * 16);
+    __builtin_amdgcn_sched_barrier(0);
+    if (blockIdx.x == 0 && a.E_out) {            // uniform branch: whole block participates
+        float v = 0.0f;
+        for (int i = tid; i < a.n_partial; i += 256) v += a.partial[i];
+        const float s = block_sum_256(v, red);
+        if (tid == 0) a.E_out[0] = s;
+        __syncthreads();
+    }
+    // ---- direct term, poses and row exponents
+    if (tid < NODE_TILE * 8) {
+        float dv = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) dv += ov[j];
+        if (upd) {
+            const float* op = a.Ocsr + (size_t)beg * a.P + p1;
+            for (int q0 = 16; q0 < cnt; q0 += 16) {
+                float v[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] = q0 + j < cnt ? op[(size_t)(q0 + j) * a.P] : 0.0f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) dv += v[j];
+            }
+        }
+        xs[nl1][p1] = xv;
+        dir[nl1][p1] = dv;
+        float amax = fabsf(xv);
+        amax = fmaxf(amax, __shfl_xor(amax, 1));
+        amax = fmaxf(amax, __shfl_xor(amax, 2));
+        amax = fmaxf(amax, __shfl_xor(amax, 4));
+        if (p1 == 0) sexp[nl1] = h2_scale_exp(fmaf(w.c1, amax, w.c2));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i;
+        w0s[idx >> 3][idx & 7] = w0r[i];
+    }
+    // ---- sum of the node's GP rows in ascending row order (first four rows already in flight)
+    float4 gp[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gp[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = rb; q < re; q += 4) {
+        if (q > rb) {
+            int id[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) id[i] = a.nrow_idx[q + i < re ? q + i : re - 1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gv[i][j] = *reinterpret_cast<const float4*>(a.GP + (size_t)id[i] * H + c00 + j * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (q + i < re) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { gp[j].x += gv[i][j].x; gp[j].y += gv[i][j].y; gp[j].z += gv[i][j].z; gp[j].w += gv[i][j].w; }
+            }
+    }
+    __syncthreads();
+    {   // layer 1: pre-activations kept in fp32 (SiLU' in the backward), activations as fp16 planes
+        const int j = tid % KC;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int nn = tid / KC + 2 * i;
+            float acc = 0.0f;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) acc = fmaf(xs[nn][d], w0t[d], acc);
+            acc += b0j;
+            y1[nn][j] = acc;
+            unsigned short h1, h2;
+            split2h(ldexpf(silu_fast(acc), sexp[nn]), h1, h2);
+            s1h[nn * LD1 + j] = h1;
+            s1h[(NODE_TILE + nn) * LD1 + j] = h2;
+        }
+    }
+    __syncthreads();
+    const half8* wt = reinterpret_cast<const half8*>(W2TH) + (size_t)wave * 16 * 64 + lane;
+    half8 wb[8][2][2];                                            // backward fragments [k-step][plane][tile]
+    {   // y2^T tiles = W2 . s1^T; g_y2 = (sum of the node's GP rows) * SiLU'(y2)
+        floatx4 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+        const unsigned short* bp = s1h + nl * LD1 + 8 * (lane >> 4);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const half8 b1 = *reinterpret_cast<const half8*>(bp + ks * 32);
+            const half8 b2 = *reinterpret_cast<const half8*>(bp + NODE_TILE * LD1 + ks * 32);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ks][1][j], b1, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ks][0][j], b2, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ks][0][j], b1, acc[j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)                            // (the forward fragments are dead: their registers take these)
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) wb[ks][pp][t] = wt[(size_t)pp * 4096 + (ks * 2 + t) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        const int eu = -(sexp[nl] + w.w2_exp);
+        float g[4][4];
+        float m = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gpj[4] = {gp[j].x, gp[j].y, gp[j].z, gp[j].w};
+            const float bjj[4] = {bj[j].x, bj[j].y, bj[j].z, bj[j].w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                g[j][r] = gpj[r] * silu_grad_fast(ldexpf(acc[j][r], eu) + bjj[r]);
+                m = fmaxf(m, fabsf(g[j][r]));
+            }
+        }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        if (lane < NODE_TILE) smax[wave][lane] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(smax[0][nl], smax[1][nl]), fmaxf(smax[2][nl], smax[3][nl]));
+        const int eg = h2_scale_exp(m);
+        if (wave == 0 && lane < NODE_TILE) sexp[lane] = eg;      // (layer 1's exponents are dead: every wave read its own above)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned short h1[4], h2[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) split2h(ldexpf(g[j][r], eg), h1[r], h2[r]);
+            const int c0 = c00 + j * 16;
+            *reinterpret_cast<uint2*>(g2h + nl * LD2 + c0) = make_uint2(h1[0] | ((unsigned)h1[1] << 16), h1[2] | ((unsigned)h1[3] << 16));
+            *reinterpret_cast<uint2*>(g2h + (NODE_TILE + nl) * LD2 + c0) = make_uint2(h2[0] | ((unsigned)h2[1] << 16), h2[2] | ((unsigned)h2[3] << 16));
+        }
+    }
+    __syncthreads();
+    {   // g_s1^T tiles = W2^T . g_y2^T  (contraction over the H outputs);  g_y1 = g_s1 * SiLU'(y1)
+        floatx4 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+        const unsigned short* bp = g2h + nl * LD2 + 8 * (lane >> 4);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const half8 b1 = *reinterpret_cast<const half8*>(bp + ks * 32);
+            const half8 b2 = *reinterpret_cast<const half8*>(bp + NODE_TILE * LD2 + ks * 32);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ks][1][t], b1, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ks][0][t], b2, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ks][0][t], b1, acc[t], 0, 0, 0);
+        }
+        const int eu = -(sexp[nl] + w.w2_exp);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int k0 = wave * 32 + t * 16 + 4 * (lane >> 4);
+            float4 gq;
+            gq.x = ldexpf(acc[t][0], eu) * silu_grad_fast(y1[nl][k0]);     gq.y = ldexpf(acc[t][1], eu) * silu_grad_fast(y1[nl][k0 + 1]);
+            gq.z = ldexpf(acc[t][2], eu) * silu_grad_fast(y1[nl][k0 + 2]); gq.w = ldexpf(acc[t][3], eu) * silu_grad_fast(y1[nl][k0 + 3]);
+            *reinterpret_cast<float4*>(&y1[nl][k0]) = gq;     // each (node, unit) is read and written by this lane only
+        }
+    }
+    __syncthreads();
+    {   // grad = direct term + W0^T g_y1: two threads per (node, component), each half of the hidden units in ascending order
+        const int half = tid >> 7, t7 = tid & 127;
+        const int nl2 = t7 / 8, p = t7 % 8;
+        float gx = 0.0f;
+#pragma unroll 16
+        for (int k = half * (KC / 2); k < (half + 1) * (KC / 2); ++k) gx = fmaf(y1[nl2][k], w0s[k][p], gx);
+        if (half == 1) red[t7] = gx;
+        __syncthreads();
+        const int n2 = node0 + nl2;
+        if (half == 0 && n2 < a.N && p < a.P) a.grad[(size_t)n2 * a.P + p] = dir[nl2][p] + (gx + red[t7]);
+    }
+}
+
 // acceptance counts -> mean acceptance rate per timestep
 __global__ void k_accept_rates(int T, const int* __restrict__ count, const int* __restrict__ denom, float* __restrict__ out) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;

@@ -1095,6 +1095,7 @@ struct ccsp_model {
     unsigned short* Wd1TH = nullptr;  // [2][H][H/2]      fp16 planes of pose_decoder.0.weight^T * 2^wd_exp
     float wd2_absmax = 0.0f;          // max |pose_decoder.2.weight| (row-exponent bound of k_edge_bwd_h2)
     unsigned short* pe2_wH = nullptr; // pose_encoder.2.weight * 2^pe2_exp, fp16 planes in fragment order (k_pack_enc_frag_h2); CCSP_ENC=f32 leaves it null
+    unsigned short* pe2_wTH = nullptr;    // the same tensor transposed, for the energy backward (k_pack_enc_frag_h2t; energy_wrapper models)
     int pe2_exp = 0;
     float pe0_c1 = 0.0f, pe0_c2 = 0.0f;   // bound of the pose encoder's layer-1 pre-activation: c1 max|x| + c2
     int energy_bwd_h2 = 1;            // CCSP_ENERGY_BWD=bf16x3 keeps the backward GEMMs on the six-product bf16 kernels
@@ -1542,7 +1543,14 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     static const bool valu_node_energy = getenv("CCSP_NODE_ENERGY_VALU") != nullptr;     // the pre-MFMA kernel, kept for A/B runs
     prof_mark(g, s, CCSP_K_NODE_ENERGY);
     if (valu_node_energy) hipLaunchKernelGGL(k_node_energy<H>, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_node_energy_mfma<H>, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a, (const float*)m->pe2_wF);
+    else {
+        bool h2n = false;
+        if constexpr (H == 256) {
+            h2n = m->pe2_wTH != nullptr;
+            if (h2n) hipLaunchKernelGGL(k_node_energy_h2, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a, enc_pose(m), (const unsigned short*)m->pe2_wTH);
+        }
+        if (!h2n) hipLaunchKernelGGL(k_node_energy_mfma<H>, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a, (const float*)m->pe2_wF);
+    }
     prof_mark(g, s, -1);
     return 0;
 }
@@ -2295,6 +2303,10 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
                     m->pe2_exp = host_exp(h_mx[3]);
                     TRY(dev_alloc(reg, &m->pe2_wH, (size_t)2 * H * (H / 2)));
                     hipLaunchKernelGGL(k_pack_enc_frag_h2, dim3(nblk((long)H * (H / 2), 256)), dim3(256), 0, s, m->pe2_w, m->pe2_exp, m->pe2_wH);
+                    if (d->energy_wrapper) {
+                        TRY(dev_alloc(reg, &m->pe2_wTH, (size_t)2 * H * (H / 2)));
+                        hipLaunchKernelGGL(k_pack_enc_frag_h2t, dim3(nblk((long)H * (H / 2), 256)), dim3(256), 0, s, m->pe2_w, m->pe2_exp, m->pe2_wTH);
+                    }
                 }
             }
             TRY(dev_alloc(reg, &m->WpH, (size_t)2 * nwp));
