@@ -1,3 +1,5 @@
+"""s_memtime phase tables of the three evaluation kernels on a small batch (the build with the stamps comes from
+tools/trace_build.py).  usage (GPU box): python tools/trace_run.py [c5 | <number of 8-object qualitative graphs>]"""
 import os, sys, ctypes as C
 ROOT = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
 sys.path.insert(0, ROOT)
@@ -16,7 +18,8 @@ den = ConstraintDiffuser(dims=worlds.MODE_DIMS[mode], hidden_dim=256, input_mode
 den.load_state_dict(load_weights(os.path.join(ROOT, 'tests', 'golden', wf)))
 gd = GaussianDiffusion(den, timesteps=1000, EBM='ULA', samples_per_step=10)
 b = batch.to_torch(dev)
-x = gd.p_sample_segment(b, torch.zeros(b.x.shape[0], worlds.MODE_DIMS[mode][1][0] if False else den.dims[1][0] if hasattr(den, 'dims') else 4, device=dev), 500, 495, seed=3)
+x0 = torch.zeros(b.x.shape[0], worlds.MODE_DIMS[mode][1][0], device=dev)
+x = gd.p_sample_segment(b, x0, 500, 495, seed=3)
 torch.cuda.synchronize()
 buf = np.zeros(3 * 64 * 32, dtype=np.uint64)
 L = _lib.lib()
