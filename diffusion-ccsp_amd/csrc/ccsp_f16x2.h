@@ -27,18 +27,24 @@
 //                          feeds two MFMA tiles: 8 ds_read_b128 per 12 MFMAs, against 9 per 12 at half the
 //                          flops each in k_rowgemm_bf2); epilogue per wave through a wave-private LDS tile:
 //                          16-byte row-contiguous base loads / U stores and the row maxima of U for the edge
-//                          kernel.  MODE picks the staging by residency (launch_rowgemm_h2): 0 = one 16 KB
-//                          stage and one register set, 3 workgroups per CU (tile lists longer than 2 per CU);
+//                          kernel.  MODE picks the staging by the length of the tile list (rowgemm_h2_mode):
+//                          0 = one 16 KB stage and one register set, 3 workgroups per CU (lists longer than 2 per CU);
 //                          1 = two stages, two register sets (chunk c+2 in flight while c is multiplied);
-//                          2 = two stages filled by global_load_lds_dwordx4, swizzle applied to the source
-//                          address.  <256, 512> is the forward GEMM, <512, 256> the energy mode's transpose GEMM
-//   k_edge_h2<ENERGY, MT>  MT = 2: 128 rows = 64 sorted edges x both output halves per workgroup (the decoder
+//                          2 = two stages filled by global_load_lds_dwordx4, swizzle applied to the source address;
+//                          3 = ring of four such stages, counted s_waitcnt vmcnt, bare s_barrier (one workgroup per CU);
+//                          4 = the ring on 64 x 128 tiles (32 x 64 per wave), three stages: tile lists of at most one
+//                              workgroup per CU, where the kernel is a latency chain and not a throughput problem.
+//                          <256, 512> is the forward GEMM, <512, 256> the energy mode's transpose GEMM
+//   k_edge_h2<ENERGY, MT, L2>  MT = 2: 128 rows = 64 sorted edges x both output halves per workgroup (the decoder
 //                          weight chunk is staged once for both halves); MT = 1: 32 edges, 3 workgroups per CU
 //                          (default whenever all tiles then fit in one round).  SiLU + scale + split of chunk
-//                          c+1 issued between the MFMA groups of chunk c
+//                          c+1 issued between the MFMA groups of chunk c.  L2 = 1 (grids of at most one workgroup
+//                          per CU): the second decoder layer split over the waves (h2_decoder_l2)
 //   k_edge_bwd_h2          energy mode: g_h = g_o Wd2 (VALU), g_q = g_h SiLU'(q), g_z = (g_q Wd1) SiLU'(z) with the
 //                          GEMM on the same three products; the row exponent comes from the bound
 //                          1.1 * max|Wd2| * sum|g_o| >= |g_h|
+// The pose encoder's second layer (k_node, k_node_energy_h2) runs on the same scheme with v_mfma_f32_16x16x32_f16:
+// encode_tile_h2 in ccsp_hip.hip.
 // Included inside the anonymous namespace of ccsp_hip.hip.
 #pragma once
 
