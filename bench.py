@@ -100,8 +100,15 @@ def backward_mode(mma):
     return mma
 
 
+def encoder_mode(mma):
+    """pipe of the pose encoder's second layer in the node kernels (CCSP_ENC=f32 keeps v_mfma_f32_16x16x4_f32)"""
+    return 'f16x2' if mma == 'f16x2' and os.environ.get('CCSP_ENC', '') != 'f32' else 'f32'
+
+
 def kernel_symbol(label, mma):
     row = KERNEL_SYMBOLS.get(label, {})
+    if label == 'node energy backward':
+        return 'k_node_energy_h2' if encoder_mode(mma) == 'f16x2' else 'k_node_energy_mfma'
     return row.get(backward_mode(mma) if label in ('edge decoder backward', 'row GEMM (transpose)') else mma, '')
 
 
@@ -110,14 +117,15 @@ def executed_work(label, N, E, R, H, mma):
     ccsp_kernel_stats label -- what the kernels EXECUTE after the row factorisation; None for non-matrix kernels"""
     prod = {'f16x2': (3, 'f16'), 'bf16x3': (6, 'bf16'), 'f32': (1, 'f32')}[mma]
     bwd = {'f16x2': (3, 'f16'), 'bf16x3': (6, 'bf16'), 'f32': (1, 'f32')}[backward_mode(mma)]
+    enc = (3, 'f16') if encoder_mode(mma) == 'f16x2' else (1, 'f32')       # the pose encoder's second layer (node kernels)
     table = {
         'row GEMM (forward)': (2.0 * R * (2 * H) * H,) + prod,
         'edge decoder (forward)': (2.0 * (2 * E) * (H // 2) * H,) + prod,
-        'node update + pose encoder': (2.0 * N * H * (H // 2), 1, 'f32'),
+        'node update + pose encoder': (2.0 * N * H * (H // 2),) + enc,
         # energy-mode backward kernels: same scheme as the forward ones unless CCSP_ENERGY_BWD=bf16x3
         'edge decoder backward': (2.0 * (2 * E) * H * (H // 2),) + bwd,
         'row GEMM (transpose)': (2.0 * R * H * (2 * H),) + bwd,
-        'node energy backward': (2.0 * 2 * N * H * (H // 2), 1, 'f32'),
+        'node energy backward': (2.0 * 2 * N * H * (H // 2),) + enc,
     }
     return table.get(label)
 
@@ -125,7 +133,7 @@ def executed_work(label, N, E, R, H, mma):
 KERNEL_SYMBOLS = {      # label -> kernel symbol prefix by GEMM mode (for the PMC traffic lookup and the report)
     'row GEMM (forward)': {'f16x2': 'k_rowgemm_h2<256, 512', 'bf16x3': 'k_rowgemm_bf2<256, 512', 'f32': 'k_rowgemm<256, 512>'},
     'edge decoder (forward)': {'f16x2': 'k_edge_h2', 'bf16x3': 'k_edge_bf2', 'f32': 'k_edge<256'},
-    'node update + pose encoder': {m: 'k_node<256>' for m in ('f16x2', 'bf16x3', 'f32')},
+    'node update + pose encoder': {m: 'k_node<256' for m in ('f16x2', 'bf16x3', 'f32')},
     'edge decoder backward': {'f16x2': 'k_edge_bwd_h2', 'bf16x3': 'k_edge_bwd_bf', 'f32': 'k_edge_bwd<256>'},
     'row GEMM (transpose)': {'f16x2': 'k_rowgemm_h2<512, 256', 'bf16x3': 'k_rowgemm_bf2<512, 256>', 'f32': 'k_rowgemm<512, 256>'},
     'node energy backward': {m: 'k_node_energy_mfma' for m in ('f16x2', 'bf16x3', 'f32')},
