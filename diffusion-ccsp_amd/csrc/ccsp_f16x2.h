@@ -416,9 +416,10 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : (MODE == 3 ? 1 : 2)) void k_ro
 // reads per lane instead of the 128 of a whole dot product per (row, p) item: 2.3 k cycles shorter per workgroup, which is what
 // counts when the grid is a single round (k_edge_h2<., ., 1>, small batches: C5 +3.5 %); with several workgroups per CU in flight
 // the extra barrier costs more than the reads (C2 -1 %), so large grids keep the one-pass form.  PP > 0: pose_dim at compile time.
-template <int PP>
+template <int PP, int NROWS = 64>
 __device__ __forceinline__ void h2_decoder_l2(const float* __restrict__ S1, int s1_ld, const float* __restrict__ Wd2, int P, float* __restrict__ RED,
                                               int wave, int lane) {
+    if (NROWS < 64 && lane >= NROWS) return;                      // (32-row tiles: the upper half-wave has no row)
     const int kq = __builtin_amdgcn_readfirstlane(wave) * 32;
     float part[8];
 #pragma unroll
@@ -434,7 +435,7 @@ __device__ __forceinline__ void h2_decoder_l2(const float* __restrict__ S1, int 
     }
 #pragma unroll
     for (int p = 0; p < 8; ++p)
-        if (PP > 0 ? p < PP : p < P) RED[(wave * 8 + p) * 64 + lane] = part[p];
+        if (PP > 0 ? p < PP : p < P) RED[(wave * 8 + p) * NROWS + lane] = part[p];
 }
 
 template <bool ENERGY, int MT, int L2>
@@ -604,6 +605,160 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void k_edge_h2(int E_act, int
         __syncthreads();
     }
     if constexpr (ENERGY) {
+        const float tot = block_sum_256(e2, reinterpret_cast<float*>(smem));
+        if (tid == 0) en.partial[blockIdx.x] = tot;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_edge_h2s: k_edge_h2 for grids that leave most of the chip empty (at most one workgroup per CU even at 16 edges per
+// workgroup: small batches).  There the kernel is the lifetime of ONE workgroup with one wave per SIMD; inside a wave the LDS
+// round trips, the SiLU / scale / split of the A rows on the VALU and the MFMAs do not overlap, so what counts is the work per
+// wave: the tile is 16 sorted edges x both halves = 32 rows, all four waves share them and take 32 of the 128 decoder columns
+// each -- half the activation work per thread and half the MFMAs per wave of the 32-edge tile, twice the workgroups.  Same
+// operands, same scaling, same epilogue arithmetic as k_edge_h2<ENERGY, 1, 1>.
+// ------------------------------------------------------------------------------------------
+template <bool ENERGY>
+__global__ __launch_bounds__(256, 2) void k_edge_h2s(int E_act, int P, const int* __restrict__ e_u0, const int* __restrict__ e_u1,
+                                                     const float* __restrict__ U, const float* __restrict__ umax /*[R][8]*/,
+                                                     const unsigned short* __restrict__ Wd1H /*[2][128][256]*/, int wd_exp,
+                                                     const float* __restrict__ bd1, const float* __restrict__ Wd2,
+                                                     const float* __restrict__ bd2, const int* __restrict__ ent_pos, float* __restrict__ O,
+                                                     EdgeEnergyArgs en, int* __restrict__ counter_inc) {
+    if (counter_inc && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(counter_inc, 1);     // hipGraph mode: next table entry
+    constexpr int H = 256, BN = 128, NCH = H / H2_BK;
+    constexpr int ME = 16, ROWS = 2 * ME;
+    constexpr int APL = ROWS * H2_BK, STAGE = 2 * APL + 2 * H2_BPL;       // 4 KB of A planes + 16 KB of B planes
+    constexpr int S1_LD = BN + 1;
+    static_assert((ROWS * S1_LD + 4 * 8 * ROWS) * 4 <= 2 * STAGE * 2, "epilogue tile and the layer-2 partials must fit the stages");
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * STAGE + 2 * ROWS];
+    int* sE = reinterpret_cast<int*>(smem + 2 * STAGE);
+    const int e0 = xcd_remap(blockIdx.x, gridDim.x) * ME;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lr = tid >> 3, lq = tid & 7;                        // A producer: tile row lr, fp32 columns 4 lq .. + 3 of the chunk
+    const int hs = lr / ME;                                       // half (slot) of the row
+    int kk = e0 + (lr % ME);
+    kk = kk < E_act ? kk : E_act - 1;
+    const int r0 = e_u0[kk], r1 = e_u1[kk];
+    const float* u0_ptr = U + (size_t)r0 * (2 * H) + hs * H + lq * 4;
+    const float* u1_ptr = U + (size_t)r1 * (2 * H) + hs * H + lq * 4;
+    const float4 m0 = *reinterpret_cast<const float4*>(umax + (size_t)r0 * 8 + 4 * hs);
+    const float4 m1 = *reinterpret_cast<const float4*>(umax + (size_t)r1 * 8 + 4 * hs);
+    const int brow = tid >> 2, bq = tid & 3;                      // B copy: rows brow, brow + 64, piece bq, both planes
+    const unsigned short* b_ptr = Wd1H + (size_t)brow * H + bq * 8;
+    const int b_st = h2_off(brow, bq);
+    const int a_st = h2_off(lr, lq >> 1) + (lq & 1) * 4;
+    float4 ua[2], ub[2];                                          // [register set]
+    ushort8 rb[4];
+    auto gload_a = [&](int c, int set) {
+        ua[set] = *reinterpret_cast<const float4*>(u0_ptr + c * H2_BK);
+        ub[set] = *reinterpret_cast<const float4*>(u1_ptr + c * H2_BK);
+    };
+    auto gload_b = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                rb[i * 2 + p] = *reinterpret_cast<const ushort8*>(b_ptr + (size_t)p * BN * H + (size_t)i * 64 * H + c * H2_BK);
+    };
+    gload_a(0, 0);
+    gload_b(0);
+    gload_a(1, 1);
+    // |SiLU(z)| <= |z| <= max|U[u0]| + max|U[u1]| over the half's four 64-column pieces
+    const int a_exp = h2_scale_exp(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)) + fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w)));
+    if (lq == 0) sE[lr] = a_exp;
+    auto store_a = [&](int stage, int set) {                      // SiLU + scale + split -> the A planes of the stage
+        unsigned short* As = smem + stage * STAGE;
+        const float h[4] = {silu_fast(ua[set].x + ub[set].x), silu_fast(ua[set].y + ub[set].y),
+                            silu_fast(ua[set].z + ub[set].z), silu_fast(ua[set].w + ub[set].w)};
+        unsigned short p1[4], p2[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split2h(ldexpf(h[e], a_exp), p1[e], p2[e]);
+        unsigned short* d = As + a_st;
+        *reinterpret_cast<uint2*>(d) = make_uint2(p1[0] | ((unsigned)p1[1] << 16), p1[2] | ((unsigned)p1[3] << 16));
+        *reinterpret_cast<uint2*>(d + APL) = make_uint2(p2[0] | ((unsigned)p2[1] << 16), p2[2] | ((unsigned)p2[3] << 16));
+    };
+    auto store_b = [&](int stage) {
+        unsigned short* Bs = smem + stage * STAGE + 2 * APL;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                *reinterpret_cast<ushort8*>(Bs + p * H2_BPL + b_st + i * 64 * H2_BK) = rb[i * 2 + p];
+    };
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    store_a(0, 0);
+    store_b(0);
+    gload_b(1);
+    gload_a(2, 0);
+    __syncthreads();
+    auto kstep = [&](const unsigned short* st, int ks) {          // 32 x 32 of the wave: rows 0..31, columns 32 wave .. + 31
+        const int piece = (lane >> 5) + 2 * ks;
+        half8 a[2], b[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            a[p] = *reinterpret_cast<const half8*>(st + p * APL + h2_off(lane & 31, piece));
+            b[p] = *reinterpret_cast<const half8*>(st + 2 * APL + p * H2_BPL + h2_off(wave * 32 + (lane & 31), piece));
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], acc, 0, 0, 0);      // smallest terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], acc, 0, 0, 0);
+    };
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {                               // fully unrolled: the register-set index is a constant
+        const unsigned short* st = smem + (c & 1) * STAGE;
+        const int nx = (c + 1) & 1;                               // next stage, and the register set holding chunk c+1
+        kstep(st, 0);
+        if (c + 1 < NCH) store_a(nx, nx);                         // in the shadow of the MFMAs just issued
+        kstep(st, 1);
+        if (c + 1 < NCH) store_b(nx);
+        if (c + 2 < NCH) gload_b(c + 2);
+        if (c + 3 < NCH) gload_a(c + 3, nx);
+        __syncthreads();
+    }
+    // epilogue: 32 rows (half = row / 16, edge e0 + row % 16)
+    float* S1 = reinterpret_cast<float*>(smem);
+    float* RED = S1 + ROWS * S1_LD;
+    {
+        const int col = wave * 32 + (lane & 31);
+        const float bj = bd1[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const float q = ldexpf(acc[r], -(sE[row] + wd_exp)) + bj;
+            S1[row * S1_LD + col] = silu_fast(q);
+            if constexpr (ENERGY) {
+                const int k = e0 + (row % ME);
+                if (en.Q && k < E_act) en.Q[((size_t)2 * k + row / ME) * BN + col] = q;
+            }
+        }
+    }
+    __syncthreads();
+    if (P == 4) h2_decoder_l2<4, ROWS>(S1, S1_LD, Wd2, P, RED, wave, lane);
+    else if (P == 5) h2_decoder_l2<5, ROWS>(S1, S1_LD, Wd2, P, RED, wave, lane);
+    else h2_decoder_l2<0, ROWS>(S1, S1_LD, Wd2, P, RED, wave, lane);
+    __syncthreads();
+    float e2 = 0.0f;
+    for (int idx = tid; idx < ROWS * P; idx += 256) {
+        const int row = idx & (ROWS - 1), p = idx / ROWS;
+        const float* rp = RED + p * ROWS + row;
+        const float o = ((rp[0] + rp[8 * ROWS]) + (rp[16 * ROWS] + rp[24 * ROWS])) + bd2[p];
+        const int k = e0 + (row % ME), s = row / ME;
+        if (k < E_act) {
+            if constexpr (ENERGY) {
+                const int node = s == 0 ? en.e_a[k] : en.e_b[k];
+                const float d = o - en.xeval[(size_t)node * P + p];
+                e2 = fmaf(d, d, e2);
+                O[(size_t)ent_pos[2 * k + s] * P + p] = -2.0f * d;
+            } else {
+                O[(size_t)ent_pos[2 * k + s] * P + p] = o;                 // straight to the node's CSR slot
+            }
+        }
+    }
+    if constexpr (ENERGY) {
+        __syncthreads();
         const float tot = block_sum_256(e2, reinterpret_cast<float*>(smem));
         if (tid == 0) en.partial[blockIdx.x] = tot;
     }

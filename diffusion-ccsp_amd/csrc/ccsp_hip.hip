@@ -1269,6 +1269,12 @@ template <bool ENERGY>
 int launch_edge_h2(ccsp_model* m, ccsp_graph* g, EdgeEnergyArgs en, int* cinc, hipStream_t s) {
     const int E_act = g->plan.E_act;
     const int mt = m->edge_mt > 0 ? m->edge_mt : (nblk(E_act, 32) <= 3 * m->ncu ? 1 : 2);
+    if (m->edge_mt <= 0 && nblk(E_act, 16) <= m->ncu) {        // most of the chip would idle even at 16 edges per workgroup
+        const int nws = nblk(E_act, 16);
+        hipLaunchKernelGGL(k_edge_h2s<ENERGY>, dim3(nws), dim3(256), 0, s, E_act, m->d.pose_dim, g->e_u0, g->e_u1, g->U, g->umax, m->Wd1H, m->wd_exp,
+                           m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, en, cinc);
+        return nws;
+    }
     const int nwg = nblk(E_act, 32 * mt);
 #define CCSP_EDGE_F(MT, L2)                                                                                                                          \
     hipLaunchKernelGGL((k_edge_h2<ENERGY, MT, L2>), dim3(nwg), dim3(256), 0, s, E_act, m->d.pose_dim, g->e_u0, g->e_u1, g->U, g->umax, m->Wd1H, m->wd_exp, \
@@ -1418,13 +1424,14 @@ int energy_prepare(ccsp_model* m, ccsp_graph* g, hipStream_t s) {
     if (dev_upload(reg, &g->tileb_row0, p.tile_row0, s) || dev_upload(reg, &g->tileb_nrows, p.tile_nrows, s) || dev_upload(reg, &g->tileb_ts, p.tile_ts, s)) return 1;
     const int BMf = H == 256 ? 32 * EdgeCfg<256>::WM : 32 * EdgeCfg<64>::WM;
     g->n_edge_blocks = 2 * nblk(p.E_act, BMf);
+    const size_t n_partial = (size_t)(nblk(p.E_act, 16) > g->n_edge_blocks ? nblk(p.E_act, 16) : g->n_edge_blocks) + 1;   // (k_edge_h2s: one per 16 edges)
     if (dev_alloc(reg, &g->Q, (size_t)2 * p.E_act * (H / 2)) || dev_alloc(reg, &g->GZ, (size_t)p.E_act * 2 * H) ||
         dev_alloc(reg, &g->GZR, (size_t)p.R * 2 * H) || dev_alloc(reg, &g->GP, (size_t)p.R * H) ||
-        dev_alloc(reg, &g->xhat, (size_t)g->N * P) || dev_alloc(reg, &g->partial, (size_t)g->n_edge_blocks + 1) ||
+        dev_alloc(reg, &g->xhat, (size_t)g->N * P) || dev_alloc(reg, &g->partial, n_partial) ||
         dev_alloc(reg, &g->Escal, 4) || dev_alloc(reg, &g->acc_count, (size_t)T) || dev_alloc(reg, &g->acc_denom, (size_t)T))
         return 1;
     HIP_TRY(hipMemsetAsync(g->Escal, 0, 4 * sizeof(float), s));
-    HIP_TRY(hipMemsetAsync(g->partial, 0, ((size_t)g->n_edge_blocks + 1) * sizeof(float), s));
+    HIP_TRY(hipMemsetAsync(g->partial, 0, n_partial * sizeof(float), s));
     g->energy_ready = true;
     return 0;
 }
