@@ -132,7 +132,7 @@ def executed_work(label, N, E, R, H, mma):
 
 KERNEL_SYMBOLS = {      # label -> kernel symbol prefix by GEMM mode (for the PMC traffic lookup and the report)
     'row GEMM (forward)': {'f16x2': 'k_rowgemm_h2<256, 512', 'bf16x3': 'k_rowgemm_bf2<256, 512', 'f32': 'k_rowgemm<256, 512>'},
-    'edge decoder (forward)': {'f16x2': 'k_edge_h2', 'bf16x3': 'k_edge_bf2', 'f32': 'k_edge<256'},
+    'edge decoder (forward)': {'f16x2': 'k_edge_h2', 'bf16x3': 'k_edge_bf2', 'f32': 'k_edge<256'},     # (k_edge_h2s on small batches: same prefix)
     'node update + pose encoder': {m: 'k_node<256' for m in ('f16x2', 'bf16x3', 'f32')},
     'edge decoder backward': {'f16x2': 'k_edge_bwd_h2', 'bf16x3': 'k_edge_bwd_bf', 'f32': 'k_edge_bwd<256>'},
     'row GEMM (transpose)': {'f16x2': 'k_rowgemm_h2<512, 256', 'bf16x3': 'k_rowgemm_bf2<512, 256>', 'f32': 'k_rowgemm<512, 256>'},

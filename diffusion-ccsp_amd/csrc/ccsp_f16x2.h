@@ -40,6 +40,7 @@
 //                          (default whenever all tiles then fit in one round).  SiLU + scale + split of chunk
 //                          c+1 issued between the MFMA groups of chunk c.  L2 = 1 (grids of at most one workgroup
 //                          per CU): the second decoder layer split over the waves (h2_decoder_l2)
+//   k_edge_h2s<ENERGY>     the edge kernel of small batches (<= 4096 active edges): 16-edge tiles, four waves sharing the rows
 //   k_edge_bwd_h2          energy mode: g_h = g_o Wd2 (VALU), g_q = g_h SiLU'(q), g_z = (g_q Wd1) SiLU'(z) with the
 //                          GEMM on the same three products; the row exponent comes from the bound
 //                          1.1 * max|Wd2| * sum|g_o| >= |g_h|
