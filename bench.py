@@ -266,6 +266,35 @@ def main():
                    'outputs_finite': finite, 'graphs_with_nonfinite_poses': nan_graphs},
     }
 
+    if cfg['EBM'] == 'MALA' and rank == 0:
+        # MALA: the gradient evaluation of an inner step whose predecessor accepted no node is skipped on the device (exact: the
+        # state has not moved; include/ccsp.h, ccsp_chain_skipped).  Report what that was worth: the acceptance of the last timed
+        # chain, the evaluations it skipped, and the same chain WITH every evaluation recomputed (one extra untimed-region chain).
+        st = gd.chain_stats()
+        acc = gd.last_accept_rates
+        reuse_on = os.environ.get('CCSP_MALA_REUSE', '1') != '0'
+        rec['mala'] = {'rejected_step_reuse': reuse_on, 'evaluations_enqueued_per_chain': int(st['evals']),
+                       'evaluations_skipped_last_chain': int(st['evals_skipped']),
+                       'mean_acceptance_rate': float(acc.float().mean().item()) if acc is not None else None,
+                       'note': 'an inner step that accepts no node leaves x unchanged; E(x) and dE/dx of the next step are then the values already '
+                               'computed, and their kernels return at once.  Bitwise the chain that recomputes '
+                               '(test_mala_rejected_step_reuse_is_bitwise_identical); the gain is workload-dependent (acceptance rate).'}
+        if reuse_on and dist is None:
+            os.environ['CCSP_MALA_REUSE'] = '0'
+            den0 = ConstraintDiffuser(dims=worlds.MODE_DIMS[cfg['mode']], hidden_dim=HIDDEN, input_mode=cfg['mode'], EBM=cfg['EBM'],
+                                      energy_wrapper=cfg['energy'], device=dev, verbose=False)
+            den0.load_state_dict(sd)
+            gd0 = GaussianDiffusion(ComposedEBMDenoiseFn(den0) if cfg['energy'] else den0, timesteps=T_STEPS, EBM=cfg['EBM'], samples_per_step=S_LANGEVIN)
+            os.environ['CCSP_MALA_REUSE'] = '1'
+            gd0.sample(base.clone(), seed=999)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            x0 = gd0.sample(base.clone(), seed=1000 + args.warmup + args.steps - 1, row_offset=rank * n_nodes)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            rec['mala']['value_recomputing_every_evaluation'] = B / dt
+            rec['mala']['recomputing_chain_bitwise_equal'] = bool(torch.equal(x0, x) or ((x0 == x) | (torch.isnan(x0) & torch.isnan(x))).all().item())
+
     if cname == 'c2':
         # "solved?" check (diffusion-ccsp_amd/checker.py); outside the timed region
         from diffusion_ccsp_amd import checker, evaluate

@@ -161,7 +161,9 @@ __global__ __launch_bounds__(256) void k_rowsum(int R, int W2, const int* __rest
 // row maximum is one shuffle butterfly (no LDS, no barrier) and a row's edge indices are fetched four at a time ahead of the
 // GZ rows they address (the sum keeps the ascending edge order)
 __global__ __launch_bounds__(256) void k_rowsum_h2(int R, const int* __restrict__ row_ptr, const int* __restrict__ row_edge,
-                                                   const float* __restrict__ GZ, unsigned short* __restrict__ GZRH, int* __restrict__ gexp) {
+                                                   const float* __restrict__ GZ, unsigned short* __restrict__ GZRH, int* __restrict__ gexp,
+                                                   const int* __restrict__ skip /*MALA reuse, or null*/) {
+    if (skip && *skip == 0) return;
     constexpr int W2 = 512;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (r >= R) return;                                           // (wave-uniform)
@@ -225,6 +227,7 @@ struct EnergyNodeArgs {
     const float* W2;         // pose_encoder.2.weight [H, H/2]
     const float* W2T;        // [H/2, H]
     const float* b2;
+    const int* skip;         // MALA reuse: if non-null and *skip == 0 the launch returns at once (k_node_energy_h2)
 };
 
 template <int H>
@@ -528,6 +531,10 @@ __global__ __launch_bounds__(256) void k_node_energy_h2(EnergyNodeArgs a, EncW w
     __shared__ float red[256];
     __shared__ float smax[4][NODE_TILE];
     __shared__ int sexp[NODE_TILE];
+    if (a.skip && *a.skip == 0) {                                 // (uniform) MALA reuse: gradient and E(x) of the unmoved state stand
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(const_cast<int*>(a.skip) + 1, 1);      // [1]: evaluations skipped
+        return;
+    }
     const int node0 = blockIdx.x * NODE_TILE;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nl = lane & 15, n = node0 + nl;

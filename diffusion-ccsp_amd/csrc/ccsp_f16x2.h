@@ -225,6 +225,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : (MODE == 3 ? 1 : 2)) void k_ro
                                                        const float* __restrict__ base, const float* __restrict__ tau_t,
                                                        float* __restrict__ U, float* __restrict__ umax, StepRef ref, size_t tau_stride) {
     static_assert(ND % 128 == 0 && KD % H2_BK == 0 && KD / H2_BK >= 3, "shape");
+    if (ref.skip && *ref.skip == 0) return;                       // (uniform) MALA reuse: the state has not moved since this was computed
     constexpr int NCT = ND / 128, NCH = KD / H2_BK;
     constexpr int MI = MODE == 4 ? 1 : 2, TM = 64 * MI;           // 32-row MFMA tiles per wave, rows per workgroup tile
     constexpr int APL = TM * H2_BK, STAGE = 2 * APL + 2 * H2_BPL;         // 32 KB per stage (24 KB for 64-row tiles)
@@ -446,6 +447,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void k_edge_h2(int E_act, int
                                                     const float* __restrict__ bd1, const float* __restrict__ Wd2,
                                                     const float* __restrict__ bd2, const int* __restrict__ ent_pos, float* __restrict__ O,
                                                     EdgeEnergyArgs en, int* __restrict__ counter_inc) {
+    if constexpr (ENERGY) { if (en.skip && *en.skip == 0) return; }                        // (uniform) MALA reuse
     if (counter_inc && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(counter_inc, 1);     // hipGraph mode: next table entry
     constexpr int H = 256, BN = 128, NCH = H / H2_BK;
     constexpr int ME = 32 * MT, ROWS = 2 * ME;                    // edges, tile rows
@@ -626,6 +628,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_h2s(int E_act, int P, const int
                                                      const float* __restrict__ bd1, const float* __restrict__ Wd2,
                                                      const float* __restrict__ bd2, const int* __restrict__ ent_pos, float* __restrict__ O,
                                                      EdgeEnergyArgs en, int* __restrict__ counter_inc) {
+    if constexpr (ENERGY) { if (en.skip && *en.skip == 0) return; }                        // (uniform) MALA reuse
     if (counter_inc && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(counter_inc, 1);     // hipGraph mode: next table entry
     constexpr int H = 256, BN = 128, NCH = H / H2_BK;
     constexpr int ME = 16, ROWS = 2 * ME;
@@ -777,7 +780,9 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_h2(int E_act, int P, const 
                                                         const int* __restrict__ ent_pos, const float* __restrict__ U,
                                                         const float* __restrict__ Ocsr, const float* __restrict__ Q /*[2E,128]*/,
                                                         const unsigned short* __restrict__ Wd1TH /*[2][256][128]*/, int wd_exp, float wd2_absmax,
-                                                        const float* __restrict__ Wd2 /*[P,128]*/, float* __restrict__ GZ) {
+                                                        const float* __restrict__ Wd2 /*[P,128]*/, float* __restrict__ GZ,
+                                                        const int* __restrict__ skip /*MALA reuse, or null*/) {
+    if (skip && *skip == 0) return;
     constexpr int H = 256, KD = 128, BM = 64, BN = 128, NCH = KD / H2_BK;
     constexpr int APL = BM * H2_BK, STAGE = 2 * APL + 2 * H2_BPL;             // 8 KB of A planes + 16 KB of B planes per stage
     constexpr int C_LD = BN + 4;

@@ -690,6 +690,7 @@ struct EdgeEnergyArgs {
     const float* xeval;      // [N, P] evaluation point
     float* Q;                // [2 E_act, H/2] or null
     float* partial;          // [gridDim.x]
+    const int* skip;         // MALA reuse: if non-null and *skip == 0 the launch returns at once
 };
 
 template <int H, bool ENERGY>
@@ -846,6 +847,7 @@ struct ChainHeader {
 struct StepRef {
     const StepEntry* tab;
     int* counter;
+    const int* skip;        // MALA reuse (CCSP_MALA_REUSE): if non-null and *skip == 0 the launch returns at once
 };
 
 struct NodeArgs {
@@ -871,6 +873,7 @@ struct NodeArgs {
     const float* E_hat_partial;   // MALA accept: if non-null, E(x_hat) is the sum of these per-workgroup partials of the edge
     int n_hat_partial;            // kernel (same order as k_energy_sum) and E_hat is not read: one launch less per inner step
     int* acc_count;         // MALA: accepted-node counter of this timestep
+    int* changed;           // MALA reuse: reset by the propose step, += accepted nodes by the accept step (or null)
     // schedule scalars of this timestep
     float a_t, b_t, c1, c2, sigma, kappa, ss, std_;
     NoiseArg noise;
@@ -902,6 +905,7 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, EncOut eo) {
     }
     const int node0 = blockIdx.x * NODE_TILE;
     const int tid = threadIdx.x;
+    if (a.step == STEP_MALA_PROPOSE && a.changed && blockIdx.x == 0 && tid == 0) *a.changed = 0;
     // The chain of this kernel is CSR range -> edge outputs -> update -> encoder.  Vector-memory loads return in order, so
     // the chain's loads are issued FIRST and the encoder's weights (160 VGPRs of them in the f16 form) behind them: they are
     // in flight under the update and never in front of a load the update waits for.
@@ -1001,6 +1005,7 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, EncOut eo) {
                     else u = ccsp::philox_uniform(a.noise.seed, a.noise.row_offset + (unsigned long long)n, a.noise.ucall);
                     const float accf = (u < expf(la)) ? 1.0f : 0.0f;
                     if (p == 0 && accf != 0.0f && a.acc_count) atomicAdd(a.acc_count, 1);
+                    if (p == 0 && accf != 0.0f && a.changed) atomicAdd(a.changed, 1);
                     xv = accf * a.xhat[i] + (1.0f - accf) * xv;
                 } else {                                        // ddpm.py:273
                     xv = 0.5f * z;
@@ -1099,6 +1104,9 @@ struct ccsp_model {
     int pe2_exp = 0;
     float pe0_c1 = 0.0f, pe0_c2 = 0.0f;   // bound of the pose encoder's layer-1 pre-activation: c1 max|x| + c2
     int energy_bwd_h2 = 1;            // CCSP_ENERGY_BWD=bf16x3 keeps the backward GEMMs on the six-product bf16 kernels
+    int mala_reuse = 1;               // (CCSP_MALA_REUSE=0 turns it off) an inner step that accepted NO node leaves x where it was, so the next step's
+                                      // E(x) and gradient are the ones already computed; their kernels return at once (bitwise the
+                                      // same chain: every kernel is deterministic).  f16x2 energy kernels, no shard hook.
     int ncu = 256;          // compute units of the device (residency-based kernel selection)
     ccsp_energy_hook energy_hook = nullptr;   // MALA global-batch mode (ccsp_model_set_energy_hook)
     void* energy_hook_ctx = nullptr;
@@ -1149,6 +1157,7 @@ struct ccsp_graph {
     int* gexp = nullptr;               // [R]
     float *Q = nullptr, *GZ = nullptr, *GZR = nullptr, *GP = nullptr, *xhat = nullptr, *partial = nullptr, *Escal = nullptr;
     int *acc_count = nullptr, *acc_denom = nullptr;
+    int* mala_changed = nullptr;       // MALA reuse: nodes accepted by the last accept step
     float *hmc_vk = nullptr, *hmc_vp = nullptr, *hmc_vl = nullptr;   // HMC momenta (allocated on first use)
     std::vector<int> h_denom;      // host copy kept alive for the async upload
     std::vector<int> h_t2;         // (row0 | nrows | ts) of the 128-row tiles, kept alive for the async upload
@@ -1428,7 +1437,8 @@ int energy_prepare(ccsp_model* m, ccsp_graph* g, hipStream_t s) {
     if (dev_alloc(reg, &g->Q, (size_t)2 * p.E_act * (H / 2)) || dev_alloc(reg, &g->GZ, (size_t)p.E_act * 2 * H) ||
         dev_alloc(reg, &g->GZR, (size_t)p.R * 2 * H) || dev_alloc(reg, &g->GP, (size_t)p.R * H) ||
         dev_alloc(reg, &g->xhat, (size_t)g->N * P) || dev_alloc(reg, &g->partial, n_partial) ||
-        dev_alloc(reg, &g->Escal, 4) || dev_alloc(reg, &g->acc_count, (size_t)T) || dev_alloc(reg, &g->acc_denom, (size_t)T))
+        dev_alloc(reg, &g->Escal, 4) || dev_alloc(reg, &g->acc_count, (size_t)T) || dev_alloc(reg, &g->acc_denom, (size_t)T) ||
+        dev_alloc(reg, &g->mala_changed, 2))                 // [0] nodes accepted by the last accept step, [1] evaluations skipped
         return 1;
     HIP_TRY(hipMemsetAsync(g->Escal, 0, 4 * sizeof(float), s));
     HIP_TRY(hipMemsetAsync(g->partial, 0, n_partial * sizeof(float), s));
@@ -1440,7 +1450,8 @@ int energy_prepare(ccsp_model* m, ccsp_graph* g, hipStream_t s) {
 // with_grad: dE/dposes -> g->eps and E -> E_out;  otherwise only E -> E_out.
 // E_out == nullptr (energy-only evaluations): leave the per-workgroup partials in g->partial / g->n_part_last for the consumer
 template <int H>
-int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, bool with_grad, float* E_out, hipStream_t s) {
+int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, bool with_grad, float* E_out, hipStream_t s,
+                       const int* skip = nullptr /*MALA reuse: every kernel of the evaluation returns at once if *skip == 0*/) {
     const ccsp::Plan& p = g->plan;
     const int P = m->d.pose_dim;
     g->evals++;
@@ -1455,7 +1466,7 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     bool h2 = false;
     if constexpr (H == 256) h2 = m->f16x2 != 0;
     if (h2) {            // the forward row GEMM is the direct-mode one (planes written by k_node)
-        launch_rowgemm_h2(m, g, tau_t, StepRef{nullptr, nullptr}, (size_t)0, s);
+        launch_rowgemm_h2(m, g, tau_t, StepRef{nullptr, nullptr, skip}, (size_t)0, s);
     } else if (m->bf16x3)
         hipLaunchKernelGGL((k_rowgemm_bf2<H, 2 * H>), dim3(g->n_tiles2 * (2 * H / RB2_TN)), dim3(512), 0, s, g->pembS, (size_t)g->N * H, g->urow_node,
                            g->t2_row0, g->t2_nrows, g->t2_ts, m->WpS, (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, g->base, tau_t, g->U,
@@ -1464,7 +1475,7 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     hipLaunchKernelGGL((k_rowgemm<H, 2 * H>), dim3(nw_u < m->max_wgs ? nw_u : m->max_wgs), dim3(256), 0, s, nw_u, g->pemb, g->urow_node, g->tile_row0,
                        g->tile_nrows, g->tile_ts, m->Wp, (size_t)2 * H * H, g->base, tau_t, g->U);
     prof_mark(g, s, CCSP_K_EDGE);
-    EdgeEnergyArgs en{g->e_a, g->e_b, xeval, with_grad ? g->Q : nullptr, g->partial};
+    EdgeEnergyArgs en{g->e_a, g->e_b, xeval, with_grad ? g->Q : nullptr, g->partial, skip};
     int n_part = g->n_edge_blocks;                                                           // one energy partial per workgroup
     bool edge_done = false;
     if constexpr (H == 256) {
@@ -1497,7 +1508,7 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     if constexpr (H == 256) {
         if (h2_bwd) {
             hipLaunchKernelGGL(k_edge_bwd_h2, dim3(nblk(p.E_act, 64) * 4), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->ent_pos, g->U, g->O, g->Q,
-                               m->Wd1TH, m->wd_exp, m->wd2_absmax, m->pd2_w, g->GZ);
+                               m->Wd1TH, m->wd_exp, m->wd2_absmax, m->pd2_w, g->GZ, skip);
             bwd_done = true;
         } else if (m->bf16x3 && m->edge_kernel == 2) {
             hipLaunchKernelGGL(k_edge_bwd_bf, dim3(nblk(p.E_act, 64) * 4), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->ent_pos, g->U, g->O, g->Q,
@@ -1513,7 +1524,7 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     if (h2_bwd && !g->GZRH && (dev_alloc(g->allocs, &g->GZRH, (size_t)2 * p.R * 2 * H) || dev_alloc(g->allocs, &g->gexp, (size_t)p.R))) return 1;
     prof_mark(g, s, CCSP_K_ROWSUM);
     if (h2_bwd)
-        hipLaunchKernelGGL(k_rowsum_h2, dim3(nblk(p.R, 4)), dim3(256), 0, s, p.R, g->row_ptr, g->row_edge, g->GZ, g->GZRH, g->gexp);
+        hipLaunchKernelGGL(k_rowsum_h2, dim3(nblk(p.R, 4)), dim3(256), 0, s, p.R, g->row_ptr, g->row_edge, g->GZ, g->GZRH, g->gexp, skip);
     else
     hipLaunchKernelGGL(k_rowsum, dim3(nblk((long)p.R * (2 * H / 4), 256)), dim3(256), 0, s, p.R, 2 * H, g->row_ptr, g->row_edge, g->GZ, g->GZR,
                        bf_bwd ? g->GZRS : (unsigned short*)nullptr);
@@ -1529,7 +1540,7 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
 #define CCSP_ROWGEMM_T(MODE)                                                                                                                        \
             hipLaunchKernelGGL((k_rowgemm_h2<2 * H, H, MODE>), dim3(work), dim3(256), 0, s, g->GZRH, (size_t)p.R * 2 * H, g->gexp, no_map,              \
                                small ? g->tile_row0 : g->t2_row0, small ? g->tile_nrows : g->t2_nrows, small ? g->tile_ts : g->t2_ts, m->WpTH,          \
-                               (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, m->wp_exp, nof, nof, g->GP, nou, StepRef{nullptr, nullptr},     \
+                               (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, m->wp_exp, nof, nof, g->GP, nou, StepRef{nullptr, nullptr, skip}, \
                                (size_t)0)
             if (mode == 4) CCSP_ROWGEMM_T(4); else if (mode == 3) CCSP_ROWGEMM_T(3); else if (mode == 2) CCSP_ROWGEMM_T(2);
             else if (mode == 1) CCSP_ROWGEMM_T(1); else CCSP_ROWGEMM_T(0);
@@ -1546,7 +1557,7 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
                        g->tileb_nrows, g->tileb_ts, m->WpT, (size_t)2 * H * H, nof, nof, g->GP);
     }
     EnergyNodeArgs a{g->N, P, g->node_ptr, g->O, g->nrow_ptr, g->nrow_idx, g->GP, xeval, g->eps, g->partial, n_part, E_out,
-                     m->pe0_w, m->pe0_b, m->pe2_w, m->pe2_wT, m->pe2_b};
+                     m->pe0_w, m->pe0_b, m->pe2_w, m->pe2_wT, m->pe2_b, skip};
     static const bool valu_node_energy = getenv("CCSP_NODE_ENERGY_VALU") != nullptr;     // the pre-MFMA kernel, kept for A/B runs
     prof_mark(g, s, CCSP_K_NODE_ENERGY);
     if (valu_node_energy) hipLaunchKernelGGL(k_node_energy<H>, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a);
@@ -1637,6 +1648,7 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
         std::vector<uint64_t> ucall0(T, 0);
         if (energy_prepare(m, g, s)) return 1;
         HIP_TRY(hipMemsetAsync(g->acc_count, 0, (size_t)T * sizeof(int), s));
+        HIP_TRY(hipMemsetAsync(g->mala_changed, 0, 2 * sizeof(int), s));
         HIP_TRY(hipStreamSynchronize(s));      // a previous chain may still be reading h_denom
         g->h_denom.assign(T, 0);
         uint64_t uc0 = 0;
@@ -1724,8 +1736,14 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
                 encode_at(g->x);          // pose embeddings of the state for the next timestep's p_sample
                 continue;
             }
+            // MALA reuse: from the second inner step on, the gradient evaluation at x is skipped on the device when the previous
+            // accept step moved nothing (the kernels read g->mala_changed: reset by the propose step, += accepted nodes by accept)
+            bool reuse = false;
+            if constexpr (H == 256)
+                reuse = sampler == CCSP_SAMPLER_MALA && m->mala_reuse && m->f16x2 && m->energy_bwd_h2 && m->WpTH && m->pe2_wTH && !m->energy_hook &&
+                        !g->profile;        // (a profiled chain times every kernel at full work)
             for (int e = 1; e <= S; ++e) {
-                if (launch_eval_energy<H>(m, g, t, g->x, true, E_x, s)) return 1;
+                if (launch_eval_energy<H>(m, g, t, g->x, true, E_x, s, (reuse && e >= 2) ? g->mala_changed : (const int*)nullptr)) return 1;
                 NodeArgs a = node_args(m, g);
                 a.src = 1; a.eps_buf = g->eps; a.do_encode = 1; a.xhat = g->xhat;
                 sched(a, t);
@@ -1738,6 +1756,7 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
                     continue;
                 }
                 a.step = STEP_MALA_PROPOSE;
+                a.changed = reuse ? g->mala_changed : nullptr;
                 launch_node<H>(m, g, a, s);                                   // x_hat, and its pose embedding
                 // without a shard hook the accept kernel sums the proposal's energy partials itself (no k_energy_sum launch)
                 const bool fold_sum = m->energy_hook == nullptr && g->plan.E_act > 0;
@@ -1748,6 +1767,7 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
                 NodeArgs b = node_args(m, g);
                 b.src = 1; b.eps_buf = g->eps; b.do_encode = 1; b.xhat = g->xhat; b.step = STEP_MALA_ACCEPT;
                 b.E_x = E_x; b.E_hat = E_hat; b.acc_count = g->acc_count + t;
+                b.changed = reuse ? g->mala_changed : nullptr;
                 if (fold_sum) { b.E_hat_partial = g->partial; b.n_hat_partial = g->n_part_last; }
                 b.reset_mask = (e == S);
                 b.hist = e == S ? hist_at(L, T - t) : nullptr;
@@ -2322,6 +2342,7 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
             hipLaunchKernelGGL(k_split2h, dim3(nblk(nwd, 256)), dim3(256), 0, s, nwd, m->pd0_w, m->wd_exp, m->Wd1H);
             if (d->energy_wrapper) {    // the backward GEMMs' weights: the same tensors transposed, the same exponents
                 if (const char* e = getenv("CCSP_ENERGY_BWD")) m->energy_bwd_h2 = strcmp(e, "bf16x3") != 0;
+                if (const char* e = getenv("CCSP_MALA_REUSE")) m->mala_reuse = atoi(e) != 0;
                 TRY(dev_alloc(reg, &m->WpTH, (size_t)2 * nwp));
                 TRY(dev_alloc(reg, &m->Wd1TH, (size_t)2 * nwd));
                 hipLaunchKernelGGL(k_split2h, dim3(nblk(nwp, 256)), dim3(256), 0, s, nwp, m->WpT, m->wp_exp, m->WpTH);
@@ -2673,6 +2694,16 @@ int ccsp_kernel_stats(ccsp_graph* g, int32_t which, int64_t* calls, float* ms_me
     if (calls) *calls = n;
     if (ms_mean) *ms_mean = n ? (float)(acc / (double)n) : 0.0f;
     if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s", kKernelNames[which]);
+    return 0;
+}
+
+int ccsp_chain_skipped(ccsp_graph* g, int64_t* evaluations_skipped) {
+    if (!g || !evaluations_skipped) return fail("chain_skipped: null argument");
+    if (!g->have_events) return fail("chain_skipped: no chain has run on this graph");
+    HIP_TRY(hipEventSynchronize(g->ev1));
+    int n = 0;
+    if (g->mala_changed) HIP_TRY(hipMemcpy(&n, g->mala_changed + 1, sizeof(int), hipMemcpyDeviceToHost));
+    *evaluations_skipped = n;
     return 0;
 }
 

@@ -234,7 +234,9 @@ class GaussianDiffusion(object):
             raise _lib.CcspError('no chain has run')
         ev, ms, mu, me = C.c_int64(), C.c_float(), C.c_float(), C.c_float()
         _lib.check(_lib.lib().ccsp_chain_stats(g.h, C.byref(ev), C.byref(ms), C.byref(mu), C.byref(me)))
-        return dict(evals=ev.value, ms_total=ms.value, ms_ugemm=mu.value, ms_edge=me.value)
+        sk = C.c_int64()
+        _lib.check(_lib.lib().ccsp_chain_skipped(g.h, C.byref(sk)))
+        return dict(evals=ev.value, ms_total=ms.value, ms_ugemm=mu.value, ms_edge=me.value, evals_skipped=sk.value)
 
     def kernel_stats(self):
         """per-kernel launch counts and mean durations (ms) of the last PROFILED chain: {label: (calls, ms_mean)}"""

@@ -184,6 +184,12 @@ int ccsp_model_set_energy_hook(ccsp_model* model, ccsp_energy_hook hook, void* c
  * row GEMM / edge kernel (0 when profiling is off).  Synchronises on the chain's end. */
 int ccsp_profile_enable(ccsp_graph* graph, int32_t on);
 int ccsp_chain_stats(ccsp_graph* graph, int64_t* evals, float* ms_total, float* ms_ugemm, float* ms_edge);
+/* MALA chains (ddpm.py:999-1047): an inner step that accepted NO node leaves x where it was, so E(x) and dE/dx of the next
+ * inner step are the values already computed; unless CCSP_MALA_REUSE=0 the kernels of that gradient evaluation then return
+ * at once (decided on the device from the accept kernel's count; every kernel is deterministic, so the chain is bitwise the
+ * one that recomputes -- tests/test_hip_parity.py::test_mala_rejected_step_reuse_is_bitwise_identical).  `evals` of
+ * ccsp_chain_stats counts the evaluations ENQUEUED; this returns how many of them the last chain skipped.  Synchronises. */
+int ccsp_chain_skipped(ccsp_graph* graph, int64_t* evaluations_skipped);
 /* Per-kernel timing of a profiled chain (ccsp_profile_enable): while profiling, an event is recorded before every
  * launch of the kernels below (the first CCSP_PROFILE_MARKS marks of a chain); which = CCSP_K_*; calls = launches
  * seen, ms_mean = their mean duration, launch to next mark on the stream; name = a short label (may be NULL). */
