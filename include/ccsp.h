@@ -184,7 +184,7 @@ int ccsp_model_set_energy_hook(ccsp_model* model, ccsp_energy_hook hook, void* c
  * row GEMM / edge kernel (0 when profiling is off).  Synchronises on the chain's end. */
 int ccsp_profile_enable(ccsp_graph* graph, int32_t on);
 int ccsp_chain_stats(ccsp_graph* graph, int64_t* evals, float* ms_total, float* ms_ugemm, float* ms_edge);
-/* MALA chains (ddpm.py:999-1047): an inner step that accepted NO node leaves x where it was, so E(x) and dE/dx of the next
+/* MALA chains (ddpm.py:1012-1047; the gradient and E(x) of ddpm.py:1019,1026): an inner step that accepted NO node leaves x where it was, so E(x) and dE/dx of the next
  * inner step are the values already computed; unless CCSP_MALA_REUSE=0 the kernels of that gradient evaluation then return
  * at once (decided on the device from the accept kernel's count; every kernel is deterministic, so the chain is bitwise the
  * one that recomputes -- tests/test_hip_parity.py::test_mala_rejected_step_reuse_is_bitwise_identical).  `evals` of
