@@ -278,7 +278,8 @@ def main():
                        'mean_acceptance_rate': float(acc.float().mean().item()) if acc is not None else None,
                        'note': 'an inner step that accepts no node leaves x unchanged; E(x) and dE/dx of the next step are then the values already '
                                'computed, and their kernels return at once.  Bitwise the chain that recomputes '
-                               '(test_mala_rejected_step_reuse_is_bitwise_identical); the gain is workload-dependent (acceptance rate).'}
+                               '(test_mala_rejected_step_reuse_is_bitwise_identical); the gain is workload-dependent (acceptance rate).  The profiled chain of the '
+                               'roofline block recomputes every evaluation (kernels timed at full work).'}
         if reuse_on and dist is None:
             os.environ['CCSP_MALA_REUSE'] = '0'
             den0 = ConstraintDiffuser(dims=worlds.MODE_DIMS[cfg['mode']], hidden_dim=HIDDEN, input_mode=cfg['mode'], EBM=cfg['EBM'],
