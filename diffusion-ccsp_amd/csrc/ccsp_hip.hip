@@ -1106,7 +1106,7 @@ struct ccsp_model {
     int energy_bwd_h2 = 1;            // CCSP_ENERGY_BWD=bf16x3 keeps the backward GEMMs on the six-product bf16 kernels
     int mala_reuse = 1;               // (CCSP_MALA_REUSE=0 turns it off) an inner step that accepted NO node leaves x where it was, so the next step's
                                       // E(x) and gradient are the ones already computed; their kernels return at once (bitwise the
-                                      // same chain: every kernel is deterministic).  f16x2 energy kernels, no shard hook.
+                                      // same chain: every kernel is deterministic).  f16x2 energy kernels.
     int ncu = 256;          // compute units of the device (residency-based kernel selection)
     ccsp_energy_hook energy_hook = nullptr;   // MALA global-batch mode (ccsp_model_set_energy_hook)
     void* energy_hook_ctx = nullptr;
@@ -1740,10 +1740,15 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
             // accept step moved nothing (the kernels read g->mala_changed: reset by the propose step, += accepted nodes by accept)
             bool reuse = false;
             if constexpr (H == 256)
-                reuse = sampler == CCSP_SAMPLER_MALA && m->mala_reuse && m->f16x2 && m->energy_bwd_h2 && m->WpTH && m->pe2_wTH && !m->energy_hook &&
+                reuse = sampler == CCSP_SAMPLER_MALA && m->mala_reuse && m->f16x2 && m->energy_bwd_h2 && m->WpTH && m->pe2_wTH &&
                         !g->profile;        // (a profiled chain times every kernel at full work)
+            // with a shard hook the kernels write the shard's own energies to Escal[2..3]; a copy of them goes through the hook
+            // (Escal[0..1], reduced in place) every inner step, so a skipped evaluation leaves the LOCAL E(x) standing
+            const bool hook = sampler == CCSP_SAMPLER_MALA && m->energy_hook != nullptr;
+            float* E_xl = hook ? g->Escal + 2 : E_x;
+            float* E_hatl = hook ? g->Escal + 3 : E_hat;
             for (int e = 1; e <= S; ++e) {
-                if (launch_eval_energy<H>(m, g, t, g->x, true, E_x, s, (reuse && e >= 2) ? g->mala_changed : (const int*)nullptr)) return 1;
+                if (launch_eval_energy<H>(m, g, t, g->x, true, E_xl, s, (reuse && e >= 2) ? g->mala_changed : (const int*)nullptr)) return 1;
                 NodeArgs a = node_args(m, g);
                 a.src = 1; a.eps_buf = g->eps; a.do_encode = 1; a.xhat = g->xhat;
                 sched(a, t);
@@ -1760,10 +1765,13 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
                 launch_node<H>(m, g, a, s);                                   // x_hat, and its pose embedding
                 // without a shard hook the accept kernel sums the proposal's energy partials itself (no k_energy_sum launch)
                 const bool fold_sum = m->energy_hook == nullptr && g->plan.E_act > 0;
-                if (launch_eval_energy<H>(m, g, t, g->xhat, false, fold_sum ? (float*)nullptr : E_hat, s)) return 1;
+                if (launch_eval_energy<H>(m, g, t, g->xhat, false, fold_sum ? (float*)nullptr : E_hatl, s)) return 1;
                 // global-batch mode: E(x), E(x_hat) of this shard -> sums over all shards (the reference's energies are
                 // one scalar for the WHOLE batch, ddpm.py:1026-1038); the hook enqueues the reduction on the chain's stream
-                if (m->energy_hook && m->energy_hook(m->energy_hook_ctx, g->Escal, (void*)s)) return fail("chain_run: the energy hook failed");
+                if (hook) {
+                    HIP_TRY(hipMemcpyAsync(g->Escal, g->Escal + 2, 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+                    if (m->energy_hook(m->energy_hook_ctx, g->Escal, (void*)s)) return fail("chain_run: the energy hook failed");
+                }
                 NodeArgs b = node_args(m, g);
                 b.src = 1; b.eps_buf = g->eps; b.do_encode = 1; b.xhat = g->xhat; b.step = STEP_MALA_ACCEPT;
                 b.E_x = E_x; b.E_hat = E_hat; b.acc_count = g->acc_count + t;
