@@ -873,7 +873,7 @@ struct NodeArgs {
     const float* E_hat_partial;   // MALA accept: if non-null, E(x_hat) is the sum of these per-workgroup partials of the edge
     int n_hat_partial;            // kernel (same order as k_energy_sum) and E_hat is not read: one launch less per inner step
     int* acc_count;         // MALA: accepted-node counter of this timestep
-    int* changed;           // MALA reuse: reset by the propose step, += accepted nodes by the accept step (or null)
+    int* changed;           // MALA reuse: reset by the propose step, += pose elements the accept step changed bitwise (or null)
     // schedule scalars of this timestep
     float a_t, b_t, c1, c2, sigma, kappa, ss, std_;
     NoiseArg noise;
@@ -969,6 +969,7 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, EncOut eo) {
             }
             if (a.eps_out) a.eps_out[i] = eps;
             float xv = a.x_in ? a.x_in[i] : (a.step == STEP_INIT ? 0.0f : a.x[i]);
+            const float x_old = xv;
             if (a.step != STEP_NONE) {
                 float z = 0.0f;
                 if (a.step != STEP_MALA_ACCEPT) {
@@ -1005,7 +1006,6 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, EncOut eo) {
                     else u = ccsp::philox_uniform(a.noise.seed, a.noise.row_offset + (unsigned long long)n, a.noise.ucall);
                     const float accf = (u < expf(la)) ? 1.0f : 0.0f;
                     if (p == 0 && accf != 0.0f && a.acc_count) atomicAdd(a.acc_count, 1);
-                    if (p == 0 && accf != 0.0f && a.changed) atomicAdd(a.changed, 1);
                     xv = accf * a.xhat[i] + (1.0f - accf) * xv;
                 } else {                                        // ddpm.py:273
                     xv = 0.5f * z;
@@ -1014,6 +1014,9 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, EncOut eo) {
                     a.xhat[i] = xv;                             // the chain state x is untouched until the accept step
                 } else {
                     if (a.reset_mask && masked) xv = a.xfeat[(size_t)n * a.F + a.pose_begin + p];
+                    // MALA reuse: the next gradient evaluation may be skipped only if NO stored element moved.  A rejected node can
+                    // move too (0 * Inf = NaN from a non-finite proposal, like the reference), so compare bit patterns
+                    if (a.step == STEP_MALA_ACCEPT && a.changed && __float_as_uint(xv) != __float_as_uint(x_old)) atomicAdd(a.changed, 1);
                     a.x[i] = xv;
                     if (a.hist) a.hist[i] = xv;
                 }
@@ -1056,6 +1059,18 @@ __global__ void k_unsort_edges(int E_act, int P, const int* __restrict__ e_orig,
 }
 
 inline int nblk(long n, int b) { return (int)((n + b - 1) / b); }
+
+// stream-ordered scratch of the operator entry points, released on every path out of the scope
+struct StreamBuf {
+    void* p = nullptr;
+    hipStream_t s;
+    explicit StreamBuf(hipStream_t st) : s(st) {}
+    ~StreamBuf() { if (p) (void)hipFreeAsync(p, s); }
+    StreamBuf(const StreamBuf&) = delete;
+    StreamBuf& operator=(const StreamBuf&) = delete;
+    int alloc(size_t bytes) { HIP_TRY(hipMallocAsync(&p, bytes, s)); return 0; }
+    float* f() const { return (float*)p; }
+};
 
 }  // namespace
 
@@ -1104,6 +1119,7 @@ struct ccsp_model {
     int pe2_exp = 0;
     float pe0_c1 = 0.0f, pe0_c2 = 0.0f;   // bound of the pose encoder's layer-1 pre-activation: c1 max|x| + c2
     int energy_bwd_h2 = 1;            // CCSP_ENERGY_BWD=bf16x3 keeps the backward GEMMs on the six-product bf16 kernels
+    int valu_node_energy = 0;         // CCSP_NODE_ENERGY_VALU: the pre-MFMA node-energy kernel (A/B runs; never combined with the reuse below)
     int mala_reuse = 1;               // (CCSP_MALA_REUSE=0 turns it off) an inner step that accepted NO node leaves x where it was, so the next step's
                                       // E(x) and gradient are the ones already computed; their kernels return at once (bitwise the
                                       // same chain: every kernel is deterministic).  f16x2 energy kernels.
@@ -1298,7 +1314,7 @@ int launch_edge_h2(ccsp_model* m, ccsp_graph* g, EdgeEnergyArgs en, int* cinc, h
 template <int H>
 int launch_eval(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s, bool tabled = false) {
     // U = pose_emb . Wp^T ; O = decoder(...)
-    // tabled (hipGraph mode, bf16x3 kernels only): the timestep comes from the device step table, see StepEntry
+    // tabled (hipGraph mode): the timestep comes from the device step table, see StepEntry
     const ccsp::Plan& p = g->plan;
     if (p.E_act == 0) return 0;
     prof_mark(g, s, CCSP_K_ROWGEMM);
@@ -1558,7 +1574,7 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     }
     EnergyNodeArgs a{g->N, P, g->node_ptr, g->O, g->nrow_ptr, g->nrow_idx, g->GP, xeval, g->eps, g->partial, n_part, E_out,
                      m->pe0_w, m->pe0_b, m->pe2_w, m->pe2_wT, m->pe2_b, skip};
-    static const bool valu_node_energy = getenv("CCSP_NODE_ENERGY_VALU") != nullptr;     // the pre-MFMA kernel, kept for A/B runs
+    const bool valu_node_energy = m->valu_node_energy != 0;                              // the pre-MFMA kernel, kept for A/B runs
     prof_mark(g, s, CCSP_K_NODE_ENERGY);
     if (valu_node_energy) hipLaunchKernelGGL(k_node_energy<H>, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a);
     else {
@@ -1741,6 +1757,7 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
             bool reuse = false;
             if constexpr (H == 256)
                 reuse = sampler == CCSP_SAMPLER_MALA && m->mala_reuse && m->f16x2 && m->energy_bwd_h2 && m->WpTH && m->pe2_wTH &&
+                        !m->valu_node_energy &&      // (k_node_energy<H> has no skip prologue)
                         !g->profile;        // (a profiled chain times every kernel at full work)
             // with a shard hook the kernels write the shard's own energies to Escal[2..3]; a copy of them goes through the hook
             // (Escal[0..1], reduced in place) every inner step, so a skipped evaluation leaves the LOCAL E(x) standing
@@ -2169,6 +2186,7 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     m->f16x2 = (H == 256 && d->model_kind == CCSP_MODEL_DIFFUSION_CCSP) ? 1 : 0;
     if (const char* e = getenv("CCSP_ROW_MODE")) { const int v = atoi(e); if (v >= 0 && v <= 4) m->row_mode = v; }
     if (const char* e = getenv("CCSP_EDGE_MT")) m->edge_mt = atoi(e) == 2 ? 2 : 1;
+    m->valu_node_energy = getenv("CCSP_NODE_ENERGY_VALU") != nullptr;
     {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -2414,17 +2432,15 @@ int ccsp_encode(ccsp_model* m, int32_t which, int32_t n, const float* in, float*
 
 int ccsp_time_mlp(ccsp_model* m, int32_t n, const float* t_values, float* out, void* stream) {
     if (!m || !t_values || !out) return fail("time_mlp: null argument");
-    if (n < 1) return fail("time_mlp: n=%d", n);
+    if (n < 0) return fail("time_mlp: n=%d", n);
+    if (n == 0) return 0;                                     // an empty t gives an empty [0, H] result, like the encoders
     const int H = m->d.hidden_dim;
     hipStream_t s = (hipStream_t)stream;
-    float *sinus = nullptr, *hid = nullptr;
-    HIP_TRY(hipMallocAsync((void**)&sinus, (size_t)n * H * sizeof(float), s));
-    HIP_TRY(hipMallocAsync((void**)&hid, (size_t)n * 4 * H * sizeof(float), s));
-    hipLaunchKernelGGL(k_sinusoid_values, dim3(nblk((long)n * (H / 2), 256)), dim3(256), 0, s, n, H, t_values, sinus);
-    hipLaunchKernelGGL(k_linear_rows, dim3(nblk((long)n * 4 * H, 256)), dim3(256), 0, s, n, H, 4 * H, sinus, H, m->tm1_w, H, m->tm1_b, 1, hid, 4 * H);
-    hipLaunchKernelGGL(k_linear_rows, dim3(nblk((long)n * H, 256)), dim3(256), 0, s, n, 4 * H, H, hid, 4 * H, m->tm3_w, 4 * H, m->tm3_b, 0, out, H);
-    HIP_TRY(hipFreeAsync(sinus, s));
-    HIP_TRY(hipFreeAsync(hid, s));
+    StreamBuf sinus(s), hid(s);
+    if (sinus.alloc((size_t)n * H * sizeof(float)) || hid.alloc((size_t)n * 4 * H * sizeof(float))) return 1;
+    hipLaunchKernelGGL(k_sinusoid_values, dim3(nblk((long)n * (H / 2), 256)), dim3(256), 0, s, n, H, t_values, sinus.f());
+    hipLaunchKernelGGL(k_linear_rows, dim3(nblk((long)n * 4 * H, 256)), dim3(256), 0, s, n, H, 4 * H, sinus.f(), H, m->tm1_w, H, m->tm1_b, 1, hid.f(), 4 * H);
+    hipLaunchKernelGGL(k_linear_rows, dim3(nblk((long)n * H, 256)), dim3(256), 0, s, n, 4 * H, H, hid.f(), 4 * H, m->tm3_w, 4 * H, m->tm3_b, 0, out, H);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -2435,22 +2451,21 @@ int ccsp_process_constraint(ccsp_model* m, int32_t type, int32_t n, const float*
     const ccsp_model_desc& d = m->d;
     if (d.model_kind != CCSP_MODEL_DIFFUSION_CCSP) return fail("process_constraint: StructDiffusion has no per-constraint MLPs");
     if (type < 0 || type >= d.n_types) return fail("process_constraint: constraint type %d out of range", type);
-    if (n < 1) return fail("process_constraint: n=%d", n);
+    if (n < 0) return fail("process_constraint: n=%d", n);
+    if (n == 0) return 0;
     if ((d.grasp_dim > 0) != (grasp_emb != nullptr)) return fail("process_constraint: grasp_emb must be given exactly for 'robot' models");
     const int H = d.hidden_dim, P = d.pose_dim;
     const size_t WS = (size_t)2 * H * H;
     hipStream_t s = (hipStream_t)stream;
-    float *h = nullptr, *q = nullptr;
-    HIP_TRY(hipMallocAsync((void**)&h, (size_t)n * 2 * H * sizeof(float), s));
-    HIP_TRY(hipMallocAsync((void**)&q, (size_t)n * 2 * (H / 2) * sizeof(float), s));
+    StreamBuf hb(s), qb(s);
+    if (hb.alloc((size_t)n * 2 * H * sizeof(float)) || qb.alloc((size_t)n * 2 * (H / 2) * sizeof(float))) return 1;
+    float *h = hb.f(), *q = qb.f();
     hipLaunchKernelGGL(k_type_mlp_rows, dim3(nblk((long)n * 2 * H, 256)), dim3(256), 0, s, n, H, grasp_emb, geoms_emb, poses_emb, time_emb,
                        m->Wr ? m->Wr + (size_t)(2 * type) * WS : (const float*)nullptr, m->Wg + (size_t)(2 * type) * WS, m->Wg + (size_t)(2 * type + 1) * WS,
                        m->Wp + (size_t)(2 * type) * WS, m->Wp + (size_t)(2 * type + 1) * WS, m->Wt + (size_t)type * WS, m->bt + (size_t)type * 2 * H, h);
     // pose_decoder on both halves: h [n, 2H] read as [2n, H]  (denoise_fn.py:357-366)
     hipLaunchKernelGGL(k_linear_rows, dim3(nblk((long)2 * n * (H / 2), 256)), dim3(256), 0, s, 2 * n, H, H / 2, h, H, m->pd0_w, H, m->pd0_b, 2, q, H / 2);
     hipLaunchKernelGGL(k_linear_rows, dim3(nblk((long)2 * n * P, 256)), dim3(256), 0, s, 2 * n, H / 2, P, q, H / 2, m->pd2_w, H / 2, m->pd2_b, 0, out, P);
-    HIP_TRY(hipFreeAsync(h, s));
-    HIP_TRY(hipFreeAsync(q, s));
     HIP_TRY(hipGetLastError());
     return 0;
 }

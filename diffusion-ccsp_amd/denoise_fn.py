@@ -123,6 +123,7 @@ class ConstraintDiffuser(object):
             raise ValueError("'robot' input modes need dims with a grasp group")
         self._params = None       # name -> device tensor
         self._h = None
+        self._energy_hook = None  # (ctypes trampoline, views) of the MALA shard hook: re-installed on every new native model
         self._generation = 0      # bumped for every native model created: handles are compared by this, not by address
         self._graphs = {}                     # id(batch) -> (weakref to the batch, content key, _Graph)
         self._live_graphs = weakref.WeakSet()  # every _Graph built on the current native model, wherever it is referenced
@@ -267,6 +268,11 @@ class ConstraintDiffuser(object):
             _lib.check(L.ccsp_model_create(C.byref(d), arr, _stream_ptr(self.device), C.byref(h)))
         self._h = h
         self._generation += 1
+        hook = getattr(self, '_energy_hook', None)
+        if hook is not None:
+            # MALA global-batch mode (sharding.enable_global_batch_energy): the hook lives on the native model, which was just
+            # re-created (weights reloaded, or another `timesteps` bound) -- without it the shards would silently decouple
+            _lib.check(L.ccsp_model_set_energy_hook(h, C.cast(hook[0], C.c_void_p), None))
         return h
 
     def _graph(self, batch):
@@ -300,6 +306,8 @@ class ConstraintDiffuser(object):
         (SinusoidalPosEmb + the time MLP, denoise_fn.py:38-50,259-264)"""
         tv = torch.as_tensor(t).detach().to(self.device, torch.float32).reshape(-1).contiguous()
         out = torch.empty((tv.shape[0], self.hidden_dim), device=self.device, dtype=torch.float32)
+        if tv.shape[0] == 0:
+            return out
         _lib.check(_lib.lib().ccsp_time_mlp(self._handle(), tv.shape[0], _ptr(tv), _ptr(out), _stream_ptr(self.device)))
         return out
 

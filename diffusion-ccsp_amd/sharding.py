@@ -119,8 +119,8 @@ class _DevicePair(object):
 def enable_global_batch_energy(gd, dist):
     """MALA global-batch mode on the HIP path (ccsp_model_set_energy_hook): every inner step's shard energies are summed
     over the ranks of `dist` on the chain's stream before the accept test -- ``ncclAllReduce(sum, 2 floats)`` over
-    RCCL/xGMI.  Call again after the denoiser's weights are reloaded (the native model is re-created).  ``dist=None``
-    removes the hook.  The per-timestep acceptance rates a rank reads back remain those of its own shard."""
+    RCCL/xGMI.  The hook is kept on the denoiser and re-installed whenever its native model is re-created (weights reloaded,
+    another ``timesteps`` bound).  ``dist=None`` removes it.  The per-timestep acceptance rates a rank reads back remain those of its own shard."""
     from . import _lib
     core = gd._core()
     h = gd._handle()

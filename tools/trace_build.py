@@ -24,10 +24,10 @@ def main():
     hip = open(os.path.join(tmp, 'ccsp_hip.hip')).read()
     h2 = open(os.path.join(tmp, 'ccsp_f16x2.h')).read()
     hip = rep(hip, 'namespace {\n\nthread_local char g_err[512] = "";',
-              '__device__ unsigned long long g_trace[3 * 64 * 32];\n#define TRK(kern, k) do { if (threadIdx.x == 0 && blockIdx.x < 64) '
-              'g_trace[((kern) * 64 + blockIdx.x) * 32 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)\nnamespace {\n\nthread_local char g_err[512] = "";')
+              '__device__ unsigned long long g_trace[3 * 256 * 32];\n#define TRK(kern, k) do { if (threadIdx.x == 0 && (blockIdx.x & 7) == 0 && blockIdx.x < 2048) '
+              'g_trace[((kern) * 256 + (blockIdx.x >> 3)) * 32 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)\nnamespace {\n\nthread_local char g_err[512] = "";')
     hip = rep(hip, 'int ccsp_profile_enable(ccsp_graph* g, int32_t on) {',
-              'int ccsp_debug_trace(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * 3 * 64 * 32) '
+              'int ccsp_debug_trace(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * 3 * 256 * 32) '
               '== hipSuccess ? 0 : 1; }\nint ccsp_profile_enable(ccsp_graph* g, int32_t on) {')
     # k_node<256, true>
     hip = rep(hip, '    __builtin_amdgcn_s_setprio(3);\n    if (a.tab) {', '    TRK(2, 0);\n    __builtin_amdgcn_s_setprio(3);\n    if (a.tab) {')
@@ -52,6 +52,19 @@ def main():
              '            __builtin_amdgcn_s_barrier();\n            __builtin_amdgcn_sched_barrier(0);\n            if (KD == 256) TRK(0, 10);\n')
     h2 = rep(h2, '                         (tau_t && (ts & 1) == 0) ? tau_t + (size_t)(ts >> 1) * ND : nullptr, U, umax, 2 * NCT, 2 * ct + wn);\n}',
              '                         (tau_t && (ts & 1) == 0) ? tau_t + (size_t)(ts >> 1) * ND : nullptr, U, umax, 2 * NCT, 2 * ct + wn);\n    if (KD == 256) TRK(0, 12);\n}')
+    # k_rowgemm_h2<256, 512, 0 | 2>: the forms C2-sized batches run
+    h2 = rep(h2, '        glds(0, 0);\n        __syncthreads();\n#pragma unroll\n        for (int c = 0; c < NCH; ++c) {\n            if (c + 1 < NCH) glds(c + 1, (c + 1) & 1);',
+             '        if (KD == 256) TRK(0, 1);\n        glds(0, 0);\n        __syncthreads();\n#pragma unroll\n        for (int c = 0; c < NCH; ++c) {\n            if (c + 1 < NCH) glds(c + 1, (c + 1) & 1);')
+    h2 = rep(h2, '            __syncthreads();                                      // (drains the LDS-DMA of chunk c+1 as well)\n',
+             '            __syncthreads();\n            if (KD == 256) TRK(0, 2 + c);\n')
+    h2 = rep(h2, '        gload(0, 0);\n        lstore(0, 0);\n        gload(1, 0);\n        __syncthreads();\n        for (int c = 0; c < NCH; ++c) {',
+             '        if (KD == 256) TRK(0, 1);\n        gload(0, 0);\n        lstore(0, 0);\n        gload(1, 0);\n        __syncthreads();\n        for (int c = 0; c < NCH; ++c) {')
+    h2 = rep(h2, '            __syncthreads();                                      // every wave is done reading the stage\n',
+             '            __syncthreads();\n            if (KD == 256) TRK(0, 2 + c);\n')
+    h2 = rep(h2, '        asm volatile("" ::: "memory");                            // (compiler ordering only: the LDS runs one wave\'s operations in order)\n',
+             '        asm volatile("" ::: "memory");\n        if (ND == 512) TRK(0, 13 + 2 * i);\n')
+    h2 = rep(h2, '        asm volatile("" ::: "memory");\n    }\n}\n\n// s_waitcnt vmcnt(n) lgkmcnt(0) with n known',
+             '        asm volatile("" ::: "memory");\n        if (ND == 512) TRK(0, 14 + 2 * i);\n    }\n    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n    if (ND == 512) TRK(0, 17);\n}\n\n// s_waitcnt vmcnt(n) lgkmcnt(0) with n known')
     # k_edge_h2
     h2 = rep(h2, '    constexpr int H = 256, BN = 128, NCH = H / H2_BK;\n    constexpr int ME = 32 * MT, ROWS = 2 * ME;',
              '    TRK(1, 0);\n    constexpr int H = 256, BN = 128, NCH = H / H2_BK;\n    constexpr int ME = 32 * MT, ROWS = 2 * ME;')

@@ -21,23 +21,32 @@ b = batch.to_torch(dev)
 x0 = torch.zeros(b.x.shape[0], worlds.MODE_DIMS[mode][1][0], device=dev)
 x = gd.p_sample_segment(b, x0, 500, 495, seed=3)
 torch.cuda.synchronize()
-buf = np.zeros(3 * 64 * 32, dtype=np.uint64)
+buf = np.zeros(3 * 256 * 32, dtype=np.uint64)
 L = _lib.lib()
 L.ccsp_debug_trace.argtypes = [C.c_void_p]
 assert L.ccsp_debug_trace(buf.ctypes.data) == 0
-t = buf.reshape(3, 64, 32).astype(np.int64)
-names = {0: ['entry', 'index setup'] + ['chunk %d landed' % c for c in range(8)] + ['K loop done', '-', 'epilogue done'],
+t = buf.reshape(3, 256, 32).astype(np.int64)
+names = {0: ['entry', 'index setup'] + ['chunk %d landed' % c for c in range(8)] + ['K loop done (ring)', '-', 'epilogue returned', 'row tile 0 in LDS',
+             'row tile 0 stores issued', 'row tile 1 in LDS', 'row tile 1 stores issued', 'stores drained'],
          1: ['entry', 'indices+umax', 'stage 0 built'] + ['chunk %d done' % c for c in range(8)] + ['S1 written', 'layer-2 partials', 'O stored'],
          2: ['entry', 'CSR sum + update', 'layer 1', 'layer 2 MFMA', 'row max', 'planes stored']}
-for kern, title in ((0, 'k_rowgemm_h2 ring'), (1, 'k_edge_h2'), (2, 'k_node')):
+for kern, title in ((0, 'k_rowgemm_h2'), (1, 'k_edge_h2'), (2, 'k_node')):
     tk = t[kern]
-    live = tk[:, 0] > 0
-    tk = tk[live]
+    tk = tk[tk[:, 0] > 0]
+    if not len(tk):
+        continue
     nn = names[kern]
-    idx = [i for i, n in enumerate(nn) if n != '-']
+    idx = [i for i, n in enumerate(nn) if n != '-' and (tk[:, i] > 0).all()]
     d = tk[:, idx] - tk[:, :1]
     med = np.median(d, axis=0)
-    print('%s: %d traced workgroups; cycles since entry (median) and delta' % (title, len(tk)))
-    for j, i in enumerate(idx):
-        print('  %-18s %8.0f  +%6.0f' % (nn[i], med[j], med[j] - (med[j - 1] if j else 0)))
-    print('  span of entry times %d, of exit times %d' % (tk[:, 0].max() - tk[:, 0].min(), tk[:, idx[-1]].max() - tk[:, idx[-1]].min()))
+    order = np.argsort(med, kind='stable')
+    print('%s: %d traced workgroups; cycles since entry (median, p10, p90) and delta of the medians' % (title, len(tk)))
+    prev = 0.0
+    for j in order:
+        print('  %-26s %8.0f %8.0f %8.0f  +%6.0f' % (nn[idx[j]], med[j], np.percentile(d[:, j], 10), np.percentile(d[:, j], 90), med[j] - prev))
+        prev = med[j]
+    last = idx[order[-1]]
+    e0 = tk[:, 0] - tk[:, 0].min()
+    x1 = tk[:, last] - tk[:, 0].min()
+    print('  entry times since the first entry: median %d, p90 %d, max %d;  exit times: median %d, p90 %d, max %d' %
+          (np.median(e0), np.percentile(e0, 90), e0.max(), np.median(x1), np.percentile(x1, 90), x1.max()))
