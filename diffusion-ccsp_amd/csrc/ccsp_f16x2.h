@@ -107,20 +107,88 @@ __device__ __forceinline__ void h2_kstep(const unsigned short* __restrict__ As, 
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][PA[q]], b[j][PB[q]], acc[i][j], 0, 0, 0);
 }
 
+// Both k-steps of a staged chunk with every LDS fragment read issued up front (16 ds_read_b128, 64 VGPRs) and the MFMAs behind
+// them in the order the fragments arrive: with ONE wave per SIMD (tile lists of about one workgroup per CU: the lanes of a C2
+// batch, small batches) nothing else covers the four read -> wait -> multiply round trips per chunk of h2_kstep, 0.5 k of a
+// chunk's 1.9 k cycles (profiles/r03_findings.md); with three waves per SIMD (MODE 0) the other waves do, and the registers
+// are not there.
+template <int MI>
+__device__ __forceinline__ void h2_chunk_ahead(const unsigned short* __restrict__ As, int apl, const unsigned short* __restrict__ Bs,
+                                               int am0, int bn0, floatx16 (&acc)[MI][2]) {
+    const int lane = threadIdx.x & 63;
+    half8 a[2][MI][2], b[2][2][2];                               // [k-step][tile][plane]
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int piece = (lane >> 5) + 2 * ks;
+        // in the order the products below consume them: (a lo, b hi), (a hi, b lo), (a hi, b hi)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[ks][i][1] = *reinterpret_cast<const half8*>(As + apl + h2_off(am0 + 32 * i + (lane & 31), piece));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[ks][j][0] = *reinterpret_cast<const half8*>(Bs + h2_off(bn0 + 32 * j + (lane & 31), piece));
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[ks][i][0] = *reinterpret_cast<const half8*>(As + h2_off(am0 + 32 * i + (lane & 31), piece));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[ks][j][1] = *reinterpret_cast<const half8*>(Bs + H2_BPL + h2_off(bn0 + 32 * j + (lane & 31), piece));
+    }
+    __builtin_amdgcn_sched_barrier(0);                            // (reads first; hipcc would sink each next to its use)
+    constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};           // smallest terms first; consecutive MFMAs go to different accumulators
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][i][PA[q]], b[ks][j][PB[q]], acc[i][j], 0, 0, 0);
+}
+
 // Epilogue of the row GEMMs, one WAVE at a time and without workgroup barriers: the wave's 64 x 64 accumulators (MFMA
 // layout: one column, 16 rows per lane) go through a wave-private LDS tile [32][H2_CW_LD] (row tile i = 0, 1) and are
 // re-read as rows -- 8 lanes x 16 bytes per row segment -- so the base loads and U stores are 128-byte row segments and
-// the maximum of a row's 64 columns is a 3-step shuffle.  LDS operations of one wave execute in order, so the tile needs
-// no barrier; the base / time-term loads of a row tile are requested before its accumulators are written to LDS.
-// (Measured with s_memtime on k_rowgemm_h3: the same epilogue on workgroup-wide tiles with four __syncthreads and the
-// loads issued pass by pass was 19 k of the kernel's 53 k cycles.)
+// the maximum of a row's 64 columns stays inside 8 neighbouring lanes.  LDS operations of one wave execute in order, so the
+// tile needs no barrier.
 //   U[row0 + r, colw + c] = 2^-(sE[r] + w_exp) acc + base + tau;   umax[(row0 + r) * umax_ld + umax_col] = max_c |U|
+// Round 3 (profiles/r03_findings.md): the first form of this function spent 8 k of the kernel's 32 k cycles in its store loop
+// with NO memory traffic left in it (ablation builds without base loads and without U stores: the same 8 k).  gfx950 counts
+// loads AND stores on vmcnt, and hipcc's wait insertion takes the minimum over all control-flow paths: with the base loads
+// under a `base != nullptr` branch and the stores under `row < nrows`, every use of a prefetched base value came out as
+// s_waitcnt vmcnt(0) -- i.e. each of the eight store groups waited for the previous group's stores to be acknowledged by
+// memory -- and the row maxima went through three dependent ds_bpermute round trips per group.  Now: what is present is a
+// template parameter (FWD), the base + time-term sums are formed once, BEFORE the first store (the only wait for loads), the
+// store loop of a full tile is straight-line code, and the row maxima use DPP lane exchanges (no LDS).
 constexpr int H2_CW_LD = 68;
 constexpr int H2_CW_SZ = 32 * H2_CW_LD;      // floats per wave
 
-// base (+ time term) values of row tile i of the wave, in the epilogue's row layout; requested ahead of their use
+// maximum over the 8 lanes that share lane >> 3 (fmaxf semantics: a NaN operand is skipped), by DPP: two quad permutations
+// and a half-row mirror -- no LDS crossbar round trips (__shfl_xor compiles to ds_bpermute_b32)
+__device__ __forceinline__ float h2_max8(float m) {
+    m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xF, 0xF, true)));    // quad_perm [1,0,3,2]
+    m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x4E, 0xF, 0xF, true)));    // quad_perm [2,3,0,1]
+    m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x141, 0xF, 0xF, true)));   // row_half_mirror
+    return m;
+}
+
+// Loads the compiler must neither move nor wait for: inline asm (cdna_hip_programming.md 5.7).  hipcc sinks an ordinary load whose
+// value is first used in the epilogue out of the K loop, past every sched_barrier, to that use (measured: all eighteen prefetch
+// loads of this kernel ended up behind the last barrier -- and the counted waits of the loop, which assume them in the queue,
+// then released a chunk whose operands were still in flight); and beside LDS-DMA loads it waits vmcnt(0) for any load it knows.
+// An asm load is invisible to its wait insertion: the wait is h2_ld_wait* below, a statement that names every destination.
+typedef float h2_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void h2_ld16(h2_f4& d, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+__device__ __forceinline__ void h2_ld4(int& d, const int* p) { asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+// s_waitcnt vmcnt(N) for the 8 base values of one row tile (+ the 2 time-term values), N a literal
+template <int N>
+__device__ __forceinline__ void h2_ld_wait(h2_f4 (&b)[4][2]) {
+    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[2][0]), "+v"(b[2][1]), "+v"(b[3][0]), "+v"(b[3][1]) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void h2_ld_wait2(h2_f4 (&t)[2]) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(t[0]), "+v"(t[1]) : "n"(N) : "memory"); }
+
+// base values of row tile i of the wave, in the epilogue's row layout (lane: rows er + 8 st, columns 4 eq + 32 k); requested
+// ahead of their use: 8 loads per lane.  No branches: rows past the tile's end read the tile's last row (never stored).
 template <int ND>
-__device__ __forceinline__ void h2_epilogue_prefetch(float4 (&bs)[4][2], int i, int wrow0, int nrows, int row0, int colw,
+__device__ __forceinline__ void h2_epilogue_prefetch(h2_f4 (&bs)[4][2], int i, int wrow0, int nrows, int row0, int colw,
                                                      const float* __restrict__ base) {
     const int lane = threadIdx.x & 63;
     const int er = lane >> 3, eq = lane & 7;
@@ -129,32 +197,43 @@ __device__ __forceinline__ void h2_epilogue_prefetch(float4 (&bs)[4][2], int i, 
         const int trow = wrow0 + i * 32 + er + 8 * st;
         const int tr = trow < nrows ? trow : (nrows - 1 > 0 ? nrows - 1 : 0);
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
-            bs[st][k] = base ? *reinterpret_cast<const float4*>(base + (size_t)(row0 + tr) * ND + colw + 4 * eq + 32 * k)
-                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < 2; ++k) h2_ld16(bs[st][k], base + (size_t)(row0 + tr) * ND + colw + 4 * eq + 32 * k);
     }
 }
 
-// bs0: the prefetched base values of row tile 0 (h2_epilogue_prefetch, issued under the last K chunk); tile 1's are
-// requested here before tile 0 is processed
-template <int ND, int MI>
-__device__ __forceinline__ void h2_epilogue_wave(const floatx16 (&acc)[MI][2], float4 (&bs0)[4][2], float* __restrict__ Cw,
+// FWD: the forward GEMM (base, time term on slot-0 tiles, row maxima); otherwise plain U = 2^-e acc (the transpose GEMM).
+// PRE1: the caller requested row tile 1's base values (bs1) itself, under the K loop; otherwise they are requested here.
+// bs0 (and bs1) and the time-term values tv (requested in the kernel's prologue; has_tau false: discarded, slot-1 tiles) may
+// still be in flight (h2_ld16): the waits are here.
+template <int ND, int MI, bool FWD, bool PRE1>
+__device__ __forceinline__ void h2_epilogue_wave(const floatx16 (&acc)[MI][2], h2_f4 (&bs0)[4][2], h2_f4 (&bs1)[4][2], h2_f4 (&tv)[2], float* __restrict__ Cw,
                                                  int wrow0 /*first tile row of the wave*/, int nrows, int row0,
                                                  int colw /*first global column of the wave*/, const int* __restrict__ sE, int w_exp,
-                                                 const float* __restrict__ base, const float* __restrict__ tau_row /*or null*/,
+                                                 const float* __restrict__ base, bool has_tau,
                                                  float* __restrict__ U, float* __restrict__ umax, int umax_ld, int umax_col) {
     const int lane = threadIdx.x & 63;
     const int er = lane >> 3, eq = lane & 7;                      // rows er + 8 s (s < 4) of a 32-row tile, columns 4 eq + 32 k (k < 2)
-    float4 tv[2];
+    if constexpr (FWD) {
+        if constexpr (MI == 2 && !PRE1) h2_epilogue_prefetch<ND>(bs1, 1, wrow0, nrows, row0, colw, base);
+        // bs0 (older than tv), tv -- and bs1 when it was requested under the K loop -- have landed; a bs1 requested just now
+        // stays in flight while row tile 0 is processed
+        if constexpr (MI == 2 && !PRE1) { h2_ld_wait<8>(bs0); h2_ld_wait2<8>(tv); }
+        else { h2_ld_wait<0>(bs0); h2_ld_wait2<0>(tv); if constexpr (MI == 2) h2_ld_wait<0>(bs1); }
+        if (!has_tau) { tv[0] = h2_f4{0.f, 0.f, 0.f, 0.f}; tv[1] = h2_f4{0.f, 0.f, 0.f, 0.f}; }
+    }
+    if (wrow0 >= nrows) {                                         // (wave-uniform) nothing of the tile in this wave's rows
+        if constexpr (FWD && MI == 2 && !PRE1) h2_ld_wait<0>(bs1);        // (its registers must not be reused under the loads)
+        return;
+    }
+    int ex[MI][4];                                                // -(row exponent + weight exponent) of this lane's rows
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
-        tv[k] = tau_row ? *reinterpret_cast<const float4*>(tau_row + colw + 4 * eq + 32 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (wrow0 >= nrows) return;                                   // (wave-uniform) nothing of the tile in this wave's rows
-    float4 bs1[4][2];
-    if constexpr (MI == 2) h2_epilogue_prefetch<ND>(bs1, 1, wrow0, nrows, row0, colw, base);
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int st = 0; st < 4; ++st) ex[i][st] = -(sE[wrow0 + i * 32 + er + 8 * st] + w_exp);
+    const bool full = wrow0 + 32 * MI <= nrows;                   // (wave-uniform) every row of the wave's tiles exists: straight-line stores
+    float* const Ub = U + (size_t)row0 * ND + colw + 4 * eq;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-        float4 (&bs)[4][2] = i == 0 ? bs0 : bs1;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -163,33 +242,50 @@ __device__ __forceinline__ void h2_epilogue_wave(const floatx16 (&acc)[MI][2], f
                 Cw[rr * H2_CW_LD + j * 32 + (lane & 31)] = acc[i][j][r];
             }
         asm volatile("" ::: "memory");                            // (compiler ordering only: the LDS runs one wave's operations in order)
+        CCSP_TRK(0, 13 + 2 * i);
+        if constexpr (FWD && MI == 2 && !PRE1) { if (i == 1) h2_ld_wait<0>(bs1); }      // (also drains row tile 0's stores: once per wave)
+        h2_f4 bt[4][2];                                           // base + time term of the tile's rows, before its first store
 #pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            const int trow = wrow0 + i * 32 + er + 8 * st;
-            if (trow < nrows) {
-                const int e = -(sE[trow] + w_exp);
-                const size_t grow = (size_t)(row0 + trow);
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if constexpr (FWD) bt[st][k] = (i == 0 ? bs0[st][k] : bs1[st][k]) + tv[k];
+                else bt[st][k] = h2_f4{0.f, 0.f, 0.f, 0.f};
+            }
+        float4 cv[4][2];                                          // the lane's 4 x 2 row segments: all LDS reads in flight together
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) cv[st][k] = *reinterpret_cast<const float4*>(Cw + (er + 8 * st) * H2_CW_LD + 4 * eq + 32 * k);
+        auto rows = [&](auto all_rows) {
+            constexpr bool ALL = decltype(all_rows)::value;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int trow = wrow0 + i * 32 + er + 8 * st;
+                const int e = ex[i][st];
+                float4 o[2];
                 float m = 0.0f;
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    const float4 v = *reinterpret_cast<const float4*>(Cw + (er + 8 * st) * H2_CW_LD + 4 * eq + 32 * k);
-                    float4 o;
-                    o.x = ldexpf(v.x, e) + (bs[st][k].x + tv[k].x);
-                    o.y = ldexpf(v.y, e) + (bs[st][k].y + tv[k].y);
-                    o.z = ldexpf(v.z, e) + (bs[st][k].z + tv[k].z);
-                    o.w = ldexpf(v.w, e) + (bs[st][k].w + tv[k].w);
-                    m = fmaxf(fmaxf(m, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
-                    *reinterpret_cast<float4*>(U + grow * ND + colw + 4 * eq + 32 * k) = o;
+                    const float4 v = cv[st][k];
+                    o[k].x = ldexpf(v.x, e) + bt[st][k][0];
+                    o[k].y = ldexpf(v.y, e) + bt[st][k][1];
+                    o[k].z = ldexpf(v.z, e) + bt[st][k][2];
+                    o[k].w = ldexpf(v.w, e) + bt[st][k][3];
+                    if constexpr (FWD) m = fmaxf(fmaxf(m, fmaxf(fabsf(o[k].x), fabsf(o[k].y))), fmaxf(fabsf(o[k].z), fabsf(o[k].w)));
                 }
-                if (umax) {                                       // (the 8 lanes of a row take the branch together)
-                    m = fmaxf(m, __shfl_xor(m, 1));
-                    m = fmaxf(m, __shfl_xor(m, 2));
-                    m = fmaxf(m, __shfl_xor(m, 4));
-                    if (eq == 0) umax[grow * umax_ld + umax_col] = m;
+                if constexpr (FWD) m = h2_max8(m);                // (every lane takes part: the 8 lanes of a row are active together)
+                if (ALL || trow < nrows) {
+                    float* up = Ub + (size_t)trow * ND;
+                    *reinterpret_cast<float4*>(up) = o[0];
+                    *reinterpret_cast<float4*>(up + 32) = o[1];
+                    if constexpr (FWD) { if (eq == 0) umax[(size_t)(row0 + trow) * umax_ld + umax_col] = m; }
                 }
             }
-        }
+        };
+        if (full) rows(std::true_type{}); else rows(std::false_type{});
         asm volatile("" ::: "memory");
+        CCSP_TRK(0, 14 + 2 * i);
     }
 }
 
@@ -203,10 +299,11 @@ __device__ __forceinline__ void h2_wait_vm_lgkm0(int n) {
 }
 
 // ------------------------------------------------------------------------------------------
-// k_rowgemm_h2<KD, ND, DB>:  U[row0 + r, col0 + c] = 2^-(ea[r] + ew) * sum_k A[src(r), k] W[ts][col0 + c, k]  + base + tau
+// k_rowgemm_h2<KD, ND, MODE>:  U[row0 + r, col0 + c] = 2^-(ea[r] + ew) * sum_k A[src(r), k] W[ts][col0 + c, k]  + base + tau
 //   A planes [2][n_src][KD] fp16 bits scaled by 2^a_exp[src], rows gathered by urow_node; W planes [2][n_ts][ND][KD]
-//   scaled by 2^w_exp.  umax[row, (col0 + 64 wn) / 64] = max |U| over 64 columns (null: not written).
-//   The kernel is one latency chain per tile (descriptor -> row indices -> operands -> 8 chunks -> epilogue) and a launch
+//   scaled by 2^w_exp.  umax[row, (col0 + 64 wn) / 64] = max |U| over 64 columns (forward GEMM only).
+//   tile_desc[tile] = {first row, rows, 2 type + slot, -}: one scalar load.
+//   The kernel is one latency chain per tile (descriptor -> row indices -> operands -> chunks -> epilogue) and a launch
 //   is as long as the chains it runs one after the other on a CU slot, so the residency is chosen per launch:
 //   MODE 0: one stage + one register set, 33 KB and <= 168 VGPRs, 3 workgroups per CU -- the whole tile list of a
 //           C2-sized batch (640 tiles) is resident at once instead of running as a full and a 20 %-full round;
@@ -215,71 +312,44 @@ __device__ __forceinline__ void h2_wait_vm_lgkm0(int n) {
 //           ds_write -- the 16-byte stores were half of the kernel's LDS-instruction cycles).  A wave-instruction
 //           writes 64 lanes x 16 bytes = sixteen consecutive 64-byte rows of one plane, lane-linear, so the XOR
 //           swizzle of the stage is applied on the SOURCE side: the lane in physical slot s of row r fetches logical
-//           piece s ^ ((r >> 2) & 3).
+//           piece s ^ ((r >> 2) & 3).  Bare s_barrier + counted s_waitcnt: the base values of BOTH row tiles are requested
+//           two / one chunks before the K loop ends and stay in flight across the barriers (a __syncthreads() would drain
+//           them: the fabric-side latency of `base` used to sit in the last chunk's barrier and in the epilogue);
+//   MODE 3 / 4: see below.
+//   In every mode the weight operand of chunk 0 is requested BEFORE the row indices arrive (its address needs the tile
+//   descriptor only), the A rows behind it, and the row exponents (a second dependent gather) last: they are needed by the
+//   epilogue only.
 // ------------------------------------------------------------------------------------------
 template <int KD, int ND, int MODE>
 __global__ __launch_bounds__(256, MODE == 0 ? 3 : (MODE == 3 ? 1 : 2)) void k_rowgemm_h2(const unsigned short* __restrict__ A, size_t a_plane, const int* __restrict__ a_exp,
-                                                       const int* __restrict__ urow_node, const int* __restrict__ tile_row0,
-                                                       const int* __restrict__ tile_nrows, const int* __restrict__ tile_ts,
+                                                       const int* __restrict__ urow_node, const int4* __restrict__ tile_desc,
                                                        const unsigned short* __restrict__ W, size_t w_plane, size_t w_stride, int w_exp,
                                                        const float* __restrict__ base, const float* __restrict__ tau_t,
                                                        float* __restrict__ U, float* __restrict__ umax, StepRef ref, size_t tau_stride) {
-    static_assert(ND % 128 == 0 && KD % H2_BK == 0 && KD / H2_BK >= 3, "shape");
+    static_assert(ND % 128 == 0 && KD % H2_BK == 0 && KD / H2_BK >= 4, "shape");
+    constexpr bool FWD = KD < ND;                                 // <256, 512>: the forward GEMM (base, time term, row maxima); <512, 256>: the transpose
+    CCSP_TRK(0, 0);
+    CCSP_TRK_RT(0, 30);
     if (ref.skip && *ref.skip == 0) return;                       // (uniform) MALA reuse: the state has not moved since this was computed
     constexpr int NCT = ND / 128, NCH = KD / H2_BK;
     constexpr int MI = MODE == 4 ? 1 : 2, TM = 64 * MI;           // 32-row MFMA tiles per wave, rows per workgroup tile
     constexpr int APL = TM * H2_BK, STAGE = 2 * APL + 2 * H2_BPL;         // 32 KB per stage (24 KB for 64-row tiles)
     constexpr bool DB = MODE == 1;
     constexpr int NST = MODE == 0 ? 1 : (MODE == 3 ? 4 : (MODE == 4 ? 3 : 2));      // LDS stages
-    constexpr int NRS = MODE == 1 ? 2 : 1;                        // register sets (MODE 2 and 3 use none)
+    constexpr int NRS = MODE == 1 ? 2 : 1;                        // register sets (MODE 2 and above use none)
+    constexpr bool PRE1 = FWD && MI == 2 && MODE >= 2;            // row tile 1's base values requested under the K loop (VGPRs to spare)
     constexpr int SMEM_US = (NST * STAGE * 2 > 4 * H2_CW_SZ * 4 ? NST * STAGE : 4 * H2_CW_SZ * 2);
     __shared__ __attribute__((aligned(16))) unsigned short smem[SMEM_US + 256];      // stages (epilogue tiles on top) + 128 row exponents
     int* sE = reinterpret_cast<int*>(smem + SMEM_US);
     if (ref.tab) tau_t += (size_t)ref.tab[*ref.counter].t * tau_stride;      // hipGraph mode: timestep from the device table
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tile = bid / NCT, ct = bid % NCT;
-    const int row0 = tile_row0[tile], nrows = tile_nrows[tile], ts = tile_ts[tile];
+    const int4 td = tile_desc[tile];
+    const int row0 = td.x, nrows = td.y, ts = td.z;
     const int col0 = ct * 128;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const int lrow = tid >> 2, lq = tid & 3;                      // staging: rows lrow, lrow + 64, 16-byte piece lq, both planes
-    const unsigned short* a_ptr[2] = {nullptr, nullptr};          // (register staging: MODE 0 and 1 only)
-    if constexpr (MODE < 2) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int r = lrow + 64 * i;
-            r = r < nrows ? r : nrows - 1;
-            const int src = urow_node ? urow_node[row0 + r] : row0 + r;
-            a_ptr[i] = A + (size_t)src * KD + lq * 8;
-        }
-    }
-    if (tid < TM) {
-        const int r = tid < nrows ? tid : nrows - 1;
-        sE[tid] = a_exp[urow_node ? urow_node[row0 + r] : row0 + r];
-    }
-    const unsigned short* b_ptr = W + (size_t)ts * w_stride + (size_t)(col0 + lrow) * KD + lq * 8;
-    const int st_off = h2_off(lrow, lq);                          // (row + 64 has the same swizzle: + 64 * H2_BK)
-    ushort8 ra[NRS][4], rb[NRS][4];                               // [register set][row half * 2 + plane]
-    auto gload = [&](int c, int set) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                ra[set][i * 2 + p] = *reinterpret_cast<const ushort8*>(a_ptr[i] + (size_t)p * a_plane + c * H2_BK);
-                rb[set][i * 2 + p] = *reinterpret_cast<const ushort8*>(b_ptr + (size_t)i * 64 * KD + (size_t)p * w_plane + c * H2_BK);
-            }
-    };
-    auto lstore = [&](int stage, int set) {
-        unsigned short* As = smem + stage * STAGE;
-        unsigned short* Bs = As + 2 * APL;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                *reinterpret_cast<ushort8*>(As + p * APL + st_off + i * 64 * H2_BK) = ra[set][i * 2 + p];
-                *reinterpret_cast<ushort8*>(Bs + p * H2_BPL + st_off + i * 64 * H2_BK) = rb[set][i * 2 + p];
-            }
-    };
     floatx16 acc[MI][2];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -287,8 +357,18 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : (MODE == 3 ? 1 : 2)) void k_ro
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    float4 bs0[4][2];
+    h2_f4 bs0[4][2], bs1[4][2];
     const int wr0 = wm * 32 * MI;                                 // first tile row of the wave
+    const int colw = col0 + wn * 64;
+    // the time term of the wave's columns (slot-0 tiles of the forward GEMM; other tiles read the same bytes of `base` and
+    // discard them: a select instead of a branch).  The first loads of the kernel: older than every counted wait below.
+    const bool has_tau = FWD && tau_t && (ts & 1) == 0;
+    h2_f4 tv[2] = {h2_f4{0.f, 0.f, 0.f, 0.f}, h2_f4{0.f, 0.f, 0.f, 0.f}};
+    if constexpr (FWD) {
+        const float* tp = (has_tau ? tau_t + (size_t)(ts >> 1) * ND : base) + colw + 4 * (lane & 7);
+        h2_ld16(tv[0], tp);
+        h2_ld16(tv[1], tp + 32);
+    }
     if constexpr (MODE >= 2) {
         // a wave-instruction fills one 1 KB block = (plane, sixteen rows); wave w owns blocks NA w .. NA w + NA - 1 of the A
         // planes (2 x TM / 16 blocks) and 4 w .. 4 w + 3 of the B planes
@@ -299,16 +379,6 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : (MODE == 3 ? 1 : 2)) void k_ro
         const unsigned short* gb[4];
         int loa[NA], lob[4];                                      // wave-uniform stage offsets of the blocks (fp16 elements)
 #pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const int blk = NA * wave + j, plane = blk / ARB, rb16 = blk % ARB;
-            const int row = rb16 * 16 + (lane >> 2);
-            const int piece = (lane & 3) ^ ((row >> 2) & 3);
-            const int r = row < nrows ? row : nrows - 1;
-            const int src = urow_node ? urow_node[row0 + r] : row0 + r;
-            ga[j] = A + (size_t)plane * a_plane + (size_t)src * KD + piece * 8;
-            loa[j] = __builtin_amdgcn_readfirstlane(plane * APL + rb16 * 16 * H2_BK);
-        }
-#pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int blk = 4 * wave + j, plane = blk >> 3, rb16 = blk & 7;
             const int row = rb16 * 16 + (lane >> 2);
@@ -316,89 +386,215 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : (MODE == 3 ? 1 : 2)) void k_ro
             gb[j] = W + (size_t)plane * w_plane + (size_t)ts * w_stride + (size_t)(col0 + row) * KD + piece * 8;
             lob[j] = __builtin_amdgcn_readfirstlane(plane * H2_BPL + rb16 * 16 * H2_BK);
         }
-        auto glds = [&](int c, int stage) {
+        auto glds_b = [&](int c, int stage) {
             unsigned short* st = smem + stage * STAGE;
-#pragma unroll
-            for (int j = 0; j < NA; ++j) __builtin_amdgcn_global_load_lds((gptr)(ga[j] + c * H2_BK), (lptr)(st + loa[j]), 16, 0, 0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds((gptr)(gb[j] + c * H2_BK), (lptr)(st + 2 * APL + lob[j]), 16, 0, 0);
         };
+        auto glds_a = [&](int c, int stage) {
+            unsigned short* st = smem + stage * STAGE;
+#pragma unroll
+            for (int j = 0; j < NA; ++j) __builtin_amdgcn_global_load_lds((gptr)(ga[j] + c * H2_BK), (lptr)(st + loa[j]), 16, 0, 0);
+        };
+        auto glds = [&](int c, int stage) { glds_a(c, stage); glds_b(c, stage); };
+        int src[NA];
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {                            // the A rows: one dependent gather (row index -> plane row)
+            const int blk = NA * wave + j, rb16 = blk % ARB;
+            const int row = rb16 * 16 + (lane >> 2);
+            const int r = row < nrows ? row : nrows - 1;
+            src[j] = urow_node ? urow_node[row0 + r] : row0 + r;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        glds_b(0, 0);                                             // the weights of chunk 0 are on their way while the row indices arrive
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int blk = NA * wave + j, plane = blk / ARB, rb16 = blk % ARB;
+            const int row = rb16 * 16 + (lane >> 2);
+            const int piece = (lane & 3) ^ ((row >> 2) & 3);
+            ga[j] = A + (size_t)plane * a_plane + (size_t)src[j] * KD + piece * 8;
+            loa[j] = __builtin_amdgcn_readfirstlane(plane * APL + rb16 * 16 * H2_BK);
+        }
+        // the row exponents (epilogue only) come from the lanes that hold a row's plane index: no second dependent gather
+        int ea[NA];
+        auto exps_load = [&]() {                                      // (asm loads: pinned where they are issued, see h2_ld16)
+#pragma unroll
+            for (int j = 0; j < NA; ++j) h2_ld4(ea[j], a_exp + src[j]);
+        };
+        auto exps_wait = [&]() {
+#pragma unroll
+            for (int j = 0; j < NA; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ea[j]) :: "memory");
+        };
+        auto exps_store = [&]() {
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                const int blk = NA * wave + j;
+                if (blk / ARB == 0 && (lane & 3) == 0) sE[(blk % ARB) * 16 + (lane >> 2)] = ea[j];
+            }
+        };
+        CCSP_TRK(0, 1);
+        constexpr int NL = NA + 4;                                // loads per chunk and thread
         if constexpr (MODE >= 3) {
             // Low-latency forms for short tile lists (small batches: the kernel is one dependent chain, not a throughput
             // problem): a ring of NST stages with NST - 1 chunks of operands in flight and COUNTED waits -- s_waitcnt vmcnt(n)
             // lets the loads of the younger chunks stay outstanding while chunk c is multiplied (vector-memory loads retire
-            // in order).  The barriers are bare s_barrier: __syncthreads() carries a fence that drains every load.  `base` of
-            // the first row tile is requested before anything else (older than the ring's loads, so it has landed first).
+            // in order).  The barriers are bare s_barrier: __syncthreads() carries a fence that drains every load.  `base` is
+            // requested right behind the first chunk's operands (older than the rest of the ring, so it has landed early).
             //   MODE 3: 128-row tiles, four stages;  MODE 4: 64-row tiles (32 x 64 per wave), three stages, 72 KB -- a quarter of
             //   the MFMA and epilogue work per wave and twice the workgroups, for tile lists that leave most CUs empty.
-            constexpr int NL = NA + 4, D = NST - 1;               // loads per chunk and thread; chunks requested ahead
-            h2_epilogue_prefetch<ND>(bs0, 0, wr0, nrows, row0, col0 + wn * 64, base);
+            constexpr int D = NST - 1;                            // chunks requested ahead
+            constexpr int NB = FWD ? 8 * MI : 0;                  // base loads per thread, issued between chunk 0 and chunk 1 of the ring
+            glds_a(0, 0);
+            __builtin_amdgcn_sched_barrier(0);                        // (the counted waits below rely on this issue order)
+            exps_load();
+            if constexpr (FWD) {
+                h2_epilogue_prefetch<ND>(bs0, 0, wr0, nrows, row0, colw, base);
+                if constexpr (PRE1) h2_epilogue_prefetch<ND>(bs1, 1, wr0, nrows, row0, colw, base);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int c = 0; c < D; ++c) glds(c, c);
+            for (int c = 1; c < D; ++c) glds(c, c);
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                // (lgkmcnt(0): this wave's LDS reads of the stage about to be refilled have returned)
-                h2_wait_vm_lgkm0((NCH - 1 - c < D - 1 ? NCH - 1 - c : D - 1) * NL);
+                // (lgkmcnt(0): this wave's LDS reads of the stage about to be refilled have returned, and its sE write)
+                // younger than chunk c at this point: chunks c+1 .. c+D-1 (and, for c == 0, the base loads behind chunk 0)
+                __builtin_amdgcn_sched_barrier(0);                    // (the MFMAs of chunk c - 1 stay in front of the wait: hipcc sinks register-only work past it)
+                h2_wait_vm_lgkm0((NCH - 1 - c < D - 1 ? NCH - 1 - c : D - 1) * NL + (c == 0 ? NB + NA : 0));
                 __builtin_amdgcn_s_barrier();                         // chunk c has landed for every wave; stage (c-1) % NST is free
                 __builtin_amdgcn_sched_barrier(0);
+                CCSP_TRK(0, 2 + (c < 8 ? c : 7));
                 if (c + D < NCH) glds(c + D, (c + D) % NST);
                 const unsigned short* st = smem + (c % NST) * STAGE;
-                h2_kstep<MI>(st, APL, st + 2 * APL, 0, wr0, wn * 64, acc);
-                h2_kstep<MI>(st, APL, st + 2 * APL, 1, wr0, wn * 64, acc);
+                h2_chunk_ahead<MI>(st, APL, st + 2 * APL, wr0, wn * 64, acc);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            exps_wait();
+            exps_store();                                             // (written here: a use of the loaded exponents in front of the ring would drain it)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                             // every wave is done reading the stages
+            __builtin_amdgcn_s_barrier();                             // every wave is done reading the stages; the row exponents are visible
             __builtin_amdgcn_sched_barrier(0);
         } else {
-        glds(0, 0);
-        __syncthreads();
+            glds_a(0, 0);
+            exps_load();
+            __builtin_amdgcn_sched_barrier(0);
+            exps_wait();
+            exps_store();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+#ifndef CCSP_H2_CB0
+#define CCSP_H2_CB0 3
+#define CCSP_H2_CB1 2
+#endif
+            constexpr int CB0 = NCH - CCSP_H2_CB0, CB1 = NCH - CCSP_H2_CB1;       // chunks under which the base values of row tile 0 / 1 are requested
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            if (c + 1 < NCH) glds(c + 1, (c + 1) & 1);
-            if (c == NCH - 1) h2_epilogue_prefetch<ND>(bs0, 0, wr0, nrows, row0, col0 + wn * 64, base);
-            const unsigned short* st = smem + (c & 1) * STAGE;
-            h2_kstep<MI>(st, APL, st + 2 * APL, 0, wr0, wn * 64, acc);
-            h2_kstep<MI>(st, APL, st + 2 * APL, 1, wr0, wn * 64, acc);
-            __syncthreads();                                      // (drains the LDS-DMA of chunk c+1 as well)
-        }
-        }
-    } else if constexpr (DB) {
-        gload(0, 0);
-        gload(1, 1);
-        lstore(0, 0);
-        gload(2, 0);
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {                           // fully unrolled: register-set indices are constants
-            // register set (c+1)&1 holds chunk c+1, the other one chunk c+2 (still in flight)
-            if (c + 1 < NCH) lstore((c + 1) & 1, (c + 1) & 1);
-            if (c + 3 < NCH) gload(c + 3, (c + 1) & 1);
-            if (c == NCH - 1) h2_epilogue_prefetch<ND>(bs0, 0, wr0, nrows, row0, col0 + wn * 64, base);
-            const unsigned short* st = smem + (c & 1) * STAGE;
-            h2_kstep<MI>(st, APL, st + 2 * APL, 0, wr0, wn * 64, acc);
-            h2_kstep<MI>(st, APL, st + 2 * APL, 1, wr0, wn * 64, acc);
-            __syncthreads();
+            for (int c = 0; c < NCH; ++c) {
+                CCSP_TRK(0, 2 + (c < 8 ? c : 7));
+                if (c + 1 < NCH) glds(c + 1, (c + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);                    // (the counted wait below relies on this issue order)
+                int younger = 0;                                      // loads of this iteration that are younger than chunk c + 1's
+                if constexpr (FWD) {
+                    if (c == CB0) { h2_epilogue_prefetch<ND>(bs0, 0, wr0, nrows, row0, colw, base); younger += 8; }
+                    if (c == CB1) { h2_epilogue_prefetch<ND>(bs1, 1, wr0, nrows, row0, colw, base); younger += 8; }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned short* st = smem + (c & 1) * STAGE;
+                h2_chunk_ahead<MI>(st, APL, st + 2 * APL, wr0, wn * 64, acc);
+                // chunk c + 1 has landed (the base loads behind it may still be in flight); this wave is done reading stage c & 1
+                __builtin_amdgcn_sched_barrier(0);                    // (the MFMAs above stay in front of the wait: hipcc sinks register-only work past it)
+                if (c + 1 < NCH) h2_wait_vm_lgkm0(younger);
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     } else {
-        gload(0, 0);
-        lstore(0, 0);
-        gload(1, 0);
-        __syncthreads();
-        for (int c = 0; c < NCH; ++c) {
-            if (c == NCH - 1) h2_epilogue_prefetch<ND>(bs0, 0, wr0, nrows, row0, col0 + wn * 64, base);
-            h2_kstep<MI>(smem, APL, smem + 2 * APL, 0, wr0, wn * 64, acc);
-            h2_kstep<MI>(smem, APL, smem + 2 * APL, 1, wr0, wn * 64, acc);
-            __syncthreads();                                      // every wave is done reading the stage
-            if (c + 1 < NCH) {
-                lstore(0, 0);
-                if (c + 2 < NCH) gload(c + 2, 0);
+        const unsigned short* a_ptr[2];
+        int srcr[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int r = lrow + 64 * i;
+            r = r < nrows ? r : nrows - 1;
+            srcr[i] = urow_node ? urow_node[row0 + r] : row0 + r;
+            a_ptr[i] = A + (size_t)srcr[i] * KD + lq * 8;
+        }
+        auto row_exps = [&]() {                                   // (epilogue only) behind the first operands, by the lanes that hold the row's index
+            const int e0 = a_exp[srcr[0]], e1 = a_exp[srcr[1]];
+            if (lq == 0) { sE[lrow] = e0; sE[lrow + 64] = e1; }
+        };
+        const unsigned short* b_ptr = W + (size_t)ts * w_stride + (size_t)(col0 + lrow) * KD + lq * 8;
+        const int st_off = h2_off(lrow, lq);                      // (row + 64 has the same swizzle: + 64 * H2_BK)
+        ushort8 ra[NRS][4], rb[NRS][4];                           // [register set][row half * 2 + plane]
+        auto gload = [&](int c, int set) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    rb[set][i * 2 + p] = *reinterpret_cast<const ushort8*>(b_ptr + (size_t)i * 64 * KD + (size_t)p * w_plane + c * H2_BK);
+                    ra[set][i * 2 + p] = *reinterpret_cast<const ushort8*>(a_ptr[i] + (size_t)p * a_plane + c * H2_BK);
+                }
+        };
+        auto lstore = [&](int stage, int set) {
+            unsigned short* As = smem + stage * STAGE;
+            unsigned short* Bs = As + 2 * APL;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    *reinterpret_cast<ushort8*>(As + p * APL + st_off + i * 64 * H2_BK) = ra[set][i * 2 + p];
+                    *reinterpret_cast<ushort8*>(Bs + p * H2_BPL + st_off + i * 64 * H2_BK) = rb[set][i * 2 + p];
+                }
+        };
+        CCSP_TRK(0, 1);
+        if constexpr (DB) {
+            gload(0, 0);
+            gload(1, 1);
+            row_exps();
+            lstore(0, 0);
+            gload(2, 0);
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {                       // fully unrolled: register-set indices are constants
+                // register set (c+1)&1 holds chunk c+1, the other one chunk c+2 (still in flight)
+                if (c + 1 < NCH) lstore((c + 1) & 1, (c + 1) & 1);
+                if (c + 3 < NCH) gload(c + 3, (c + 1) & 1);
+                if constexpr (FWD) { if (c == NCH - 1) h2_epilogue_prefetch<ND>(bs0, 0, wr0, nrows, row0, colw, base); }
+                const unsigned short* st = smem + (c & 1) * STAGE;
+                h2_kstep<MI>(st, APL, st + 2 * APL, 0, wr0, wn * 64, acc);
+                h2_kstep<MI>(st, APL, st + 2 * APL, 1, wr0, wn * 64, acc);
                 __syncthreads();
+            }
+        } else {
+            gload(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            row_exps();
+            lstore(0, 0);
+            gload(1, 0);
+            __syncthreads();
+            for (int c = 0; c < NCH; ++c) {
+                CCSP_TRK(0, 2 + (c < 8 ? c : 7));
+                if constexpr (FWD) { if (c == NCH - 1) h2_epilogue_prefetch<ND>(bs0, 0, wr0, nrows, row0, colw, base); }
+                h2_kstep<MI>(smem, APL, smem + 2 * APL, 0, wr0, wn * 64, acc);
+                h2_kstep<MI>(smem, APL, smem + 2 * APL, 1, wr0, wn * 64, acc);
+                __syncthreads();                                  // every wave is done reading the stage
+                if (c + 1 < NCH) {
+                    lstore(0, 0);
+                    if (c + 2 < NCH) gload(c + 2, 0);
+                    __syncthreads();
+                }
             }
         }
     }
     // (every wave is past the last barrier: the stages are free for the wave-private epilogue tiles)
-    h2_epilogue_wave<ND, MI>(acc, bs0, reinterpret_cast<float*>(smem) + wave * H2_CW_SZ, wr0, nrows, row0, col0 + wn * 64, sE, w_exp, base,
-                         (tau_t && (ts & 1) == 0) ? tau_t + (size_t)(ts >> 1) * ND : nullptr, U, umax, 2 * NCT, 2 * ct + wn);
+    CCSP_TRK(0, 10);
+    h2_epilogue_wave<ND, MI, FWD, PRE1>(acc, bs0, bs1, tv, reinterpret_cast<float*>(smem) + wave * H2_CW_SZ, wr0, nrows, row0, colw, sE, w_exp, base, has_tau,
+                                        U, umax, 2 * NCT, 2 * ct + wn);
+#ifdef CCSP_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the exit stamp: after the stores have been acknowledged)
+#endif
+    CCSP_TRK_RT(0, 31);
+    CCSP_TRK(0, 17);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -449,6 +645,8 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void k_edge_h2(int E_act, int
                                                     EdgeEnergyArgs en, int* __restrict__ counter_inc) {
     if constexpr (ENERGY) { if (en.skip && *en.skip == 0) return; }                        // (uniform) MALA reuse
     if (counter_inc && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(counter_inc, 1);     // hipGraph mode: next table entry
+    CCSP_TRK(1, 0);
+    CCSP_TRK_RT(1, 30);
     constexpr int H = 256, BN = 128, NCH = H / H2_BK;
     constexpr int ME = 32 * MT, ROWS = 2 * ME;                    // edges, tile rows
     constexpr int APL = ROWS * H2_BK, STAGE = 2 * APL + 2 * H2_BPL;
@@ -517,6 +715,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void k_edge_h2(int E_act, int
             for (int p = 0; p < 2; ++p)
                 *reinterpret_cast<ushort8*>(Bs + p * H2_BPL + b_st + i * 64 * H2_BK) = rb[i * 2 + p];
     };
+    CCSP_TRK(1, 1);
     gload_a(0, 0);
     gload_b(0);
     gload_a(1, 1);
@@ -533,6 +732,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void k_edge_h2(int E_act, int
     gload_b(1);
     gload_a(2, 0);
     __syncthreads();
+    CCSP_TRK(1, 2);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {                               // fully unrolled: the register-set index is a constant
         const unsigned short* st = smem + (c & 1) * STAGE;
@@ -551,6 +751,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void k_edge_h2(int E_act, int
         if (c + 2 < NCH) gload_b(c + 2);
         if (c + 3 < NCH) gload_a(c + 3, nx);
         __syncthreads();
+        CCSP_TRK(1, 3 + c);
     }
     // epilogue, 64 rows per pass (row tile i of every wave: 32 edges x both halves)
     float* S1 = reinterpret_cast<float*>(smem);
@@ -575,11 +776,13 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void k_edge_h2(int E_act, int
             }
         }
         __syncthreads();
+        CCSP_TRK(1, 11);
         if constexpr (L2 == 1) {                                               // (see h2_decoder_l2)
             if (P == 4) h2_decoder_l2<4>(S1, S1_LD, Wd2, P, RED, wave, lane);
             else if (P == 5) h2_decoder_l2<5>(S1, S1_LD, Wd2, P, RED, wave, lane);
             else h2_decoder_l2<0>(S1, S1_LD, Wd2, P, RED, wave, lane);
             __syncthreads();
+            CCSP_TRK(1, 12);
         }
         for (int idx = tid; idx < 64 * P; idx += 256) {
             const int lrow = idx & 63;                                         // S1 row: half (lrow >> 5), edge e0 + i * 32 + (lrow & 31)
@@ -607,6 +810,8 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void k_edge_h2(int E_act, int
         }
         __syncthreads();
     }
+    CCSP_TRK(1, 13);
+    CCSP_TRK_RT(1, 31);
     if constexpr (ENERGY) {
         const float tot = block_sum_256(e2, reinterpret_cast<float*>(smem));
         if (tid == 0) en.partial[blockIdx.x] = tot;

@@ -18,11 +18,32 @@
 #include <map>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/ccsp.h"
 #include "ccsp_philox.h"
 #include "ccsp_plan.h"
+
+// Profiling builds only (tools/trace_build.py compiles with -DCCSP_TRACE): s_memtime stamps at the phase boundaries of the
+// evaluation kernels, one record per sampled workgroup, read back through ccsp_debug_trace.  The product build has none.
+#ifdef CCSP_TRACE
+__device__ unsigned long long g_trace[3 * 256 * 32];
+#define CCSP_TRK(kern, k)                                                                             \
+    do {                                                                                              \
+        if (threadIdx.x == 0 && (blockIdx.x & 7) == 0 && blockIdx.x < 2048)                           \
+            g_trace[((kern) * 256 + (blockIdx.x >> 3)) * 32 + (k)] = __builtin_amdgcn_s_memtime();    \
+    } while (0)
+// the same on the chip-wide 100 MHz clock (s_memtime counters are per shader engine: not comparable across workgroups)
+#define CCSP_TRK_RT(kern, k)                                                                          \
+    do {                                                                                              \
+        if (threadIdx.x == 0 && (blockIdx.x & 7) == 0 && blockIdx.x < 2048)                           \
+            g_trace[((kern) * 256 + (blockIdx.x >> 3)) * 32 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define CCSP_TRK(kern, k) do { } while (0)
+#define CCSP_TRK_RT(kern, k) do { } while (0)
+#endif
 
 namespace {
 
@@ -267,6 +288,7 @@ __device__ __forceinline__ void enc_store_tile(const float (&v)[H / 64][4], floa
         m = fmaxf(m, __shfl_xor(m, 32));
         if (lane < NODE_TILE) smax[wave][lane] = m;
         __syncthreads();
+        CCSP_TRK(2, 4);
         m = fmaxf(fmaxf(smax[0][lane & 15], smax[1][lane & 15]), fmaxf(smax[2][lane & 15], smax[3][lane & 15]));
         e2 = h2_scale_exp(m);
         if (n < N && wave == 0 && lane < NODE_TILE) out.h2_exp[n] = e2;
@@ -408,6 +430,7 @@ __device__ __forceinline__ void encode_tile_h2(const EncW w, const EncPrefetchH&
         }
     }
     __syncthreads();
+    CCSP_TRK(2, 2);
     const int wave = tid >> 6, lane = tid & 63;
     floatx4 acc[4];
 #pragma unroll
@@ -425,6 +448,7 @@ __device__ __forceinline__ void encode_tile_h2(const EncW w, const EncPrefetchH&
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf.wa[ks][0][j], b1, acc[j], 0, 0, 0);
     }
+    CCSP_TRK(2, 3);
     const int eu = -(sexp[lane & 15] + w.w2_exp);
     float v[4][4];
 #pragma unroll
@@ -883,6 +907,23 @@ struct NodeArgs {
     const ChainHeader* hdr;
 };
 
+// The two update formulas of the direct-mode chain, shared by k_node and k_node_direct.  Every product and sum is rounded on
+// its own (fp contract off: never fused into an FMA; HIP's __fmul_rn / __fadd_rn are plain operators and do get fused),
+// which is the reference's arithmetic -- torch evaluates `grad * ss`, `noise * std` and the additions as separate rounded
+// tensor operations -- and makes the two kernels agree bit for bit (left to -ffp-contract, hipcc fused different pairs in
+// the two kernels: results one ulp apart).
+__device__ __forceinline__ float step_ancestral(float xv, float eps, float z, float a_t, float b_t, float c1, float c2, float sigma) {   // ddpm.py:230-258
+#pragma clang fp contract(off)
+    const float x0 = a_t * xv - b_t * eps;
+    const float mean = c1 * x0 + c2 * xv;
+    return mean + sigma * z;
+}
+__device__ __forceinline__ float step_ula(float xv, float eps, float z, float kappa, float ss, float std_) {                            // ddpm.py:956-966
+#pragma clang fp contract(off)
+    const float grad = (-eps) * kappa;
+    return (xv + grad * ss) + z * std_;
+}
+
 template <int H, bool ENCH /*second encoder layer on the f16 pipe (encode_tile_h2)*/>
 __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, EncOut eo) {
     static_assert(!ENCH || H == 256, "the f16 encoder is written for hidden_dim 256");
@@ -893,6 +934,8 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, EncOut eo) {
     __shared__ int sexp[NODE_TILE];
     // the node kernel is a short latency chain on the critical path of every evaluation; when it shares the
     // CUs with the other lane's GEMM kernels its waves should win the issue arbitration
+    CCSP_TRK(2, 0);
+    CCSP_TRK_RT(2, 30);
     __builtin_amdgcn_s_setprio(3);
     if (a.tab) {
         const StepEntry e = a.tab[*a.counter - 1];
@@ -976,16 +1019,12 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, EncOut eo) {
                     if (a.noise.mode == CCSP_NOISE_INJECTED) z = a.noise.normal[i];
                     else z = ccsp::philox_normal(a.noise.seed, a.noise.row_offset + (unsigned long long)n, a.noise.call, p);
                 }
-                if (a.step == STEP_ANCESTRAL) {                 // ddpm.py:230-258
-                    const float x0 = a.a_t * xv - a.b_t * eps;
-                    const float mean = a.c1 * x0 + a.c2 * xv;
-                    xv = mean + a.sigma * z;
-                } else if (a.step == STEP_ULA) {                // ddpm.py:956-966
-                    const float grad = (-eps) * a.kappa;
-                    xv = (xv + grad * a.ss) + z * a.std_;
+                if (a.step == STEP_ANCESTRAL) {
+                    xv = step_ancestral(xv, eps, z, a.a_t, a.b_t, a.c1, a.c2, a.sigma);
+                } else if (a.step == STEP_ULA) {
+                    xv = step_ula(xv, eps, z, a.kappa, a.ss, a.std_);
                 } else if (a.step == STEP_MALA_PROPOSE) {       // ddpm.py:1017-1023: x_hat = (x + grad ss) + noise std
-                    const float grad = (-eps) * a.kappa;
-                    xv = (xv + grad * a.ss) + z * a.std_;
+                    xv = step_ula(xv, eps, z, a.kappa, a.ss, a.std_);
                 } else if (a.step == STEP_MALA_ACCEPT) {        // ddpm.py:1026-1041
                     // one decision per node row from the batch-scalar energies and the proposal densities
                     // (the reverse density uses the SAME mu as the forward one, like the reference)
@@ -1034,8 +1073,100 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, EncOut eo) {
     }
     if (!a.do_encode) return;
     __syncthreads();
+    CCSP_TRK(2, 1);
     if constexpr (ENCH) encode_tile_h2(w, pfh, xs, reinterpret_cast<unsigned short*>(s1raw), sexp, smax, node0, a.N, eo);
     else encode_tile_mfma<H>(w, pf, xs, reinterpret_cast<float (*)[H / 2 + 1]>(s1raw), smax, node0, a.N, eo);
+    CCSP_TRK(2, 5);
+    CCSP_TRK_RT(2, 31);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_node_direct: k_node for what a direct-mode chain runs 11 000 times -- CSR reduce (src 0), ancestral or ULA step, f16
+// encoder of the new pose, hidden_dim 256 -- as ONE straight-line latency chain.  k_node serves every mode through run-time
+// branches, and on gfx950 (loads and stores on one counter, hipcc's wait insertion taking the minimum over control-flow
+// paths) that cost it most of its time: sixteen CSR loads each under its own branch, the mask / pose / feature loads issued
+// BEHIND the encoder's 128 KB of weights and waited for with vmcnt(0) -- 11 k of its 16.7 k cycles went by before the update
+// was done (profiles/r03_findings.md).  Here every load of the chain is issued at entry, unconditionally (clamped indices,
+// selects instead of branches), the CSR entries 32 per round trip, the noise draw is computed while they are in flight, and
+// the encoder's weights are requested behind them: vector-memory loads return in order, so nothing the update needs waits
+// for a weight.  Same arithmetic as k_node (same order of the CSR sum, shared step formulas): results are bitwise equal.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_node_direct(NodeArgs a, EncW w, EncOut eo, int n_ent /*2 E_act >= 1*/) {
+    __shared__ float xs[NODE_TILE][8];
+    __shared__ __attribute__((aligned(16))) float s1raw[(2 * NODE_TILE * ENC_H2_LD) / 2];
+    __shared__ float smax[4][NODE_TILE];
+    __shared__ int sexp[NODE_TILE];
+    CCSP_TRK(2, 0);
+    CCSP_TRK_RT(2, 30);
+    __builtin_amdgcn_s_setprio(3);
+    const int node0 = blockIdx.x * NODE_TILE;
+    const int tid = threadIdx.x;
+    const int nl = (tid >> 3) & (NODE_TILE - 1), p = tid & 7;
+    const int n = node0 + nl;
+    const bool live = tid < NODE_TILE * 8 && n < a.N && p < a.P;          // this thread owns pose element (n, p)
+    const int nc = n < a.N ? n : a.N - 1, pc = p < a.P ? p : a.P - 1;     // clamped: every address below is valid for every thread
+    const size_t i = (size_t)nc * a.P + pc;
+    // ---- the chain's loads, all of them, before anything else
+    const int csr_beg = a.node_ptr[nc], csr_end = a.node_ptr[nc + 1];
+    const signed char mk = a.mask[nc];
+    const float x_old = a.x[i];
+    const float xf_fill = a.xfeat[(size_t)nc * a.F + a.F - a.P + pc];     // out[mask] = x[:, -P:][mask]
+    const float xf_reset = a.xfeat[(size_t)nc * a.F + a.pose_begin + pc];
+    const bool injected = a.noise.mode == CCSP_NOISE_INJECTED;
+    const float z_inj = (injected ? a.noise.normal : a.x)[i];             // (a select, not a branch; discarded when not injected)
+    const int csr_cnt = csr_end - csr_beg;
+    float v[32];
+    {
+        const float* op = a.O + pc;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            int e = csr_beg + (j < csr_cnt ? j : 0);
+            e = e < n_ent ? e : n_ent - 1;                                // (isolated last node: csr_beg == n_ent)
+            v[j] = op[(size_t)e * a.P];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    EncPrefetchH pfh;
+    enc_prefetch_h2(w, pfh);                                              // behind the chain: in flight under the update
+    // ---- the noise draw needs no data: computed while the loads are in flight
+    float z = ccsp::philox_normal(a.noise.seed, a.noise.row_offset + (unsigned long long)nc, a.noise.call, pc);
+    z = injected ? z_inj : z;
+    // ---- CSR sum in the reference's order, count-normalise, mask fill
+    float acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) acc = j < csr_cnt ? acc + v[j] : acc;
+    for (int q0 = 32; q0 < csr_cnt; q0 += 16) {                           // (nodes with more than 32 inputs: rare)
+        const float* op = a.O + (size_t)csr_beg * a.P + pc;
+        float u[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) u[j] = q0 + j < csr_cnt ? op[(size_t)(q0 + j) * a.P] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc = q0 + j < csr_cnt ? acc + u[j] : acc;
+    }
+    if (a.normalize) acc = acc / sqrtf((float)csr_cnt);                   // 0/0 -> NaN like the reference
+    const bool masked = mk != 0;
+    const float eps = masked ? xf_fill : acc;
+    float xv = a.step == STEP_ANCESTRAL ? step_ancestral(x_old, eps, z, a.a_t, a.b_t, a.c1, a.c2, a.sigma)
+                                        : step_ula(x_old, eps, z, a.kappa, a.ss, a.std_);
+    if (a.reset_mask && masked) xv = xf_reset;
+    if (live) {
+        a.x[i] = xv;
+        if (a.hist) a.hist[i] = xv;
+    }
+    if (tid < NODE_TILE * 8) {
+        const float xnew = live ? xv : 0.0f;
+        xs[nl][p] = xnew;
+        float amax = fabsf(xnew);                                         // row exponent of the encoder's layer-1 activations (encode_tile_h2)
+        amax = fmaxf(amax, __shfl_xor(amax, 1));
+        amax = fmaxf(amax, __shfl_xor(amax, 2));
+        amax = fmaxf(amax, __shfl_xor(amax, 4));
+        if (p == 0) sexp[nl] = h2_scale_exp(fmaf(w.c1, amax, w.c2));
+    }
+    __syncthreads();
+    CCSP_TRK(2, 1);
+    encode_tile_h2(w, pfh, xs, reinterpret_cast<unsigned short*>(s1raw), sexp, smax, node0, a.N, eo);
+    CCSP_TRK(2, 5);
+    CCSP_TRK_RT(2, 31);
 }
 
 #include "ccsp_energy.h"
@@ -1119,6 +1250,7 @@ struct ccsp_model {
     int pe2_exp = 0;
     float pe0_c1 = 0.0f, pe0_c2 = 0.0f;   // bound of the pose encoder's layer-1 pre-activation: c1 max|x| + c2
     int energy_bwd_h2 = 1;            // CCSP_ENERGY_BWD=bf16x3 keeps the backward GEMMs on the six-product bf16 kernels
+    int node_generic = 0;             // CCSP_NODE=generic: k_node instead of k_node_direct in direct-mode chains (A/B runs)
     int valu_node_energy = 0;         // CCSP_NODE_ENERGY_VALU: the pre-MFMA node-energy kernel (A/B runs; never combined with the reuse below)
     int mala_reuse = 1;               // (CCSP_MALA_REUSE=0 turns it off) an inner step that accepted NO node leaves x where it was, so the next step's
                                       // E(x) and gradient are the ones already computed; their kernels return at once (bitwise the
@@ -1163,6 +1295,8 @@ struct ccsp_graph {
     float* umax = nullptr;             // [R][8] max |U| per row and 64-column piece (k_rowgemm_h2 / _h3 -> k_edge_h2)
     int *t2_row0 = nullptr, *t2_nrows = nullptr, *t2_ts = nullptr;   // 128-row tiles of k_rowgemm_bf2 (pairs of plan tiles)
     int n_tiles2 = 0;
+    int4 *td64 = nullptr, *td128 = nullptr;   // the same tile lists as {row0, nrows, 2 type + slot, 0} records (k_rowgemm_h2: one scalar load per tile)
+    std::vector<int4> h_td;                   // kept alive for the async upload
     int* urow_ts;
     // energy mode (allocated on first use)
     bool energy_ready = false;
@@ -1282,7 +1416,7 @@ void launch_rowgemm_h2(ccsp_model* m, ccsp_graph* g, const float* tau_t, StepRef
     const int work = (small ? g->n_tiles : g->n_tiles2) * (2 * H / 128);
 #define CCSP_ROWGEMM_F(MODE)                                                                                                                          \
     hipLaunchKernelGGL((k_rowgemm_h2<H, 2 * H, MODE>), dim3(work), dim3(256), 0, s, g->pembH, (size_t)g->N * H, g->pexp, g->urow_node,                  \
-                       small ? g->tile_row0 : g->t2_row0, small ? g->tile_nrows : g->t2_nrows, small ? g->tile_ts : g->t2_ts, m->WpH,                   \
+                       small ? g->td64 : g->td128, m->WpH,                                                                                              \
                        (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, m->wp_exp, g->base, tau_t, g->U, g->umax, ref, tau_stride)
     if (mode == 4) CCSP_ROWGEMM_F(4); else if (mode == 3) CCSP_ROWGEMM_F(3); else if (mode == 2) CCSP_ROWGEMM_F(2);
     else if (mode == 1) CCSP_ROWGEMM_F(1); else CCSP_ROWGEMM_F(0);
@@ -1395,6 +1529,14 @@ void launch_node(ccsp_model* m, ccsp_graph* g, const NodeArgs& a, hipStream_t s)
     bool ench = false;
     if constexpr (H == 256) ench = m->pe2_wH != nullptr;
     if constexpr (H == 256) {
+        // the straight-line form of the hot case (see k_node_direct); CCSP_NODE=generic keeps k_node for A/B runs
+        const bool direct = ench && h2 && !m->node_generic && a.src == 0 && (a.step == STEP_ANCESTRAL || a.step == STEP_ULA) && a.do_encode &&
+                            !a.x_in && !a.eps_out && !a.tab && g->plan.E_act > 0 && !eo.f32;
+        if (direct) {
+            hipLaunchKernelGGL(k_node_direct, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a, enc_pose(m), eo, 2 * g->plan.E_act);
+            prof_mark(g, s, -1);
+            return;
+        }
         if (ench) hipLaunchKernelGGL((k_node<H, true>), dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a, enc_pose(m), eo);
     }
     if (!ench) hipLaunchKernelGGL((k_node<H, false>), dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a, enc_pose(m), eo);
@@ -1555,7 +1697,7 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
             float* nou = nullptr;
 #define CCSP_ROWGEMM_T(MODE)                                                                                                                        \
             hipLaunchKernelGGL((k_rowgemm_h2<2 * H, H, MODE>), dim3(work), dim3(256), 0, s, g->GZRH, (size_t)p.R * 2 * H, g->gexp, no_map,              \
-                               small ? g->tile_row0 : g->t2_row0, small ? g->tile_nrows : g->t2_nrows, small ? g->tile_ts : g->t2_ts, m->WpTH,          \
+                               small ? g->td64 : g->td128, m->WpTH,                                                                                     \
                                (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, m->wp_exp, nof, nof, g->GP, nou, StepRef{nullptr, nullptr, skip}, \
                                (size_t)0)
             if (mode == 4) CCSP_ROWGEMM_T(4); else if (mode == 3) CCSP_ROWGEMM_T(3); else if (mode == 2) CCSP_ROWGEMM_T(2);
@@ -2026,6 +2168,11 @@ int graph_build(ccsp_model* m, int N, int E, int F, const float* x, const signed
         int* t2 = nullptr;
         TRY(dev_upload(reg, &t2, g->h_t2, s));
         g->t2_row0 = t2; g->t2_nrows = t2 + g->n_tiles2; g->t2_ts = t2 + 2 * g->n_tiles2;
+        for (size_t i = 0; i < p.tile_row0.size(); ++i) g->h_td.push_back(make_int4(p.tile_row0[i], p.tile_nrows[i], p.tile_ts[i], 0));
+        for (size_t i = 0; i < r0.size(); ++i) g->h_td.push_back(make_int4(r0[i], nr[i], tsv[i], 0));
+        int4* td = nullptr;
+        TRY(dev_upload(reg, &td, g->h_td, s));
+        g->td64 = td; g->td128 = td + p.tile_row0.size();
     }
     TRY(dev_alloc(reg, &g->base, (size_t)p.R * 2 * H));
     TRY(dev_alloc(reg, &g->U, (size_t)p.R * 2 * H));
@@ -2187,6 +2334,7 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     if (const char* e = getenv("CCSP_ROW_MODE")) { const int v = atoi(e); if (v >= 0 && v <= 4) m->row_mode = v; }
     if (const char* e = getenv("CCSP_EDGE_MT")) m->edge_mt = atoi(e) == 2 ? 2 : 1;
     m->valu_node_energy = getenv("CCSP_NODE_ENERGY_VALU") != nullptr;
+    if (const char* e = getenv("CCSP_NODE")) m->node_generic = strcmp(e, "generic") == 0;
     {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -2688,6 +2836,12 @@ int ccsp_chain_run(ccsp_model* m, ccsp_graph* g, int32_t sampler, const ccsp_noi
     HIP_TRY(hipEventRecord(g->ev1, s));
     return rc;
 }
+
+#ifdef CCSP_TRACE
+int ccsp_debug_trace(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * 3 * 256 * 32) == hipSuccess ? 0 : 1;
+}
+#endif
 
 int ccsp_profile_enable(ccsp_graph* g, int32_t on) {
     if (!g) return fail("profile_enable: null graph");

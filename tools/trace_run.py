@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 import diffusion_ccsp_amd
 from diffusion_ccsp_amd import _lib, ConstraintDiffuser, GaussianDiffusion, worlds
-_lib.SO = os.path.join(ROOT, 'tools', 'abl_trace.so'); _lib._stale = lambda: False
+_lib.SO = os.environ.get('CCSP_SO') or os.path.join(ROOT, 'tools', 'abl_trace.so'); _lib._stale = lambda: False
 from bench import load_weights
 dev = torch.device('cuda:0')
 which = sys.argv[1] if len(sys.argv) > 1 else 'c5'
@@ -27,7 +27,8 @@ L.ccsp_debug_trace.argtypes = [C.c_void_p]
 assert L.ccsp_debug_trace(buf.ctypes.data) == 0
 t = buf.reshape(3, 256, 32).astype(np.int64)
 names = {0: ['entry', 'index setup'] + ['chunk %d landed' % c for c in range(8)] + ['K loop done (ring)', '-', 'epilogue returned', 'row tile 0 in LDS',
-             'row tile 0 stores issued', 'row tile 1 in LDS', 'row tile 1 stores issued', 'stores drained'],
+             'row tile 0 stores issued', 'row tile 1 in LDS', 'row tile 1 stores issued', 'stores drained'] +
+            ['tile %d group %d computed' % (i, st) for i in range(2) for st in range(4)] + ['tile 0 bt formed', 'tile 1 bt formed'],
          1: ['entry', 'indices+umax', 'stage 0 built'] + ['chunk %d done' % c for c in range(8)] + ['S1 written', 'layer-2 partials', 'O stored'],
          2: ['entry', 'CSR sum + update', 'layer 1', 'layer 2 MFMA', 'row max', 'planes stored']}
 for kern, title in ((0, 'k_rowgemm_h2'), (1, 'k_edge_h2'), (2, 'k_node')):
@@ -45,8 +46,13 @@ for kern, title in ((0, 'k_rowgemm_h2'), (1, 'k_edge_h2'), (2, 'k_node')):
     for j in order:
         print('  %-26s %8.0f %8.0f %8.0f  +%6.0f' % (nn[idx[j]], med[j], np.percentile(d[:, j], 10), np.percentile(d[:, j], 90), med[j] - prev))
         prev = med[j]
-    last = idx[order[-1]]
-    e0 = tk[:, 0] - tk[:, 0].min()
-    x1 = tk[:, last] - tk[:, 0].min()
-    print('  entry times since the first entry: median %d, p90 %d, max %d;  exit times: median %d, p90 %d, max %d' %
-          (np.median(e0), np.percentile(e0, 90), e0.max(), np.median(x1), np.percentile(x1, 90), x1.max()))
+    rt = t[kern][t[kern][:, 30] > 0][:, 30:32]
+    rt = rt[rt[:, 0] > rt[:, 0].max() - 2000]                   # the last launch (100 MHz ticks: 20 us window)
+    e0 = (rt[:, 0] - rt[:, 0].min()) * 10.0
+    x1 = (rt[:, 1] - rt[:, 0].min()) * 10.0
+    print('  chip-wide clock, ns since the first traced entry (%d workgroups of the last launch): entries median %d p90 %d max %d; exits median %d p90 %d max %d' %
+          (len(rt), np.median(e0), np.percentile(e0, 90), e0.max(), np.median(x1), np.percentile(x1, 90), x1.max()))
+if os.environ.get('TRACE_RAW'):
+    for kern in (0, 1, 2):
+        tk = t[kern]; tk = tk[tk[:, 0] > 0]
+        e = np.sort(tk[:, 0]); print('raw entry offsets kernel', kern, (e - e.min())[:60].tolist())
