@@ -609,8 +609,8 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : (MODE == 3 ? 1 : 2)) void k_ro
 //   SIMDs win until the tile list no longer fits the CUs at once.
 // ------------------------------------------------------------------------------------------
 // second decoder layer of a 64-row S1 tile (o[row, p] = sum_j S1[row, j] Wd2[p, j], 128 hidden units): wave w multiplies hidden
-// units 32 w .. 32 w + 31 of all 64 rows (lane = row: conflict-free LDS reads at the odd row stride, weights wave-uniform ->
-// scalar loads) and leaves its P partial sums in RED[w][p][row]; the caller adds the four partials in a fixed order.  32 LDS
+// units 32 w .. 32 w + 31 of all 64 rows (lane = row: conflict-free 16-byte LDS reads at the 132-word row stride, weights
+// wave-uniform -> scalar loads) and leaves its P partial sums in RED[w][p][row]; the caller adds the four partials in a fixed order.  32 LDS
 // reads per lane instead of the 128 of a whole dot product per (row, p) item: 2.3 k cycles shorter per workgroup, which is what
 // counts when the grid is a single round (k_edge_h2<., ., 1>, small batches: C5 +3.5 %); with several workgroups per CU in flight
 // the extra barrier costs more than the reads (C2 -1 %), so large grids keep the one-pass form.  PP > 0: pose_dim at compile time.
@@ -622,14 +622,17 @@ __device__ __forceinline__ void h2_decoder_l2(const float* __restrict__ S1, int 
     float part[8];
 #pragma unroll
     for (int p = 0; p < 8; ++p) part[p] = 0.0f;
-    const float* srow = S1 + lane * s1_ld + kq;
+    const float4* srow = reinterpret_cast<const float4*>(S1 + lane * s1_ld + kq);      // (s1_ld = 132: 16-byte aligned rows, conflict-free b128 reads)
     const float* w = Wd2 + kq;
-#pragma unroll 8
-    for (int k = 0; k < 32; ++k) {
-        const float sv = srow[k];
 #pragma unroll
-        for (int p = 0; p < 8; ++p)
-            if (PP > 0 ? p < PP : p < P) part[p] = fmaf(sv, w[p * 128 + k], part[p]);
+    for (int k4 = 0; k4 < 8; ++k4) {
+        const float4 sv4 = srow[k4];
+        const float sv[4] = {sv4.x, sv4.y, sv4.z, sv4.w};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+                if (PP > 0 ? p < PP : p < P) part[p] = fmaf(sv[kk], w[p * 128 + 4 * k4 + kk], part[p]);
     }
 #pragma unroll
     for (int p = 0; p < 8; ++p)
@@ -651,30 +654,34 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void k_edge_h2(int E_act, int
     constexpr int ME = 32 * MT, ROWS = 2 * ME;                    // edges, tile rows
     constexpr int APL = ROWS * H2_BK, STAGE = 2 * APL + 2 * H2_BPL;
     constexpr int NPASS = ROWS / 32;                              // producer passes per chunk: rows lr + 32 i
-    constexpr int S1_LD = BN + 1;
-    static_assert((64 * S1_LD + 4 * 8 * 64) * 4 <= 2 * STAGE * 2, "epilogue tile and the layer-2 partials must fit the stages");
+    constexpr int S1_LD = BN + 4;                                 // 16-byte aligned rows; one row per lane reads conflict-free (b128: 4 rows x 132 words = all 64 banks per 16 lanes)
+    static_assert((64 * S1_LD + 8 * BN + 4 * 8 * 64) * 4 <= 2 * STAGE * 2, "epilogue tile, the layer-2 weights and partials must fit the stages");
     __shared__ __attribute__((aligned(16))) unsigned short smem[2 * STAGE + 2 * ROWS];
     int* sE = reinterpret_cast<int*>(smem + 2 * STAGE);
     const int e0 = xcd_remap(blockIdx.x, gridDim.x) * ME;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = tid >> 3, lq = tid & 7;                        // A producer: rows lr + 32 i, fp32 columns 4 lq .. + 3 of the chunk
+    // The kernel is one latency chain per tile: edge -> row indices -> U rows -> ... .  Issue order (vector-memory loads return
+    // in order): the row indices; then, the moment they are here, the U rows of the first two chunks and the weights of the
+    // first; only then the row maxima (the exponents are needed when chunk 0 is written to LDS, not before) and what the
+    // epilogue needs -- CSR slot, biases, second-layer weights -- so that no load sits in the epilogue's path.
+    int r0v[NPASS], r1v[NPASS];
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+        int k = e0 + ((lr + 32 * i) % ME);
+        k = k < E_act ? k : E_act - 1;
+        r0v[i] = e_u0[k];
+        r1v[i] = e_u1[k];
+    }
     const float* u0_ptr[NPASS];
     const float* u1_ptr[NPASS];
     int a_st[NPASS], a_exp[NPASS];
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
         const int row = lr + 32 * i, s = row / ME;
-        int k = e0 + (row % ME);
-        k = k < E_act ? k : E_act - 1;
-        const int r0 = e_u0[k], r1 = e_u1[k];
-        u0_ptr[i] = U + (size_t)r0 * (2 * H) + s * H + lq * 4;
-        u1_ptr[i] = U + (size_t)r1 * (2 * H) + s * H + lq * 4;
-        const float4 m0 = *reinterpret_cast<const float4*>(umax + (size_t)r0 * 8 + 4 * s);
-        const float4 m1 = *reinterpret_cast<const float4*>(umax + (size_t)r1 * 8 + 4 * s);
-        // |SiLU(z)| <= |z| <= max|U[u0]| + max|U[u1]| over the half's four 64-column pieces
-        a_exp[i] = h2_scale_exp(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)) + fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w)));
-        if (lq == 0) sE[row] = a_exp[i];
+        u0_ptr[i] = U + (size_t)r0v[i] * (2 * H) + s * H + lq * 4;
+        u1_ptr[i] = U + (size_t)r1v[i] * (2 * H) + s * H + lq * 4;
         a_st[i] = h2_off(row, lq >> 1) + (lq & 1) * 4;
     }
     const int brow = tid >> 2, bq = tid & 3;                      // B copy: rows brow, brow + 64, piece bq, both planes
@@ -715,10 +722,38 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void k_edge_h2(int E_act, int
             for (int p = 0; p < 2; ++p)
                 *reinterpret_cast<ushort8*>(Bs + p * H2_BPL + b_st + i * 64 * H2_BK) = rb[i * 2 + p];
     };
-    CCSP_TRK(1, 1);
     gload_a(0, 0);
     gload_b(0);
     gload_a(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+        const int row = lr + 32 * i, s = row / ME;
+        const float4 m0 = *reinterpret_cast<const float4*>(umax + (size_t)r0v[i] * 8 + 4 * s);
+        const float4 m1 = *reinterpret_cast<const float4*>(umax + (size_t)r1v[i] * 8 + 4 * s);
+        // |SiLU(z)| <= |z| <= max|U[u0]| + max|U[u1]| over the half's four 64-column pieces
+        a_exp[i] = h2_scale_exp(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)) + fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w)));
+    }
+    // what the epilogue reads, requested now: the first-layer bias of the lane's two columns, the CSR slots / bias of the
+    // (row, p) outputs this thread produces (one per 64-row pass when 64 P <= 256), its share of the second-layer weights
+    float bj1[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bj1[j] = bd1[wn * 64 + j * 32 + (lane & 31)];
+    const int o_p = tid >> 6, o_row = tid & 63;                   // output item of this thread in a 64-row pass: S1 row o_row, component o_p
+    int o_slot[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        int k = e0 + i * 32 + (o_row & 31);
+        k = k < E_act ? k : E_act - 1;
+        o_slot[i] = ent_pos[2 * k + (o_row >> 5)];
+    }
+    const float o_b2 = bd2[o_p < P ? o_p : 0];
+    const float4 w2v = *reinterpret_cast<const float4*>(Wd2 + ((tid * 4) < P * BN ? tid * 4 : 0));      // Wd2 is [P][128] row-major: 4 P x 32 float4
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i)
+        if (lq == 0) sE[lr + 32 * i] = a_exp[i];
+    CCSP_TRK(1, 1);
     floatx16 acc[MT][2];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -755,19 +790,20 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void k_edge_h2(int E_act, int
     }
     // epilogue, 64 rows per pass (row tile i of every wave: 32 edges x both halves)
     float* S1 = reinterpret_cast<float*>(smem);
-    float* RED = S1 + 64 * S1_LD;
+    float* W2s = S1 + 64 * S1_LD;                                 // pose_decoder.2.weight [P][128] (read as broadcast b128 rows)
+    float* RED = W2s + 8 * BN;
+    if (tid * 4 < P * BN) *reinterpret_cast<float4*>(W2s + tid * 4) = w2v;
     float e2 = 0.0f;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = wn * 64 + j * 32 + (lane & 31);
-            const float bj = bd1[col];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int row = wm * ME + i * 32 + rr;                         // tile row: half wm, edge e0 + i * 32 + rr
-                const float q = ldexpf(acc[i][j][r], -(sE[row] + wd_exp)) + bj;
+                const float q = ldexpf(acc[i][j][r], -(sE[row] + wd_exp)) + bj1[j];
                 S1[(wm * 32 + rr) * S1_LD + col] = silu_fast(q);
                 if constexpr (ENERGY) {
                     const int k = e0 + i * 32 + rr;
@@ -786,29 +822,38 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void k_edge_h2(int E_act, int
         }
         for (int idx = tid; idx < 64 * P; idx += 256) {
             const int lrow = idx & 63;                                         // S1 row: half (lrow >> 5), edge e0 + i * 32 + (lrow & 31)
+            const int p = idx >> 6;
             float o;
             if constexpr (L2 == 1) {
-                const int p = idx >> 6;
                 const float* rp = RED + p * 64 + lrow;
                 o = ((rp[0] + rp[8 * 64]) + (rp[16 * 64] + rp[24 * 64])) + bd2[p];
             } else {
-                const int p = __builtin_amdgcn_readfirstlane(idx >> 6);       // uniform per wave: scalar weight loads
-                o = dot4<BN>(S1 + lrow * S1_LD, Wd2 + (size_t)p * BN) + bd2[p];
+                // one (row, p) dot product per thread: S1 row and weight row as 16-byte LDS reads (the weight row is the same
+                // address for the whole wave: a broadcast), four independent chains summed as dot4 does
+                const float4* sr = reinterpret_cast<const float4*>(S1 + lrow * S1_LD);
+                const float4* wr = reinterpret_cast<const float4*>(W2s + p * BN);
+                float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;
+#pragma unroll
+                for (int j = 0; j < BN / 4; ++j) {
+                    const float4 sv = sr[j], wv = wr[j];
+                    o0 = fmaf(sv.x, wv.x, o0); o1 = fmaf(sv.y, wv.y, o1); o2 = fmaf(sv.z, wv.z, o2); o3 = fmaf(sv.w, wv.w, o3);
+                }
+                o = ((o0 + o1) + (o2 + o3)) + (idx == tid ? o_b2 : bd2[p]);
             }
-            const int p = idx >> 6;
             const int k = e0 + i * 32 + (lrow & 31), s = lrow >> 5;
             if (k < E_act) {
+                const int slot = idx == tid ? o_slot[i] : ent_pos[2 * k + s];  // (the first 256 items' slots were requested in the prologue)
                 if constexpr (ENERGY) {
                     const int node = s == 0 ? en.e_a[k] : en.e_b[k];
                     const float d = o - en.xeval[(size_t)node * P + p];
                     e2 = fmaf(d, d, e2);
-                    O[(size_t)ent_pos[2 * k + s] * P + p] = -2.0f * d;
+                    O[(size_t)slot * P + p] = -2.0f * d;
                 } else {
-                    O[(size_t)ent_pos[2 * k + s] * P + p] = o;                 // straight to the node's CSR slot
+                    O[(size_t)slot * P + p] = o;                               // straight to the node's CSR slot
                 }
             }
         }
-        __syncthreads();
+        if (i + 1 < MT || ENERGY) __syncthreads();                             // (the next pass / the energy reduction reuse S1)
     }
     CCSP_TRK(1, 13);
     CCSP_TRK_RT(1, 31);
@@ -838,7 +883,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_h2s(int E_act, int P, const int
     constexpr int H = 256, BN = 128, NCH = H / H2_BK;
     constexpr int ME = 16, ROWS = 2 * ME;
     constexpr int APL = ROWS * H2_BK, STAGE = 2 * APL + 2 * H2_BPL;       // 4 KB of A planes + 16 KB of B planes
-    constexpr int S1_LD = BN + 1;
+    constexpr int S1_LD = BN + 4;
     static_assert((ROWS * S1_LD + 4 * 8 * ROWS) * 4 <= 2 * STAGE * 2, "epilogue tile and the layer-2 partials must fit the stages");
     __shared__ __attribute__((aligned(16))) unsigned short smem[2 * STAGE + 2 * ROWS];
     int* sE = reinterpret_cast<int*>(smem + 2 * STAGE);

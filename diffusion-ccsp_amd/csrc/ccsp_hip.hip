@@ -1259,6 +1259,7 @@ struct ccsp_model {
     ccsp_energy_hook energy_hook = nullptr;   // MALA global-batch mode (ccsp_model_set_energy_hook)
     void* energy_hook_ctx = nullptr;
     int row_mode = -1, edge_mt = -1;  // CCSP_ROW_MODE / CCSP_EDGE_MT: force a variant of the f16x2 kernels (-1: by tile count)
+    int edge_small = -1;              // CCSP_EDGE_SMALL=1 / 0: always / never the 16-edge-tile kernel k_edge_h2s (-1: by tile count)
     // StructDiffusion baseline (model_kind 1): transformer weights as given ([out, in] row-major)
     struct SdLayer { float *in_w, *in_b, *out_w, *out_b, *ln1_g, *ln1_b, *fc_w, *fc_b, *proj_w, *proj_b, *ln2_g, *ln2_b; };
     int Wd = 0;            // transformer width: 2H, or 3H with a grasp group
@@ -1428,7 +1429,7 @@ template <bool ENERGY>
 int launch_edge_h2(ccsp_model* m, ccsp_graph* g, EdgeEnergyArgs en, int* cinc, hipStream_t s) {
     const int E_act = g->plan.E_act;
     const int mt = m->edge_mt > 0 ? m->edge_mt : (nblk(E_act, 32) <= 3 * m->ncu ? 1 : 2);
-    if (m->edge_mt <= 0 && nblk(E_act, 16) <= m->ncu) {        // most of the chip would idle even at 16 edges per workgroup
+    if (m->edge_small > 0 || (m->edge_small < 0 && m->edge_mt <= 0 && nblk(E_act, 16) <= m->ncu)) {        // most of the chip would idle even at 16 edges per workgroup
         const int nws = nblk(E_act, 16);
         hipLaunchKernelGGL(k_edge_h2s<ENERGY>, dim3(nws), dim3(256), 0, s, E_act, m->d.pose_dim, g->e_u0, g->e_u1, g->U, g->umax, m->Wd1H, m->wd_exp,
                            m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, en, cinc);
@@ -2333,6 +2334,7 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     m->f16x2 = (H == 256 && d->model_kind == CCSP_MODEL_DIFFUSION_CCSP) ? 1 : 0;
     if (const char* e = getenv("CCSP_ROW_MODE")) { const int v = atoi(e); if (v >= 0 && v <= 4) m->row_mode = v; }
     if (const char* e = getenv("CCSP_EDGE_MT")) m->edge_mt = atoi(e) == 2 ? 2 : 1;
+    if (const char* e = getenv("CCSP_EDGE_SMALL")) m->edge_small = atoi(e) != 0;
     m->valu_node_energy = getenv("CCSP_NODE_ENERGY_VALU") != nullptr;
     if (const char* e = getenv("CCSP_NODE")) m->node_generic = strcmp(e, "generic") == 0;
     {
