@@ -639,13 +639,57 @@ __device__ __forceinline__ void h2_decoder_l2(const float* __restrict__ S1, int 
         if (PP > 0 ? p < PP : p < P) RED[(wave * 8 + p) * NROWS + lane] = part[p];
 }
 
-template <bool ENERGY, int MT, int L2>
-__global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void k_edge_h2(int E_act, int P, const int* __restrict__ e_u0, const int* __restrict__ e_u1,
+// Tail of the fused edge kernels (FUSE): the node update of every 16-node block this workgroup is the LAST to deliver edge
+// outputs to (FuseArgs, ccsp_hip.hip).  The outputs were stored write-through (sc1: they leave the XCD's L2 at once); every
+// wave drains its stores, the workgroup synchronises, then one relaxed agent-scope fetch_add per touched block -- the
+// publish form R1 of cdna_hip_programming.md Guideline 16, with the arrival counter as the flag.  Nobody waits: whoever
+// completes a block runs it (sc1 loads of the edge outputs), so a launch has no barrier and cannot hang.  lds: the stages,
+// free after the epilogue.
+// one row of P edge outputs, write-through (sc1), from ONE lane in 16-byte pieces: a 4-byte sc1 store is one fabric write each
+// (MI355X_MICROARCH.md: 6x the time per byte of a 16-byte one) -- the first fused build, one element per lane, ran the chain
+// at a third of the speed.  The asm stores are invisible to hipcc's wait insertion: edge_node_tail drains them.
+__device__ __forceinline__ void h2_store_row_sc1(float* dst, const float* src /*LDS, 16-byte aligned*/, int P) {
+    int c = 0;
+    for (; c + 4 <= P; c += 4) {
+        const h2_f4 v = *reinterpret_cast<const h2_f4*>(src + c);
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst + c), "v"(v) : "memory");
+    }
+    for (; c < P; ++c) __hip_atomic_store(dst + c, src[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void edge_node_tail(const FuseArgs& fu, int wg, void* lds) {
+    const int tid = threadIdx.x;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's write-through stores have been acknowledged
+    __syncthreads();                                              // ... every wave's; and the epilogue's LDS tiles are dead
+    int* s_list = reinterpret_cast<int*>(reinterpret_cast<char*>(lds) + ((NODE_LDS_BYTES + 15) & ~15));         // [256]
+    const int b0 = fu.wg_blk_ptr[wg], nb = fu.wg_blk_ptr[wg + 1] - b0;
+    for (int base = 0; base < nb; base += 256) {
+        const int cnt = nb - base < 256 ? nb - base : 256;
+        if (tid < cnt) {
+            const int b = fu.wg_blk[b0 + base + tid];
+            const unsigned int old = __hip_atomic_fetch_add(fu.blk_count + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_list[tid] = (old + 1u == (unsigned int)fu.blk_expect[b] * fu.epoch) ? b : -1;
+        }
+        __syncthreads();
+        for (int j = 0; j < cnt; ++j) {                           // (uniform: the list is in LDS)
+            const int b = s_list[j];
+            if (b >= 0) {
+                node_block_direct<true>(fu.node, fu.w, fu.eo, fu.n_ent, b * NODE_TILE, node_lds(lds));
+                __syncthreads();                                  // (the block's LDS is reused by the next one)
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <bool ENERGY, int MT, int L2, bool FUSE = false>
+__global__ __launch_bounds__(256, (MT == 1 && !FUSE) ? 3 : 2) void k_edge_h2(int E_act, int P, const int* __restrict__ e_u0, const int* __restrict__ e_u1,
                                                     const float* __restrict__ U, const float* __restrict__ umax /*[R][8]*/,
                                                     const unsigned short* __restrict__ Wd1H /*[2][128][256]*/, int wd_exp,
                                                     const float* __restrict__ bd1, const float* __restrict__ Wd2,
                                                     const float* __restrict__ bd2, const int* __restrict__ ent_pos, float* __restrict__ O,
-                                                    EdgeEnergyArgs en, int* __restrict__ counter_inc) {
+                                                    EdgeEnergyArgs en, int* __restrict__ counter_inc, FuseArgs fu) {
+    static_assert(!(FUSE && ENERGY), "the fused node update is the direct-mode one");
     if constexpr (ENERGY) { if (en.skip && *en.skip == 0) return; }                        // (uniform) MALA reuse
     if (counter_inc && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(counter_inc, 1);     // hipGraph mode: next table entry
     CCSP_TRK(1, 0);
@@ -655,7 +699,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void k_edge_h2(int E_act, int
     constexpr int APL = ROWS * H2_BK, STAGE = 2 * APL + 2 * H2_BPL;
     constexpr int NPASS = ROWS / 32;                              // producer passes per chunk: rows lr + 32 i
     constexpr int S1_LD = BN + 4;                                 // 16-byte aligned rows; one row per lane reads conflict-free (b128: 4 rows x 132 words = all 64 banks per 16 lanes)
-    static_assert((64 * S1_LD + 8 * BN + 4 * 8 * 64) * 4 <= 2 * STAGE * 2, "epilogue tile, the layer-2 weights and partials must fit the stages");
+    static_assert((64 * S1_LD + 8 * BN + 4 * 8 * 64 + 64 * 8) * 4 <= 2 * STAGE * 2, "epilogue tile, the layer-2 weights, partials and output rows must fit the stages");
     __shared__ __attribute__((aligned(16))) unsigned short smem[2 * STAGE + 2 * ROWS];
     int* sE = reinterpret_cast<int*>(smem + 2 * STAGE);
     const int e0 = xcd_remap(blockIdx.x, gridDim.x) * ME;
@@ -792,6 +836,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void k_edge_h2(int E_act, int
     float* S1 = reinterpret_cast<float*>(smem);
     float* W2s = S1 + 64 * S1_LD;                                 // pose_decoder.2.weight [P][128] (read as broadcast b128 rows)
     float* RED = W2s + 8 * BN;
+    float* Os = RED + 4 * 8 * 64;                                 // FUSE: the 64 x P outputs of a pass, one row per lane for the 16-byte stores
     if (tid * 4 < P * BN) *reinterpret_cast<float4*>(W2s + tid * 4) = w2v;
     float e2 = 0.0f;
 #pragma unroll
@@ -833,7 +878,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void k_edge_h2(int E_act, int
                 const float4* sr = reinterpret_cast<const float4*>(S1 + lrow * S1_LD);
                 const float4* wr = reinterpret_cast<const float4*>(W2s + p * BN);
                 float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;
-#pragma unroll
+#pragma unroll 8
                 for (int j = 0; j < BN / 4; ++j) {
                     const float4 sv = sr[j], wv = wr[j];
                     o0 = fmaf(sv.x, wv.x, o0); o1 = fmaf(sv.y, wv.y, o1); o2 = fmaf(sv.z, wv.z, o2); o3 = fmaf(sv.w, wv.w, o3);
@@ -848,12 +893,27 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void k_edge_h2(int E_act, int
                     const float d = o - en.xeval[(size_t)node * P + p];
                     e2 = fmaf(d, d, e2);
                     O[(size_t)slot * P + p] = -2.0f * d;
-                } else {
+                } else if constexpr (!FUSE) {
                     O[(size_t)slot * P + p] = o;                               // straight to the node's CSR slot
                 }
             }
+            if constexpr (FUSE) Os[lrow * 8 + p] = o;
+        }
+        if constexpr (FUSE) {                                                  // rows out through LDS: one lane per row, 16-byte write-through stores
+            __syncthreads();
+            if (tid < 64) {
+                const int k = e0 + i * 32 + (tid & 31);
+                if (k < E_act) h2_store_row_sc1(O + (size_t)o_slot[i] * P, Os + tid * 8, P);
+            }
         }
         if (i + 1 < MT || ENERGY) __syncthreads();                             // (the next pass / the energy reduction reuse S1)
+    }
+    if constexpr (FUSE) {
+        CCSP_TRK(1, 13);
+        edge_node_tail(fu, e0 / ME, smem);
+        CCSP_TRK_RT(1, 31);
+        CCSP_TRK(1, 14);
+        return;
     }
     CCSP_TRK(1, 13);
     CCSP_TRK_RT(1, 31);
@@ -871,20 +931,21 @@ __global__ __launch_bounds__(256, MT == 1 ? 3 : 2) void k_edge_h2(int E_act, int
 // each -- half the activation work per thread and half the MFMAs per wave of the 32-edge tile, twice the workgroups.  Same
 // operands, same scaling, same epilogue arithmetic as k_edge_h2<ENERGY, 1, 1>.
 // ------------------------------------------------------------------------------------------
-template <bool ENERGY>
+template <bool ENERGY, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void k_edge_h2s(int E_act, int P, const int* __restrict__ e_u0, const int* __restrict__ e_u1,
                                                      const float* __restrict__ U, const float* __restrict__ umax /*[R][8]*/,
                                                      const unsigned short* __restrict__ Wd1H /*[2][128][256]*/, int wd_exp,
                                                      const float* __restrict__ bd1, const float* __restrict__ Wd2,
                                                      const float* __restrict__ bd2, const int* __restrict__ ent_pos, float* __restrict__ O,
-                                                     EdgeEnergyArgs en, int* __restrict__ counter_inc) {
+                                                     EdgeEnergyArgs en, int* __restrict__ counter_inc, FuseArgs fu) {
+    static_assert(!(FUSE && ENERGY), "the fused node update is the direct-mode one");
     if constexpr (ENERGY) { if (en.skip && *en.skip == 0) return; }                        // (uniform) MALA reuse
     if (counter_inc && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(counter_inc, 1);     // hipGraph mode: next table entry
     constexpr int H = 256, BN = 128, NCH = H / H2_BK;
     constexpr int ME = 16, ROWS = 2 * ME;
     constexpr int APL = ROWS * H2_BK, STAGE = 2 * APL + 2 * H2_BPL;       // 4 KB of A planes + 16 KB of B planes
     constexpr int S1_LD = BN + 4;
-    static_assert((ROWS * S1_LD + 4 * 8 * ROWS) * 4 <= 2 * STAGE * 2, "epilogue tile and the layer-2 partials must fit the stages");
+    static_assert((ROWS * S1_LD + 4 * 8 * ROWS + 8 * ROWS) * 4 <= 2 * STAGE * 2, "epilogue tile, the layer-2 partials and the output rows must fit the stages");
     __shared__ __attribute__((aligned(16))) unsigned short smem[2 * STAGE + 2 * ROWS];
     int* sE = reinterpret_cast<int*>(smem + 2 * STAGE);
     const int e0 = xcd_remap(blockIdx.x, gridDim.x) * ME;
@@ -1006,10 +1067,19 @@ __global__ __launch_bounds__(256, 2) void k_edge_h2s(int E_act, int P, const int
                 const float d = o - en.xeval[(size_t)node * P + p];
                 e2 = fmaf(d, d, e2);
                 O[(size_t)ent_pos[2 * k + s] * P + p] = -2.0f * d;
-            } else {
+            } else if constexpr (!FUSE) {
                 O[(size_t)ent_pos[2 * k + s] * P + p] = o;                 // straight to the node's CSR slot
             }
         }
+        if constexpr (FUSE) (RED + 4 * 8 * ROWS)[row * 8 + p] = o;
+    }
+    if constexpr (FUSE) {                                             // rows out through LDS: one lane per row, 16-byte write-through stores
+        __syncthreads();
+        if (tid < ROWS) {
+            const int k = e0 + (tid % ME), s = tid / ME;
+            if (k < E_act) h2_store_row_sc1(O + (size_t)ent_pos[2 * k + s] * P, RED + 4 * 8 * ROWS + tid * 8, P);
+        }
+        edge_node_tail(fu, e0 / ME, smem);
     }
     if constexpr (ENERGY) {
         __syncthreads();

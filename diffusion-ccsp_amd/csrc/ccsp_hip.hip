@@ -17,6 +17,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <algorithm>
 #include <thread>
 #include <type_traits>
 #include <vector>
@@ -1091,15 +1092,97 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, EncOut eo) {
 // the encoder's weights are requested behind them: vector-memory loads return in order, so nothing the update needs waits
 // for a weight.  Same arithmetic as k_node (same order of the CSR sum, shared step formulas): results are bitwise equal.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_node_direct(NodeArgs a, EncW w, EncOut eo, int n_ent /*2 E_act >= 1*/) {
-    __shared__ float xs[NODE_TILE][8];
-    __shared__ __attribute__((aligned(16))) float s1raw[(2 * NODE_TILE * ENC_H2_LD) / 2];
-    __shared__ float smax[4][NODE_TILE];
-    __shared__ int sexp[NODE_TILE];
-    CCSP_TRK(2, 0);
-    CCSP_TRK_RT(2, 30);
-    __builtin_amdgcn_s_setprio(3);
-    const int node0 = blockIdx.x * NODE_TILE;
+// encode_tile_h2 with the layer-2 weight fragments streamed per k-step (two register sets of 32 VGPRs) instead of held in 128:
+// the form that fits next to the edge kernel's registers (node update folded into its tail).  Same products in the same order.
+__device__ __forceinline__ void encode_tile_h2_stream(const EncW w, float (*xs)[8], unsigned short* s1h, int* sexp, float (*smax)[NODE_TILE],
+                                                      int node0, int N, const EncOut out) {
+    constexpr int H = 256, LD = ENC_H2_LD;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const half8* wh = reinterpret_cast<const half8*>(w.W2H) + (size_t)wave * 16 * 64 + lane;
+    half8 wa[2][2][4];                                            // [register set][plane][tile]
+    auto wload = [&](int ks, int set) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wa[set][p][q] = wh[(size_t)p * 4096 + (ks * 4 + q) * 64];
+    };
+    wload(0, 0);
+    wload(1, 1);
+    {
+        const int j = tid % 128;
+        float w0[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) w0[d] = d < w.in_dim ? w.W0[j * w.in_dim + d] : 0.0f;
+        const float b0 = w.b0[j];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int n = tid / 128 + 2 * i;
+            float acc = 0.0f;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) acc = fmaf(xs[n][d], w0[d], acc);         // columns >= in_dim are 0
+            unsigned short h1, h2;
+            split2h(ldexpf(silu_fast(acc + b0), sexp[n]), h1, h2);
+            s1h[n * LD + j] = h1;
+            s1h[(NODE_TILE + n) * LD + j] = h2;
+        }
+    }
+    float b2[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b2[q][r] = w.b2[wave * 64 + q * 16 + 4 * (lane >> 4) + r];
+    __syncthreads();
+    floatx4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+    const unsigned short* bp = s1h + (lane & 15) * LD + 8 * (lane >> 4);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int set = ks & 1;
+        const half8 b1 = *reinterpret_cast<const half8*>(bp + ks * 32);
+        const half8 b2h = *reinterpret_cast<const half8*>(bp + NODE_TILE * LD + ks * 32);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[set][1][j], b1, acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[set][0][j], b2h, acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[set][0][j], b1, acc[j], 0, 0, 0);
+        if (ks + 2 < 4) wload(ks + 2, set);
+    }
+    const int eu = -(sexp[lane & 15] + w.w2_exp);
+    float v[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[j][r] = silu_fast(ldexpf(acc[j][r], eu) + b2[j][r]);
+    enc_store_tile<H>(v, smax, node0, N, out);
+}
+
+// LDS of one node block (k_node_direct's own; a region of the stages in the fused edge kernel)
+struct NodeLds {
+    float (*xs)[8];                 // [NODE_TILE][8]
+    unsigned short* s1h;            // [2][NODE_TILE][ENC_H2_LD]
+    float (*smax)[NODE_TILE];       // [4][NODE_TILE]
+    int* sexp;                      // [NODE_TILE]
+};
+constexpr int NODE_LDS_BYTES = NODE_TILE * 8 * 4 + 2 * NODE_TILE * ENC_H2_LD * 2 + 4 * NODE_TILE * 4 + NODE_TILE * 4;
+__device__ __forceinline__ NodeLds node_lds(void* base) {
+    char* b = reinterpret_cast<char*>(base);
+    NodeLds l;
+    l.s1h = reinterpret_cast<unsigned short*>(b);                          // (first: 16-byte aligned fragment reads)
+    l.xs = reinterpret_cast<float (*)[8]>(b + 2 * NODE_TILE * ENC_H2_LD * 2);
+    l.smax = reinterpret_cast<float (*)[NODE_TILE]>(b + 2 * NODE_TILE * ENC_H2_LD * 2 + NODE_TILE * 8 * 4);
+    l.sexp = reinterpret_cast<int*>(b + 2 * NODE_TILE * ENC_H2_LD * 2 + NODE_TILE * 8 * 4 + 4 * NODE_TILE * 4);
+    return l;
+}
+
+// One 16-node block of the direct-mode update: CSR reduce in the reference's order, count-normalise, mask fill, ancestral /
+// ULA step with its noise draw, mask reset, history, encoder of the new pose.  All 256 threads; ends with the planes stored.
+// FUSED (tail of the edge kernel, run by the workgroup that delivered the block's last edge outputs): the edge outputs were
+// stored write-through (sc1) by workgroups on any XCD and are read with sc1 loads -- the L2-served pair of
+// cdna_hip_programming.md Guideline 16 -- and the encoder streams its weights.
+template <bool FUSED>
+__device__ __forceinline__ void node_block_direct(const NodeArgs& a, const EncW& w, const EncOut& eo, int n_ent, int node0, const NodeLds lds) {
     const int tid = threadIdx.x;
     const int nl = (tid >> 3) & (NODE_TILE - 1), p = tid & 7;
     const int n = node0 + nl;
@@ -1115,6 +1198,10 @@ __global__ __launch_bounds__(256) void k_node_direct(NodeArgs a, EncW w, EncOut 
     const bool injected = a.noise.mode == CCSP_NOISE_INJECTED;
     const float z_inj = (injected ? a.noise.normal : a.x)[i];             // (a select, not a branch; discarded when not injected)
     const int csr_cnt = csr_end - csr_beg;
+    auto o_load = [&](const float* ptr) -> float {
+        if constexpr (FUSED) return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return *ptr;
+    };
     float v[32];
     {
         const float* op = a.O + pc;
@@ -1122,12 +1209,12 @@ __global__ __launch_bounds__(256) void k_node_direct(NodeArgs a, EncW w, EncOut 
         for (int j = 0; j < 32; ++j) {
             int e = csr_beg + (j < csr_cnt ? j : 0);
             e = e < n_ent ? e : n_ent - 1;                                // (isolated last node: csr_beg == n_ent)
-            v[j] = op[(size_t)e * a.P];
+            v[j] = o_load(op + (size_t)e * a.P);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
     EncPrefetchH pfh;
-    enc_prefetch_h2(w, pfh);                                              // behind the chain: in flight under the update
+    if constexpr (!FUSED) enc_prefetch_h2(w, pfh);                        // behind the chain: in flight under the update
     // ---- the noise draw needs no data: computed while the loads are in flight
     float z = ccsp::philox_normal(a.noise.seed, a.noise.row_offset + (unsigned long long)nc, a.noise.call, pc);
     z = injected ? z_inj : z;
@@ -1139,7 +1226,7 @@ __global__ __launch_bounds__(256) void k_node_direct(NodeArgs a, EncW w, EncOut 
         const float* op = a.O + (size_t)csr_beg * a.P + pc;
         float u[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) u[j] = q0 + j < csr_cnt ? op[(size_t)(q0 + j) * a.P] : 0.0f;
+        for (int j = 0; j < 16; ++j) u[j] = q0 + j < csr_cnt ? o_load(op + (size_t)(q0 + j) * a.P) : 0.0f;
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc = q0 + j < csr_cnt ? acc + u[j] : acc;
     }
@@ -1155,19 +1242,44 @@ __global__ __launch_bounds__(256) void k_node_direct(NodeArgs a, EncW w, EncOut 
     }
     if (tid < NODE_TILE * 8) {
         const float xnew = live ? xv : 0.0f;
-        xs[nl][p] = xnew;
+        lds.xs[nl][p] = xnew;
         float amax = fabsf(xnew);                                         // row exponent of the encoder's layer-1 activations (encode_tile_h2)
         amax = fmaxf(amax, __shfl_xor(amax, 1));
         amax = fmaxf(amax, __shfl_xor(amax, 2));
         amax = fmaxf(amax, __shfl_xor(amax, 4));
-        if (p == 0) sexp[nl] = h2_scale_exp(fmaf(w.c1, amax, w.c2));
+        if (p == 0) lds.sexp[nl] = h2_scale_exp(fmaf(w.c1, amax, w.c2));
     }
     __syncthreads();
     CCSP_TRK(2, 1);
-    encode_tile_h2(w, pfh, xs, reinterpret_cast<unsigned short*>(s1raw), sexp, smax, node0, a.N, eo);
+    if constexpr (FUSED) encode_tile_h2_stream(w, lds.xs, lds.s1h, lds.sexp, lds.smax, node0, a.N, eo);
+    else encode_tile_h2(w, pfh, lds.xs, lds.s1h, lds.sexp, lds.smax, node0, a.N, eo);
+}
+
+__global__ __launch_bounds__(256) void k_node_direct(NodeArgs a, EncW w, EncOut eo, int n_ent /*2 E_act >= 1*/) {
+    __shared__ __attribute__((aligned(16))) char lds_raw[NODE_LDS_BYTES];
+    CCSP_TRK(2, 0);
+    CCSP_TRK_RT(2, 30);
+    __builtin_amdgcn_s_setprio(3);
+    node_block_direct<false>(a, w, eo, n_ent, blockIdx.x * NODE_TILE, node_lds(lds_raw));
     CCSP_TRK(2, 5);
     CCSP_TRK_RT(2, 31);
 }
+
+// the node update folded into the edge kernel's tail (k_edge_h2 / k_edge_h2s, FUSE): which 16-node blocks a workgroup's
+// outputs touch, how many workgroups touch each block, and the arrival counters (zeroed when a chain starts; `epoch` = index of
+// this evaluation since then, from 1).  The workgroup whose arrival completes a block runs node_block_direct<true> for it --
+// nobody waits for anybody, so no grid barrier and no spinning.
+struct FuseArgs {
+    const int* wg_blk_ptr;      // [workgroups + 1]
+    const int* wg_blk;          // node blocks, ascending, per workgroup
+    const int* blk_expect;      // [node blocks]
+    unsigned int* blk_count;    // [node blocks]
+    unsigned int epoch;
+    int n_ent;
+    NodeArgs node;
+    EncW w;
+    EncOut eo;
+};
 
 #include "ccsp_energy.h"
 #include "ccsp_bf16x3.h"
@@ -1250,6 +1362,8 @@ struct ccsp_model {
     int pe2_exp = 0;
     float pe0_c1 = 0.0f, pe0_c2 = 0.0f;   // bound of the pose encoder's layer-1 pre-activation: c1 max|x| + c2
     int energy_bwd_h2 = 1;            // CCSP_ENERGY_BWD=bf16x3 keeps the backward GEMMs on the six-product bf16 kernels
+    int fuse_node = 0;                // CCSP_FUSE_NODE=1: fold the node update into the edge kernel's tail (FuseArgs).  Measured slower than
+                                      // the separate launch (C2 467 -> 383, C5 250 -> 182 samples/s, profiles/r03_findings.md), so off by default
     int node_generic = 0;             // CCSP_NODE=generic: k_node instead of k_node_direct in direct-mode chains (A/B runs)
     int valu_node_energy = 0;         // CCSP_NODE_ENERGY_VALU: the pre-MFMA node-energy kernel (A/B runs; never combined with the reuse below)
     int mala_reuse = 1;               // (CCSP_MALA_REUSE=0 turns it off) an inner step that accepted NO node leaves x where it was, so the next step's
@@ -1296,6 +1410,13 @@ struct ccsp_graph {
     float* umax = nullptr;             // [R][8] max |U| per row and 64-column piece (k_rowgemm_h2 / _h3 -> k_edge_h2)
     int *t2_row0 = nullptr, *t2_nrows = nullptr, *t2_ts = nullptr;   // 128-row tiles of k_rowgemm_bf2 (pairs of plan tiles)
     int n_tiles2 = 0;
+    // node update folded into the edge kernel's tail (FuseArgs): lists for edge tiles of fuse_me edges, arrival counters
+    int *fuse_ptr = nullptr, *fuse_list = nullptr, *fuse_expect = nullptr;
+    int *fuse_u0 = nullptr, *fuse_u1 = nullptr, *fuse_pos = nullptr;      // e_u0 / e_u1 / ent_pos in the fused kernel's edge order
+    unsigned int* fuse_count = nullptr;
+    int fuse_me = 0, fuse_blocks = 0;
+    unsigned int fuse_epoch = 0;
+    std::vector<int> h_fuse;                  // kept alive for the async upload
     int4 *td64 = nullptr, *td128 = nullptr;   // the same tile lists as {row0, nrows, 2 type + slot, 0} records (k_rowgemm_h2: one scalar load per tile)
     std::vector<int4> h_td;                   // kept alive for the async upload
     int* urow_ts;
@@ -1424,30 +1545,111 @@ void launch_rowgemm_h2(ccsp_model* m, ccsp_graph* g, const float* tau_t, StepRef
 #undef CCSP_ROWGEMM_F
 }
 
-// returns the number of workgroups (= energy partials)
-template <bool ENERGY>
-int launch_edge_h2(ccsp_model* m, ccsp_graph* g, EdgeEnergyArgs en, int* cinc, hipStream_t s) {
-    const int E_act = g->plan.E_act;
+// edges per workgroup of the f16x2 edge kernel for a batch of E_act active edges: 16 (k_edge_h2s) when most of the chip would
+// idle even then, else 32 if the tiles then fit three per CU, else 64
+int edge_tile_edges(const ccsp_model* m, int E_act) {
+    if (m->edge_small > 0 || (m->edge_small < 0 && m->edge_mt <= 0 && nblk(E_act, 16) <= m->ncu)) return 16;
     const int mt = m->edge_mt > 0 ? m->edge_mt : (nblk(E_act, 32) <= 3 * m->ncu ? 1 : 2);
-    if (m->edge_small > 0 || (m->edge_small < 0 && m->edge_mt <= 0 && nblk(E_act, 16) <= m->ncu)) {        // most of the chip would idle even at 16 edges per workgroup
+    return 32 * mt;
+}
+
+// returns the number of workgroups (= energy partials).  fu: fold the node update into the kernel's tail (direct mode)
+template <bool ENERGY>
+int launch_edge_h2(ccsp_model* m, ccsp_graph* g, EdgeEnergyArgs en, int* cinc, hipStream_t s, const FuseArgs* fu = nullptr) {
+    const int E_act = g->plan.E_act;
+    const int me = edge_tile_edges(m, E_act);
+    FuseArgs f0;
+    memset(&f0, 0, sizeof(f0));
+    // (the fused forms hold the node update's registers: two workgroups per CU, so only for tile lists that fit that)
+    const bool fuse = !ENERGY && fu != nullptr && me == g->fuse_me && nblk(E_act, me) <= 2 * m->ncu;
+    const FuseArgs& fa = fuse ? *fu : f0;
+    if (me == 16) {
         const int nws = nblk(E_act, 16);
-        hipLaunchKernelGGL(k_edge_h2s<ENERGY>, dim3(nws), dim3(256), 0, s, E_act, m->d.pose_dim, g->e_u0, g->e_u1, g->U, g->umax, m->Wd1H, m->wd_exp,
-                           m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, en, cinc);
+#define CCSP_EDGE_S(FUSE)                                                                                                                            \
+        hipLaunchKernelGGL((k_edge_h2s<ENERGY, FUSE>), dim3(nws), dim3(256), 0, s, E_act, m->d.pose_dim, FUSE ? g->fuse_u0 : g->e_u0,                     \
+                           FUSE ? g->fuse_u1 : g->e_u1, g->U, g->umax, m->Wd1H, m->wd_exp, m->pd0_b, m->pd2_w, m->pd2_b, FUSE ? g->fuse_pos : g->ent_pos, \
+                           g->O, en, cinc, fa)
+        if constexpr (!ENERGY) { if (fuse) CCSP_EDGE_S(true); else CCSP_EDGE_S(false); }
+        else CCSP_EDGE_S(false);
+#undef CCSP_EDGE_S
         return nws;
     }
-    const int nwg = nblk(E_act, 32 * mt);
-#define CCSP_EDGE_F(MT, L2)                                                                                                                          \
-    hipLaunchKernelGGL((k_edge_h2<ENERGY, MT, L2>), dim3(nwg), dim3(256), 0, s, E_act, m->d.pose_dim, g->e_u0, g->e_u1, g->U, g->umax, m->Wd1H, m->wd_exp, \
-                       m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, en, cinc)
-    if (mt == 1 && nwg <= m->ncu) CCSP_EDGE_F(1, 1);          // a single round of workgroups: the short-latency second layer
-    else if (mt == 1) CCSP_EDGE_F(1, 0);
-    else CCSP_EDGE_F(2, 0);
+    const int mt = me / 32;
+    const int nwg = nblk(E_act, me);
+#define CCSP_EDGE_F(MT, L2, FUSE)                                                                                                                    \
+    hipLaunchKernelGGL((k_edge_h2<ENERGY, MT, L2, FUSE>), dim3(nwg), dim3(256), 0, s, E_act, m->d.pose_dim, FUSE ? g->fuse_u0 : g->e_u0,                \
+                       FUSE ? g->fuse_u1 : g->e_u1, g->U, g->umax, m->Wd1H, m->wd_exp, m->pd0_b, m->pd2_w, m->pd2_b, FUSE ? g->fuse_pos : g->ent_pos,     \
+                       g->O, en, cinc, fa)
+    if constexpr (!ENERGY) {
+        if (fuse && mt == 1) {
+            if (nwg <= m->ncu) CCSP_EDGE_F(1, 1, true); else CCSP_EDGE_F(1, 0, true);
+            return nwg;
+        }
+    }
+    if (mt == 1 && nwg <= m->ncu) CCSP_EDGE_F(1, 1, false);  // a single round of workgroups: the short-latency second layer
+    else if (mt == 1) CCSP_EDGE_F(1, 0, false);
+    else CCSP_EDGE_F(2, 0, false);
 #undef CCSP_EDGE_F
     return nwg;
 }
 
+// Tables of the fused node update for edge tiles of `me` edges.  The edge kernel may take the edges in any order (the decoder is
+// shared by all types; every output goes to its own CSR slot), so the fused form walks them NODE-BLOCK-major instead of
+// type-major: a tile's outputs then land in one or two 16-node blocks and a block is completed by the few neighbouring tiles
+// that feed it -- in the middle of the launch, on many different workgroups.  (Type-major order made the last type's tiles the
+// last arrivers of nearly every block: a handful of workgroups ran all the node blocks one after the other, 85 us per launch.)
+// Uploads: the permuted edge tables, the blocks each tile touches, the tiles per block.
+int fuse_prepare(ccsp_model* m, ccsp_graph* g, int me, hipStream_t s) {
+    if (g->fuse_me == me) return 0;
+    const ccsp::Plan& p = g->plan;
+    const int n_wg = nblk(p.E_act, me), n_blk = nblk(g->N, NODE_TILE);
+    std::vector<int> perm(p.E_act);
+    for (int k = 0; k < p.E_act; ++k) perm[k] = k;
+    std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) {
+        const int bx = (p.e_a[x] < p.e_b[x] ? p.e_a[x] : p.e_b[x]) / NODE_TILE, by = (p.e_a[y] < p.e_b[y] ? p.e_a[y] : p.e_b[y]) / NODE_TILE;
+        return bx < by;
+    });
+    std::vector<std::vector<int>> per_wg(n_wg);
+    std::vector<int> expect(n_blk, 0), stamp(n_blk, -1);
+    for (int w = 0; w < n_wg; ++w) {
+        for (int j = w * me; j < (w + 1) * me && j < p.E_act; ++j)
+            for (int b : {p.e_a[perm[j]] / NODE_TILE, p.e_b[perm[j]] / NODE_TILE})
+                if (stamp[b] != w) { stamp[b] = w; per_wg[w].push_back(b); expect[b]++; }
+    }
+    for (int b = 0; b < n_blk; ++b)                         // blocks no edge reaches (isolated nodes): their update still has to run
+        if (expect[b] == 0) { per_wg[b % n_wg].push_back(b); expect[b] = 1; }
+    std::vector<int> ptr(n_wg + 1, 0), list;
+    for (int w = 0; w < n_wg; ++w) {
+        std::sort(per_wg[w].begin(), per_wg[w].end());
+        list.insert(list.end(), per_wg[w].begin(), per_wg[w].end());
+        ptr[w + 1] = (int)list.size();
+    }
+    std::vector<int> pu0(p.E_act), pu1(p.E_act), ppos((size_t)2 * p.E_act);
+    for (int j = 0; j < p.E_act; ++j) {
+        pu0[j] = p.e_u0[perm[j]]; pu1[j] = p.e_u1[perm[j]];
+        ppos[2 * j] = p.ent_pos[2 * perm[j]]; ppos[2 * j + 1] = p.ent_pos[2 * perm[j] + 1];
+    }
+    HIP_TRY(hipStreamSynchronize(s));                       // (a previous upload may still be reading h_fuse)
+    g->h_fuse = ptr;
+    g->h_fuse.insert(g->h_fuse.end(), list.begin(), list.end());
+    g->h_fuse.insert(g->h_fuse.end(), expect.begin(), expect.end());
+    g->h_fuse.insert(g->h_fuse.end(), pu0.begin(), pu0.end());
+    g->h_fuse.insert(g->h_fuse.end(), pu1.begin(), pu1.end());
+    g->h_fuse.insert(g->h_fuse.end(), ppos.begin(), ppos.end());
+    int* d = nullptr;
+    if (dev_upload(g->allocs, &d, g->h_fuse, s)) return 1;
+    g->fuse_ptr = d; g->fuse_list = d + ptr.size(); g->fuse_expect = g->fuse_list + list.size();
+    g->fuse_u0 = g->fuse_expect + n_blk; g->fuse_u1 = g->fuse_u0 + p.E_act; g->fuse_pos = g->fuse_u1 + p.E_act;
+    if (!g->fuse_count || g->fuse_blocks != n_blk) { if (dev_alloc(g->allocs, &g->fuse_count, (size_t)n_blk)) return 1; }
+    g->fuse_blocks = n_blk;
+    g->fuse_me = me;
+    return 0;
+}
+
+// fused: if non-null (direct-mode chain, f16x2 kernels), the node update with these arguments is folded into the edge kernel's
+// tail and *did_fuse is set; the caller then launches no node kernel
 template <int H>
-int launch_eval(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s, bool tabled = false) {
+int launch_eval(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s, bool tabled = false, const NodeArgs* fused = nullptr, bool* did_fuse = nullptr) {
     // U = pose_emb . Wp^T ; O = decoder(...)
     // tabled (hipGraph mode): the timestep comes from the device step table, see StepEntry
     const ccsp::Plan& p = g->plan;
@@ -1462,7 +1664,18 @@ int launch_eval(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s, bool tabled 
         if (m->f16x2) {
             launch_rowgemm_h2(m, g, tau_t, ref, tau_stride, s);
             prof_mark(g, s, CCSP_K_EDGE);
-            launch_edge_h2<false>(m, g, EdgeEnergyArgs{}, cinc, s);
+            FuseArgs fu;
+            const bool fuse = fused != nullptr && g->fuse_me > 0 && g->fuse_me == edge_tile_edges(m, p.E_act) && g->fuse_me <= 32 &&
+                              nblk(p.E_act, g->fuse_me) <= 2 * m->ncu;
+            if (fuse) {
+                memset(&fu, 0, sizeof(fu));
+                fu.wg_blk_ptr = g->fuse_ptr; fu.wg_blk = g->fuse_list; fu.blk_expect = g->fuse_expect; fu.blk_count = g->fuse_count;
+                fu.epoch = ++g->fuse_epoch; fu.n_ent = 2 * p.E_act;
+                fu.node = *fused; fu.w = enc_pose(m);
+                fu.eo.f32 = nullptr; fu.eo.bf3 = nullptr; fu.eo.h2 = g->pembH; fu.eo.h2_exp = g->pexp;
+            }
+            launch_edge_h2<false>(m, g, EdgeEnergyArgs{}, cinc, s, fuse ? &fu : nullptr);
+            if (did_fuse) *did_fuse = fuse;
             prof_mark(g, s, -1);
             g->evals++;
             return 0;
@@ -2022,26 +2235,43 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
             g->evals += 1 + S;
         }
     } else {
+        // the node update rides in the edge kernel's tail when the f16x2 kernels run with 16- / 32-edge tiles (FuseArgs)
+        for (const Lane& L : lanes) {
+            ccsp_graph* g = L.g;
+            bool can = false;
+            if constexpr (H == 256)
+                can = m->fuse_node && m->f16x2 && m->bf16x3 && m->pe2_wH && !m->node_generic && m->d.model_kind == CCSP_MODEL_DIFFUSION_CCSP &&
+                      !m->d.energy_wrapper && g->plan.E_act > 0 && edge_tile_edges(m, g->plan.E_act) <= 32 &&
+                      nblk(g->plan.E_act, edge_tile_edges(m, g->plan.E_act)) <= 2 * m->ncu;
+            if (can) {
+                if (fuse_prepare(m, g, edge_tile_edges(m, g->plan.E_act), L.s)) return 1;
+                HIP_TRY(hipMemsetAsync(g->fuse_count, 0, (size_t)g->fuse_blocks * sizeof(unsigned int), L.s));
+                g->fuse_epoch = 0;
+            } else {
+                g->fuse_me = 0;
+            }
+        }
         for (int t = t_first; t >= t_last; --t) {
             const int S = steps_at(m, sampler, t);
             for (int e = 0; e <= S; ++e) {
                 for (const Lane& L : lanes) {
                     ccsp_graph* g = L.g;
                     NodeArgs a = node_args(m, g);
-                    if (m->d.model_kind == CCSP_MODEL_STRUCT_DIFFUSION) {
-                        if (launch_eval_sd<H>(m, g, t, L.s)) return 1;
-                        a.src = 1; a.eps_buf = g->eps;
-                    } else {
-                        if (launch_eval<H>(m, g, t, L.s)) return 1;
-                        a.src = 0;
-                    }
                     a.do_encode = 1;
                     a.step = e == 0 ? STEP_ANCESTRAL : STEP_ULA;
                     a.reset_mask = (e == S);
                     a.hist = e == S ? hist_at(L, T - t) : nullptr;
                     sched(a, t);
                     if (noise_for(L, call0[t] + (uint64_t)e, a.noise)) return 1;
-                    launch_node<H>(m, g, a, L.s);
+                    bool fused = false;
+                    if (m->d.model_kind == CCSP_MODEL_STRUCT_DIFFUSION) {
+                        if (launch_eval_sd<H>(m, g, t, L.s)) return 1;
+                        a.src = 1; a.eps_buf = g->eps;
+                    } else {
+                        a.src = 0;
+                        if (launch_eval<H>(m, g, t, L.s, false, g->fuse_me > 0 ? &a : nullptr, &fused)) return 1;
+                    }
+                    if (!fused) launch_node<H>(m, g, a, L.s);
                 }
             }
         }
@@ -2337,6 +2567,7 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     if (const char* e = getenv("CCSP_EDGE_SMALL")) m->edge_small = atoi(e) != 0;
     m->valu_node_energy = getenv("CCSP_NODE_ENERGY_VALU") != nullptr;
     if (const char* e = getenv("CCSP_NODE")) m->node_generic = strcmp(e, "generic") == 0;
+    if (const char* e = getenv("CCSP_FUSE_NODE")) m->fuse_node = atoi(e) != 0;
     {
         int dev = 0;
         hipDeviceProp_t prop;
