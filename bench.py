@@ -18,10 +18,17 @@ in HBM before the timed region.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+    python bench.py --gpus N --scaling strong     C3 proper: 2048 graphs in total, split over the N ranks (default: weak, 256 per GPU)
+
 Rank 0 prints ONE JSON line.  Extra blocks:
   "roofline"      every kernel of the chain timed launch by launch with HIP events on the chain's own stream in a separate
-                  profiled pass (ccsp_kernel_stats); the dominant kernel priced as EXECUTED matrix-pipe flops / its mean
-                  duration / the dense peak of the pipe that runs them (frac <= 1).  The reference formulation's
+                  profiled pass (ccsp_kernel_stats); the dominant kernel priced twice -- EXECUTED matrix-pipe flops / its mean
+                  duration / the dense peak of the pipe that runs them (frac_mfma), and its fabric-side bytes / duration /
+                  8 TB/s (frac_bytes) -- and `bound` names the larger.  The bytes are measured in THIS run: two rocprofv3 --pmc
+                  passes (FETCH_SIZE, WRITE_SIZE; separate passes, FETCH_SIZE doubled: MI355X_MICROARCH.md, HBM section) over
+                  tools/profile_eval.py on the same batch, kernel symbol and variant checked against what the timed pass ran;
+                  if rocprofv3 is not available the committed summary under profiles/ is used instead and stamped with its
+                  git blob hash (and refused when it was taken on another kernel variant).  The reference formulation's
                   ALGORITHMIC flops over the same time are reported beside it, not as the fraction: the
                   row factorisation executes 3.7x fewer flops than the reference's per-edge products.
   "cpu_baseline"  the cost-faithful PyTorch-CPU port of the reference sampler (oracle/torch_proxy.py) timed on this box's
@@ -105,8 +112,10 @@ def encoder_mode(mma):
     return 'f16x2' if mma == 'f16x2' and os.environ.get('CCSP_ENC', '') != 'f32' else 'f32'
 
 
-def kernel_symbol(label, mma):
+def kernel_symbol(label, mma, energy=False):
     row = KERNEL_SYMBOLS.get(label, {})
+    if label == 'node update + pose encoder':      # direct-mode chains on the f16x2 kernels run the straight-line form
+        return 'k_node_direct' if (mma == 'f16x2' and not energy and os.environ.get('CCSP_NODE', '') != 'generic') else 'k_node<256'
     if label == 'node energy backward':
         return 'k_node_energy_h2' if encoder_mode(mma) == 'f16x2' else 'k_node_energy_mfma'
     return row.get(backward_mode(mma) if label in ('edge decoder backward', 'row GEMM (transpose)') else mma, '')
@@ -142,26 +151,79 @@ KERNEL_SYMBOLS = {      # label -> kernel symbol prefix by GEMM mode (for the PM
 }
 
 
-def pmc_traffic(config, symbol):
-    """fabric-side bytes per launch of `symbol` from THIS round's rocprofv3 --pmc passes (profiles/r02_pmc_<config>.txt,
-    made by tools/pmc_run.sh: separate passes, FETCH_SIZE and WRITE_SIZE in KiB per dispatch; FETCH_SIZE doubled per
-    MI355X_MICROARCH.md, HBM section: 16-B/lane reads are tallied at half their bytes on gfx950).  Infinity-Cache hits are
-    included in these counters, so this is an upper bound on HBM bytes.  None when the summary does not hold the kernel."""
-    path = os.path.join(ROOT, 'profiles', 'r02_pmc_%s.txt' % config)
-    try:
-        cur, got = None, {}
-        for line in open(path):
-            if not line.startswith(' '):
-                cur = line.strip()
-                continue
-            f = line.split()
-            if f and f[0] in ('FETCH_SIZE', 'WRITE_SIZE') and cur is not None and cur.startswith(symbol):
-                got[f[0]] = float(f[2])
-        if len(got) != 2:
-            return None
-        return got['FETCH_SIZE'] * 1024.0 * 2.0 + got['WRITE_SIZE'] * 1024.0
-    except OSError:
-        return None
+def _git_blob_hash(path):
+    import hashlib
+    data = open(path, 'rb').read()
+    return hashlib.sha1(b'blob %d\0' % len(data) + data).hexdigest()
+
+
+def pmc_traffic_file(config, symbols):
+    """fabric-side bytes per launch of each kernel whose name starts with one of `symbols`, from the COMMITTED rocprofv3 --pmc
+    summary of this round (profiles/r03_pmc_<config>.txt, made by tools/pmc_run.sh).  -> ({symbol: {kernel name, bytes}}, stamp)"""
+    path = os.path.join(ROOT, 'profiles', 'r03_pmc_%s.txt' % config)
+    if not os.path.isfile(path):
+        return {}, None
+    cur, got = None, {}
+    for line in open(path):
+        if not line.startswith(' '):
+            cur = line.strip()
+            continue
+        f = line.split()
+        if f and f[0] in ('FETCH_SIZE', 'WRITE_SIZE') and cur is not None:
+            got.setdefault(cur, {})[f[0]] = float(f[2])
+    out = {}
+    for sym in symbols:
+        for name, d in got.items():
+            if name.startswith(sym) and len(d) == 2:
+                out[sym] = {'kernel_name': name, 'bytes': d['FETCH_SIZE'] * 1024.0 * 2.0 + d['WRITE_SIZE'] * 1024.0}
+    return out, {'source': 'profiles/r03_pmc_%s.txt' % config, 'git_blob': _git_blob_hash(path)}
+
+
+def pmc_traffic_live(config, graphs, symbols, timeout=240):
+    """the same figures measured NOW: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two passes: they do not fit one) over
+    tools/profile_eval.py -- single evaluations of the same per-GPU batch in a child process -- with nothing but --kernel-trace next
+    to the counters.  Units: KiB per dispatch; FETCH_SIZE doubled (16-byte-per-lane reads are tallied at half their bytes on
+    gfx950, MI355X_MICROARCH.md HBM section).  Infinity-Cache hits are included: an upper bound on HBM bytes.
+    -> ({symbol: {kernel name, bytes}}, stamp) or ({}, reason)"""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.isfile('/opt/rocm/bin/rocprofv3') else None)
+    if exe is None:
+        return {}, {'source': 'none', 'reason': 'rocprofv3 not found'}
+    vals = {}
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = tempfile.mkdtemp(prefix='ccsp_pmc_', dir='/tmp')
+        try:
+            cmd = [exe, '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', d, '--', sys.executable,
+                   os.path.join(ROOT, 'tools', 'profile_eval.py'), '6', str(graphs), config]
+            r = subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+            files = glob.glob(d + '/**/*counter_collection.csv', recursive=True)
+            if r.returncode != 0 or not files:
+                return {}, {'source': 'none', 'reason': 'rocprofv3 --pmc %s failed (rc %d)' % (counter, r.returncode)}
+            acc = {}
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if row['Counter_Name'] == counter:
+                        name = row['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
+                        acc.setdefault(name, []).append(float(row['Counter_Value']))
+            vals[counter] = {k: sum(v) / len(v) for k, v in acc.items()}
+        except Exception as e:           # noqa: a profiler problem must not take the benchmark down
+            return {}, {'source': 'none', 'reason': 'rocprofv3 --pmc %s: %s' % (counter, e)}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    out = {}
+    for sym in symbols:
+        for name in vals['FETCH_SIZE']:
+            if name.startswith(sym) and name in vals['WRITE_SIZE']:
+                out[sym] = {'kernel_name': name, 'bytes': vals['FETCH_SIZE'][name] * 1024.0 * 2.0 + vals['WRITE_SIZE'][name] * 1024.0}
+    return out, {'source': 'live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two passes) over tools/profile_eval.py 6 %d %s in this run' % (graphs, config)}
+
+
+def algorithmic_bytes(n_nodes, n_types_present, H, P, grasp):
+    """bytes one evaluation must touch -- the weights of the present types + encoders / decoder + state"""
+    kin = (6 if grasp else 5) * H
+    per_type = (2 * H * kin + 2 * H) * 4
+    shared = ((H // 2) * 8 + H * (H // 2) + (H // 2) * P + H * (H // 2) + (H // 2) * H + P * (H // 2) + 3 * H) * 4
+    return n_types_present * per_type + shared + 3 * n_nodes * P * 4
 
 
 def main():
@@ -171,6 +233,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--config', default='c2', choices=sorted(CONFIGS) + ['c3'])
     ap.add_argument('--graphs-per-gpu', type=int, default=0, help='override the configuration\'s per-GPU shard size')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                    help='weak: the configuration\'s shard on every GPU (C3 at N = 8).  strong: C3 proper -- 2048 graphs in total (8 shards '
+                         'of the configuration), split over the N ranks')
+    ap.add_argument('--no-live-pmc', action='store_true', help='do not run the rocprofv3 --pmc passes (roofline.traffic from profiles/ instead)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-evaluate', action='store_true', help='skip the Trainer.evaluate-style solved accounting (c2 only)')
@@ -200,6 +266,11 @@ def main():
     from diffusion_ccsp_amd import (ComposedEBMDenoiseFn, ConstraintDiffuser, GaussianDiffusion, device_info, sharding, worlds)
     from diffusion_ccsp_amd import _lib
     B = args.graphs_per_gpu or cfg['graphs']
+    if args.scaling == 'strong':
+        total = 8 * cfg['graphs']
+        if total % world:
+            raise SystemExit('--scaling strong: %d graphs do not split over %d ranks' % (total, world))
+        B = total // world
     mode, energy = cfg['mode'], cfg['energy']
     dims = worlds.MODE_DIMS[mode]
     P, grasp = dims[-1][0], len(dims) == 3
@@ -252,10 +323,14 @@ def main():
     evals_per_chain = T_STEPS * (1 + (2 if cfg['EBM'] == 'MALA' else 1) * S_LANGEVIN)
 
     rec = {
-        'metric': 'samples/sec (all chains; solved_samples_per_s counts the solved ones), T=1000 %s, %s' % (cfg['EBM'], cfg['label'].split(':')[1].split(',')[0].strip() + ' %d-obj' % cfg['n_objects']),
+        'metric': 'solved samples/sec, T=1000 %s, %s (value = all chains per second; solved_samples_per_s = value x solved_fraction, both top-level)' %
+                  (cfg['EBM'], cfg['label'].split(':')[1].split(',')[0].strip() + ' %d-obj' % cfg['n_objects']),
         'value': value, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': args.scaling,
+        'vs_baseline': None,
+        'dtype': {'f16x2': 'f32 (f16x2 split operands: 3 fp16 MFMA products per fp32 product, fp32 accumulate)',
+                  'bf16x3': 'f32 (bf16x3 split operands: 6 bf16 MFMA products per fp32 product, fp32 accumulate)'}.get(os.environ.get('CCSP_MMA', 'f16x2'), 'f32'),
+        'data': 'synthetic',
         'config': {'workload': '%s, %d graphs per GPU, hidden_dim %d' % (cfg['label'], B, HIDDEN),
                    'name': args.config, 'graphs_per_gpu': B, 'nodes_per_gpu': n_nodes, 'edges_per_gpu': n_edges,
                    'evaluations_per_chain': evals_per_chain,
@@ -337,19 +412,40 @@ def main():
         R, E_act = plan['R'], plan['E_act']
         mma = os.environ.get('CCSP_MMA', 'f16x2')
         f_eval, f_node, f_edge = algorithmic_flops(n_nodes, E_act, HIDDEN, P, grasp)
+        # which variants of the tile kernels this (one-lane, full-batch) pass ran, and the counters of the same variants
+        row_mode, edge_tile = gd.kernel_variant()
+        variant = {'row GEMM (forward)': 'k_rowgemm_h2<256, 512, %d>' % row_mode,
+                   'edge decoder (forward)': 'k_edge_h2s' if edge_tile == 16 else 'k_edge_h2<%s, %d' % ('true' if energy else 'false', edge_tile // 32)}
+        syms = sorted(set(filter(None, (kernel_symbol(label, mma, energy) for label in ks))))
+        pmc_cfg = args.config if args.config != 'c3' else 'c2'
+        traffic, stamp = ({}, None)
+        if world == 1 and not args.no_live_pmc and mma == 'f16x2':
+            del b
+            traffic, stamp = pmc_traffic_live(pmc_cfg, B, syms)
+        if not traffic:
+            live_reason = stamp
+            traffic, stamp = pmc_traffic_file(pmc_cfg, syms)
+            if stamp is not None and live_reason is not None:
+                stamp['live_pass'] = live_reason.get('reason', 'not run')
         kernels = []
         for label, (calls, ms) in ks.items():
             w = executed_work(label, n_nodes, E_act, R, HIDDEN, mma)
-            sym = kernel_symbol(label, mma)
+            sym = kernel_symbol(label, mma, energy)
             ent = {'kernel': label, 'symbol': sym, 'calls_timed': calls, 'us_mean': 1e3 * ms}
             if w is not None:
                 flops, prods, pipe = w
                 ent.update({'executed_flops_fp32_equiv': flops, 'products_per_fp32_product': prods, 'pipe': pipe,
                             'pipe_tflops': prods * flops / (ms * 1e-3) / 1e12, 'pipe_peak_tflops': PEAKS[pipe],
                             'frac': prods * flops / (ms * 1e-3) / 1e12 / PEAKS[pipe]})
-            tr = pmc_traffic(args.config if args.config != 'c3' else 'c2', sym) if sym else None
+            tr = traffic.get(sym)
             if tr is not None:
-                ent['fabric_bytes_per_launch'] = tr
+                want = variant.get(label)
+                if want is None or tr['kernel_name'].startswith(want):
+                    ent['fabric_bytes_per_launch'] = tr['bytes']
+                    ent['frac_bytes'] = tr['bytes'] / (ms * 1e-3) / 8.0e12
+                    ent['counters_taken_on'] = tr['kernel_name']
+                else:                        # counters of another variant of the kernel: not this launch's traffic
+                    ent['fabric_bytes_refused'] = 'counters are of %s, the timed pass ran %s' % (tr['kernel_name'], want)
             kernels.append(ent)
         timed = sum(k['us_mean'] * k['calls_timed'] for k in kernels)
         for k in kernels:
@@ -358,12 +454,27 @@ def main():
         # evaluations seen by the profiler = launches of the forward row GEMM
         n_eval_timed = ks.get('row GEMM (forward)', (0, 0.0))[0]
         us_eval = timed / n_eval_timed if n_eval_timed else None
+        frac_mfma = dom['frac']
+        frac_bytes = dom.get('frac_bytes')
+        by_bytes = frac_bytes is not None and frac_bytes > frac_mfma
+        eval_labels = [k for k in kernels if k['kernel'] not in ('energy sum', 'HMC elementwise')]
+        fabric_eval = sum(k['fabric_bytes_per_launch'] for k in eval_labels) if eval_labels and all('fabric_bytes_per_launch' in k for k in eval_labels) else None
+        types_present = int(len(set(np.asarray(batch_np.edge_attr).astype(np.int64).tolist()) & set(range(cfg['n_types']))))
+        alg_bytes = algorithmic_bytes(n_nodes, types_present, HIDDEN, P, grasp)
         rec['roofline'] = {
-            'bound': 'mfma', 'achieved': dom['pipe_tflops'], 'peak': dom['pipe_peak_tflops'], 'unit': 'TFLOP/s', 'frac': dom['frac'],
-            'traffic': dom.get('fabric_bytes_per_launch'),
-            'kernel': '%s: %s' % (dom['kernel'], dom['symbol']),
-            'note': 'achieved = flops the dominant kernel EXECUTES on the %s matrix pipe (%d MFMA products per fp32 product after the row '
-                    'factorisation) / its mean launch duration (HIP events on the chain stream, launch to next mark); peak = dense %s peak' %
+            'bound': 'hbm' if by_bytes else 'mfma',
+            'achieved': (dom['fabric_bytes_per_launch'] / (dom['us_mean'] * 1e-6) / 1e9) if by_bytes else dom['pipe_tflops'],
+            'peak': 8000.0 if by_bytes else dom['pipe_peak_tflops'], 'unit': 'GB/s' if by_bytes else 'TFLOP/s',
+            'frac': frac_bytes if by_bytes else frac_mfma,
+            'frac_mfma': frac_mfma, 'frac_bytes': frac_bytes,
+            'traffic': dom.get('fabric_bytes_per_launch'), 'traffic_source': stamp,
+            'fabric_bytes_per_evaluation': fabric_eval, 'algorithmic_bytes_per_evaluation': alg_bytes,
+            'wasted_traffic_ratio': (fabric_eval / alg_bytes) if fabric_eval else None,
+            'kernel': '%s: %s' % (dom['kernel'], dom.get('counters_taken_on') or variant.get(dom['kernel']) or dom['symbol']),
+            'note': 'the dominant kernel priced twice: frac_mfma = flops it EXECUTES on the %s matrix pipe (%d MFMA products per fp32 product after '
+                    'the row factorisation) / its mean launch duration (HIP events on the chain stream, launch to next mark) / the dense %s peak; '
+                    'frac_bytes = its fabric-side bytes (2 x FETCH_SIZE + WRITE_SIZE: Infinity-Cache hits included, an upper bound on HBM bytes) / '
+                    'the same duration / 8 TB/s.  `bound`, `achieved`, `peak`, `frac` are those of the larger fraction' %
                     (dom['pipe'], dom['products_per_fp32_product'], dom['pipe']),
             'frac_fp32_equiv': dom['executed_flops_fp32_equiv'] / (dom['us_mean'] * 1e-6) / 1e12 / PEAKS['f32'],
             'kernels': kernels,

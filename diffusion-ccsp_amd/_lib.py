@@ -109,6 +109,7 @@ def lib():
     L.ccsp_model_set_energy_hook.argtypes = [vp, vp, vp]
     L.ccsp_kernel_stats.argtypes = [vp, i32, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.c_char_p, i32]
     L.ccsp_chain_skipped.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.ccsp_graph_variant.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.ccsp_plan_host.argtypes = [i32, i32, i32] + [vp] * 14
     _lib = L
     return L

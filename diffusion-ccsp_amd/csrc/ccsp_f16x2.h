@@ -1107,7 +1107,13 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_h2(int E_act, int P, const 
     constexpr int APL = BM * H2_BK, STAGE = 2 * APL + 2 * H2_BPL;             // 8 KB of A planes + 16 KB of B planes per stage
     constexpr int C_LD = BN + 4;
     static_assert(2 * STAGE * 2 >= BM * C_LD * 4, "epilogue tile must fit the stages");
-    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * STAGE + 2 * 8 * KD];          // stages + pose_decoder.2.weight [8][128] fp32
+    float* W2s = reinterpret_cast<float*>(smem + 2 * STAGE);
+    // Round 3: this kernel spent most of its 30 us in serialized round trips -- the P loads of -O under `p < P` branches, and the P
+    // rows of pose_decoder.2.weight re-read from global memory for EVERY row pass of EVERY chunk, each load under its own branch
+    // and waited for with vmcnt(0) (hipcc's wait insertion takes the minimum over paths, and gfx950 counts loads and stores on
+    // one counter).  Now: the weight is staged in LDS once, rows p >= P zeroed, and the -O loads are unconditional (clamped
+    // index, select) -- no branch touches a load.
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int ct = bid & 1, s = (bid >> 1) & 1, e0 = (bid >> 2) * BM;
     const int n0 = ct * BN;
@@ -1150,11 +1156,11 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_h2(int E_act, int P, const 
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
-            if (p < P) {
-                const float4 w2 = *reinterpret_cast<const float4*>(Wd2 + (size_t)p * KD + c * H2_BK + lq * 4);
-                g.x = fmaf(go[i][p], w2.x, g.x); g.y = fmaf(go[i][p], w2.y, g.y);
-                g.z = fmaf(go[i][p], w2.z, g.z); g.w = fmaf(go[i][p], w2.w, g.w);
-            }
+            const float4 w2 = *reinterpret_cast<const float4*>(W2s + p * KD + c * H2_BK + lq * 4);
+            const float gp = go[i][p];
+            // (terms p >= P: go = 0 and a zero weight row -- exactly 0, added to nothing: the select keeps a NaN / Inf out)
+            g.x = p < P ? fmaf(gp, w2.x, g.x) : g.x; g.y = p < P ? fmaf(gp, w2.y, g.y) : g.y;
+            g.z = p < P ? fmaf(gp, w2.z, g.z) : g.z; g.w = p < P ? fmaf(gp, w2.w, g.w) : g.w;
         }
         const float4 q = rq[set][i];
         const float h[4] = {g.x * silu_grad_fast(q.x), g.y * silu_grad_fast(q.y), g.z * silu_grad_fast(q.z), g.w * silu_grad_fast(q.w)};
@@ -1182,7 +1188,8 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_h2(int E_act, int P, const 
         float sum = 0.0f;
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
-            go[i][p] = p < P ? -o[p] : 0.0f;                       // 2 d = -(-2 d)
+            const float ov = o[p < P ? p : P - 1];                 // (unconditional load, clamped: no branch)
+            go[i][p] = p < P ? -ov : 0.0f;                         // 2 d = -(-2 d)
             sum += fabsf(go[i][p]);
         }
         a_exp[i] = h2_scale_exp(1.1f * wd2_absmax * sum);
@@ -1192,6 +1199,8 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_h2(int E_act, int P, const 
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.0f;
+    for (int idx = threadIdx.x; idx < 8 * KD; idx += 256) W2s[idx] = idx < P * KD ? Wd2[idx < P * KD ? idx : 0] : 0.0f;
+    __syncthreads();                                              // (the staged weight is read by store_a below)
     store_a(0, 0, 0, 0);
     store_a(0, 0, 0, 1);
     store_b(0);

@@ -3107,6 +3107,16 @@ int ccsp_kernel_stats(ccsp_graph* g, int32_t which, int64_t* calls, float* ms_me
     return 0;
 }
 
+int ccsp_graph_variant(ccsp_graph* g, int32_t* row_mode, int32_t* edge_tile) {
+    if (!g) return fail("graph_variant: null graph");
+    ccsp_model* m = g->m;
+    if (!m) return fail("graph_variant: the graph's model was destroyed");
+    const bool h2 = m->f16x2 && m->d.hidden_dim == 256 && m->d.model_kind == CCSP_MODEL_DIFFUSION_CCSP && g->plan.E_act > 0;
+    if (row_mode) *row_mode = h2 ? rowgemm_h2_mode(m, g, 4) : -1;
+    if (edge_tile) *edge_tile = h2 ? edge_tile_edges(m, g->plan.E_act) : -1;
+    return 0;
+}
+
 int ccsp_chain_skipped(ccsp_graph* g, int64_t* evaluations_skipped) {
     if (!g || !evaluations_skipped) return fail("chain_skipped: null argument");
     if (!g->have_events) return fail("chain_skipped: no chain has run on this graph");

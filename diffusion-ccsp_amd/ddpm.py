@@ -251,6 +251,15 @@ class GaussianDiffusion(object):
                 out[name.value.decode()] = (int(n.value), float(ms.value))
         return out
 
+    def kernel_variant(self):
+        """(MODE of k_rowgemm_h2, edges per workgroup of the edge kernel) a one-lane launch on the last chain's graph runs"""
+        g = getattr(self, '_last_graph', None)
+        if g is None:
+            raise _lib.CcspError('no chain has run')
+        rm, et = C.c_int32(), C.c_int32()
+        _lib.check(_lib.lib().ccsp_graph_variant(g.h, C.byref(rm), C.byref(et)))
+        return int(rm.value), int(et.value)
+
     def profile(self, batch, on=True):
         """bracket the evaluation kernels of the next chains on this batch with HIP events"""
         g = self._core()._graph(batch)

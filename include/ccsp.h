@@ -15,6 +15,14 @@
  *    ccsp_edge_outputs never do.  ccsp_chain_run does not wait for the chain it enqueues; it waits
  *    for EARLIER work on the stream only where a host table of a previous chain on the same graph is
  *    about to be rewritten (energy-mode samplers, the opt-in hipGraph mode);
+ *  - streams and threads the library owns: a direct-mode ccsp_chain_run on a batch of >= 6144 active edges cuts it into two
+ *    independent sub-batches ("lanes") that run on two streams created once per model, forked from and joined to the caller's
+ *    stream by events; the two lanes are enqueued by two std::thread workers that live for the duration of the call (a
+ *    chain is 33 000 launches per lane: one thread alternating between streams is launch-bound).  The call returns when both
+ *    have enqueued everything, i.e. it blocks for the enqueue time but not for the chain.  Host cost measured on an MI355X
+ *    box (profiles/r03_findings.md): pinned to two cores (`taskset -c 0-1`) the C2 chain runs at the unpinned rate; with one
+ *    lane (CCSP_LANES=1: no threads) pinned to ONE core likewise.  Energy mode, the transformer baseline and profiled runs
+ *    use the caller's stream only;
  *  - return value 0 = ok, non-zero = error; ccsp_last_error() gives the thread-local message;
  *  - no exceptions cross the boundary; handles are not thread-safe (one per device & stream);
  *  - NaN is data, not an error (isolated nodes give 0/0 exactly like the reference,
@@ -30,7 +38,7 @@ extern "C" {
 #endif
 
 #define CCSP_VERSION_MAJOR 0
-#define CCSP_VERSION_MINOR 3
+#define CCSP_VERSION_MINOR 4
 #define CCSP_MAX_SAMPLES_PER_STEP 100000
 
 typedef struct ccsp_model ccsp_model;   /* ConstraintDiffuser weights + GaussianDiffusion schedule */
@@ -197,6 +205,11 @@ enum { CCSP_K_ROWGEMM = 0, CCSP_K_EDGE = 1, CCSP_K_NODE = 2, CCSP_K_EDGE_BWD = 3
        CCSP_K_NODE_ENERGY = 6, CCSP_K_ENERGY_SUM = 7, CCSP_K_HMC = 8, CCSP_K_SD_EVAL = 9, CCSP_K_COUNT = 10 };
 #define CCSP_PROFILE_MARKS 16384
 int ccsp_kernel_stats(ccsp_graph* graph, int32_t which, int64_t* calls, float* ms_mean, char* name, int32_t name_len);
+/* Which variants of the f16x2 evaluation kernels a ONE-lane launch on this graph runs (they are chosen by tile count, see
+ * csrc/ccsp_f16x2.h): row_mode = MODE of k_rowgemm_h2 (0..4), edge_tile = edges per workgroup of the edge kernel (16: k_edge_h2s,
+ * 32 / 64: k_edge_h2<., 1 | 2, .>); -1 each when the model does not run the f16x2 kernels.  For reports that pair a timing with
+ * counters taken in another process (bench.py). */
+int ccsp_graph_variant(ccsp_graph* graph, int32_t* row_mode, int32_t* edge_tile);
 
 /* Host-only planning entry (needs no device): the one-time index tables ccsp_graph_create builds
  * from the edge lists -- type-sorted edges, the distinct (type, slot, node) rows, their row tiles

@@ -8,6 +8,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
+os.environ.setdefault('CCSP_LANES', '1')          # counters of the one-lane, full-batch launches (the variants bench.py's timed pass runs)
 from bench import CONFIGS, load_weights
 from diffusion_ccsp_amd import ConstraintDiffuser, worlds, _lib
 if os.environ.get('CCSP_SO'):          # ablation builds (tools only)
@@ -24,8 +25,16 @@ wrel = next(w for w in reversed(cfg['weights']) if os.path.isfile(os.path.join(R
 den.load_state_dict(load_weights(os.path.join(ROOT, wrel)))
 batch = getattr(worlds, cfg['batch'])(B, cfg['n_objects'], seed=5).to_torch(dev)
 x = (torch.randn(batch.x.shape[0], dims[-1][0]) * 0.7).to(dev)
-for i in range(n):
-    out = den(x, batch, torch.tensor([500 - i]), eval=True, tag='EBM')
-    out = out[0] if isinstance(out, tuple) else out
+if cfg['energy']:
+    for i in range(n):
+        out = den(x, batch, torch.tensor([500 - i]), eval=True, tag='EBM')
+        out = out[0] if isinstance(out, tuple) else out
+else:
+    # direct mode: a few timesteps of the chain itself on ONE lane (the kernels a chain launches, k_node_direct included;
+    # n evaluations rounded up to whole timesteps of 1 + S)
+    from diffusion_ccsp_amd import GaussianDiffusion
+    gd = GaussianDiffusion(den, timesteps=1000, EBM=cfg['EBM'], samples_per_step=10)
+    nt = max(1, (n + 10) // 11)
+    out = gd.p_sample_segment(batch, x, 500, 500 - nt + 1, seed=3)
 torch.cuda.synchronize()
 print('ok', float(out.abs().max()))
