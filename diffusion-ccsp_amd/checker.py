@@ -15,10 +15,13 @@ Restated here without trimesh / python-fcl:
   * the labeller is worlds.qualitative_constraints (pinned against the reference by golden vectors);
   * FCL is not importable in the build container, so box-box collision is a separating-axis test on the
     oriented footprints (all bodies span the same z range).  Strictly overlapping / strictly apart boxes agree
-    with any exact box-box query by geometry.  **At exact contact the two may differ**: here projections that
-    overlap by <= 1e-9 count as touching = not colliding, FCL may report a contact at zero distance; this can
-    only matter for poses that lie exactly on a boundary -- a measure-zero set for sampled poses, and the
-    generator's scenes keep > 1e-4 clearance (tests/test_checker.py::test_touching_and_near_touching_boxes).
+    with any exact box-box query by geometry.  Contact convention = FCL's: its box-box narrow phase (boxBox2, the
+    ODE dBoxBox test python-fcl's fcl.collide runs for two fcl.Box shapes, envs/collisions.py:62-66,118-127)
+    declares an axis separating only when the gap along it is STRICTLY positive (`s2 = |t.axis| - (ra + rb);
+    if (s2 > 0) return 0`), so boxes at exactly zero distance are in contact = colliding.  Same rule here (round 2
+    had the opposite: touching = free).  It only matters on a measure-zero set of poses; the generator's own scenes
+    keep > 1e-4 clearance.  tests/test_checker.py checks the rule against an independent polygon-distance computation
+    on several hundred configurations at gaps -1e-6, 0 (exactly representable ones), +1e-6 and +1e-4.
 
 Reference quirk kept: the feature columns are stored [w, l, x, y, cs, sn] but unpacked as
 ``w, l, x, y, sn, cs`` (data_utils.py:246), so the yaw used downstream is atan2(col4, col5).
@@ -60,8 +63,9 @@ def _corners(cx, cy, bw, bl, yaw):
     return pts
 
 
-def rects_overlap(a, b, eps=1e-9):
-    """separating-axis test of two oriented rectangles (cx, cy, w, l, yaw); touching is not overlap"""
+def rects_overlap(a, b):
+    """separating-axis test of two oriented rectangles (cx, cy, w, l, yaw); FCL's rule: an axis separates only if the gap
+    along it is strictly positive, so boxes at zero distance collide"""
     if any(math.isnan(v) for v in a) or any(math.isnan(v) for v in b):
         return True                              # an undefined pose counts as a violation
     pa, pb = _corners(*a), _corners(*b)
@@ -70,7 +74,7 @@ def rects_overlap(a, b, eps=1e-9):
         for ax in ((c, s), (-s, c)):
             ja = [p[0] * ax[0] + p[1] * ax[1] for p in pa]
             jb = [p[0] * ax[0] + p[1] * ax[1] for p in pb]
-            if max(ja) <= min(jb) + eps or max(jb) <= min(ja) + eps:
+            if max(ja) < min(jb) or max(jb) < min(ja):
                 return False
     return True
 

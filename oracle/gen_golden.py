@@ -83,7 +83,7 @@ def build_reference(mode, H, weights, energy=False, EBM='ULA', T=1000, S=10, dty
     if dtype == torch.float64:
         torch.set_default_dtype(torch.float64)
     try:
-        model = dfn.ConstraintDiffuser(dims=dims, hidden_dim=H, EBM=EBM, input_mode=mode, energy_wrapper=energy,
+        model = dfn.ConstraintDiffuser(dims=dims, hidden_dim=H, EBM=EBM, input_mode=worlds.ref_mode(mode), energy_wrapper=energy,
                                        device='cpu', verbose=False, model=model_name)
         model.load_state_dict({k: torch.from_numpy(v).to(dtype) for k, v in weights.items()})
         den = dfn.ComposedEBMDenoiseFn(model, ebm_per_steps) if energy else model
@@ -365,6 +365,14 @@ def gen_single_eval_h256():
     ])
 
 
+def gen_single_eval_box():
+    """the reference's default dims (pose_dim 2, RandomSplitWorld boxes) at both widths"""
+    gen_single_eval('single_eval_box', 97, [
+        ('b64', 'diffuse_pairwise_box', 64, 'weights_diffuse_pairwise_box_h64.npz', worlds.box_batch(3, 6, seed=29)),
+        ('b256', 'diffuse_pairwise_box', 256, 'weights_diffuse_pairwise_box_h256.npz', worlds.box_batch(2, 8, seed=30)),
+    ])
+
+
 def gen_single_eval(out_name='single_eval', rng_seed=99, cases=None):
     """single network evaluations, direct mode and energy mode"""
     rec = {}
@@ -573,6 +581,11 @@ def gen_chains(which):
                                                        ebm_per_steps=2),
         'chain_t64_ula': lambda: run_chain('chain_t64_ula', 'diffuse_pairwise', 64, 'weights_diffuse_pairwise_h64.npz',
                                            worlds.triangular_batch(2, 12, seed=35).to_torch(), 'ULA', S=3),
+        # the reference's default dims ((2,0,2),(2,2,4)): pose_dim 2 (RandomSplitWorld boxes, input_mode 'diffuse_pairwise')
+        'chain_b64_ula': lambda: run_chain('chain_b64_ula', 'diffuse_pairwise_box', 64, 'weights_diffuse_pairwise_box_h64.npz',
+                                           worlds.box_batch(3, 6, seed=46).to_torch(), 'ULA', S=5),
+        'chain_b256_ula': lambda: run_chain('chain_b256_ula', 'diffuse_pairwise_box', 256, 'weights_diffuse_pairwise_box_h256.npz',
+                                            worlds.box_batch(2, 8, seed=47).to_torch(), 'ULA', T=200, S=10),
         'chain_r64_ula': lambda: run_chain('chain_r64_ula', 'robot_box', 64, 'weights_robot_box_h64.npz',
                                            worlds.robot_box_batch(2, 10, seed=36).to_torch(), 'ULA', S=5),
         # BASELINE configs C4 / C5 at their hidden width (H = 256): 12-triangle graphs under MALA S = 10 with the
@@ -621,6 +634,8 @@ if __name__ == '__main__':
         gen_single_eval()
     if not which or 'single_eval_h256' in which:
         gen_single_eval_h256()
+    if not which or 'single_eval_box' in which:
+        gen_single_eval_box()
     if not which or 'pre_transform' in which:
         gen_pre_transform()
     if not which or 'struct_diffusion' in which:

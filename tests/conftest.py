@@ -46,7 +46,7 @@ def golden_batch(z, prefix=''):
     return b
 
 
-MODE_TYPES = {'qualitative': 13, 'diffuse_pairwise': 2, 'robot_box': 2, 'stability_flat': 3}
+MODE_TYPES = {'qualitative': 13, 'diffuse_pairwise': 2, 'diffuse_pairwise_box': 2, 'robot_box': 2, 'stability_flat': 3}
 _weights = {}
 
 

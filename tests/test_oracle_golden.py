@@ -48,6 +48,21 @@ def test_single_evaluation_direct(tag, mode, H, wfile):
         assert np.isnan(z[tag + '/out']).any()
 
 
+BOX_CASES = [('b64', 'diffuse_pairwise_box', 64, 'weights_diffuse_pairwise_box_h64.npz'),
+             ('b256', 'diffuse_pairwise_box', 256, 'weights_diffuse_pairwise_box_h256.npz')]
+
+
+@pytest.mark.parametrize('tag,mode,H,wfile', BOX_CASES)
+def test_single_evaluation_default_dims(tag, mode, H, wfile):
+    """the reference's DEFAULT dims ((2,0,2),(2,2,4)) (denoise_fn.py:185, train_utils.py:273: RandomSplitWorld boxes, pose_dim 2)"""
+    z = golden('single_eval_box')
+    m = oracle_model(mode, H, wfile)
+    g = m.graph(golden_batch(z, tag + '/'))
+    assert z[tag + '/poses'].shape[-1] == 2
+    for i, t in enumerate(z[tag + '/t']):
+        assert rel_err(g.denoise(z[tag + '/poses'][i], int(t)), z[tag + '/out'][i]) < 2e-5, (tag, t)
+
+
 def test_single_evaluation_energy():
     z = golden('single_eval')
     tag = 't64e'
@@ -60,7 +75,7 @@ def test_single_evaluation_energy():
 
 
 CHAINS = ['chain_q64_T1000_B4', 'chain_q64_T100_B1', 'chain_q256_T100_B1', 'chain_q64_noebm',
-          'chain_q64_ulaplus', 'chain_t64_ula', 'chain_r64_ula']
+          'chain_q64_ulaplus', 'chain_t64_ula', 'chain_r64_ula', 'chain_b64_ula', 'chain_b256_ula']
 
 
 def _run_oracle_chain(z, f64=False, history=True):

@@ -11,6 +11,11 @@ package's RandomSplitQualitativeWorld generator.  Output: reference state_dict k
 int8 row-quantised like the fixtures (the dequantised values ARE the weights).
 
 usage: python tools/train_gpu.py <minutes> <out.npz> [hidden_dim]
+
+TRAIN_RECIPE=reference: the reference's recipe AS WRITTEN for input_mode 'qualitative' (train_utils.py:87,142-156,217-218;
+ddpm.py:444,519-556): a FIXED set of TRAIN_WORLDS (30000) worlds of TRAIN_OBJECTS (2..5) objects, a DataLoader-style pass over
+a fresh random permutation of it every epoch (batch 128, last batch of an epoch short), TRAIN_STEPS (300000) Adam steps at 5e-4,
+no EMA (the reference's ema_model is None, ddpm.py:426); <minutes> is then only a safety limit.  Checkpoints at CKPT_KSTEPS.
 """
 import math
 import os
@@ -71,15 +76,19 @@ class Denoiser(nn.Module):
 
 
 def to_dev(batch):
-    ei = torch.from_numpy(batch.edge_index).to(dev)
-    ea = torch.from_numpy(batch.edge_attr).to(dev).long()
-    d = {'x': torch.from_numpy(batch.x).to(dev), 'mask': torch.from_numpy(batch.mask).to(dev).bool(), 'ea': [], 'eb': []}
+    """the batch on the device with its per-type edge lists (selected on the host: no device round trip per type)"""
+    ei = np.asarray(batch.edge_index)
+    ea = np.asarray(batch.edge_attr).astype(np.int64)
+    d = {'x': torch.from_numpy(batch.x).to(dev, non_blocking=True), 'mask': torch.from_numpy(batch.mask).to(dev, non_blocking=True).bool(), 'ea': [], 'eb': []}
+    order = np.argsort(ea, kind='stable')
+    bounds = np.searchsorted(ea[order], np.arange(C + 1))
+    e0 = torch.from_numpy(np.ascontiguousarray(ei[0][order])).to(dev, non_blocking=True)
+    e1 = torch.from_numpy(np.ascontiguousarray(ei[1][order])).to(dev, non_blocking=True)
     for i in range(C):
-        sel = ea == i
-        d['ea'].append(ei[0][sel])
-        d['eb'].append(ei[1][sel])
-    cnt = torch.bincount(ei.reshape(-1), minlength=d['x'].shape[0]).float()
-    d['cnt'] = cnt
+        d['ea'].append(e0[bounds[i]:bounds[i + 1]])
+        d['eb'].append(e1[bounds[i]:bounds[i + 1]])
+    cnt = np.bincount(ei.reshape(-1), minlength=batch.x.shape[0]).astype(np.float32)
+    d['cnt'] = torch.from_numpy(cnt).to(dev, non_blocking=True)
     return d
 
 
@@ -107,24 +116,37 @@ def loss_on(net, b, t, noise, sa, sb):
 def main():
     t_end = time.time() + 60.0 * minutes
     rng = np.random.default_rng(0)
-    print('generating worlds ...', flush=True)
+    reference = os.environ.get('TRAIN_RECIPE', '') == 'reference'
+    n_worlds = int(os.environ.get('TRAIN_WORLDS', '30000' if reference else '20000'))
+    lo, hi = [int(v) for v in os.environ.get('TRAIN_OBJECTS', '2,5' if reference else '2,8').split(',')]
+    n_steps = int(os.environ.get('TRAIN_STEPS', '300000')) if reference else None
+    print('generating %d worlds of %d..%d objects ...' % (n_worlds, lo, hi), flush=True)
     pool = []
     t0 = time.time()
-    while len(pool) < 20000 and time.time() - t0 < 150:
-        wd = worlds.sample_qualitative_world(rng, int(rng.integers(2, 9)))
+    while len(pool) < n_worlds and (reference or time.time() - t0 < 150):
+        wd = worlds.sample_qualitative_world(rng, int(rng.integers(lo, hi + 1)))
         pool.append(worlds.encode_qualitative(wd['nodes'], wd['constraints']))
     print('%d graphs in %.0fs' % (len(pool), time.time() - t0), flush=True)
     batches = []
-    for _ in range(1500):
-        idx = rng.integers(0, len(pool), BATCH)
-        batches.append(to_dev(worlds.collate([pool[i] for i in idx])))
+    if reference:
+        # every epoch a new permutation of the fixed set (DataLoader(shuffle=True), ddpm.py:444); the epochs' batches are collated
+        # once and kept on the device as index lists (234 + 1 batches per epoch): an epoch is re-collated when it starts
+        def epoch_batches():
+            perm = rng.permutation(len(pool))
+            return [to_dev(worlds.collate([pool[i] for i in perm[k:k + BATCH]])) for k in range(0, len(pool), BATCH)]
+    else:
+        for _ in range(1500):
+            idx = rng.integers(0, len(pool), BATCH)
+            batches.append(to_dev(worlds.collate([pool[i] for i in idx])))
     torch.manual_seed(0)
     net = Denoiser().to(dev)
     opt = torch.optim.Adam(net.parameters(), lr=5e-4)
     sa, sb = schedule_tables()
     step, t0, run = 0, time.time(), 0.0
     ckpts = set(int(v) * 1000 for v in os.environ.get('CKPT_KSTEPS', '').split(',') if v)
-    while time.time() < t_end:
+    while time.time() < t_end and (n_steps is None or step < n_steps):
+        if reference and step % ((len(pool) + BATCH - 1) // BATCH) == 0:
+            batches = epoch_batches()
         b = batches[step % len(batches)]
         t = torch.randint(0, T, (1,), device=dev)
         loss = loss_on(net, b, t, torch.randn_like(b['x'][:, dims[-1][1]:dims[-1][2]]), sa, sb)
