@@ -40,6 +40,11 @@ class ModelDesc(C.Structure):
         'timesteps', 'normalize', 'energy_wrapper', 'ebm_per_steps', 'model_kind')]
 
 
+class Compose(C.Structure):
+    """ccsp_compose of include/ccsp.h"""
+    _fields_ = [('zero_col', C.c_int32), ('weight_first', C.c_float), ('weight_second', C.c_float), ('normalize', C.c_int32)]
+
+
 class Noise(C.Structure):
     _fields_ = [('mode', C.c_int32), ('_pad', C.c_int32), ('seed', C.c_uint64), ('row_offset', C.c_uint64),
                 ('normal', C.c_void_p), ('n_normal', C.c_uint64), ('uniform', C.c_void_p),
@@ -110,6 +115,8 @@ def lib():
     L.ccsp_kernel_stats.argtypes = [vp, i32, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.c_char_p, i32]
     L.ccsp_chain_skipped.argtypes = [vp, C.POINTER(C.c_int64)]
     L.ccsp_graph_variant.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    L.ccsp_compose_denoise.argtypes = [vp, vp, vp, vp, C.POINTER(Compose), vp, i32, vp, vp]
+    L.ccsp_compose_chain_run.argtypes = [vp, vp, vp, vp, C.POINTER(Compose), i32, C.POINTER(Noise), vp, i32, i32, i32, vp, vp]
     L.ccsp_plan_host.argtypes = [i32, i32, i32] + [vp] * 14
     _lib = L
     return L

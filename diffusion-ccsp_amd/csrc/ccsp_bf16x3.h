@@ -267,6 +267,7 @@ __global__ __launch_bounds__(512) void k_rowgemm_bf2(const unsigned short* __res
 // ------------------------------------------------------------------------------------------
 template <int H> struct EdgeBfCfg;
 template <> struct EdgeBfCfg<256> { static constexpr int WM = 2, WN = 2, TN = 2; };
+template <> struct EdgeBfCfg<128> { static constexpr int WM = 2, WN = 2, TN = 1; };
 template <> struct EdgeBfCfg<64> { static constexpr int WM = 4, WN = 1, TN = 1; };
 
 template <int H>

@@ -31,6 +31,7 @@ __global__ __launch_bounds__(256) void k_energy_sum(const float* __restrict__ pa
 // ------------------------------------------------------------------------------------------
 template <int H> struct BwdCfg;
 template <> struct BwdCfg<256> { static constexpr int WM = 2, WN = 2, TN = 2; };   // 64 x 128 tile, 2 column tiles
+template <> struct BwdCfg<128> { static constexpr int WM = 2, WN = 2, TN = 1; };   // 64 x 64 tile, 2 column tiles
 template <> struct BwdCfg<64> { static constexpr int WM = 2, WN = 2, TN = 1; };    // 64 x 64 tile, 1 column tile
 
 template <int H>

@@ -704,6 +704,7 @@ __device__ __forceinline__ float dot4(const float* __restrict__ a, const float* 
 
 template <int H> struct EdgeCfg;
 template <> struct EdgeCfg<256> { static constexpr int WM = 1, WN = 4, TN = 1; };
+template <> struct EdgeCfg<128> { static constexpr int WM = 2, WN = 2, TN = 1; };
 template <> struct EdgeCfg<64> { static constexpr int WM = 4, WN = 1, TN = 1; };
 
 // ENERGY = true (denoise_fn.py:373-375): the CSR slot receives -2 d = -2 (o - pose) (the direct term of
@@ -1304,6 +1305,14 @@ __global__ void k_unsort_edges(int E_act, int P, const int* __restrict__ e_orig,
 inline int nblk(long n, int b) { return (int)((n + b - 1) / b); }
 
 // stream-ordered scratch of the operator entry points, released on every path out of the scope
+// hidden_dim -> the kernels' compile-time H: the widths built are 64, 128 and 256 (ccsp_model_create rejects the rest)
+template <typename F>
+auto dispatch_h(int H, F&& f) {
+    if (H == 256) return f(std::integral_constant<int, 256>{});
+    if (H == 128) return f(std::integral_constant<int, 128>{});
+    return f(std::integral_constant<int, 64>{});
+}
+
 struct StreamBuf {
     void* p = nullptr;
     hipStream_t s;
@@ -1803,7 +1812,7 @@ int energy_prepare(ccsp_model* m, ccsp_graph* g, hipStream_t s) {
         return 1;
     // identity row tiles of the backward row GEMM (same tiles, rows taken as they are)
     if (dev_upload(reg, &g->tileb_row0, p.tile_row0, s) || dev_upload(reg, &g->tileb_nrows, p.tile_nrows, s) || dev_upload(reg, &g->tileb_ts, p.tile_ts, s)) return 1;
-    const int BMf = H == 256 ? 32 * EdgeCfg<256>::WM : 32 * EdgeCfg<64>::WM;
+    const int BMf = dispatch_h(H, [](auto hc) { return 32 * EdgeCfg<decltype(hc)::value>::WM; });
     g->n_edge_blocks = 2 * nblk(p.E_act, BMf);
     const size_t n_partial = (size_t)(nblk(p.E_act, 16) > g->n_edge_blocks ? nblk(p.E_act, 16) : g->n_edge_blocks) + 1;   // (k_edge_h2s: one per 16 edges)
     if (dev_alloc(reg, &g->Q, (size_t)2 * p.E_act * (H / 2)) || dev_alloc(reg, &g->GZ, (size_t)p.E_act * 2 * H) ||
@@ -2425,13 +2434,12 @@ int graph_build(ccsp_model* m, int N, int E, int F, const float* x, const signed
         const EncW wg{m->ge0_w, m->ge0_b, m->ge2_wT, m->ge2_b, d.geom_dim, nullptr};
         const EncW wr{m->gr0_w, m->gr0_b, m->gr2_wT, m->gr2_b, d.grasp_dim, nullptr};
         if (d.grasp_dim > 0) TRY(dev_alloc(reg, &g->remb, (size_t)N * H));
-        if (H == 256) {
-            hipLaunchKernelGGL(k_encode<256>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, 0, wg, g->gemb);
-            if (d.grasp_dim > 0) hipLaunchKernelGGL(k_encode<256>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, d.grasp_begin, wr, g->remb);
-        } else {
-            hipLaunchKernelGGL(k_encode<64>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, 0, wg, g->gemb);
-            if (d.grasp_dim > 0) hipLaunchKernelGGL(k_encode<64>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, d.grasp_begin, wr, g->remb);
-        }
+        dispatch_h(H, [&](auto hc) {
+            constexpr int HH = decltype(hc)::value;
+            hipLaunchKernelGGL(k_encode<HH>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, 0, wg, g->gemb);
+            if (d.grasp_dim > 0) hipLaunchKernelGGL(k_encode<HH>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, d.grasp_begin, wr, g->remb);
+            return 0;
+        });
     } else if (p.E_act > 0) {
         float *gemb = nullptr, *UR = nullptr, *remb = nullptr;
         TRY(dev_alloc(reg, &gemb, (size_t)N * H));
@@ -2439,24 +2447,22 @@ int graph_build(ccsp_model* m, int N, int E, int F, const float* x, const signed
         const int gwork = g->n_tiles * (2 * H / TILE_N);
         const dim3 ggrid(gwork < m->max_wgs ? gwork : m->max_wgs);
         const float* nof = nullptr;
-        if (H == 256) {
-            hipLaunchKernelGGL(k_encode<256>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, 0, wg, gemb);
-            hipLaunchKernelGGL((k_rowgemm<256, 512>), ggrid, dim3(256), 0, s, gwork, gemb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wg, (size_t)2 * H * H, nof, nof, g->base);
-        } else {
-            hipLaunchKernelGGL(k_encode<64>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, 0, wg, gemb);
-            hipLaunchKernelGGL((k_rowgemm<64, 128>), ggrid, dim3(256), 0, s, gwork, gemb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wg, (size_t)2 * H * H, nof, nof, g->base);
-        }
+        dispatch_h(H, [&](auto hc) {
+            constexpr int HH = decltype(hc)::value;
+            hipLaunchKernelGGL(k_encode<HH>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, 0, wg, gemb);
+            hipLaunchKernelGGL((k_rowgemm<HH, 2 * HH>), ggrid, dim3(256), 0, s, gwork, gemb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wg, (size_t)2 * H * H, nof, nof, g->base);
+            return 0;
+        });
         if (d.grasp_dim > 0) {
             TRY(dev_alloc(reg, &remb, (size_t)N * H));
             TRY(dev_alloc(reg, &UR, (size_t)p.R * 2 * H));
             const EncW wr{m->gr0_w, m->gr0_b, m->gr2_wT, m->gr2_b, d.grasp_dim, nullptr};
-            if (H == 256) {
-                hipLaunchKernelGGL(k_encode<256>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, d.grasp_begin, wr, remb);
-                hipLaunchKernelGGL((k_rowgemm<256, 512>), ggrid, dim3(256), 0, s, gwork, remb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wr, (size_t)2 * H * H, nof, nof, UR);
-            } else {
-                hipLaunchKernelGGL(k_encode<64>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, d.grasp_begin, wr, remb);
-                hipLaunchKernelGGL((k_rowgemm<64, 128>), ggrid, dim3(256), 0, s, gwork, remb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wr, (size_t)2 * H * H, nof, nof, UR);
-            }
+            dispatch_h(H, [&](auto hc) {
+                constexpr int HH = decltype(hc)::value;
+                hipLaunchKernelGGL(k_encode<HH>, dim3(nblk(N, NODE_TILE)), dim3(256), 0, s, N, g->xfeat, F, d.grasp_begin, wr, remb);
+                hipLaunchKernelGGL((k_rowgemm<HH, 2 * HH>), ggrid, dim3(256), 0, s, gwork, remb, g->urow_node, g->tile_row0, g->tile_nrows, g->tile_ts, m->Wr, (size_t)2 * H * H, nof, nof, UR);
+                return 0;
+            });
             hipLaunchKernelGGL(k_rowbase, dim3(nblk((long)p.R * 2 * H, 256)), dim3(256), 0, s, p.R, 2 * H, g->urow_ts, UR, g->base);
         }
     }
@@ -2466,6 +2472,94 @@ int graph_build(ccsp_model* m, int N, int E, int F, const float* x, const signed
         return fail("graph_create: device set-up failed: %s", hipGetErrorString(hipGetLastError()));
     }
     *out = g;
+    return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Composition of two constraint domains on one set of nodes (reference networks/denoise_fn.py:287-291 the second
+// encoder / decoder set, :310-311 which constraint types use it, :341-371 the zero column and the composing weights,
+// :487-503 the second domain's inputs).  The reference loops over the types of both domains and scatter-adds every
+// type's decoded outputs into one [N, P] sum with one count per node; a sum over types is the sum of the two domains'
+// sums, so the composed evaluation is TWO ordinary evaluations -- each on its own model and graph, through the same three
+// kernels as any other -- taken unnormalised, plus one elementwise kernel:
+//     out = (w1 * S1 + w2 * widen(S2)) / sqrt(count1 + count2),   out[mask] = x[:, -P:][mask]
+// widen() inserts the zero column (the pose coordinate the second domain does not know: z).  The second domain sees
+// poses_2 = [poses[:, :2] | x[:, -(P2 - 2):]] (denoise_fn.py:499), built by k_compose_pack.
+// ------------------------------------------------------------------------------------------
+__global__ void k_compose_pack(int N, int P, int P2, const float* __restrict__ poses, const float* __restrict__ xfeat, int F, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * P2) return;
+    const int n = i / P2, c = i % P2;
+    out[i] = c < 2 ? poses[(size_t)n * P + c] : xfeat[(size_t)n * F + F - (P2 - c)];
+}
+
+__global__ void k_compose_outputs(int N, int P, int P2, int zero_col, const float* __restrict__ s1, const float* __restrict__ s2,
+                                  const int* __restrict__ nptr1, const int* __restrict__ nptr2, float w1, float w2, int normalize,
+                                  const signed char* __restrict__ mask, const float* __restrict__ xfeat, int F, float* __restrict__ out) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * P) return;
+    const int n = i / P, c = i % P;
+    float v = s1[i];
+    if (w1 != 1.0f) v = v * w1;                                   // (denoise_fn.py:362-363: applied only when != 1)
+    float u = 0.0f;
+    if (c != zero_col) {
+        u = s2[(size_t)n * P2 + (c < zero_col ? c : c - 1)];
+        if (w2 != 1.0f) u = u * w2;
+    }
+    v = v + u;
+    if (normalize) {
+        const int cnt = (nptr1 ? nptr1[n + 1] - nptr1[n] : 0) + (nptr2 ? nptr2[n + 1] - nptr2[n] : 0);
+        v = v / sqrtf((float)cnt);                                // 0/0 -> NaN like the reference (denoise_fn.py:523-524)
+    }
+    if (mask[n]) v = xfeat[(size_t)n * F + F - P + c];            // denoise_fn.py:531-532
+    out[i] = v;
+}
+
+struct ComposeScratch { float *s1, *s2, *p2; };
+
+int compose_check(const ccsp_model* m1, const ccsp_graph* g1, const ccsp_model* m2, const ccsp_graph* g2, const ccsp_compose* c, const char* who) {
+    if (!m1 || !g1 || !m2 || !g2 || !c) return fail("%s: null argument", who);
+    if (g1->m != m1 || g2->m != m2) return fail("%s: a graph belongs to another model", who);
+    if (m1->d.model_kind != CCSP_MODEL_DIFFUSION_CCSP || m2->d.model_kind != CCSP_MODEL_DIFFUSION_CCSP) return fail("%s: both domains must be Diffusion-CCSP models", who);
+    if (m1->d.energy_wrapper || m2->d.energy_wrapper) return fail("%s: composition is built for direct-mode (non energy_wrapper) models", who);
+    if (m2->d.pose_dim + 1 != m1->d.pose_dim) return fail("%s: the second domain's pose_dim (%d) must be the first's (%d) minus the zero column", who, m2->d.pose_dim, m1->d.pose_dim);
+    if (m2->d.pose_dim < 2 || g1->F < m2->d.pose_dim - 2) return fail("%s: bad second-domain pose layout", who);
+    if (c->zero_col < 0 || c->zero_col >= m1->d.pose_dim) return fail("%s: zero_col=%d out of range", who, c->zero_col);
+    if (g1->N != g2->N) return fail("%s: the two graphs have %d and %d nodes", who, g1->N, g2->N);
+    if (m1->d.timesteps != m2->d.timesteps) return fail("%s: the two models have %d and %d timesteps", who, m1->d.timesteps, m2->d.timesteps);
+    return 0;
+}
+
+// unnormalised sums of one domain at the pose state `poses` (nullptr = the graph's own state g->x, already encoded)
+template <int H>
+int compose_domain_sums(ccsp_model* m, ccsp_graph* g, const float* poses, int t, float* sums, hipStream_t s) {
+    if (poses) {
+        NodeArgs a = node_args(m, g);
+        a.src = 2; a.step = STEP_NONE; a.do_encode = 1; a.x_in = poses;
+        launch_node<H>(m, g, a, s);
+    }
+    if (launch_eval<H>(m, g, t, s)) return 1;
+    NodeArgs b = node_args(m, g);
+    b.src = 0; b.step = STEP_NONE; b.do_encode = 0; b.eps_out = sums; b.x_in = poses; b.normalize = 0;
+    launch_node<H>(m, g, b, s);
+    return 0;
+}
+int compose_domain_sums(ccsp_model* m, ccsp_graph* g, const float* poses, int t, float* sums, hipStream_t s) {
+    return dispatch_h(m->d.hidden_dim, [&](auto hc) { return compose_domain_sums<decltype(hc)::value>(m, g, poses, t, sums, s); });
+}
+
+// one composed evaluation at `poses` (or at g1's state): result in `out` [N, P]
+int compose_eval(ccsp_model* m1, ccsp_graph* g1, ccsp_model* m2, ccsp_graph* g2, const ccsp_compose* c, const float* poses, int t,
+                 const ComposeScratch& w, float* out, hipStream_t s) {
+    const int N = g1->N, P = m1->d.pose_dim, P2 = m2->d.pose_dim;
+    if (compose_domain_sums(m1, g1, poses, t, w.s1, s)) return 1;
+    hipLaunchKernelGGL(k_compose_pack, dim3(nblk((long)N * P2, 256)), dim3(256), 0, s, N, P, P2, poses ? poses : g1->x, g1->xfeat, g1->F, w.p2);
+    if (compose_domain_sums(m2, g2, w.p2, t, w.s2, s)) return 1;
+    hipLaunchKernelGGL(k_compose_outputs, dim3(nblk((long)N * P, 256)), dim3(256), 0, s, N, P, P2, c->zero_col, w.s1, w.s2,
+                       g1->plan.E_act > 0 ? g1->node_ptr : (const int*)nullptr, g2->plan.E_act > 0 ? g2->node_ptr : (const int*)nullptr,
+                       c->weight_first, c->weight_second, c->normalize, g1->mask, g1->xfeat, g1->F, out);
     return 0;
 }
 
@@ -2539,7 +2633,7 @@ int ccsp_schedule_get(const ccsp_model* m, int32_t which, float* out) {
 int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void* stream, ccsp_model** out) {
     if (!d || !params || !out) return fail("model_create: null argument");
     const int H = d->hidden_dim, P = d->pose_dim, C = d->n_types, T = d->timesteps;
-    if (H != 64 && H != 256) return fail("model_create: hidden_dim %d not supported (64, 256)", H);
+    if (H != 64 && H != 128 && H != 256) return fail("model_create: hidden_dim %d not supported (64, 128, 256)", H);
     if (P < 1 || P > 8) return fail("model_create: pose_dim %d not supported (1..8)", P);
     if (d->geom_dim < 1 || d->geom_dim > 8 || d->grasp_dim < 0 || d->grasp_dim > 8) return fail("model_create: geometry/grasp width not supported (1..8)");
     if (C < 1 || T < 1) return fail("model_create: bad n_types/timesteps");
@@ -2805,8 +2899,10 @@ int ccsp_encode(ccsp_model* m, int32_t which, int32_t n, const float* in, float*
         w = EncW{m->gr0_w, m->gr0_b, m->gr2_wT, m->gr2_b, d.grasp_dim, nullptr};
     } else return fail("encode: unknown encoder %d", which);
     hipStream_t s = (hipStream_t)stream;
-    if (d.hidden_dim == 256) hipLaunchKernelGGL(k_encode<256>, dim3(nblk(n, NODE_TILE)), dim3(256), 0, s, n, in, w.in_dim, 0, w, out);
-    else hipLaunchKernelGGL(k_encode<64>, dim3(nblk(n, NODE_TILE)), dim3(256), 0, s, n, in, w.in_dim, 0, w, out);
+    dispatch_h(d.hidden_dim, [&](auto hc) {
+        hipLaunchKernelGGL(k_encode<decltype(hc)::value>, dim3(nblk(n, NODE_TILE)), dim3(256), 0, s, n, in, w.in_dim, 0, w, out);
+        return 0;
+    });
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -2898,14 +2994,18 @@ int ccsp_denoise(ccsp_model* m, ccsp_graph* g, const float* poses_in, int32_t t,
     NodeArgs b = node_args(m, g);
     b.src = 0; b.step = STEP_NONE; b.do_encode = 0; b.eps_out = out; b.x_in = poses_in;
     if (m->d.model_kind == CCSP_MODEL_STRUCT_DIFFUSION) {
-        if (m->d.hidden_dim == 256) { launch_node<256>(m, g, a, s); if (launch_eval_sd<256>(m, g, t, s)) return 1; }
-        else { launch_node<64>(m, g, a, s); if (launch_eval_sd<64>(m, g, t, s)) return 1; }
+        if (dispatch_h(m->d.hidden_dim, [&](auto hc) { constexpr int HH = decltype(hc)::value; launch_node<HH>(m, g, a, s); return launch_eval_sd<HH>(m, g, t, s); })) return 1;
         HIP_TRY(hipMemcpyAsync(out, g->eps, (size_t)g->N * m->d.pose_dim * sizeof(float), hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipGetLastError());
         return 0;
     }
-    if (m->d.hidden_dim == 256) { launch_node<256>(m, g, a, s); if (launch_eval<256>(m, g, t, s)) return 1; launch_node<256>(m, g, b, s); }
-    else { launch_node<64>(m, g, a, s); if (launch_eval<64>(m, g, t, s)) return 1; launch_node<64>(m, g, b, s); }
+    if (dispatch_h(m->d.hidden_dim, [&](auto hc) {
+            constexpr int HH = decltype(hc)::value;
+            launch_node<HH>(m, g, a, s);
+            if (launch_eval<HH>(m, g, t, s)) return 1;
+            launch_node<HH>(m, g, b, s);
+            return 0;
+        })) return 1;
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -2967,8 +3067,7 @@ int ccsp_edge_outputs(ccsp_model* m, ccsp_graph* g, const float* poses_in, int32
     const int P = m->d.pose_dim;
     NodeArgs a = node_args(m, g);
     a.src = 2; a.step = STEP_NONE; a.do_encode = 1; a.x_in = poses_in;
-    if (m->d.hidden_dim == 256) { launch_node<256>(m, g, a, s); if (launch_eval<256>(m, g, t, s)) return 1; }
-    else { launch_node<64>(m, g, a, s); if (launch_eval<64>(m, g, t, s)) return 1; }
+    if (dispatch_h(m->d.hidden_dim, [&](auto hc) { constexpr int HH = decltype(hc)::value; launch_node<HH>(m, g, a, s); return launch_eval<HH>(m, g, t, s); })) return 1;
     if (g->E > 0) hipLaunchKernelGGL(k_fill, dim3(nblk((long)g->E * 2 * P, 256)), dim3(256), 0, s, out, (long)g->E * 2 * P, nanf(""));
     if (g->plan.E_act > 0)
         hipLaunchKernelGGL(k_unsort_edges, dim3(nblk((long)g->plan.E_act * 2 * P, 256)), dim3(256), 0, s, g->plan.E_act, P, g->e_orig, g->ent_pos, g->O, out);
@@ -2986,8 +3085,11 @@ int ccsp_energy_grad(ccsp_model* m, ccsp_graph* g, const float* poses_in, int32_
     const size_t NP = (size_t)g->N * m->d.pose_dim;
     NodeArgs a = node_args(m, g);
     a.src = 2; a.step = STEP_NONE; a.do_encode = 1; a.x_in = poses_in;
-    if (m->d.hidden_dim == 256) { launch_node<256>(m, g, a, s); if (launch_eval_energy<256>(m, g, t, poses_in, true, energy, s)) return 1; }
-    else { launch_node<64>(m, g, a, s); if (launch_eval_energy<64>(m, g, t, poses_in, true, energy, s)) return 1; }
+    if (dispatch_h(m->d.hidden_dim, [&](auto hc) {
+            constexpr int HH = decltype(hc)::value;
+            launch_node<HH>(m, g, a, s);
+            return launch_eval_energy<HH>(m, g, t, poses_in, true, energy, s);
+        })) return 1;
     HIP_TRY(hipMemcpyAsync(grad, g->eps, NP * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipGetLastError());
     return 0;
@@ -3033,8 +3135,9 @@ int ccsp_chain_run(ccsp_model* m, ccsp_graph* g, int32_t sampler, const ccsp_noi
     }
     int rc = 0;
     auto run = [&](const std::vector<Lane>& ls) -> int {
-        return m->d.hidden_dim == 256 ? chain_run_impl<256>(m, ls, NP_total, sampler, nz, x, init, t_first, t_last, history, accept)
-                                      : chain_run_impl<64>(m, ls, NP_total, sampler, nz, x, init, t_first, t_last, history, accept);
+        return dispatch_h(m->d.hidden_dim, [&](auto hc) {
+            return chain_run_impl<decltype(hc)::value>(m, ls, NP_total, sampler, nz, x, init, t_first, t_last, history, accept);
+        });
     };
     if (!forked) {
         rc = run(lanes);
@@ -3148,6 +3251,90 @@ int ccsp_chain_stats(ccsp_graph* g, int64_t* evals, float* ms_total, float* ms_u
 // Host-only planning entry (no device needed): lets CPU tests check the index tables.
 // Arrays are HOST pointers sized by the caller: per-edge arrays [E], urow_* [2E], tile_* [2E + 2C],
 // node_ptr [N+1], node_ent [2E].  counts = {E_act, R, n_tiles}.
+int ccsp_compose_denoise(ccsp_model* m1, ccsp_graph* g1, ccsp_model* m2, ccsp_graph* g2, const ccsp_compose* c, const float* poses_in,
+                         int32_t t, float* out, void* stream) {
+    if (compose_check(m1, g1, m2, g2, c, "compose_denoise")) return 1;
+    if (!poses_in || !out) return fail("compose_denoise: null argument");
+    if (t < 0 || t >= m1->d.timesteps) return fail("compose_denoise: t=%d out of range", t);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t N = (size_t)g1->N;
+    StreamBuf b1(s), b2(s), b3(s);
+    if (b1.alloc(N * m1->d.pose_dim * sizeof(float)) || b2.alloc(N * m2->d.pose_dim * sizeof(float)) || b3.alloc(N * m2->d.pose_dim * sizeof(float))) return 1;
+    const ComposeScratch w{b1.f(), b2.f(), b3.f()};
+    if (compose_eval(m1, g1, m2, g2, c, poses_in, t, w, out, s)) return 1;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ccsp_compose_chain_run(ccsp_model* m1, ccsp_graph* g1, ccsp_model* m2, ccsp_graph* g2, const ccsp_compose* c, int32_t sampler,
+                           const ccsp_noise* nz, float* x, int32_t init, int32_t t_first, int32_t t_last, float* history, void* stream) {
+    if (compose_check(m1, g1, m2, g2, c, "compose_chain_run")) return 1;
+    if (!nz || !x) return fail("compose_chain_run: null argument");
+    ccsp_model* m = m1;
+    ccsp_graph* g = g1;
+    const int T = m->d.timesteps, P = m->d.pose_dim;
+    if (sampler != CCSP_SAMPLER_NONE && sampler != CCSP_SAMPLER_ULA && sampler != CCSP_SAMPLER_ULA_PLUS)
+        return fail("compose_chain_run: sampler %d needs an energy model; composition runs the direct-mode samplers (none, ULA, ULA+)", sampler);
+    if (t_first >= T || t_last < 0 || t_first < t_last - 1) return fail("compose_chain_run: bad timestep range [%d,%d]", t_first, t_last);
+    if (nz->mode != CCSP_NOISE_PHILOX && nz->mode != CCSP_NOISE_INJECTED) return fail("compose_chain_run: unknown noise mode %d", nz->mode);
+    if (nz->mode == CCSP_NOISE_INJECTED && !nz->normal) return fail("compose_chain_run: injected noise without a normal stream");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t N = (size_t)g->N, NP = N * P;
+    StreamBuf b1(s), b2(s), b3(s);
+    if (b1.alloc(NP * sizeof(float)) || b2.alloc(N * m2->d.pose_dim * sizeof(float)) || b3.alloc(N * m2->d.pose_dim * sizeof(float))) return 1;
+    const ComposeScratch w{b1.f(), b2.f(), b3.f()};
+    std::vector<uint64_t> call0(T);
+    {
+        uint64_t k = 1;
+        for (int t = T - 1; t >= 0; --t) { call0[t] = k; k += 1 + (uint64_t)steps_at(m, sampler, t); }
+    }
+    auto noise_for = [&](uint64_t call, NoiseArg& na) -> int {
+        na.mode = nz->mode; na.seed = nz->seed; na.row_offset = nz->row_offset;
+        na.call = (unsigned int)call; na.normal = nullptr; na.uniform = nullptr; na.ucall = 0;
+        if (nz->mode == CCSP_NOISE_INJECTED) {
+            if (call < nz->call_base || call - nz->call_base >= nz->n_normal) return fail("compose_chain_run: injected normal stream exhausted at call %llu", (unsigned long long)call);
+            na.normal = nz->normal + (size_t)(call - nz->call_base) * NP;
+        }
+        return 0;
+    };
+    auto node = [&](const NodeArgs& a) { dispatch_h(m->d.hidden_dim, [&](auto hc) { launch_node<decltype(hc)::value>(m, g, a, s); return 0; }); };
+    g->evals = 0; g->kev_used = 0;
+    if (!g->have_events) { HIP_TRY(hipEventCreate(&g->ev0)); HIP_TRY(hipEventCreate(&g->ev1)); g->have_events = true; }
+    HIP_TRY(hipEventRecord(g->ev0, s));
+    {
+        NodeArgs a = node_args(m, g);
+        a.src = 2; a.do_encode = 1;
+        if (init) {
+            a.step = STEP_INIT; a.reset_mask = 1; a.hist = history;
+            if (noise_for(0, a.noise)) return 1;
+        } else {
+            HIP_TRY(hipMemcpyAsync(g->x, x, NP * sizeof(float), hipMemcpyDeviceToDevice, s));
+            a.step = STEP_NONE;
+        }
+        node(a);
+    }
+    for (int t = t_first; t >= t_last; --t) {
+        const int S = steps_at(m, sampler, t);
+        for (int e = 0; e <= S; ++e) {
+            if (compose_eval(m1, g1, m2, g2, c, nullptr, t, w, g->eps, s)) return 1;
+            NodeArgs a = node_args(m, g);
+            a.src = 1; a.eps_buf = g->eps; a.do_encode = 1;
+            a.step = e == 0 ? STEP_ANCESTRAL : STEP_ULA;
+            a.reset_mask = (e == S);
+            a.hist = (e == S && history) ? history + (size_t)(T - t) * NP : nullptr;
+            a.a_t = m->sqrt_recip_ac[t]; a.b_t = m->sqrt_recipm1_ac[t]; a.c1 = m->coef1[t]; a.c2 = m->coef2[t];
+            a.sigma = t != 0 ? expf(0.5f * m->post_lv[t]) : 0.0f;
+            a.kappa = m->kappa[t]; a.ss = m->step[t]; a.std_ = sqrtf(2.0f * m->step[t]);
+            if (noise_for(call0[t] + (uint64_t)e, a.noise)) return 1;
+            node(a);
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(x, g->x, NP * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipEventRecord(g->ev1, s));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int ccsp_plan_host(int32_t N, int32_t E, int32_t C, const int64_t* edge_index, const float* edge_attr, int32_t* counts,
                    int32_t* e_orig, int32_t* e_type, int32_t* e_u0, int32_t* e_u1, int32_t* urow_node, int32_t* urow_ts,
                    int32_t* tile_row0, int32_t* tile_nrows, int32_t* tile_ts, int32_t* node_ptr, int32_t* node_ent) {

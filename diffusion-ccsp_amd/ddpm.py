@@ -183,10 +183,26 @@ class GaussianDiffusion(object):
         L = _lib.lib()
         core = self._core()
         h = self._handle()
-        g = core._graph(batch)
         dev = self.device
         T = self.num_timesteps
         nz, keep = self._noise_struct(seed, noise, row_offset)
+        if getattr(core, '_second', None) is not None:
+            # two composed domains (ConstraintDiffuser.compose): one evaluation per domain and evaluation, ccsp_compose_chain_run
+            if self._sampler() in ('MALA', 'HMC'):
+                raise NotImplementedError('composed domains run the direct-mode samplers (EBM=False, ULA, ULA+)')
+            first, second = core._composed_parts()
+            h = self._handle()
+            g1, g2 = core._composed_graphs(batch)
+            hist = torch.empty((T + 1, g1.N, self.dims[-1][0]), device=dev, dtype=torch.float32) if return_history else None
+            c = core._compose_struct()
+            with torch.cuda.device(dev):
+                _lib.check(L.ccsp_compose_chain_run(h, g1.h, second._h, g2.h, C.byref(c), _lib.SAMPLERS[self._sampler()], C.byref(nz), _ptr(x),
+                                                    int(init), int(t_first), int(t_last), None if hist is None else _ptr(hist), _stream_ptr(dev)))
+            self._last_graph = g1
+            self._keepalive = keep + [g2]
+            self.last_accept_rates = None
+            return hist
+        g = core._graph(batch)
         hist = torch.empty((T + 1, g.N, self.dims[-1][0]), device=dev, dtype=torch.float32) if return_history else None
         acc = torch.zeros(T, device=dev, dtype=torch.float32) if self._sampler() in ('MALA', 'HMC') else None
         with torch.cuda.device(dev):
@@ -202,8 +218,7 @@ class GaussianDiffusion(object):
         """GaussianDiffusion.p_sample_loop (ddpm.py:260-340)"""
         T = self.num_timesteps
         self._handle()                         # (binds the denoiser's native model to this object's schedule first)
-        g = self._core()._graph(batch)
-        x = torch.empty((g.N, self.dims[-1][0]), device=self.device, dtype=torch.float32)
+        x = torch.empty((batch.x.shape[0], self.dims[-1][0]), device=self.device, dtype=torch.float32)
         hist = self._run(batch, x, 1, T - 1, 0, return_history, seed, noise, row_offset)
         if return_history:
             return x, [hist[i] for i in range(T + 1)]

@@ -51,6 +51,13 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+class _SubBatch(object):
+    """one domain's share of a composed batch (compose()): the four tensors _Graph reads"""
+
+    def __init__(self, x, edge_index, edge_attr, mask):
+        self.x, self.edge_index, self.edge_attr, self.mask = x, edge_index.contiguous(), edge_attr.contiguous(), mask
+
+
 class _Graph(object):
     """one collated batch uploaded to the library (ccsp_graph_create)"""
 
@@ -121,6 +128,10 @@ class ConstraintDiffuser(object):
         self._grasp = 'robot' in input_mode
         if self._grasp and len(self.dims) != 3:
             raise ValueError("'robot' input modes need dims with a grasp group")
+        # composing with a second domain (denoise_fn.py:287-291): set by compose()
+        self.pose_encoder_2 = self.geom_encoder_2 = self.pose_decoder_2 = self.time_mlp_2 = None
+        self.composing_weight = (1, 1)
+        self._second = None       # the second domain's ConstraintDiffuser
         self._params = None       # name -> device tensor
         self._h = None
         self._energy_hook = None  # (ctypes trampoline, views) of the MALA shard hook: re-installed on every new native model
@@ -130,6 +141,10 @@ class ConstraintDiffuser(object):
         if self.device.type != 'cuda':
             raise _lib.CcspError("ConstraintDiffuser(device=%r): the HIP path needs a GPU device ('cuda'); "
                                  "there is no CPU fallback" % (device,))
+
+    def _n_own_types(self):
+        """constraint types whose MLPs live in THIS model (a composed model lists the second domain's types after them)"""
+        return self._n_first if self._second is not None else len(self.constraint_sets)
 
     # ---- weights ------------------------------------------------------------------------
     def shapes(self):
@@ -149,7 +164,7 @@ class ConstraintDiffuser(object):
                 sh.update({pre + 'attn.in_proj_': (3 * W, W), pre + 'attn.out_proj': (W, W), pre + 'ln_1': (W,),
                            pre + 'mlp.c_fc': (4 * W, W), pre + 'mlp.c_proj': (W, 4 * W), pre + 'ln_2': (W,)})
             return sh
-        for i in range(len(self.constraint_sets)):
+        for i in range(self._n_own_types()):
             sh['mlps.%d.0' % i] = (2 * H, kin)
         return sh
 
@@ -222,6 +237,76 @@ class ConstraintDiffuser(object):
     def cuda(self):
         return self
 
+    # ---- composition of two domains -----------------------------------------------------
+    def compose(self, second, composing_weight=(1, 1)):
+        """Attach a second constraint domain the way the reference's 'robot_qualitative' mode expects it (denoise_fn.py:
+        287-291,310-311): `second` is the other domain's ConstraintDiffuser (qualitative: pose_dim = this one's - 1, its
+        poses are [x, y | the last columns of batch.x], denoise_fn.py:499).  Afterwards constraint types >=
+        len(self.constraint_sets) are the second domain's types (renumbered from there), its encoders / decoder / time MLP
+        are reachable as pose_encoder_2 / geom_encoder_2 / pose_decoder_2 / time_mlp_2, and forward / p_sample_loop evaluate
+        both domains (ccsp_compose_denoise / ccsp_compose_chain_run).  composing_weight as in the reference (:291,362-370)."""
+        if self.input_mode != 'robot_qualitative':
+            raise ValueError("compose(): the reference composes domains under input_mode 'robot_qualitative' (denoise_fn.py:311)")
+        if self.model != 'Diffusion-CCSP' or second.model != 'Diffusion-CCSP':
+            raise NotImplementedError('compose(): Diffusion-CCSP models only')
+        if second.dims[-1][0] + 1 != self.dims[-1][0] or second.hidden_dim != self.hidden_dim:
+            raise ValueError('compose(): the second domain needs pose_dim %d and hidden_dim %d' % (self.dims[-1][0] - 1, self.hidden_dim))
+        if second._params is None or self._params is None:
+            raise _lib.CcspError('compose(): load the weights of both models first')
+        self._n_first = len(constraint_set(self.input_mode))
+        self.constraint_sets = list(constraint_set(self.input_mode)) + list(second.constraint_sets)
+        self._second = second
+        self.composing_weight = tuple(composing_weight)
+        self.pose_encoder_2, self.geom_encoder_2 = second.pose_encoder, second.geom_encoder
+        self.time_mlp_2 = second.time_mlp
+        self.pose_decoder_2 = second          # (the reference's attribute holds the module; the decoder runs inside _process_constraint)
+        return self
+
+    def _composed_parts(self):
+        """the two single-domain models of the composed forward, bound to the same number of timesteps"""
+        self._second._bind(self.timesteps)
+        self._handle()
+        self._second._handle()
+        return self, self._second
+
+    def _compose_struct(self):
+        return _lib.Compose(zero_col=2, weight_first=float(self.composing_weight[0]), weight_second=float(self.composing_weight[1]),
+                            normalize=int(bool(self.normalize)))
+
+    def _composed_graphs(self, batch):
+        """(first-domain _Graph, second-domain _Graph) of a batch whose edge types run over both domains; cached like _graph()"""
+        first, second = self._composed_parts()
+        fields = (batch.x, batch.edge_index, batch.edge_attr, batch.mask)
+        key = tuple((t.data_ptr(), tuple(t.shape), t._version) for t in fields)
+        ent = self._graphs.get(id(batch))
+        if ent is not None:
+            ref, k, gs = ent
+            if ref() is batch and k == key and isinstance(gs, tuple) and gs[0].h and gs[1].h and \
+                    gs[0].model_handle == first._generation and gs[1].model_handle == second._generation:
+                return gs
+            del self._graphs[id(batch)]
+        n1 = self._n_first
+        ea = batch.edge_attr.detach().to(torch.float32)
+        ei = batch.edge_index.detach()
+        sel1, sel2 = ea < n1, ea >= n1
+        x = batch.x.detach().to(torch.float32)
+        g2w, p2 = self._second.dims[0][0], self._second.dims[-1][0]
+        x2 = torch.cat([x[:, self.dims[0][1]:self.dims[0][1] + g2w], torch.zeros((x.shape[0], p2), dtype=x.dtype, device=x.device)], dim=1)
+        b1 = _SubBatch(x, ei[:, sel1], ea[sel1], batch.mask)
+        b2 = _SubBatch(x2, ei[:, sel2], ea[sel2] - n1, batch.mask)
+        with torch.cuda.device(self.device):
+            gs = (first._graph(b1), second._graph(b2))
+        gs[0]._keep, gs[1]._keep = b1, b2
+        bid = id(batch)
+        try:
+            ref = weakref.ref(batch, lambda _r, d=self._graphs, i=bid: d.pop(i, None))
+        except TypeError:
+            return gs
+        while len(self._graphs) > 8:
+            self._graphs.pop(next(iter(self._graphs)))
+        self._graphs[bid] = (ref, key, gs)
+        return gs
+
     # ---- native handles -----------------------------------------------------------------
     def _drop_handle(self):
         # graphs first, then the model they were built on (a GaussianDiffusion may still hold one as _last_graph; the
@@ -254,12 +339,12 @@ class ConstraintDiffuser(object):
         grasp = self._grasp
         d = _lib.ModelDesc(hidden_dim=self.hidden_dim, pose_dim=self.dims[-1][0], pose_begin=self.dims[-1][1],
                            geom_dim=self.dims[0][0], grasp_dim=self.dims[1][0] if grasp else 0,
-                           grasp_begin=self.dims[1][1] if grasp else 0, n_types=len(self.constraint_sets),
+                           grasp_begin=self.dims[1][1] if grasp else 0, n_types=self._n_own_types(),
                            timesteps=self.timesteps, normalize=int(bool(self.normalize)),
                            energy_wrapper=int(bool(self.energy_wrapper)), ebm_per_steps=int(self.ebm_per_steps),
                            model_kind=MODEL_KINDS[self.model])
         ptrs = []
-        for wk, bk in param_names(len(self.constraint_sets), grasp, self.model):
+        for wk, bk in param_names(self._n_own_types(), grasp, self.model):
             ptrs.append(self._params[wk].data_ptr())
             ptrs.append(self._params[bk].data_ptr())
         arr = (C.c_void_p * len(ptrs))(*ptrs)
@@ -338,6 +423,16 @@ class ConstraintDiffuser(object):
     def _process_constraint(self, i, input_dict):
         """ConstraintDiffuser._process_constraint (denoise_fn.py:341-371): the type-i MLP on [geoms_emb | poses_emb |
         time_embedding] (+ grasp_emb first for 'robot' modes) and the pose decoder on both output halves -> [b, 2, P]"""
+        if self._second is not None and i >= self._n_first:
+            # second-domain type (denoise_fn.py:342-344,364-370): its own MLP and decoder, a zero column at index 2, its weight
+            d = {'geoms_emb': input_dict['geoms_emb_2'], 'poses_emb': input_dict['poses_emb_2'], 'time_embedding': input_dict['time_embedding']}
+            o = self._second._process_constraint(i - self._n_first, d)
+            o = torch.cat([o[:, :, :2], torch.zeros_like(o[:, :, 0:1]), o[:, :, 2:]], dim=-1)
+            return o * self.composing_weight[1] if self.composing_weight[1] != 1 else o
+        out = self._process_own_constraint(i, input_dict)
+        return out * self.composing_weight[0] if self.composing_weight[0] != 1 else out
+
+    def _process_own_constraint(self, i, input_dict):
         ge = input_dict['geoms_emb'].detach().to(self.device, torch.float32).contiguous()
         pe = input_dict['poses_emb'].detach().to(self.device, torch.float32).contiguous()
         te = input_dict['time_embedding'].detach().to(self.device, torch.float32).contiguous()
@@ -366,6 +461,18 @@ class ConstraintDiffuser(object):
         """ConstraintDiffuser.forward (denoise_fn.py:453-537).  direct mode -> [N,P];
         energy mode (tag == 'EBM' and energy_wrapper) -> (gradients [N,P], energy scalar)"""
         L = _lib.lib()
+        if self._second is not None:
+            if tag == 'EBM' and self.energy_wrapper:
+                raise NotImplementedError('composed domains are evaluated in direct mode only (DESIGN.md: the second domain\'s energy '
+                                          'compares against poses its encoder does not see, denoise_fn.py:373-375,499)')
+            g1, g2 = self._composed_graphs(batch)
+            first, second = self, self._second
+            p = poses_in.detach().to(self.device, torch.float32).contiguous()
+            out = torch.empty_like(p)
+            c = self._compose_struct()
+            _lib.check(L.ccsp_compose_denoise(first._h, g1.h, second._h, g2.h, C.byref(c), _ptr(p), int(torch.as_tensor(t).reshape(-1)[0]),
+                                              _ptr(out), _stream_ptr(self.device)))
+            return out
         g = self._graph(batch)
         p = poses_in.detach().to(self.device, torch.float32).contiguous()
         tv = int(torch.as_tensor(t).reshape(-1)[0])

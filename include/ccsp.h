@@ -38,7 +38,7 @@ extern "C" {
 #endif
 
 #define CCSP_VERSION_MAJOR 0
-#define CCSP_VERSION_MINOR 4
+#define CCSP_VERSION_MINOR 5
 #define CCSP_MAX_SAMPLES_PER_STEP 100000
 
 typedef struct ccsp_model ccsp_model;   /* ConstraintDiffuser weights + GaussianDiffusion schedule */
@@ -48,7 +48,7 @@ typedef struct ccsp_graph ccsp_graph;   /* one collated batch of constraint grap
  * GaussianDiffusion (networks/ddpm.py:168-228).  `dims` is the reference's tuple of
  * (length, begin, end) per variable group (train_utils.py:266-278). */
 typedef struct {
-    int32_t hidden_dim;     /* H: -hidden_dim (train_utils.py:107); supported: 64, 256          */
+    int32_t hidden_dim;     /* H: -hidden_dim (train_utils.py:107); supported: 64, 128, 256     */
     int32_t pose_dim;       /* P = dims[-1][0] (4 or 5)                                          */
     int32_t pose_begin;     /* dims[-1][1]: ground-truth pose columns x[:, pose_begin:+P]        */
     int32_t geom_dim;       /* dims[0][0]: geometry columns x[:, 0:geom_dim]                     */
@@ -175,6 +175,29 @@ int ccsp_edge_outputs(ccsp_model* model, ccsp_graph* graph, const float* poses_i
 int ccsp_chain_run(ccsp_model* model, ccsp_graph* graph, int32_t sampler, const ccsp_noise* noise,
                    float* x, int32_t init, int32_t t_first, int32_t t_last, float* history,
                    float* accept, void* stream);
+
+/* Composition of two constraint domains on one set of nodes -- the reference's input_mode 'robot_qualitative'
+ * (networks/denoise_fn.py:287-291 pose_encoder_2 / geom_encoder_2 / pose_decoder_2 / time_mlp_2 and composing_weight,
+ * :310-311 the types >= n_types(first) use the second set, :341-371 their decoded outputs get a zero column and both
+ * domains their weight, :487-503 the second domain's inputs).  `first` / `graph_first` hold the first domain (all P pose
+ * columns, the edges of its types); `second` / `graph_second` the second domain: pose_dim P - 1, the SAME N nodes, the
+ * edges of the second domain with their types renumbered from 0, and node features whose pose columns are placeholders
+ * (the library fills poses_2 = [poses[:, :2] | x[:, -(P-3):]] itself, x = graph_first's features, denoise_fn.py:499).
+ * One composed evaluation = one ordinary evaluation per domain + one elementwise kernel:
+ *     out = (w1 * sum1 + w2 * widen(sum2)) / sqrt(count1 + count2);  out[mask] = x[:, -P:][mask]
+ * Both models must be direct-mode (energy_wrapper 0) Diffusion-CCSP models with the same `timesteps`; their own
+ * `normalize` flags are not used.  The chain form runs samplers NONE / ULA / ULA+ with the schedule of `first`. */
+typedef struct ccsp_compose {
+    int32_t zero_col;       /* column of the P-wide pose the second domain does not produce (2: z) */
+    float weight_first;     /* composing_weight[0] */
+    float weight_second;    /* composing_weight[1] */
+    int32_t normalize;      /* ConstraintDiffuser.normalize */
+} ccsp_compose;
+int ccsp_compose_denoise(ccsp_model* first, ccsp_graph* graph_first, ccsp_model* second, ccsp_graph* graph_second,
+                         const ccsp_compose* compose, const float* poses_in, int32_t t, float* out, void* stream);
+int ccsp_compose_chain_run(ccsp_model* first, ccsp_graph* graph_first, ccsp_model* second, ccsp_graph* graph_second,
+                           const ccsp_compose* compose, int32_t sampler, const ccsp_noise* noise, float* x, int32_t init,
+                           int32_t t_first, int32_t t_last, float* history, void* stream);
 
 /* MALA across shards.  The reference's accept test uses ONE energy for the whole batch
  * (logp_x, logp_x_hat of shape [1], ddpm.py:1026-1038), so a batch cut into per-GPU shards only reproduces the

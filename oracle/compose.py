@@ -1,0 +1,118 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement of the reference's DOMAIN COMPOSITION (input_mode 'robot_qualitative'),
+on top of the C oracle's per-edge operator (ccsp_oracle.c edge_outputs = ConstraintDiffuser._process_constraint).
+Used by tests/ only; the product path (diffusion-ccsp_amd/csrc: ccsp_compose_*) never touches it.
+
+Pinned by tests/golden/composed.npz and chain_c{64,256}_ula.npz, which oracle/gen_golden.py:gen_composed wrote by running
+the reference's own ConstraintDiffuser.forward / GaussianDiffusion.sample with the second module set attached.
+
+What is restated (reference networks/denoise_fn.py):
+  :287-291   pose_encoder_2 / geom_encoder_2 / pose_decoder_2 / time_mlp_2, composing_weight
+  :310-311   constraint types i >= 2 use the second set
+  :341-371   second-domain outputs: decoder_2, a zero column inserted at index 2, scaled by composing_weight[1] (only if != 1);
+             first-domain outputs scaled by composing_weight[0] (only if != 1)
+  :373-389   scatter of every type's outputs into one sum with one count per node (types in increasing order)
+  :487-503   second-domain inputs: geoms_in[:, :2], poses_in_2 = [poses_in[:, :2] | x[:, -2:]]
+  :523-533   count normalisation, masked rows = x[:, -P:]
+and the chain around it (networks/ddpm.py:245-258 p_sample, :956-966 ULA step, :260-340 loop), the arithmetic of
+ccsp_oracle.c:795-890 in numpy fp32.
+"""
+import numpy as np
+
+import oracle as oracle_mod
+
+
+class _Sub(object):
+    """a batch restricted to some edges (fields as OracleGraph reads them)"""
+
+    def __init__(self, x, edge_index, edge_attr, mask):
+        self.x, self.edge_index, self.edge_attr, self.mask = x, edge_index, edge_attr, mask
+
+
+class ComposedOracleGraph(object):
+    def __init__(self, first, second, batch, weight=(1, 1), zero_col=2, normalize=True):
+        self.m1, self.m2 = first, second
+        self.weight, self.zero_col, self.normalize = tuple(float(w) for w in weight), int(zero_col), bool(normalize)
+        self.x = np.ascontiguousarray(oracle_mod._np(batch.x), dtype=np.float32)
+        ei = np.asarray(oracle_mod._np(batch.edge_index), dtype=np.int64).reshape(2, -1)
+        ea = np.asarray(oracle_mod._np(batch.edge_attr), dtype=np.float32)
+        self.mask = np.asarray(oracle_mod._np(batch.mask)).astype(bool)
+        self.N, self.P, self.P2 = self.x.shape[0], first.P, second.P
+        n1 = first.C
+        self.n_types = n1 + second.C
+        # edges by domain, each in the caller's order (torch.where(edge_attr == i) keeps it, denoise_fn.py:317)
+        self.sel1 = np.nonzero(ea < n1)[0]
+        self.sel2 = np.nonzero(ea >= n1)[0]
+        self.ei, self.ea = ei, ea
+        m8 = self.mask.astype(np.int8)
+        self.g1 = first.graph(_Sub(self.x, ei[:, self.sel1], ea[self.sel1], m8))
+        # the second domain's features: geometry = the first two geometry columns, pose columns filled per evaluation
+        g2 = self.x[:, first.dims[0][1]:first.dims[0][1] + second.dims[0][0]]
+        self.x2 = np.ascontiguousarray(np.concatenate([g2, np.zeros((self.N, self.P2), np.float32)], axis=1))
+        self.g2 = second.graph(_Sub(self.x2, ei[:, self.sel2], ea[self.sel2] - n1, m8))
+
+    def edge_outputs(self, poses, t):
+        """[E, 2, P] per-edge outputs of BOTH domains in the caller's edge order (NaN rows for unmatched types)"""
+        poses = np.asarray(poses, dtype=np.float32)
+        out = np.full((self.ea.shape[0], 2, self.P), np.nan, dtype=np.float32)
+        o1 = self.g1.edge_outputs(poses, t)
+        if self.weight[0] != 1:
+            o1 = o1 * np.float32(self.weight[0])
+        out[self.sel1] = o1
+        p2 = np.ascontiguousarray(np.concatenate([poses[:, :2], self.x[:, -(self.P2 - 2):]], axis=1), dtype=np.float32)
+        o2 = self.g2.edge_outputs(p2, t)                                        # [E2, 2, P2]
+        z = self.zero_col
+        o2w = np.concatenate([o2[:, :, :z], np.zeros_like(o2[:, :, :1]), o2[:, :, z:]], axis=2)
+        if self.weight[1] != 1:
+            o2w = o2w * np.float32(self.weight[1])
+        out[self.sel2] = o2w
+        return out
+
+    def denoise(self, poses, t):
+        o = self.edge_outputs(poses, t)
+        acc = np.zeros((self.N, self.P), dtype=np.float32)
+        cnt = np.zeros(self.N, dtype=np.float32)
+        for i in range(self.n_types):                                            # denoise_fn.py:510-519
+            for e in np.nonzero(self.ea == i)[0]:
+                for slot in (0, 1):
+                    n = self.ei[slot, e]
+                    acc[n] = acc[n] + o[e, slot]
+                    cnt[n] += 1
+        if self.normalize:
+            with np.errstate(divide='ignore', invalid='ignore'):
+                acc = (acc / np.sqrt(cnt)[:, None]).astype(np.float32)
+        acc[self.mask] = self.x[:, -self.P:][self.mask]
+        return acc
+
+    def chain(self, normal, samples_per_step, sampler='ULA', history=False):
+        """full reverse chain with injected normal draws [n_calls, N, P]; sampler 'ULA' or None"""
+        m = self.m1
+        sc = m.schedule()
+        T, N, P = m.T, self.N, self.P
+        f = np.float32
+        gt = self.x[:, m.dims[-1][1]:m.dims[-1][1] + P]
+        z = np.asarray(normal, dtype=np.float32)
+        S = int(samples_per_step) if sampler == 'ULA' else 0
+        x = (f(0.5) * z[0]).astype(np.float32)
+        x[self.mask] = gt[self.mask]
+        hist = [x.copy()]
+        call = 1
+        for t in range(T - 1, -1, -1):
+            a_t, b_t = f(sc['sqrt_recip_alphas_cumprod'][t]), f(sc['sqrt_recipm1_alphas_cumprod'][t])
+            c1, c2 = f(sc['posterior_mean_coef1'][t]), f(sc['posterior_mean_coef2'][t])
+            sigma = f(np.exp(f(0.5) * f(sc['posterior_log_variance_clipped'][t]))) if t != 0 else f(0)
+            kappa, ss = f(sc['kappa'][t]), f(sc['step_sizes'][t])
+            std = f(np.sqrt(f(2) * ss))
+            with np.errstate(all='ignore'):
+                eps = self.denoise(x, t)
+                x0 = (a_t * x - b_t * eps).astype(np.float32)
+                mean = (c1 * x0 + c2 * x).astype(np.float32)
+                x = (mean + sigma * z[call]).astype(np.float32)
+                call += 1
+                for _ in range(S):
+                    eps = self.denoise(x, t)
+                    grad = ((-eps) * kappa).astype(np.float32)
+                    x = ((x + grad * ss).astype(np.float32) + (z[call] * std).astype(np.float32)).astype(np.float32)
+                    call += 1
+            x[self.mask] = gt[self.mask]
+            hist.append(x.copy())
+        return (x, np.stack(hist)) if history else x

@@ -365,6 +365,14 @@ def gen_single_eval_h256():
     ])
 
 
+def gen_single_eval_h128():
+    """a hidden width between the two tuned ones (the reference's -hidden_dim is free, train_utils.py:107): direct and energy mode"""
+    gen_single_eval('single_eval_h128', 95, [
+        ('q128', 'qualitative', 128, 'weights_qualitative_h128.npz', worlds.qualitative_batch(3, 7, seed=61)),
+        ('t128e', 'diffuse_pairwise', 128, 'weights_diffuse_pairwise_h128_energy.npz', worlds.triangular_batch(2, 12, seed=62)),
+    ])
+
+
 def gen_single_eval_box():
     """the reference's default dims (pose_dim 2, RandomSplitWorld boxes) at both widths"""
     gen_single_eval('single_eval_box', 97, [
@@ -552,6 +560,86 @@ def gen_options():
     print('options.npz  randn calls %d  |final|max %.3g  |hist|max %.3g' % (pn.c, np.abs(rec['final']).max(), np.abs(rec['hist']).max()))
 
 
+def build_composed_reference(H, W_robot, W_qual, weight=(1, 1), T=1000, S=10, EBM='ULA'):
+    """the reference's composed denoiser the way its code expects to be assembled (nothing in the repository does the
+    assembly: pose_encoder_2 & co. are None after the constructor, denoise_fn.py:287-291): a 'robot_qualitative'
+    ConstraintDiffuser holding the robot domain's weights, the qualitative model's thirteen type MLPs appended to its
+    ModuleList (so that type i >= 2 is qualitative type i - 2, denoise_fn.py:24,310-311), and the qualitative model's
+    encoders / decoder / time MLP as the *_2 modules."""
+    model = dfn.ConstraintDiffuser(dims=worlds.MODE_DIMS['robot_box'], hidden_dim=H, EBM=EBM, input_mode='robot_qualitative',
+                                   device='cpu', verbose=False)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in W_robot.items()})
+    qual = dfn.ConstraintDiffuser(dims=worlds.MODE_DIMS['qualitative'], hidden_dim=H, EBM=EBM, input_mode='qualitative',
+                                  device='cpu', verbose=False)
+    qual.load_state_dict({k: torch.from_numpy(v) for k, v in W_qual.items()})
+    model.mlps.extend(qual.mlps)
+    model.pose_encoder_2, model.geom_encoder_2 = qual.pose_encoder, qual.geom_encoder
+    model.pose_decoder_2, model.time_mlp_2 = qual.pose_decoder, qual.time_mlp
+    model.composing_weight = tuple(weight)
+    gd = ddpm.GaussianDiffusion(model, timesteps=T, EBM=EBM, samples_per_step=S, step_sizes='2*self.betas')
+    return model, gd.eval()
+
+
+def gen_composed():
+    """domain composition, input_mode 'robot_qualitative' (denoise_fn.py:287-291,310-311,341-371,487-503): the operator
+    (_process_constraint on second-domain types), single evaluations with composing weights (1, 1) and (0.5, 2), and
+    ULA chains, at hidden_dim 64 and 256"""
+    rec = {}
+    rng = np.random.default_rng(96)
+    for tag, H, batch in (('c64', 64, worlds.robot_qualitative_batch(3, 6, seed=51)),
+                          ('c256', 256, worlds.robot_qualitative_batch(2, 8, seed=52))):
+        Wr = oracle_mod.load_weights(os.path.join(GOLD, 'weights_robot_box_h%d.npz' % H))
+        Wq = oracle_mod.load_weights(os.path.join(GOLD, 'weights_qualitative_h%d.npz' % H))
+        b = batch.to_torch()
+        for key, val in batch_arrays(b).items():
+            rec['%s/%s' % (tag, key)] = val
+        ts = [0, 1, 37, 500, 998, 999]
+        poses = (rng.standard_normal((len(ts), b.x.shape[0], 5)) * 0.7).astype(np.float32)
+        rec['%s/t' % tag] = np.asarray(ts, dtype=np.int32)
+        rec['%s/poses' % tag] = poses
+        for wtag, weight in (('w11', (1, 1)), ('w052', (0.5, 2.0))):
+            model, _ = build_composed_reference(H, Wr, Wq, weight)
+            outs = []
+            for i, t in enumerate(ts):
+                with torch.no_grad():
+                    outs.append(model(torch.from_numpy(poses[i]).clone(), b, torch.tensor([t]), eval=True).numpy())
+            rec['%s/out_%s' % (tag, wtag)] = np.stack(outs)
+            # the operator on second-domain types: inputs built the way forward builds them (denoise_fn.py:497-503,322-334)
+            n = 9
+            geoms_in = rng.uniform(0.05, 0.9, (n, 2, 2)).astype(np.float32)
+            poses_in = rng.uniform(-1, 1, (n, 2, 4)).astype(np.float32)
+            tval = np.asarray([417.25], dtype=np.float32)
+            with torch.no_grad():
+                ge = model.geom_encoder_2(torch.from_numpy(geoms_in))
+                pe = model.pose_encoder_2(torch.from_numpy(poses_in))
+                te = model.time_mlp_2(torch.from_numpy(tval))
+                d = {'args': None, 'geoms_emb_2': ge, 'poses_emb_2': pe, 'time_embedding': te.repeat(n, 1)}
+                op = np.stack([model._process_constraint(i, d).numpy() for i in range(2, len(model.mlps))])
+            rec.update({'%s/op_geoms_in' % tag: geoms_in, '%s/op_poses_in' % tag: poses_in, '%s/op_t' % tag: tval,
+                        '%s/op_out_%s' % (tag, wtag): op})
+    np.savez_compressed(os.path.join(GOLD, 'composed.npz'), **rec)
+    print('composed.npz')
+    # chains
+    for name, H, batch, T, S, weight, seed in (('chain_c64_ula', 64, worlds.robot_qualitative_batch(2, 6, seed=53), 1000, 3, (1, 1), 11),
+                                               ('chain_c256_ula', 256, worlds.robot_qualitative_batch(2, 6, seed=54), 200, 3, (0.5, 0.5), 12)):
+        Wr = oracle_mod.load_weights(os.path.join(GOLD, 'weights_robot_box_h%d.npz' % H))
+        Wq = oracle_mod.load_weights(os.path.join(GOLD, 'weights_qualitative_h%d.npz' % H))
+        model, gd = build_composed_reference(H, Wr, Wq, weight, T=T, S=S)
+        b = batch.to_torch()
+        t0 = time.time()
+        with PatchedNoise(seed) as pn, contextlib.redirect_stdout(io.StringIO()):
+            out, hist = gd.sample(b.clone(), return_history=True)
+        dt = time.time() - t0
+        out = out.detach().numpy()
+        hist = np.stack([h.detach().numpy() for h in hist])
+        idx = sorted(set(i for i in HIST_IDX if i <= T) | {T})
+        r = dict(batch_arrays(b))
+        r.update(final=out, hist_idx=np.asarray(idx, dtype=np.int32), hist=hist[idx], seed=np.int64(seed), T=np.int32(T), S=np.int32(S),
+                 H=np.int32(H), n_randn=np.int64(pn.c), weight=np.asarray(weight, dtype=np.float32), ref_seconds=np.float64(dt))
+        np.savez_compressed(os.path.join(GOLD, name + '.npz'), **r)
+        print('%-20s %6.1fs  randn calls %d  |final|max %.3f  |hist|max %.3g' % (name, dt, pn.c, np.abs(out).max(), np.abs(hist).max()), flush=True)
+
+
 def gen_chains(which):
     jobs = {
         'chain_sd64_ula': lambda: run_chain('chain_sd64_ula', 'qualitative', 64, 'weights_qualitative_h64_sd.npz',
@@ -586,6 +674,10 @@ def gen_chains(which):
                                            worlds.box_batch(3, 6, seed=46).to_torch(), 'ULA', S=5),
         'chain_b256_ula': lambda: run_chain('chain_b256_ula', 'diffuse_pairwise_box', 256, 'weights_diffuse_pairwise_box_h256.npz',
                                             worlds.box_batch(2, 8, seed=47).to_torch(), 'ULA', T=200, S=10),
+        'chain_q128_ula': lambda: run_chain('chain_q128_ula', 'qualitative', 128, 'weights_qualitative_h128.npz',
+                                            worlds.qualitative_batch(3, 6, seed=63).to_torch(), 'ULA', T=200, S=5),
+        'chain_t128_mala': lambda: run_chain('chain_t128_mala', 'diffuse_pairwise', 128, 'weights_diffuse_pairwise_h128_energy.npz',
+                                             worlds.triangular_batch(2, 12, seed=64).to_torch(), 'MALA', T=100, S=2, energy=True, full_hist=True),
         'chain_r64_ula': lambda: run_chain('chain_r64_ula', 'robot_box', 64, 'weights_robot_box_h64.npz',
                                            worlds.robot_box_batch(2, 10, seed=36).to_torch(), 'ULA', S=5),
         # BASELINE configs C4 / C5 at their hidden width (H = 256): 12-triangle graphs under MALA S = 10 with the
@@ -636,6 +728,10 @@ if __name__ == '__main__':
         gen_single_eval_h256()
     if not which or 'single_eval_box' in which:
         gen_single_eval_box()
+    if not which or 'single_eval_h128' in which:
+        gen_single_eval_h128()
+    if not which or 'composed' in which:
+        gen_composed()
     if not which or 'pre_transform' in which:
         gen_pre_transform()
     if not which or 'struct_diffusion' in which:

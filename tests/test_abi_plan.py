@@ -24,12 +24,12 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 17
     for n in names:
         assert hasattr(L, n), n
-    assert L.ccsp_version() == 4
+    assert L.ccsp_version() == 5
     assert isinstance(L.ccsp_last_error(), bytes)
 
 
 def test_structs_match_header_layout():
-    assert ctypes.sizeof(_lib.ModelDesc) == 12 * 4 and _lib.ModelDesc.model_kind.offset == 44
+    assert ctypes.sizeof(_lib.ModelDesc) == 12 * 4 and _lib.ModelDesc.model_kind.offset == 44 and ctypes.sizeof(_lib.Compose) == 16
     assert ctypes.sizeof(_lib.Noise) == 72
     assert _lib.Noise.seed.offset == 8 and _lib.Noise.normal.offset == 24 and _lib.Noise.ucall_base.offset == 64
 

@@ -1,0 +1,134 @@
+"""Domain composition (the reference's input_mode 'robot_qualitative': networks/denoise_fn.py:287-291,310-311,341-371,
+487-503): a robot_box model and a qualitative model evaluated on ONE graph that carries both kinds of constraints.
+
+`-m "not gpu"`: the CPU restatement (oracle/compose.py) against vectors the reference itself produced
+(oracle/gen_golden.py:gen_composed -> tests/golden/composed.npz, chain_c64_ula.npz, chain_c256_ula.npz).
+`-m gpu`: the HIP path (ccsp_compose_denoise / ccsp_compose_chain_run behind ConstraintDiffuser.compose) against the same
+vectors and against the restatement on fresh inputs.  Tolerances as for the single-domain tests: 2e-5 relative on single
+evaluations, 1e-4 absolute on a chain's final poses."""
+import numpy as np
+import pytest
+import torch
+
+import compose as compose_oracle
+from conftest import golden, golden_batch, oracle_model, rel_err, weights, worlds
+from diffusion_ccsp_amd import noise
+
+CASES = [('c64', 64), ('c256', 256)]
+WEIGHTS = {'w11': (1, 1), 'w052': (0.5, 2.0)}
+
+
+def _oracle_pair(H, T=1000, S=10):
+    return (oracle_model('robot_box', H, 'weights_robot_box_h%d.npz' % H, T=T, S=S),
+            oracle_model('qualitative', H, 'weights_qualitative_h%d.npz' % H, T=T, S=S))
+
+
+@pytest.mark.parametrize('tag,H', CASES)
+def test_oracle_single_evaluation_vs_reference(tag, H):
+    z = golden('composed')
+    m1, m2 = _oracle_pair(H)
+    b = golden_batch(z, tag + '/')
+    assert (z[tag + '/edge_attr'] >= 2).any() and (z[tag + '/edge_attr'] < 2).any()       # both domains present
+    for wtag, w in WEIGHTS.items():
+        g = compose_oracle.ComposedOracleGraph(m1, m2, b, weight=w)
+        for i, t in enumerate(z[tag + '/t']):
+            want = z['%s/out_%s' % (tag, wtag)][i]
+            got = g.denoise(z[tag + '/poses'][i], int(t))
+            assert rel_err(got, want) < 2e-5, (tag, wtag, int(t))
+
+
+@pytest.mark.parametrize('name,H', [('chain_c64_ula', 64), ('chain_c256_ula', 256)])
+def test_oracle_chain_vs_reference(name, H):
+    z = golden(name)
+    T, S = int(z['T']), int(z['S'])
+    m1, m2 = _oracle_pair(H, T=T, S=S)
+    b = golden_batch(z)
+    g = compose_oracle.ComposedOracleGraph(m1, m2, b, weight=tuple(z['weight']))
+    N = z['x'].shape[0]
+    zs = noise.normal_stream(int(z['seed']), int(z['n_randn']), N, 5)
+    final, hist = g.chain(zs, S, history=True)
+    assert np.abs(final - z['final']).max() < 1e-4
+    for k, idx in enumerate(z['hist_idx']):
+        assert rel_err(hist[idx], z['hist'][k]) < 2e-3, (name, int(idx))
+
+
+# ---------------------------------------------------------------------------------------------------------------- GPU
+def _composed_model(H, device, weight=(1, 1), T=1000, S=10, EBM='ULA'):
+    from diffusion_ccsp_amd import ConstraintDiffuser, GaussianDiffusion
+    first = ConstraintDiffuser(dims=worlds.MODE_DIMS['robot_box'], hidden_dim=H, input_mode='robot_qualitative', device=device, verbose=False)
+    first.load_state_dict({k: torch.from_numpy(v) for k, v in weights('weights_robot_box_h%d.npz' % H).items()})
+    second = ConstraintDiffuser(dims=worlds.MODE_DIMS['qualitative'], hidden_dim=H, input_mode='qualitative', device=device, verbose=False)
+    second.load_state_dict({k: torch.from_numpy(v) for k, v in weights('weights_qualitative_h%d.npz' % H).items()})
+    first.compose(second, composing_weight=weight)
+    gd = GaussianDiffusion(first, timesteps=T, EBM=EBM, samples_per_step=S)
+    return first, second, gd
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag,H', CASES)
+def test_hip_single_evaluation_vs_reference(tag, H, device):
+    z = golden('composed')
+    b = golden_batch(z, tag + '/')
+    for wtag, w in WEIGHTS.items():
+        model, second, _ = _composed_model(H, device, w)
+        assert len(model.constraint_sets) == 15 and model.pose_encoder_2 is not None and model.composing_weight == tuple(w)
+        for i, t in enumerate(z[tag + '/t']):
+            got = model(torch.from_numpy(z[tag + '/poses'][i]), b, torch.tensor([int(t)])).cpu().numpy()
+            assert rel_err(got, z['%s/out_%s' % (tag, wtag)][i]) < 2e-5, (tag, wtag, int(t))
+        # the operator on second-domain types, inputs built from the *_2 encoders like forward does (denoise_fn.py:497-503)
+        ge = model.geom_encoder_2(torch.from_numpy(z[tag + '/op_geoms_in']))
+        pe = model.pose_encoder_2(torch.from_numpy(z[tag + '/op_poses_in']))
+        te = model.time_mlp_2(torch.from_numpy(z[tag + '/op_t']))
+        n = pe.shape[0]
+        d = {'args': None, 'geoms_emb_2': ge, 'poses_emb_2': pe, 'time_embedding': te.repeat(n, 1)}
+        want = z['%s/op_out_%s' % (tag, wtag)]
+        for i in range(2, 15):
+            got = model._process_constraint(i, d).cpu().numpy()
+            assert got.shape == (n, 2, 5) and np.all(got[:, :, 2] == 0)
+            assert rel_err(got, want[i - 2]) < 2e-5, (tag, wtag, i)
+        # energy mode is not composed: it must refuse, not fall back
+        model.energy_wrapper = True
+        with pytest.raises(NotImplementedError):
+            model(torch.from_numpy(z[tag + '/poses'][0]), b, torch.tensor([3]), tag='EBM')
+        model.energy_wrapper = False
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,H', [('chain_c64_ula', 64), ('chain_c256_ula', 256)])
+def test_hip_chain_vs_reference(name, H, device):
+    z = golden(name)
+    T, S = int(z['T']), int(z['S'])
+    model, second, gd = _composed_model(H, device, tuple(float(v) for v in z['weight']), T=T, S=S)
+    b = golden_batch(z)
+    x, hist = gd.p_sample_loop(b, return_history=True, seed=int(z['seed']))
+    x = x.cpu().numpy()
+    assert np.abs(x - z['final']).max() < 1e-4
+    for k, idx in enumerate(z['hist_idx']):
+        assert rel_err(hist[int(idx)].cpu().numpy(), z['hist'][k]) < 2e-3, (name, int(idx))
+    # a chain split across calls reproduces the unsplit chain bit for bit (noise draws are indexed by call number)
+    mid = T // 2
+    x1 = gd.p_sample_segment(b, hist[T - mid], mid - 1, 0, seed=int(z['seed']))
+    assert np.array_equal(x1.cpu().numpy(), x)
+
+
+@pytest.mark.gpu
+def test_hip_fresh_inputs_vs_restatement(device):
+    """inputs the fixtures do not hold: ragged graphs, a graph with no second-domain edge, unmatched type ids, no normalisation"""
+    H = 64
+    m1, m2 = _oracle_pair(H)
+    b = worlds.robot_qualitative_batch(3, 5, seed=77).to_torch()
+    ea = b.edge_attr.clone()
+    g0 = (b.edge_index[0] < 6)
+    keep = ~(g0 & (ea >= 2))                                   # graph 0: robot constraints only
+    b.edge_index, ea = b.edge_index[:, keep], ea[keep]
+    ea[3] = 15.0                                               # beyond both domains: ignored (denoise_fn.py:512-517)
+    b.edge_attr = ea
+    rng = np.random.default_rng(5)
+    poses = (rng.standard_normal((b.x.shape[0], 5)) * 0.7).astype(np.float32)
+    for normalize in (True, False):
+        model, second, _ = _composed_model(H, device, (1, 0.25))
+        model.normalize = normalize
+        g = compose_oracle.ComposedOracleGraph(m1, m2, b, weight=(1, 0.25), normalize=normalize)
+        for t in (0, 400, 999):
+            got = model(torch.from_numpy(poses), b, torch.tensor([t])).cpu().numpy()
+            assert rel_err(got, g.denoise(poses, t)) < 2e-5, (normalize, t)

@@ -63,6 +63,19 @@ def test_single_evaluation_default_dims(tag, mode, H, wfile):
         assert rel_err(g.denoise(z[tag + '/poses'][i], int(t)), z[tag + '/out'][i]) < 2e-5, (tag, t)
 
 
+def test_single_evaluation_h128():
+    """a hidden width other than the two tuned ones (the reference's -hidden_dim is free, train_utils.py:107)"""
+    z = golden('single_eval_h128')
+    g = oracle_model('qualitative', 128, 'weights_qualitative_h128.npz').graph(golden_batch(z, 'q128/'))
+    for i, t in enumerate(z['q128/t']):
+        assert rel_err(g.denoise(z['q128/poses'][i], int(t)), z['q128/out'][i]) < 2e-5, int(t)
+    g = oracle_model('diffuse_pairwise', 128, 'weights_diffuse_pairwise_h128_energy.npz', energy=True).graph(golden_batch(z, 't128e/'))
+    for i, t in enumerate(z['t128e/t']):
+        grad, E = g.energy_grad(z['t128e/poses'][i], int(t))
+        assert abs(E - z['t128e/energy'][i]) <= 2e-5 * (1 + abs(z['t128e/energy'][i]))
+        assert rel_err(grad, z['t128e/grad'][i]) < 5e-5, int(t)
+
+
 def test_single_evaluation_energy():
     z = golden('single_eval')
     tag = 't64e'
@@ -75,7 +88,7 @@ def test_single_evaluation_energy():
 
 
 CHAINS = ['chain_q64_T1000_B4', 'chain_q64_T100_B1', 'chain_q256_T100_B1', 'chain_q64_noebm',
-          'chain_q64_ulaplus', 'chain_t64_ula', 'chain_r64_ula', 'chain_b64_ula', 'chain_b256_ula']
+          'chain_q64_ulaplus', 'chain_t64_ula', 'chain_r64_ula', 'chain_b64_ula', 'chain_b256_ula', 'chain_q128_ula']
 
 
 def _run_oracle_chain(z, f64=False, history=True):
@@ -376,3 +389,12 @@ def test_timestep_restart_equals_full_chain():
     full, hist = g.chain('ULA', seed=int(z['seed']), history=True)
     x = g.chain('ULA', seed=int(z['seed']), x=hist[40], t_first=59, t_last=20)
     assert np.array_equal(x, hist[80])
+
+
+def test_mala_h128_timesteps_vs_reference():
+    z = golden('chain_t128_mala')
+    m = oracle_model('diffuse_pairwise', 128, 'weights_diffuse_pairwise_h128_energy.npz', T=int(z['T']), S=int(z['S']), energy=True)
+    g = m.graph(golden_batch(z))
+    seed = int(z['seed'])
+    bad = mala_timestep_errors(lambda x, t: g.chain('MALA', seed=seed, x=x, t_first=t, t_last=t, accept=True), z, range(int(z['T']) - 1, -1, -1))
+    assert len(bad) <= 1, bad
