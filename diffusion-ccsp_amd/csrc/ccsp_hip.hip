@@ -2337,6 +2337,19 @@ int ensure_children(ccsp_model* m, ccsp_graph* g, int want, hipStream_t s) {
         if (m->lane_streams.size() <= k) {
             hipStream_t cs = nullptr;
             hipEvent_t ce = nullptr;
+            // CCSP_LANE_CUMASK (experiment, default off): give every lane its own share of the compute units instead of letting the
+            // lanes' kernels interleave on all of them; 1 = contiguous ranges of the mask, 2 = every want-th bit
+            const char* cm = getenv("CCSP_LANE_CUMASK");
+            const int cmode = cm ? atoi(cm) : 0;
+            if (cmode == 1 || cmode == 2) {
+                const int ncu = m->ncu > 0 ? m->ncu : 256;
+                std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+                for (int i = 0; i < ncu; ++i) {
+                    const bool mine = cmode == 1 ? (i * want / ncu == (int)k) : (i % want == (int)k);
+                    if (mine) mask[i >> 5] |= 1u << (i & 31);
+                }
+                HIP_TRY(hipExtStreamCreateWithCUMask(&cs, (uint32_t)mask.size(), mask.data()));
+            } else
             HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&ce, hipEventDisableTiming));
             m->lane_streams.push_back(cs);

@@ -597,6 +597,10 @@ def gen_composed():
         poses = (rng.standard_normal((len(ts), b.x.shape[0], 5)) * 0.7).astype(np.float32)
         rec['%s/t' % tag] = np.asarray(ts, dtype=np.int32)
         rec['%s/poses' % tag] = poses
+        n = 9
+        geoms_in = rng.uniform(0.05, 0.9, (n, 2, 2)).astype(np.float32)
+        poses_in = rng.uniform(-1, 1, (n, 2, 4)).astype(np.float32)
+        tval = np.asarray([417.25], dtype=np.float32)
         for wtag, weight in (('w11', (1, 1)), ('w052', (0.5, 2.0))):
             model, _ = build_composed_reference(H, Wr, Wq, weight)
             outs = []
@@ -605,10 +609,6 @@ def gen_composed():
                     outs.append(model(torch.from_numpy(poses[i]).clone(), b, torch.tensor([t]), eval=True).numpy())
             rec['%s/out_%s' % (tag, wtag)] = np.stack(outs)
             # the operator on second-domain types: inputs built the way forward builds them (denoise_fn.py:497-503,322-334)
-            n = 9
-            geoms_in = rng.uniform(0.05, 0.9, (n, 2, 2)).astype(np.float32)
-            poses_in = rng.uniform(-1, 1, (n, 2, 4)).astype(np.float32)
-            tval = np.asarray([417.25], dtype=np.float32)
             with torch.no_grad():
                 ge = model.geom_encoder_2(torch.from_numpy(geoms_in))
                 pe = model.pose_encoder_2(torch.from_numpy(poses_in))
@@ -694,6 +694,10 @@ def gen_chains(which):
         # graphs with it -- the better the network fits, the larger the transient of the first timesteps
         'chain_q256_50k_B16': lambda: run_chain('chain_q256_50k_B16', 'qualitative', 256, 'weights/qualitative_h256_50k.npz',
                                                 worlds.qualitative_batch(16, 8, seed=19).to_torch(), 'ULA'),
+        # the reference recipe AS WRITTEN (30 000 fixed worlds of 2-5 objects, 300 000 Adam steps, tools/train_gpu.py TRAIN_RECIPE=reference;
+        # profiles/r03_train_reference_recipe_log.txt): what the REFERENCE sampler does with the final weights on 8-object graphs
+        'chain_q256_ref300k_B16': lambda: run_chain('chain_q256_ref300k_B16', 'qualitative', 256, 'weights/qualitative_h256_ref300k.npz',
+                                                    worlds.qualitative_batch(16, 8, seed=19).to_torch(), 'ULA'),
         'chain_q64_T1000_B4_f64': lambda: run_chain('chain_q64_T1000_B4_f64', 'qualitative', 64, 'weights_qualitative_h64.npz',
                                                     worlds.qualitative_batch(4, 8, seed=31).to_torch(), 'ULA', dtype=torch.float64),
     }

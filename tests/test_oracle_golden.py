@@ -398,3 +398,21 @@ def test_mala_h128_timesteps_vs_reference():
     seed = int(z['seed'])
     bad = mala_timestep_errors(lambda x, t: g.chain('MALA', seed=seed, x=x, t_first=t, t_last=t, accept=True), z, range(int(z['T']) - 1, -1, -1))
     assert len(bad) <= 1, bad
+
+
+def test_reference_recipe_weights_overflow_in_the_reference_sampler():
+    """the fixture behind DESIGN.md section 7: the reference's own sampler on weights trained with the reference's recipe as
+    written overflows fp32 on every one of sixteen 8-object graphs; the oracle reproduces the recorded transient"""
+    from bench import load_weights
+    import os
+    from conftest import ROOT
+    z = golden('chain_q256_ref300k_B16')
+    bad = ~np.isfinite(z['final']).all(axis=1)
+    assert int(bad.sum()) == 128 and np.abs(z['hist'][1]).max() > 1e8 and np.abs(z['hist'][5]).max() > 1e34
+    W = load_weights(os.path.join(ROOT, 'weights', 'qualitative_h256_ref300k.npz'))
+    m = oracle.OracleModel({k: v.numpy() if hasattr(v, 'numpy') else v for k, v in W.items()}, worlds.MODE_DIMS['qualitative'], 256, 13,
+                           timesteps=1000, samples_per_step=10)
+    g = m.graph(golden_batch(z))
+    for k in range(3):                                          # timesteps 999, 998, 997 from the recorded states
+        x1 = g.chain('ULA', seed=int(z['seed']), x=z['hist'][k], t_first=999 - k, t_last=999 - k)
+        assert rel_err(x1, z['hist'][k + 1]) < 2e-3, k
