@@ -17,7 +17,8 @@ python bench.py --config c4 --gpus 1 --force-dist --mala-global-batch --steps 1 
 python bench.py --config c4 --gpus 1 --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/c4_replica_for_comparison.log 2>&1
 tail -c 300 $OUT/rccl_c2_force_dist.log; echo; tail -c 300 $OUT/rccl_c4_mala_global_batch.log; echo
 for c in c2 c4 c5; do
-  BENCH_ARGS="--config $c --no-evaluate" bash tools/prof_stats.sh ${T}_stats_$c "CCSP_X=0" > /dev/null 2>&1
+  # (c4: the kernels at full work -- every evaluation recomputed)
+  BENCH_ARGS="--config $c --no-evaluate" bash tools/prof_stats.sh ${T}_stats_$c "CCSP_MALA_REUSE=0" > /dev/null 2>&1
   cp $R/gpurun_out/${T}_stats_$c/stats_1.csv $OUT/kernel_stats_$c.csv
   bash tools/pmc_run.sh ${T}_pmc_$c $c > /dev/null 2>&1
   cp $R/gpurun_out/${T}_pmc_$c/summary.txt $OUT/pmc_$c.txt
