@@ -16,6 +16,9 @@ from diffusion_ccsp_amd import ConstraintDiffuser, GaussianDiffusion, checker, e
 
 dev = torch.device('cuda:0')
 objects = [int(v) for v in os.environ.get('SWEEP_OBJECTS', '2,3,4,5,6,8').split(',')]
+# SPS = ULA steps per timestep (the GaussianDiffusion default is 10; the reference's train_ddpm.py passes 3, train_ddpm.py:35); SAMPLER=none: EBM False
+SPS = int(os.environ.get('SPS', '10'))
+EBM = False if os.environ.get('SAMPLER', 'ULA') == 'none' else os.environ.get('SAMPLER', 'ULA')
 rng = np.random.default_rng(11)
 sets = {}
 for n_obj in objects:
@@ -28,7 +31,7 @@ out = {}
 for path in sys.argv[2:]:
     den = ConstraintDiffuser(dims=worlds.MODE_DIMS['qualitative'], hidden_dim=256, input_mode='qualitative', EBM='ULA', device=dev, verbose=False)
     den.load_state_dict(load_weights(path))
-    gd = GaussianDiffusion(den, timesteps=1000, EBM='ULA', samples_per_step=10)
+    gd = GaussianDiffusion(den, timesteps=1000, EBM=EBM, samples_per_step=SPS)
     with tempfile.TemporaryDirectory() as td:
         log = evaluate.Evaluator(gd, sets, td).evaluate(0, tries=(10, 0), run_all=True, seed=500)
     rec = {'evaluate': {str(k): {'top1': v['success_rate'], 'top10': v.get('success_rate_top10', v.get('success_rate_top3'))} for k, v in log.items()}}
