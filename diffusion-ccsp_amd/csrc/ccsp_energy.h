@@ -229,6 +229,10 @@ struct EnergyNodeArgs {
     const float* W2T;        // [H/2, H]
     const float* b2;
     const int* skip;         // MALA reuse: if non-null and *skip == 0 the launch returns at once (k_node_energy_h2)
+    // composed domains (ccsp_compose_energy_grad): the encoder saw x_enc, not the comparison target x, and only its first
+    // enc_cols inputs are variables (the rest are constants of the batch); defaults: x_enc = x, every column
+    const float* x_enc;      // or null
+    int enc_cols;            // 0 = all P columns
 };
 
 template <int H>
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(256) void k_node_energy(EnergyNodeArgs a) {
         const int nl = tid / 8, p = tid % 8, n = node0 + nl;
         float xv = 0.0f, dv = 0.0f;
         if (n < a.N && p < a.P) {
-            xv = a.x[(size_t)n * a.P + p];
+            xv = (a.x_enc ? a.x_enc : a.x)[(size_t)n * a.P + p];
             const int beg = a.node_ptr[n], end = a.node_ptr[n + 1];
             const float* op = a.Ocsr + (size_t)beg * a.P + p;
             for (int q = 0; q < end - beg; ++q) dv += op[(size_t)q * a.P];
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(256) void k_node_energy(EnergyNodeArgs a) {
         if (n < a.N && p < a.P) {
             float gx = 0.0f;
             for (int k = 0; k < KC; ++k) gx = fmaf(y1[nl][k], a.W0[k * a.P + p], gx);
-            a.grad[(size_t)n * a.P + p] = dir[nl][p] + gx;
+            a.grad[(size_t)n * a.P + p] = (a.enc_cols && p >= a.enc_cols) ? dir[nl][p] : dir[nl][p] + gx;
         }
     }
 }
@@ -380,7 +384,7 @@ __global__ __launch_bounds__(256) void k_node_energy_mfma(EnergyNodeArgs a, cons
         const int nl1 = tid / 8, p = tid % 8, n1 = node0 + nl1;
         float xv = 0.0f, dv = 0.0f;
         if (n1 < a.N && p < a.P) {
-            xv = a.x[(size_t)n1 * a.P + p];
+            xv = (a.x_enc ? a.x_enc : a.x)[(size_t)n1 * a.P + p];
             const int beg = a.node_ptr[n1], end = a.node_ptr[n1 + 1];
             const float* op = a.Ocsr + (size_t)beg * a.P + p;
 #pragma unroll 8
@@ -497,7 +501,7 @@ __global__ __launch_bounds__(256) void k_node_energy_mfma(EnergyNodeArgs a, cons
         if (half == 1) red[t7] = gx;
         __syncthreads();
         const int n2 = node0 + nl2;
-        if (half == 0 && n2 < a.N && p < a.P) a.grad[(size_t)n2 * a.P + p] = dir[nl2][p] + (gx + red[t7]);
+        if (half == 0 && n2 < a.N && p < a.P) a.grad[(size_t)n2 * a.P + p] = (a.enc_cols && p >= a.enc_cols) ? dir[nl2][p] : dir[nl2][p] + (gx + red[t7]);
     }
 }
 
@@ -548,7 +552,7 @@ __global__ __launch_bounds__(256) void k_node_energy_h2(EnergyNodeArgs a, EncW w
     if (upd) {
         beg = a.node_ptr[n1];
         cnt = a.node_ptr[n1 + 1] - beg;
-        xv = a.x[(size_t)n1 * a.P + p1];
+        xv = (a.x_enc ? a.x_enc : a.x)[(size_t)n1 * a.P + p1];
     }
     // ---- second links: the first four U rows of the lane's node, the first sixteen CSR entries
     const int c00 = wave * 64 + 4 * (lane >> 4);
@@ -765,7 +769,7 @@ __global__ __launch_bounds__(256) void k_node_energy_h2(EnergyNodeArgs a, EncW w
         if (half == 1) red[t7] = gx;
         __syncthreads();
         const int n2 = node0 + nl2;
-        if (half == 0 && n2 < a.N && p < a.P) a.grad[(size_t)n2 * a.P + p] = dir[nl2][p] + (gx + red[t7]);
+        if (half == 0 && n2 < a.N && p < a.P) a.grad[(size_t)n2 * a.P + p] = (a.enc_cols && p >= a.enc_cols) ? dir[nl2][p] : dir[nl2][p] + (gx + red[t7]);
     }
 }
 

@@ -1832,7 +1832,8 @@ int energy_prepare(ccsp_model* m, ccsp_graph* g, hipStream_t s) {
 // E_out == nullptr (energy-only evaluations): leave the per-workgroup partials in g->partial / g->n_part_last for the consumer
 template <int H>
 int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, bool with_grad, float* E_out, hipStream_t s,
-                       const int* skip = nullptr /*MALA reuse: every kernel of the evaluation returns at once if *skip == 0*/) {
+                       const int* skip = nullptr /*MALA reuse: every kernel of the evaluation returns at once if *skip == 0*/,
+                       const float* x_enc = nullptr, int enc_cols = 0 /*composed domains: see EnergyNodeArgs*/) {
     const ccsp::Plan& p = g->plan;
     const int P = m->d.pose_dim;
     g->evals++;
@@ -1938,7 +1939,7 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
                        g->tileb_nrows, g->tileb_ts, m->WpT, (size_t)2 * H * H, nof, nof, g->GP);
     }
     EnergyNodeArgs a{g->N, P, g->node_ptr, g->O, g->nrow_ptr, g->nrow_idx, g->GP, xeval, g->eps, g->partial, n_part, E_out,
-                     m->pe0_w, m->pe0_b, m->pe2_w, m->pe2_wT, m->pe2_b, skip};
+                     m->pe0_w, m->pe0_b, m->pe2_w, m->pe2_wT, m->pe2_b, skip, x_enc, enc_cols};
     const bool valu_node_energy = m->valu_node_energy != 0;                              // the pre-MFMA kernel, kept for A/B runs
     prof_mark(g, s, CCSP_K_NODE_ENERGY);
     if (valu_node_energy) hipLaunchKernelGGL(k_node_energy<H>, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a);
@@ -2574,6 +2575,41 @@ int compose_eval(ccsp_model* m1, ccsp_graph* g1, ccsp_model* m2, ccsp_graph* g2,
                        g1->plan.E_act > 0 ? g1->node_ptr : (const int*)nullptr, g2->plan.E_act > 0 ? g2->node_ptr : (const int*)nullptr,
                        c->weight_first, c->weight_second, c->normalize, g1->mask, g1->xfeat, g1->F, out);
     return 0;
+}
+
+
+// composed energy (denoise_fn.py:373-375 on the composed outputs of :341-371): E = E1 + sum over second-domain entries of
+// |widen(o2) - poses[node]|^2.  The widened output has a zero at zero_col, so that column contributes poses[n, zero_col]^2
+// per entry; the other columns are the second model's own energy with the comparison target [poses without zero_col] while
+// its encoder saw poses_2 (k_compose_pack) -- launch_eval_energy(..., x_enc, enc_cols = 2).
+__global__ void k_compose_targets(int N, int P, int zero_col, const float* __restrict__ poses, float* __restrict__ out /*[N, P-1]*/) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * (P - 1)) return;
+    const int n = i / (P - 1), c = i % (P - 1);
+    out[i] = poses[(size_t)n * P + (c < zero_col ? c : c + 1)];
+}
+
+__global__ __launch_bounds__(256) void k_compose_energy(int N, int P, int zero_col, const float* __restrict__ poses, const float* __restrict__ g1,
+                                                        const float* __restrict__ g2, const int* __restrict__ nptr2, const float* __restrict__ E12 /*[2]*/,
+                                                        float* __restrict__ grad, float* __restrict__ energy) {
+    // one workgroup: the batch is small next to the evaluations in front of it, and the energy is one ordered sum
+    __shared__ float red[8];
+    float e = 0.0f;
+    for (int i = threadIdx.x; i < N * P; i += 256) {
+        const int n = i / P, c = i % P;
+        float v = g1[i];
+        if (c == zero_col) {
+            const float cnt = nptr2 ? (float)(nptr2[n + 1] - nptr2[n]) : 0.0f;
+            const float pz = poses[i];
+            v += 2.0f * pz * cnt;
+            e += cnt * pz * pz;
+        } else {
+            v += g2[(size_t)n * (P - 1) + (c < zero_col ? c : c - 1)];
+        }
+        grad[i] = v;
+    }
+    const float tot = block_sum_256(e, red);
+    if (threadIdx.x == 0) energy[0] = (E12[0] + E12[1]) + tot;
 }
 
 }  // namespace
@@ -3275,6 +3311,43 @@ int ccsp_compose_denoise(ccsp_model* m1, ccsp_graph* g1, ccsp_model* m2, ccsp_gr
     if (b1.alloc(N * m1->d.pose_dim * sizeof(float)) || b2.alloc(N * m2->d.pose_dim * sizeof(float)) || b3.alloc(N * m2->d.pose_dim * sizeof(float))) return 1;
     const ComposeScratch w{b1.f(), b2.f(), b3.f()};
     if (compose_eval(m1, g1, m2, g2, c, poses_in, t, w, out, s)) return 1;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ccsp_compose_energy_grad(ccsp_model* m1, ccsp_graph* g1, ccsp_model* m2, ccsp_graph* g2, const ccsp_compose* c, const float* poses_in,
+                             int32_t t, float* grad, float* energy, void* stream) {
+    if (!m1 || !g1 || !m2 || !g2 || !c || !poses_in || !grad || !energy) return fail("compose_energy_grad: null argument");
+    if (g1->m != m1 || g2->m != m2) return fail("compose_energy_grad: a graph belongs to another model");
+    if (m1->d.model_kind != CCSP_MODEL_DIFFUSION_CCSP || m2->d.model_kind != CCSP_MODEL_DIFFUSION_CCSP) return fail("compose_energy_grad: both domains must be Diffusion-CCSP models");
+    if (!m1->d.energy_wrapper || !m2->d.energy_wrapper) return fail("compose_energy_grad: both models must be energy_wrapper models");
+    if (m2->d.pose_dim + 1 != m1->d.pose_dim || m2->d.pose_dim < 2) return fail("compose_energy_grad: the second domain's pose_dim must be the first's minus the zero column");
+    if (c->zero_col < 2 || c->zero_col >= m1->d.pose_dim) return fail("compose_energy_grad: zero_col=%d (the second domain's encoder takes pose columns 0 and 1)", c->zero_col);
+    if (c->weight_first != 1.0f || c->weight_second != 1.0f) return fail("compose_energy_grad: composing weights other than (1, 1) are built for the direct mode only");
+    if (g1->N != g2->N || m1->d.hidden_dim != m2->d.hidden_dim) return fail("compose_energy_grad: the two domains differ in nodes or hidden_dim");
+    if (t < 0 || t >= m1->d.timesteps || t >= m2->d.timesteps) return fail("compose_energy_grad: t=%d out of range", t);
+    hipStream_t s = (hipStream_t)stream;
+    if (energy_prepare(m1, g1, s) || energy_prepare(m2, g2, s)) return 1;
+    const int N = g1->N, P = m1->d.pose_dim, P2 = m2->d.pose_dim;
+    StreamBuf b1(s), b2(s), b3(s);
+    if (b1.alloc((size_t)N * P2 * sizeof(float)) || b2.alloc((size_t)N * P2 * sizeof(float)) || b3.alloc(2 * sizeof(float))) return 1;
+    float *p_enc = b1.f(), *p_tgt = b2.f(), *E12 = b3.f();
+    hipLaunchKernelGGL(k_compose_pack, dim3(nblk((long)N * P2, 256)), dim3(256), 0, s, N, P, P2, poses_in, g1->xfeat, g1->F, p_enc);
+    hipLaunchKernelGGL(k_compose_targets, dim3(nblk((long)N * P2, 256)), dim3(256), 0, s, N, P, c->zero_col, poses_in, p_tgt);
+    const int rc = dispatch_h(m1->d.hidden_dim, [&](auto hc) {
+        constexpr int HH = decltype(hc)::value;
+        NodeArgs a = node_args(m1, g1);
+        a.src = 2; a.step = STEP_NONE; a.do_encode = 1; a.x_in = poses_in;
+        launch_node<HH>(m1, g1, a, s);
+        if (launch_eval_energy<HH>(m1, g1, t, poses_in, true, E12, s)) return 1;
+        NodeArgs b = node_args(m2, g2);
+        b.src = 2; b.step = STEP_NONE; b.do_encode = 1; b.x_in = p_enc;
+        launch_node<HH>(m2, g2, b, s);
+        return launch_eval_energy<HH>(m2, g2, t, p_tgt, true, E12 + 1, s, nullptr, p_enc, 2);
+    });
+    if (rc) return 1;
+    hipLaunchKernelGGL(k_compose_energy, dim3(1), dim3(256), 0, s, N, P, c->zero_col, poses_in, g1->eps, g2->eps,
+                       g2->plan.E_act > 0 ? g2->node_ptr : (const int*)nullptr, E12, grad, energy);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -462,14 +462,22 @@ class ConstraintDiffuser(object):
         energy mode (tag == 'EBM' and energy_wrapper) -> (gradients [N,P], energy scalar)"""
         L = _lib.lib()
         if self._second is not None:
-            if tag == 'EBM' and self.energy_wrapper:
-                raise NotImplementedError('composed domains are evaluated in direct mode only (DESIGN.md: the second domain\'s energy '
-                                          'compares against poses its encoder does not see, denoise_fn.py:373-375,499)')
+            energy_mode = tag == 'EBM' and self.energy_wrapper
+            if energy_mode and tuple(self.composing_weight) != (1, 1):
+                raise NotImplementedError('the energy of composed domains is built for composing_weight (1, 1)')
+            if self._second.energy_wrapper != self.energy_wrapper:       # the second native model follows this one's mode
+                self._second.energy_wrapper = self.energy_wrapper
+                self._second._drop_handle()
             g1, g2 = self._composed_graphs(batch)
             first, second = self, self._second
             p = poses_in.detach().to(self.device, torch.float32).contiguous()
             out = torch.empty_like(p)
             c = self._compose_struct()
+            if energy_mode:
+                energy = torch.zeros((), device=self.device, dtype=torch.float32)
+                _lib.check(L.ccsp_compose_energy_grad(first._h, g1.h, second._h, g2.h, C.byref(c), _ptr(p), int(torch.as_tensor(t).reshape(-1)[0]),
+                                                      _ptr(out), _ptr(energy), _stream_ptr(self.device)))
+                return out, energy
             _lib.check(L.ccsp_compose_denoise(first._h, g1.h, second._h, g2.h, C.byref(c), _ptr(p), int(torch.as_tensor(t).reshape(-1)[0]),
                                               _ptr(out), _stream_ptr(self.device)))
             return out

@@ -185,8 +185,9 @@ int ccsp_chain_run(ccsp_model* model, ccsp_graph* graph, int32_t sampler, const 
  * (the library fills poses_2 = [poses[:, :2] | x[:, -(P-3):]] itself, x = graph_first's features, denoise_fn.py:499).
  * One composed evaluation = one ordinary evaluation per domain + one elementwise kernel:
  *     out = (w1 * sum1 + w2 * widen(sum2)) / sqrt(count1 + count2);  out[mask] = x[:, -P:][mask]
- * Both models must be direct-mode (energy_wrapper 0) Diffusion-CCSP models with the same `timesteps`; their own
- * `normalize` flags are not used.  The chain form runs samplers NONE / ULA / ULA+ with the schedule of `first`. */
+ * Both models must be Diffusion-CCSP models with the same `timesteps`, direct-mode (energy_wrapper 0) for ccsp_compose_denoise
+ * and ccsp_compose_chain_run; their own `normalize` flags are not used.  The chain form runs samplers NONE / ULA / ULA+ with the
+ * schedule of `first`. */
 typedef struct ccsp_compose {
     int32_t zero_col;       /* column of the P-wide pose the second domain does not produce (2: z) */
     float weight_first;     /* composing_weight[0] */
@@ -195,6 +196,13 @@ typedef struct ccsp_compose {
 } ccsp_compose;
 int ccsp_compose_denoise(ccsp_model* first, ccsp_graph* graph_first, ccsp_model* second, ccsp_graph* graph_second,
                          const ccsp_compose* compose, const float* poses_in, int32_t t, float* out, void* stream);
+/* energy mode of the composed model (both models energy_wrapper = 1; composing weights (1, 1)): energy [1] = sum over the
+ * edges of both domains of |outputs - poses_in[args]|^2 with the second domain's outputs widened by the zero column
+ * (denoise_fn.py:373-375 on :364-370), grad [N,P] = d energy / d poses_in (the second domain's encoder sees poses_in[:, :2]
+ * only, denoise_fn.py:499) */
+int ccsp_compose_energy_grad(ccsp_model* first, ccsp_graph* graph_first, ccsp_model* second, ccsp_graph* graph_second,
+                             const ccsp_compose* compose, const float* poses_in, int32_t t, float* grad, float* energy,
+                             void* stream);
 int ccsp_compose_chain_run(ccsp_model* first, ccsp_graph* graph_first, ccsp_model* second, ccsp_graph* graph_second,
                            const ccsp_compose* compose, int32_t sampler, const ccsp_noise* noise, float* x, int32_t init,
                            int32_t t_first, int32_t t_last, float* history, void* stream);

@@ -336,6 +336,10 @@ typedef struct {
     real* y1;         /* [N,H/2] encoder pre-activations (energy mode) */
     real* y2;         /* [N,H] */
     real* o;          /* [E,2,P] decoder outputs in evaluation order */
+    /* composed domains (ccspo_energy_grad_split): the energy compares the outputs with tgt [N,P] while the encoder saw
+     * poses, of which only the first enc_cols columns are variables; defaults: tgt = poses, every column */
+    const real* tgt;
+    int enc_cols;
 } eval_ws;
 
 /* one edge: _get_constraint_inputs + _process_constraint (denoise_fn.py:313-371).
@@ -372,7 +376,7 @@ static void edge_eval(const ccspo_model* m, const ccspo_graph* g, int e, const r
     for (int s = 0; s < 2; ++s) {
         int node = s == 0 ? a : b;
         real go[16];
-        for (int p = 0; p < P; ++p) go[p] = (real)2 * (o[s * P + p] - ws->poses[(size_t)node * P + p]);
+        for (int p = 0; p < P; ++p) go[p] = (real)2 * (o[s * P + p] - (ws->tgt ? ws->tgt : ws->poses)[(size_t)node * P + p]);
         real* gs1 = (real*)alloca(sizeof(real) * h2);
         memset(gs1, 0, sizeof(real) * h2);
         lin_bwd_in(&m->pd2, go, gs1, 0, h2);
@@ -387,6 +391,7 @@ static void edge_eval(const ccspo_model* m, const ccspo_graph* g, int e, const r
 }
 
 static void ws_alloc(eval_ws* ws, const ccspo_model* m, const ccspo_graph* g) {
+    ws->tgt = NULL; ws->enc_cols = 0;
     int H = m->d.hidden_dim, P = m->d.pose_dim;
     ws->poses = (real*)xcalloc((size_t)g->N * P, sizeof(real));
     ws->pemb = (real*)xcalloc((size_t)g->N * H, sizeof(real));
@@ -607,7 +612,7 @@ static void energy_real_d(ccspo_model* m, const ccspo_graph* g, eval_ws* ws, int
         real Ee = 0;
         for (int s = 0; s < 2; ++s)
             for (int p = 0; p < P; ++p) {
-                real dlt = ws->o[((size_t)k * 2 + s) * P + p] - ws->poses[(size_t)nd[s] * P + p];
+                real dlt = ws->o[((size_t)k * 2 + s) * P + p] - (ws->tgt ? ws->tgt : ws->poses)[(size_t)nd[s] * P + p];
                 Ee += dlt * dlt;
                 grad[(size_t)nd[s] * P + p] += (real)(-2) * dlt;            /* direct term */
             }
@@ -619,6 +624,11 @@ static void energy_real_d(ccspo_model* m, const ccspo_graph* g, eval_ws* ws, int
         memset(gs1, 0, sizeof(real) * h2);
         lin_bwd_in(&m->pe2, gy2, gs1, 0, h2);
         for (int k = 0; k < h2; ++k) gs1[k] *= silu_grad(ws->y1[(size_t)n * h2 + k]);
+        if (ws->enc_cols > 0 && ws->enc_cols < P) {                             /* the other encoder inputs are constants */
+            real gx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            lin_bwd_in(&m->pe0, gs1, gx, 0, P);
+            for (int p = 0; p < ws->enc_cols; ++p) grad[(size_t)n * P + p] += gx[p];
+        } else
         lin_bwd_in(&m->pe0, gs1, grad + (size_t)n * P, 0, P);
     }
     *energy = (real)E;
@@ -662,6 +672,29 @@ int ccspo_energy_grad(ccspo_model* m, ccspo_graph* g, const float* poses_in, int
     for (size_t i = 0; i < (size_t)g->N * P; ++i) grad[i] = (float)gr[i];
     *energy = (float)E;
     free(gr); ws_free(&ws);
+    return 0;
+}
+
+/* energy and gradient of ONE domain of a composed model (reference networks/denoise_fn.py:373-375 on the outputs of :364-370 with
+ * the inputs of :499): the pose encoder sees poses_enc, of which the first enc_cols columns are the variables, and the outputs
+ * are compared with poses_tgt.  grad = d energy / d (the variables): direct term on every column of poses_tgt, encoder term on the
+ * first enc_cols. */
+int ccspo_energy_grad_split(ccspo_model* m, ccspo_graph* g, const float* poses_enc, const float* poses_tgt, int32_t enc_cols, int32_t t,
+                            float* grad, float* energy) {
+    if (!check_t(m, t)) FAIL("energy_grad_split: t=%d out of range", t);
+    int P = m->d.pose_dim;
+    if (enc_cols < 1 || enc_cols > P) FAIL("energy_grad_split: enc_cols=%d", enc_cols);
+    eval_ws ws; ws_alloc(&ws, m, g);
+    size_t NP = (size_t)g->N * P;
+    real* tg = (real*)xcalloc(NP, sizeof(real));
+    for (size_t i = 0; i < NP; ++i) { ws.poses[i] = (real)poses_enc[i]; tg[i] = (real)poses_tgt[i]; }
+    ws.tgt = tg; ws.enc_cols = enc_cols;
+    real* gr = (real*)xcalloc(NP, sizeof(real));
+    real E;
+    energy_real(m, g, &ws, t, gr, &E);
+    for (size_t i = 0; i < NP; ++i) grad[i] = (float)gr[i];
+    *energy = (float)E;
+    free(gr); free(tg); ws_free(&ws);
     return 0;
 }
 

@@ -83,6 +83,26 @@ class ComposedOracleGraph(object):
         acc[self.mask] = self.x[:, -self.P:][self.mask]
         return acc
 
+    def energy_grad(self, poses, t):
+        """energy mode of the composed model (both OracleModels energy_wrapper, weights (1, 1)): denoise_fn.py:373-375 on the widened
+        outputs.  E = E1 + [second model's energy against the poses without the zero column, its encoder fed with poses_2] +
+        sum over second-domain entries of poses[n, zero_col]^2; the gradient likewise (the zero column's term: 2 p per entry)."""
+        assert self.weight == (1.0, 1.0)
+        poses = np.asarray(poses, dtype=np.float32)
+        z = self.zero_col
+        g1, e1 = self.g1.energy_grad(poses, t)
+        p_enc = np.ascontiguousarray(np.concatenate([poses[:, :2], self.x[:, -(self.P2 - 2):]], axis=1), dtype=np.float32)
+        p_tgt = np.ascontiguousarray(np.delete(poses, z, axis=1), dtype=np.float32)
+        g2, e2 = self.g2.energy_grad_split(p_enc, p_tgt, 2, t)
+        n1 = self.m1.C
+        valid2 = (self.ea >= n1) & (self.ea < self.n_types)
+        cnt2 = np.bincount(self.ei[:, valid2].reshape(-1), minlength=self.N).astype(np.float32)
+        grad = g1.copy()
+        grad[:, :z] += g2[:, :z]
+        grad[:, z + 1:] += g2[:, z:]
+        grad[:, z] += np.float32(2) * poses[:, z] * cnt2
+        return grad, float(e1) + float(e2) + float((cnt2 * poses[:, z] ** 2).sum())
+
     def chain(self, normal, samples_per_step, sampler='ULA', history=False):
         """full reverse chain with injected normal draws [n_calls, N, P]; sampler 'ULA' or None"""
         m = self.m1

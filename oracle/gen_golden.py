@@ -608,6 +608,17 @@ def gen_composed():
                 with torch.no_grad():
                     outs.append(model(torch.from_numpy(poses[i]).clone(), b, torch.tensor([t]), eval=True).numpy())
             rec['%s/out_%s' % (tag, wtag)] = np.stack(outs)
+            if wtag == 'w11':
+                # energy mode of the composed model (denoise_fn.py:373-375,539-548 on the widened outputs): autograd gradients
+                model.energy_wrapper = True
+                grads, ens = [], []
+                for i, t in enumerate(ts):
+                    g, e = model(torch.from_numpy(poses[i]).clone(), b, torch.tensor([t]), eval=True, tag='EBM')
+                    grads.append(g.detach().numpy())
+                    ens.append(float(e.detach()))
+                model.energy_wrapper = False
+                rec['%s/grad' % tag] = np.stack(grads)
+                rec['%s/energy' % tag] = np.asarray(ens, dtype=np.float64)
             # the operator on second-domain types: inputs built the way forward builds them (denoise_fn.py:497-503,322-334)
             with torch.no_grad():
                 ge = model.geom_encoder_2(torch.from_numpy(geoms_in))

@@ -67,6 +67,7 @@ def lib(f64=False):
     L.ccspo_graph_destroy.restype = None
     L.ccspo_denoise.argtypes = [vp, vp, vp, C.c_int32, vp]
     L.ccspo_energy_grad.argtypes = [vp, vp, vp, C.c_int32, vp, vp]
+    L.ccspo_energy_grad_split.argtypes = [vp, vp, vp, vp, C.c_int32, C.c_int32, vp, vp]
     L.ccspo_edge_outputs.argtypes = [vp, vp, vp, C.c_int32, vp]
     L.ccspo_chain_run.argtypes = [vp, vp, C.c_int32, C.POINTER(Noise), vp, C.c_int32, C.c_int32, C.c_int32, vp, vp]
     _libs[key] = L
@@ -221,6 +222,14 @@ class OracleGraph(object):
         g = np.empty_like(p)
         e = np.zeros(1, dtype=np.float32)
         self.m._check(self.m.L.ccspo_energy_grad(self.m.h, self.h, _ptr(p), int(t), _ptr(g), _ptr(e)))
+        return g, float(e[0])
+
+    def energy_grad_split(self, poses_enc, poses_tgt, enc_cols, t):
+        """one domain of a composed model: the encoder sees poses_enc (first enc_cols columns variable), the energy compares with poses_tgt"""
+        pe, pt = _f32(poses_enc), _f32(poses_tgt)
+        g = np.empty_like(pe)
+        e = np.zeros(1, dtype=np.float32)
+        self.m._check(self.m.L.ccspo_energy_grad_split(self.m.h, self.h, _ptr(pe), _ptr(pt), int(enc_cols), int(t), _ptr(g), _ptr(e)))
         return g, float(e[0])
 
     def edge_outputs(self, poses, t):

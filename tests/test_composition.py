@@ -52,6 +52,20 @@ def test_oracle_chain_vs_reference(name, H):
         assert rel_err(hist[idx], z['hist'][k]) < 2e-3, (name, int(idx))
 
 
+@pytest.mark.parametrize('tag,H', CASES)
+def test_oracle_energy_mode_vs_reference(tag, H):
+    """energy and autograd gradients of the reference's composed model (tag='EBM', energy_wrapper) at composing_weight (1, 1)"""
+    z = golden('composed')
+    m1 = oracle_model('robot_box', H, 'weights_robot_box_h%d.npz' % H, energy=True)
+    m2 = oracle_model('qualitative', H, 'weights_qualitative_h%d.npz' % H, energy=True)
+    g = compose_oracle.ComposedOracleGraph(m1, m2, golden_batch(z, tag + '/'))
+    for i, t in enumerate(z[tag + '/t']):
+        grad, E = g.energy_grad(z[tag + '/poses'][i], int(t))
+        assert abs(E - z[tag + '/energy'][i]) <= 2e-5 * (1 + abs(z[tag + '/energy'][i])), int(t)
+        assert rel_err(grad, z[tag + '/grad'][i]) < 5e-5, int(t)
+        assert np.abs(z[tag + '/grad'][i][:, 2]).max() > 0          # the zero column's own term
+
+
 # ---------------------------------------------------------------------------------------------------------------- GPU
 def _composed_model(H, device, weight=(1, 1), T=1000, S=10, EBM='ULA'):
     from diffusion_ccsp_amd import ConstraintDiffuser, GaussianDiffusion
@@ -86,11 +100,19 @@ def test_hip_single_evaluation_vs_reference(tag, H, device):
             got = model._process_constraint(i, d).cpu().numpy()
             assert got.shape == (n, 2, 5) and np.all(got[:, :, 2] == 0)
             assert rel_err(got, want[i - 2]) < 2e-5, (tag, wtag, i)
-        # energy mode is not composed: it must refuse, not fall back
+        # energy mode (tag='EBM' with energy_wrapper): built for composing_weight (1, 1); other weights must refuse, not fall back
         model.energy_wrapper = True
-        with pytest.raises(NotImplementedError):
-            model(torch.from_numpy(z[tag + '/poses'][0]), b, torch.tensor([3]), tag='EBM')
+        model._drop_handle()
+        if tuple(w) == (1, 1):
+            for i, t in enumerate(z[tag + '/t']):
+                grad, E = model(torch.from_numpy(z[tag + '/poses'][i]), b, torch.tensor([int(t)]), tag='EBM')
+                assert abs(float(E) - z[tag + '/energy'][i]) <= 2e-5 * (1 + abs(z[tag + '/energy'][i])), (tag, int(t))
+                assert rel_err(grad.cpu().numpy(), z[tag + '/grad'][i]) < 5e-5, (tag, int(t))
+        else:
+            with pytest.raises(NotImplementedError):
+                model(torch.from_numpy(z[tag + '/poses'][0]), b, torch.tensor([3]), tag='EBM')
         model.energy_wrapper = False
+        model._drop_handle()
 
 
 @pytest.mark.gpu
