@@ -27,7 +27,8 @@
 //                          feeds two MFMA tiles: 8 ds_read_b128 per 12 MFMAs, against 9 per 12 at half the
 //                          flops each in k_rowgemm_bf2); epilogue per wave through a wave-private LDS tile:
 //                          16-byte row-contiguous base loads / U stores and the row maxima of U for the edge
-//                          kernel.  MODE picks the staging by the length of the tile list (rowgemm_h2_mode):
+//                          kernel.  MODE picks the staging (rowgemm_h2_mode: 4 for tile lists of at most one workgroup per CU,
+//                          else 0; 1 / 2 / 3 through CCSP_ROW_MODE -- measured equal or behind since round 3):
 //                          0 = one 16 KB stage and one register set, 3 workgroups per CU (lists longer than 2 per CU);
 //                          1 = two stages, two register sets (chunk c+2 in flight while c is multiplied);
 //                          2 = two stages filled by global_load_lds_dwordx4, swizzle applied to the source address;

@@ -1537,7 +1537,11 @@ EncW enc_pose(const ccsp_model* m) { return EncW{m->pe0_w, m->pe0_b, m->pe2_wT, 
 int rowgemm_h2_mode(const ccsp_model* m, const ccsp_graph* g, int nct) {
     if (m->row_mode >= 0) return m->row_mode;
     if (g->n_tiles * nct <= m->ncu) return 4;
-    return g->n_tiles2 * nct <= 2 * m->ncu ? 2 : 0;
+    // round 3 (tools/ab_rowmode.sh, same-call A/B): with the straight-line epilogue the register-staged MODE 0 (three workgroups
+    // per CU) is ahead of or equal to the direct-to-LDS MODE 2 at every size above the one-round limit -- C2's lanes 471-474
+    // against 462, 128 graphs in one lane 287 against 275, 512 graphs 559 against 550, C4 +1 % -- so MODE 2 (and 1, 3) are only
+    // reached through CCSP_ROW_MODE now
+    return 0;
 }
 
 void launch_rowgemm_h2(ccsp_model* m, ccsp_graph* g, const float* tau_t, StepRef ref, size_t tau_stride, hipStream_t s) {
