@@ -1182,7 +1182,7 @@ __device__ __forceinline__ NodeLds node_lds(void* base) {
 // FUSED (tail of the edge kernel, run by the workgroup that delivered the block's last edge outputs): the edge outputs were
 // stored write-through (sc1) by workgroups on any XCD and are read with sc1 loads -- the L2-served pair of
 // cdna_hip_programming.md Guideline 16 -- and the encoder streams its weights.
-template <bool FUSED>
+template <bool FUSED, bool STREAM = FUSED /*encoder weights streamed per k-step instead of prefetched into 128 VGPRs*/>
 __device__ __forceinline__ void node_block_direct(const NodeArgs& a, const EncW& w, const EncOut& eo, int n_ent, int node0, const NodeLds lds) {
     const int tid = threadIdx.x;
     const int nl = (tid >> 3) & (NODE_TILE - 1), p = tid & 7;
@@ -1215,7 +1215,7 @@ __device__ __forceinline__ void node_block_direct(const NodeArgs& a, const EncW&
     }
     __builtin_amdgcn_sched_barrier(0);
     EncPrefetchH pfh;
-    if constexpr (!FUSED) enc_prefetch_h2(w, pfh);                        // behind the chain: in flight under the update
+    if constexpr (!STREAM) enc_prefetch_h2(w, pfh);                       // behind the chain: in flight under the update
     // ---- the noise draw needs no data: computed while the loads are in flight
     float z = ccsp::philox_normal(a.noise.seed, a.noise.row_offset + (unsigned long long)nc, a.noise.call, pc);
     z = injected ? z_inj : z;
@@ -1252,7 +1252,7 @@ __device__ __forceinline__ void node_block_direct(const NodeArgs& a, const EncW&
     }
     __syncthreads();
     CCSP_TRK(2, 1);
-    if constexpr (FUSED) encode_tile_h2_stream(w, lds.xs, lds.s1h, lds.sexp, lds.smax, node0, a.N, eo);
+    if constexpr (STREAM) encode_tile_h2_stream(w, lds.xs, lds.s1h, lds.sexp, lds.smax, node0, a.N, eo);
     else encode_tile_h2(w, pfh, lds.xs, lds.s1h, lds.sexp, lds.smax, node0, a.N, eo);
 }
 
@@ -1264,6 +1264,13 @@ __global__ __launch_bounds__(256) void k_node_direct(NodeArgs a, EncW w, EncOut 
     node_block_direct<false>(a, w, eo, n_ent, blockIdx.x * NODE_TILE, node_lds(lds_raw));
     CCSP_TRK(2, 5);
     CCSP_TRK_RT(2, 31);
+}
+// the same with the encoder's weights streamed (CCSP_NODE=stream, A/B): a third of the registers, so that its waves fit next to
+// the other lane's GEMM waves on more SIMDs
+__global__ __launch_bounds__(256, 3) void k_node_direct_s(NodeArgs a, EncW w, EncOut eo, int n_ent) {
+    __shared__ __attribute__((aligned(16))) char lds_raw[NODE_LDS_BYTES];
+    __builtin_amdgcn_s_setprio(3);
+    node_block_direct<false, true>(a, w, eo, n_ent, blockIdx.x * NODE_TILE, node_lds(lds_raw));
 }
 
 // the node update folded into the edge kernel's tail (k_edge_h2 / k_edge_h2s, FUSE): which 16-node blocks a workgroup's
@@ -1374,6 +1381,7 @@ struct ccsp_model {
     int fuse_node = 0;                // CCSP_FUSE_NODE=1: fold the node update into the edge kernel's tail (FuseArgs).  Measured slower than
                                       // the separate launch (C2 467 -> 383, C5 250 -> 182 samples/s, profiles/r03_findings.md), so off by default
     int node_generic = 0;             // CCSP_NODE=generic: k_node instead of k_node_direct in direct-mode chains (A/B runs)
+    int node_stream = 0;              // CCSP_NODE=stream: k_node_direct_s
     int valu_node_energy = 0;         // CCSP_NODE_ENERGY_VALU: the pre-MFMA node-energy kernel (A/B runs; never combined with the reuse below)
     int mala_reuse = 1;               // (CCSP_MALA_REUSE=0 turns it off) an inner step that accepted NO node leaves x where it was, so the next step's
                                       // E(x) and gradient are the ones already computed; their kernels return at once (bitwise the
@@ -1760,6 +1768,8 @@ void launch_node(ccsp_model* m, ccsp_graph* g, const NodeArgs& a, hipStream_t s)
         const bool direct = ench && h2 && !m->node_generic && a.src == 0 && (a.step == STEP_ANCESTRAL || a.step == STEP_ULA) && a.do_encode &&
                             !a.x_in && !a.eps_out && !a.tab && g->plan.E_act > 0 && !eo.f32;
         if (direct) {
+            if (m->node_stream) hipLaunchKernelGGL(k_node_direct_s, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a, enc_pose(m), eo, 2 * g->plan.E_act);
+            else
             hipLaunchKernelGGL(k_node_direct, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a, enc_pose(m), eo, 2 * g->plan.E_act);
             prof_mark(g, s, -1);
             return;
@@ -2713,7 +2723,7 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     if (const char* e = getenv("CCSP_EDGE_MT")) m->edge_mt = atoi(e) == 2 ? 2 : 1;
     if (const char* e = getenv("CCSP_EDGE_SMALL")) m->edge_small = atoi(e) != 0;
     m->valu_node_energy = getenv("CCSP_NODE_ENERGY_VALU") != nullptr;
-    if (const char* e = getenv("CCSP_NODE")) m->node_generic = strcmp(e, "generic") == 0;
+    if (const char* e = getenv("CCSP_NODE")) { m->node_generic = strcmp(e, "generic") == 0; m->node_stream = strcmp(e, "stream") == 0; }
     if (const char* e = getenv("CCSP_FUSE_NODE")) m->fuse_node = atoi(e) != 0;
     {
         int dev = 0;
