@@ -154,3 +154,39 @@ def test_hip_fresh_inputs_vs_restatement(device):
         for t in (0, 400, 999):
             got = model(torch.from_numpy(poses), b, torch.tensor([t])).cpu().numpy()
             assert rel_err(got, g.denoise(poses, t)) < 2e-5, (normalize, t)
+
+
+@pytest.mark.gpu
+def test_hip_degenerate_domains_and_fresh_chain(device):
+    """a batch with NO second-domain edge, one with NO first-domain edge (an empty sub-graph on one side of the composition), and a
+    short ULA chain on a ragged batch against the numpy restatement (seeded noise, T = 40, S = 2)"""
+    H = 64
+    rng = np.random.default_rng(9)
+    for keep_first, keep_second in ((True, False), (False, True)):
+        m1, m2 = _oracle_pair(H)
+        b = worlds.robot_qualitative_batch(2, 4, seed=81).to_torch()
+        sel = (b.edge_attr < 2) if keep_first else (b.edge_attr >= 2)
+        b.edge_index, b.edge_attr = b.edge_index[:, sel].contiguous(), b.edge_attr[sel].contiguous()
+        poses = (rng.standard_normal((b.x.shape[0], 5)) * 0.7).astype(np.float32)
+        model, second, _ = _composed_model(H, device)
+        g = compose_oracle.ComposedOracleGraph(m1, m2, b)
+        got = model(torch.from_numpy(poses), b, torch.tensor([321])).cpu().numpy()
+        want = g.denoise(poses, 321)
+        assert np.array_equal(np.isnan(got), np.isnan(want))          # nodes without any edge: 0 / 0 like the reference
+        ok = ~np.isnan(want)
+        assert rel_err(got[ok], want[ok]) < 2e-5, (keep_first, keep_second)
+    # a short chain on ragged graphs
+    T, S = 40, 2
+    m1, m2 = _oracle_pair(H, T=T, S=S)
+    gs = []
+    for n_obj, seed in ((3, 1), (6, 2), (4, 3)):
+        one = worlds.robot_qualitative_batch(1, n_obj, seed=90 + seed)
+        gs.append(dict(x=one.x, edge_index=one.edge_index, edge_attr=one.edge_attr, mask=one.mask, world_dims=one.world_dims[0]))
+    b = worlds.collate(gs).to_torch()
+    model, second, gd = _composed_model(H, device, (1, 0.5), T=T, S=S)
+    x, hist = gd.p_sample_loop(b, return_history=True, seed=77)
+    zs = noise.normal_stream(77, gd.n_normal_calls(), b.x.shape[0], 5)
+    want, whist = compose_oracle.ComposedOracleGraph(m1, m2, b, weight=(1, 0.5)).chain(zs, S, history=True)
+    assert np.abs(x.cpu().numpy() - want).max() < 1e-4 * (1 + np.abs(want).max())
+    for k in (1, 5, 20, T):
+        assert rel_err(hist[k].cpu().numpy(), whist[k]) < 2e-3, k
