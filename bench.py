@@ -328,8 +328,12 @@ def main():
     evals_per_chain = T_STEPS * (1 + (2 if cfg['EBM'] == 'MALA' else 1) * S_LANGEVIN)
 
     rec = {
-        'metric': 'solved samples/sec, T=1000 %s, %s (value = all chains per second; solved_samples_per_s = value x solved_fraction, both top-level)' %
-                  (cfg['EBM'], cfg['label'].split(':')[1].split(',')[0].strip() + ' %d-obj' % cfg['n_objects']),
+        'metric': 'solved samples/sec, T=1000 %s, %s (%s)' %
+                  (cfg['EBM'], cfg['label'].split(':')[1].split(',')[0].strip() + ' %d-obj' % cfg['n_objects'],
+                   'value = all chains per second; solved_samples_per_s = value x solved_fraction, both top-level' if args.config in ('c2', 'c3') else
+                   'value = all chains per second with the gradient evaluations of unmoved states skipped, a property of the acceptance rate; '
+                   'value_recomputing_every_evaluation and mean_acceptance_rate beside it at top level; no solved check for this world' if cfg['EBM'] == 'MALA' else
+                   'value = all chains per second; no solved check for this world'),
         'value': value, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': args.scaling,
         'vs_baseline': None,
@@ -360,6 +364,7 @@ def main():
                                'computed, and their kernels return at once.  Bitwise the chain that recomputes '
                                '(test_mala_rejected_step_reuse_is_bitwise_identical); the gain is workload-dependent (acceptance rate).  The profiled chain of the '
                                'roofline block recomputes every evaluation (kernels timed at full work).'}
+        rec['mean_acceptance_rate'] = rec['mala']['mean_acceptance_rate']
         if reuse_on and dist is None:
             os.environ['CCSP_MALA_REUSE'] = '0'
             den0 = ConstraintDiffuser(dims=worlds.MODE_DIMS[cfg['mode']], hidden_dim=HIDDEN, input_mode=cfg['mode'], EBM=cfg['EBM'],
@@ -374,6 +379,7 @@ def main():
             torch.cuda.synchronize()
             dt = time.perf_counter() - t1
             rec['mala']['value_recomputing_every_evaluation'] = B / dt
+            rec['value_recomputing_every_evaluation'] = B / dt          # (the kernels-at-full-work number, next to `value`)
             rec['mala']['recomputing_chain_bitwise_equal'] = bool(torch.equal(x0, x) or ((x0 == x) | (torch.isnan(x0) & torch.isnan(x))).all().item())
 
     if cname == 'c2':
