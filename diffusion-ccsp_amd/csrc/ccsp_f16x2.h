@@ -206,6 +206,21 @@ __device__ __forceinline__ void h2_epilogue_prefetch(h2_f4 (&bs)[4][2], int i, i
 // PRE1: the caller requested row tile 1's base values (bs1) itself, under the K loop; otherwise they are requested here.
 // bs0 (and bs1) and the time-term values tv (requested in the kernel's prologue; has_tau false: discarded, slot-1 tiles) may
 // still be in flight (h2_ld16): the waits are here.
+// the row store of U (experiment switch: -DCCSP_U_STORE=1 non-temporal, =2 write-through sc1; default plain -- see profiles/r03_findings.md)
+__device__ __forceinline__ void h2_store_u(float* p, const float4& v) {
+#if defined(CCSP_U_STORE) && CCSP_U_STORE == 1
+    __builtin_nontemporal_store(v.x, p); __builtin_nontemporal_store(v.y, p + 1); __builtin_nontemporal_store(v.z, p + 2); __builtin_nontemporal_store(v.w, p + 3);
+#elif defined(CCSP_U_STORE) && CCSP_U_STORE == 2
+    h2_f4 t{v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(t) : "memory");
+#elif defined(CCSP_U_STORE) && CCSP_U_STORE == 3
+    h2_f4 t{v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(p), "v"(t) : "memory");
+#else
+    *reinterpret_cast<float4*>(p) = v;
+#endif
+}
+
 template <int ND, int MI, bool FWD, bool PRE1>
 __device__ __forceinline__ void h2_epilogue_wave(const floatx16 (&acc)[MI][2], h2_f4 (&bs0)[4][2], h2_f4 (&bs1)[4][2], h2_f4 (&tv)[2], float* __restrict__ Cw,
                                                  int wrow0 /*first tile row of the wave*/, int nrows, int row0,
@@ -278,8 +293,8 @@ __device__ __forceinline__ void h2_epilogue_wave(const floatx16 (&acc)[MI][2], h
                 if constexpr (FWD) m = h2_max8(m);                // (every lane takes part: the 8 lanes of a row are active together)
                 if (ALL || trow < nrows) {
                     float* up = Ub + (size_t)trow * ND;
-                    *reinterpret_cast<float4*>(up) = o[0];
-                    *reinterpret_cast<float4*>(up + 32) = o[1];
+                    h2_store_u(up, o[0]);
+                    h2_store_u(up + 32, o[1]);
                     if constexpr (FWD) { if (eq == 0) umax[(size_t)(row0 + trow) * umax_ld + umax_col] = m; }
                 }
             }
