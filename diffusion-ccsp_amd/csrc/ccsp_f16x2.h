@@ -177,6 +177,16 @@ __device__ __forceinline__ float h2_max8(float m) {
 // An asm load is invisible to its wait insertion: the wait is h2_ld_wait* below, a statement that names every destination.
 typedef float h2_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void h2_ld16(h2_f4& d, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+// the load of `base` (read once per evaluation, never reused inside it): -DCCSP_BASE_LOAD=1 non-temporal, =2 sc1 (experiment switch)
+__device__ __forceinline__ void h2_ld16_base(h2_f4& d, const float* p) {
+#if defined(CCSP_BASE_LOAD) && CCSP_BASE_LOAD == 1
+    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(d) : "v"(p) : "memory");
+#elif defined(CCSP_BASE_LOAD) && CCSP_BASE_LOAD == 2
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(d) : "v"(p) : "memory");
+#else
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory");
+#endif
+}
 __device__ __forceinline__ void h2_ld4(int& d, const int* p) { asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
 // s_waitcnt vmcnt(N) for the 8 base values of one row tile (+ the 2 time-term values), N a literal
 template <int N>
@@ -198,7 +208,7 @@ __device__ __forceinline__ void h2_epilogue_prefetch(h2_f4 (&bs)[4][2], int i, i
         const int trow = wrow0 + i * 32 + er + 8 * st;
         const int tr = trow < nrows ? trow : (nrows - 1 > 0 ? nrows - 1 : 0);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) h2_ld16(bs[st][k], base + (size_t)(row0 + tr) * ND + colw + 4 * eq + 32 * k);
+        for (int k = 0; k < 2; ++k) h2_ld16_base(bs[st][k], base + (size_t)(row0 + tr) * ND + colw + 4 * eq + 32 * k);
     }
 }
 
