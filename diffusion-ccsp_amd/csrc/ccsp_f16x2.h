@@ -144,6 +144,35 @@ __device__ __forceinline__ void h2_chunk_ahead(const unsigned short* __restrict_
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][i][PA[q]], b[ks][j][PB[q]], acc[i][j], 0, 0, 0);
 }
 
+// A chunk whose A fragments are already in registers (MODE 5 of k_rowgemm_h2: loaded straight from global memory in the MFMA
+// operand layout), B from the staged planes.  Same MFMA order per accumulator as h2_kstep / h2_chunk_ahead: bitwise the same sums.
+template <int MI>
+__device__ __forceinline__ void h2_chunk_regA(const half8 (&a)[2][MI][2] /*[k-step][tile][plane]*/, const unsigned short* __restrict__ Bs,
+                                              int bn0, floatx16 (&acc)[MI][2]) {
+    const int lane = threadIdx.x & 63;
+    half8 b[2][2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int piece = (lane >> 5) + 2 * ks;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            b[ks][j][0] = *reinterpret_cast<const half8*>(Bs + h2_off(bn0 + 32 * j + (lane & 31), piece));
+            b[ks][j][1] = *reinterpret_cast<const half8*>(Bs + H2_BPL + h2_off(bn0 + 32 * j + (lane & 31), piece));
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][i][PA[q]], b[ks][j][PB[q]], acc[i][j], 0, 0, 0);
+}
+
 // Epilogue of the row GEMMs, one WAVE at a time and without workgroup barriers: the wave's 64 x 64 accumulators (MFMA
 // layout: one column, 16 rows per lane) go through a wave-private LDS tile [32][H2_CW_LD] (row tile i = 0, 1) and are
 // re-read as rows -- 8 lanes x 16 bytes per row segment -- so the base loads and U stores are 128-byte row segments and
@@ -317,7 +346,10 @@ __device__ __forceinline__ void h2_epilogue_wave(const floatx16 (&acc)[MI][2], h
 
 // s_waitcnt vmcnt(n) lgkmcnt(0) with n known after unrolling (the immediate must be a literal)
 __device__ __forceinline__ void h2_wait_vm_lgkm0(int n) {
-    if (n >= 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+    if (n >= 28) asm volatile("s_waitcnt vmcnt(28) lgkmcnt(0)" ::: "memory");
+    else if (n >= 24) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");
+    else if (n >= 20) asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
+    else if (n >= 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
     else if (n >= 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
     else if (n >= 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     else if (n >= 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
@@ -359,9 +391,9 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : (MODE == 3 ? 1 : 2)) void k_ro
     if (ref.skip && *ref.skip == 0) return;                       // (uniform) MALA reuse: the state has not moved since this was computed
     constexpr int NCT = ND / 128, NCH = KD / H2_BK;
     constexpr int MI = MODE == 4 ? 1 : 2, TM = 64 * MI;           // 32-row MFMA tiles per wave, rows per workgroup tile
-    constexpr int APL = TM * H2_BK, STAGE = 2 * APL + 2 * H2_BPL;         // 32 KB per stage (24 KB for 64-row tiles)
+    constexpr int APL = TM * H2_BK, STAGE = MODE == 5 ? 2 * H2_BPL : 2 * APL + 2 * H2_BPL;   // 32 KB per stage (24 KB for 64-row tiles; MODE 5: the B planes only, 16 KB)
     constexpr bool DB = MODE == 1;
-    constexpr int NST = MODE == 0 ? 1 : (MODE == 3 ? 4 : (MODE == 4 ? 3 : 2));      // LDS stages
+    constexpr int NST = MODE == 0 ? 1 : ((MODE == 3 || MODE == 5) ? 4 : (MODE == 4 ? 3 : 2));      // LDS stages
     constexpr int NRS = MODE == 1 ? 2 : 1;                        // register sets (MODE 2 and above use none)
     constexpr bool PRE1 = FWD && MI == 2 && MODE >= 2;            // row tile 1's base values requested under the K loop (VGPRs to spare)
     constexpr int SMEM_US = (NST * STAGE * 2 > 4 * H2_CW_SZ * 4 ? NST * STAGE : 4 * H2_CW_SZ * 2);
@@ -395,7 +427,106 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : (MODE == 3 ? 1 : 2)) void k_ro
         h2_ld16(tv[0], tp);
         h2_ld16(tv[1], tp + 32);
     }
-    if constexpr (MODE >= 2) {
+    if constexpr (MODE == 5) {
+        // MODE 5 (tile lists of at most two workgroups per CU: the lanes of a C2 batch).  The K loop of the other modes is bound by
+        // the latency of the operand loads, not by the MFMAs (phase traces: 2.3 k cycles per chunk against 0.77 k of matrix work,
+        // with one chunk requested ahead) and a deeper ring of (A, B) stages does not fit two workgroups into a CU's LDS.  Here
+        // only the WEIGHT planes are staged -- a ring of four 16 KB stages filled by global_load_lds, three chunks requested ahead --
+        // and every lane loads its A fragments (rows gathered by node) straight from global memory in the MFMA operand layout,
+        // two chunks ahead, into two register sets.  Loads retire in order, so the waits are counted.
+        using gptr = const __attribute__((address_space(1))) void*;
+        using lptr = __attribute__((address_space(3))) void*;
+        const unsigned short* gb[4];
+        int lob[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int blk = 4 * wave + j, plane = blk >> 3, rb16 = blk & 7;
+            const int row = rb16 * 16 + (lane >> 2);
+            const int piece = (lane & 3) ^ ((row >> 2) & 3);
+            gb[j] = W + (size_t)plane * w_plane + (size_t)ts * w_stride + (size_t)(col0 + row) * KD + piece * 8;
+            lob[j] = __builtin_amdgcn_readfirstlane(plane * H2_BPL + rb16 * 16 * H2_BK);
+        }
+        auto glds_b = [&](int c) {
+            unsigned short* st = smem + (c % NST) * STAGE;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds((gptr)(gb[j] + c * H2_BK), (lptr)(st + lob[j]), 16, 0, 0);
+        };
+        // the lane's two A rows (tile i = 0, 1): one dependent gather, requested first
+        int src[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wr0 + 32 * i + (lane & 31);
+            const int r = row < nrows ? row : nrows - 1;
+            if (urow_node) h2_ld4(src[i], urow_node + row0 + r); else src[i] = row0 + r;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        glds_b(0);
+        glds_b(1);
+        glds_b(2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (urow_node) asm volatile("s_waitcnt vmcnt(12)" : "+v"(src[0]), "+v"(src[1]) :: "memory");      // (the twelve weight loads stay in flight)
+        const unsigned short* ap[2][2];                               // [tile][plane]
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) ap[i][pl] = A + (size_t)pl * a_plane + (size_t)src[i] * KD + 8 * (lane >> 5);
+        half8 af[2][2][2][2];                                         // [register set][k-step][tile][plane]
+        auto aload = [&](int c, int set) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(af[set][ks][i][pl]) : "v"(ap[i][pl] + c * H2_BK + 16 * ks) : "memory");
+        };
+        auto await_set = [&](int set) {                               // names the set's registers as read-write: the compiler keeps its uses behind the wait
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) asm volatile("" : "+v"(af[set][ks][i][pl]) :: "memory");
+        };
+        aload(0, 0);
+        aload(1, 1);
+        int ea[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) h2_ld4(ea[i], a_exp + src[i]);
+        __builtin_amdgcn_sched_barrier(0);
+        CCSP_TRK(0, 1);
+        constexpr int CB0 = NCH - 3, CB1 = NCH - 2;                   // iterations under which the base values of row tile 0 / 1 are requested
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            // in flight behind (A(c), B(c)) at this point -- everything issued after A(c):
+            //   c = 0: A(1), the two exponent loads;  c = 1: the exponents, B(3), A(2);  c >= 2: B(c + 2), the base values of iteration c - 1, A(c + 1)
+            int younger;
+            if (c == 0) younger = 8 + 2;
+            else if (c == 1) younger = 2 + (3 < NCH ? 4 : 0) + (2 < NCH ? 8 : 0);
+            else younger = (c + 2 < NCH ? 4 : 0) + ((FWD && (c - 1 == CB0 || c - 1 == CB1)) ? 8 : 0) + (c + 1 < NCH ? 8 : 0);
+            __builtin_amdgcn_sched_barrier(0);
+            h2_wait_vm_lgkm0(younger);
+            await_set(c & 1);
+            __builtin_amdgcn_s_barrier();                             // B(c) has landed for every wave; every wave is done reading stage (c - 1) % NST
+            __builtin_amdgcn_sched_barrier(0);
+            CCSP_TRK(0, 2 + (c < 8 ? c : 7));
+            if (c + 3 < NCH) glds_b(c + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            h2_chunk_regA<MI>(af[c & 1], smem + (c % NST) * STAGE, wn * 64, acc);
+            __builtin_amdgcn_sched_barrier(0);                        // (the MFMAs have read the register set: it can be refilled)
+            if constexpr (FWD) {
+                if (c == CB0) h2_epilogue_prefetch<ND>(bs0, 0, wr0, nrows, row0, colw, base);
+                if (c == CB1) h2_epilogue_prefetch<ND>(bs1, 1, wr0, nrows, row0, colw, base);
+            }
+            if (c + 2 < NCH) aload(c + 2, c & 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ea[0]), "+v"(ea[1]) :: "memory");      // (bs0 / bs1 / tv with them; the epilogue's own waits then pass)
+        if (wn == 0 && lane < 32) { sE[wr0 + lane] = ea[0]; sE[wr0 + 32 + lane] = ea[1]; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                 // every wave is done reading the stages; the row exponents are visible
+        __builtin_amdgcn_sched_barrier(0);
+    } else if constexpr (MODE >= 2) {
         // a wave-instruction fills one 1 KB block = (plane, sixteen rows); wave w owns blocks NA w .. NA w + NA - 1 of the A
         // planes (2 x TM / 16 blocks) and 4 w .. 4 w + 3 of the B planes
         using gptr = const __attribute__((address_space(1))) void*;
