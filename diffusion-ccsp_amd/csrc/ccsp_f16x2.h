@@ -28,11 +28,14 @@
 //                          flops each in k_rowgemm_bf2); epilogue per wave through a wave-private LDS tile:
 //                          16-byte row-contiguous base loads / U stores and the row maxima of U for the edge
 //                          kernel.  MODE picks the staging (rowgemm_h2_mode: 4 for tile lists of at most one workgroup per CU,
-//                          else 0; 1 / 2 / 3 through CCSP_ROW_MODE -- measured equal or behind since round 3):
+//                          else 6 up to 2.25 workgroups of 64-row tiles per CU, else 0; 1 / 2 / 3 / 5 through CCSP_ROW_MODE -- measured
+//                          equal or behind since round 3):
 //                          0 = one 16 KB stage and one register set, 3 workgroups per CU (lists longer than 2 per CU);
 //                          1 = two stages, two register sets (chunk c+2 in flight while c is multiplied);
 //                          2 = two stages filled by global_load_lds_dwordx4, swizzle applied to the source address;
 //                          3 = ring of four such stages, counted s_waitcnt vmcnt, bare s_barrier (one workgroup per CU);
+//                          5 = weight planes only in a four-stage ring, A fragments straight from global memory (experiment);
+//                          6 = MODE 0's register staging on 64 x 128 tiles, four workgroups per CU (mid-size tile lists);
 //                          4 = the ring on 64 x 128 tiles (32 x 64 per wave), three stages: tile lists of at most one
 //                              workgroup per CU, where the kernel is a latency chain and not a throughput problem.
 //                          <256, 512> is the forward GEMM, <512, 256> the energy mode's transpose GEMM
@@ -378,8 +381,15 @@ __device__ __forceinline__ void h2_wait_vm_lgkm0(int n) {
 //   descriptor only), the A rows behind it, and the row exponents (a second dependent gather) last: they are needed by the
 //   epilogue only.
 // ------------------------------------------------------------------------------------------
+// (the trace build's stamps push MODE 0 over its 168-register budget; a spill next to the inline-asm loads -- whose destinations the
+// compiler believes defined the moment they are issued -- is not survivable, so that build runs MODE 0 at two workgroups per CU)
+#ifdef CCSP_TRACE
+#define CCSP_H2_MODE0_WGS 2
+#else
+#define CCSP_H2_MODE0_WGS 3
+#endif
 template <int KD, int ND, int MODE>
-__global__ __launch_bounds__(256, MODE == 0 ? 3 : (MODE == 3 ? 1 : 2)) void k_rowgemm_h2(const unsigned short* __restrict__ A, size_t a_plane, const int* __restrict__ a_exp,
+__global__ __launch_bounds__(256, MODE == 0 ? CCSP_H2_MODE0_WGS : (MODE == 6 ? 4 : (MODE == 3 ? 1 : 2))) void k_rowgemm_h2(const unsigned short* __restrict__ A, size_t a_plane, const int* __restrict__ a_exp,
                                                        const int* __restrict__ urow_node, const int4* __restrict__ tile_desc,
                                                        const unsigned short* __restrict__ W, size_t w_plane, size_t w_stride, int w_exp,
                                                        const float* __restrict__ base, const float* __restrict__ tau_t,
@@ -390,12 +400,12 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : (MODE == 3 ? 1 : 2)) void k_ro
     CCSP_TRK_RT(0, 30);
     if (ref.skip && *ref.skip == 0) return;                       // (uniform) MALA reuse: the state has not moved since this was computed
     constexpr int NCT = ND / 128, NCH = KD / H2_BK;
-    constexpr int MI = MODE == 4 ? 1 : 2, TM = 64 * MI;           // 32-row MFMA tiles per wave, rows per workgroup tile
+    constexpr int MI = (MODE == 4 || MODE == 6) ? 1 : 2, TM = 64 * MI;           // 32-row MFMA tiles per wave, rows per workgroup tile (MODE 6: MODE 0's staging on 64-row tiles)
     constexpr int APL = TM * H2_BK, STAGE = MODE == 5 ? 2 * H2_BPL : 2 * APL + 2 * H2_BPL;   // 32 KB per stage (24 KB for 64-row tiles; MODE 5: the B planes only, 16 KB)
     constexpr bool DB = MODE == 1;
-    constexpr int NST = MODE == 0 ? 1 : ((MODE == 3 || MODE == 5) ? 4 : (MODE == 4 ? 3 : 2));      // LDS stages
+    constexpr int NST = (MODE == 0 || MODE == 6) ? 1 : ((MODE == 3 || MODE == 5) ? 4 : (MODE == 4 ? 3 : 2));      // LDS stages
     constexpr int NRS = MODE == 1 ? 2 : 1;                        // register sets (MODE 2 and above use none)
-    constexpr bool PRE1 = FWD && MI == 2 && MODE >= 2;            // row tile 1's base values requested under the K loop (VGPRs to spare)
+    constexpr bool PRE1 = FWD && MI == 2 && MODE >= 2 && MODE != 6;            // row tile 1's base values requested under the K loop (VGPRs to spare)
     constexpr int SMEM_US = (NST * STAGE * 2 > 4 * H2_CW_SZ * 4 ? NST * STAGE : 4 * H2_CW_SZ * 2);
     __shared__ __attribute__((aligned(16))) unsigned short smem[SMEM_US + 256];      // stages (epilogue tiles on top) + 128 row exponents
     int* sE = reinterpret_cast<int*>(smem + SMEM_US);
@@ -526,7 +536,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : (MODE == 3 ? 1 : 2)) void k_ro
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                 // every wave is done reading the stages; the row exponents are visible
         __builtin_amdgcn_sched_barrier(0);
-    } else if constexpr (MODE >= 2) {
+    } else if constexpr (MODE >= 2 && MODE != 6) {
         // a wave-instruction fills one 1 KB block = (plane, sixteen rows); wave w owns blocks NA w .. NA w + NA - 1 of the A
         // planes (2 x TM / 16 blocks) and 4 w .. 4 w + 3 of the B planes
         using gptr = const __attribute__((address_space(1))) void*;
@@ -667,29 +677,34 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : (MODE == 3 ? 1 : 2)) void k_ro
             }
         }
     } else {
-        const unsigned short* a_ptr[2];
-        int srcr[2];
+        const unsigned short* a_ptr[MI];
+        int srcr[MI];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MI; ++i) {
             int r = lrow + 64 * i;
             r = r < nrows ? r : nrows - 1;
             srcr[i] = urow_node ? urow_node[row0 + r] : row0 + r;
             a_ptr[i] = A + (size_t)srcr[i] * KD + lq * 8;
         }
         auto row_exps = [&]() {                                   // (epilogue only) behind the first operands, by the lanes that hold the row's index
-            const int e0 = a_exp[srcr[0]], e1 = a_exp[srcr[1]];
-            if (lq == 0) { sE[lrow] = e0; sE[lrow + 64] = e1; }
+            int e[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) e[i] = a_exp[srcr[i]];
+            if (lq == 0) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) sE[lrow + 64 * i] = e[i];
+            }
         };
         const unsigned short* b_ptr = W + (size_t)ts * w_stride + (size_t)(col0 + lrow) * KD + lq * 8;
         const int st_off = h2_off(lrow, lq);                      // (row + 64 has the same swizzle: + 64 * H2_BK)
-        ushort8 ra[NRS][4], rb[NRS][4];                           // [register set][row half * 2 + plane]
+        ushort8 ra[NRS][2 * MI], rb[NRS][4];                      // [register set][row half * 2 + plane]
         auto gload = [&](int c, int set) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     rb[set][i * 2 + p] = *reinterpret_cast<const ushort8*>(b_ptr + (size_t)i * 64 * KD + (size_t)p * w_plane + c * H2_BK);
-                    ra[set][i * 2 + p] = *reinterpret_cast<const ushort8*>(a_ptr[i] + (size_t)p * a_plane + c * H2_BK);
+                    if (i < MI) ra[set][(i < MI ? i : 0) * 2 + p] = *reinterpret_cast<const ushort8*>(a_ptr[i < MI ? i : 0] + (size_t)p * a_plane + c * H2_BK);
                 }
         };
         auto lstore = [&](int stage, int set) {
@@ -699,7 +714,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : (MODE == 3 ? 1 : 2)) void k_ro
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
-                    *reinterpret_cast<ushort8*>(As + p * APL + st_off + i * 64 * H2_BK) = ra[set][i * 2 + p];
+                    if (i < MI) *reinterpret_cast<ushort8*>(As + p * APL + st_off + i * 64 * H2_BK) = ra[set][(i < MI ? i : 0) * 2 + p];
                     *reinterpret_cast<ushort8*>(Bs + p * H2_BPL + st_off + i * 64 * H2_BK) = rb[set][i * 2 + p];
                 }
         };

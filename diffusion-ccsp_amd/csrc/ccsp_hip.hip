@@ -1548,20 +1548,22 @@ int rowgemm_h2_mode(const ccsp_model* m, const ccsp_graph* g, int nct) {
     // round 3 (tools/ab_rowmode.sh, same-call A/B): with the straight-line epilogue the register-staged MODE 0 (three workgroups
     // per CU) is ahead of or equal to the direct-to-LDS MODE 2 at every size above the one-round limit -- C2's lanes 471-474
     // against 462, 128 graphs in one lane 287 against 275, 512 graphs 559 against 550, C4 +1 % -- so MODE 2 (and 1, 3) are only
-    // reached through CCSP_ROW_MODE now
+    // reached through CCSP_ROW_MODE now.  Between the two, MODE 6 -- MODE 0's staging on 64-row tiles, four workgroups per CU -- while
+    // its tile list still fits a bit more than two per CU (tools/ab_env.sh: 344 workgroups +3.4 %, 560 (C4) +1 %; 636 (a C2 lane) -3 %)
+    if (g->n_tiles * nct <= 9 * m->ncu / 4) return 6;
     return 0;
 }
 
 void launch_rowgemm_h2(ccsp_model* m, ccsp_graph* g, const float* tau_t, StepRef ref, size_t tau_stride, hipStream_t s) {
     constexpr int H = 256;
     const int mode = rowgemm_h2_mode(m, g, 2 * H / 128);
-    const bool small = mode == 4;                       // 64-row plan tiles instead of their 128-row pairs
+    const bool small = mode == 4 || mode == 6;          // 64-row plan tiles instead of their 128-row pairs
     const int work = (small ? g->n_tiles : g->n_tiles2) * (2 * H / 128);
 #define CCSP_ROWGEMM_F(MODE)                                                                                                                          \
     hipLaunchKernelGGL((k_rowgemm_h2<H, 2 * H, MODE>), dim3(work), dim3(256), 0, s, g->pembH, (size_t)g->N * H, g->pexp, g->urow_node,                  \
                        small ? g->td64 : g->td128, m->WpH,                                                                                              \
                        (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, m->wp_exp, g->base, tau_t, g->U, g->umax, ref, tau_stride)
-    if (mode == 5) CCSP_ROWGEMM_F(5); else if (mode == 4) CCSP_ROWGEMM_F(4); else if (mode == 3) CCSP_ROWGEMM_F(3); else if (mode == 2) CCSP_ROWGEMM_F(2);
+    if (mode == 6) CCSP_ROWGEMM_F(6); else if (mode == 5) CCSP_ROWGEMM_F(5); else if (mode == 4) CCSP_ROWGEMM_F(4); else if (mode == 3) CCSP_ROWGEMM_F(3); else if (mode == 2) CCSP_ROWGEMM_F(2);
     else if (mode == 1) CCSP_ROWGEMM_F(1); else CCSP_ROWGEMM_F(0);
 #undef CCSP_ROWGEMM_F
 }
@@ -1930,7 +1932,7 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     if (h2_bwd) {
         if constexpr (H == 256) {       // g_p[row] = g_z[row] . Wp[type, slot]: the forward kernel with K = 2H, N = H, identity rows, no base
             const int mode = rowgemm_h2_mode(m, g, H / 128);
-            const bool small = mode == 4;
+            const bool small = mode == 4 || mode == 6;
             const int work = (small ? g->n_tiles : g->n_tiles2) * (H / 128);
             float* nou = nullptr;
 #define CCSP_ROWGEMM_T(MODE)                                                                                                                        \
@@ -1938,7 +1940,7 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
                                small ? g->td64 : g->td128, m->WpTH,                                                                                     \
                                (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, m->wp_exp, nof, nof, g->GP, nou, StepRef{nullptr, nullptr, skip}, \
                                (size_t)0)
-            if (mode == 5) CCSP_ROWGEMM_T(5); else if (mode == 4) CCSP_ROWGEMM_T(4); else if (mode == 3) CCSP_ROWGEMM_T(3); else if (mode == 2) CCSP_ROWGEMM_T(2);
+            if (mode == 6) CCSP_ROWGEMM_T(6); else if (mode == 5) CCSP_ROWGEMM_T(5); else if (mode == 4) CCSP_ROWGEMM_T(4); else if (mode == 3) CCSP_ROWGEMM_T(3); else if (mode == 2) CCSP_ROWGEMM_T(2);
             else if (mode == 1) CCSP_ROWGEMM_T(1); else CCSP_ROWGEMM_T(0);
 #undef CCSP_ROWGEMM_T
         }
@@ -2719,7 +2721,7 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     // CCSP_MMA: f16x2 (default at hidden_dim 256: two-term fp16 operands, three MFMA products per fp32 product),
     //           bf16x3 (three-term bf16 operands, six products), f32 (v_mfma_f32_32x32x2_f32)
     m->f16x2 = (H == 256 && d->model_kind == CCSP_MODEL_DIFFUSION_CCSP) ? 1 : 0;
-    if (const char* e = getenv("CCSP_ROW_MODE")) { const int v = atoi(e); if (v >= 0 && v <= 5) m->row_mode = v; }
+    if (const char* e = getenv("CCSP_ROW_MODE")) { const int v = atoi(e); if (v >= 0 && v <= 6) m->row_mode = v; }
     if (const char* e = getenv("CCSP_EDGE_MT")) m->edge_mt = atoi(e) == 2 ? 2 : 1;
     if (const char* e = getenv("CCSP_EDGE_SMALL")) m->edge_small = atoi(e) != 0;
     m->valu_node_energy = getenv("CCSP_NODE_ENERGY_VALU") != nullptr;
