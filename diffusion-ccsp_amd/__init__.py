@@ -5,10 +5,17 @@
 mirror the reference classes of the same names (networks/denoise_fn.py, networks/ddpm.py) for the
 sampling path and run it through libccsp_hip.so (include/ccsp.h).
 """
-from . import checker, noise, sharding, transforms, worlds  # noqa: F401
-from ._lib import CcspError, build, device_info  # noqa: F401
-from .denoise_fn import ComposedEBMDenoiseFn, ConstraintDiffuser  # noqa: F401
-from .ddpm import GaussianDiffusion  # noqa: F401
+import os as _os
+
+# Kernel arguments in device memory: the dispatch of every launch reads them, and a chain is 33 000 short dependent launches.  ROCm 7
+# does this by default; with HIP_FORCE_DEV_KERNARG=0 the same chain runs 13 % (C2) to 27 % (C5, C1) slower (profiles/r03_findings.md).
+# Read by the HIP runtime when it initialises, i.e. at the process's first HIP call -- set here in case an older default applies.
+_os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
+
+from . import checker, noise, sharding, transforms, worlds  # noqa: F401,E402
+from ._lib import CcspError, build, device_info  # noqa: F401,E402
+from .denoise_fn import ComposedEBMDenoiseFn, ConstraintDiffuser  # noqa: F401,E402
+from .ddpm import GaussianDiffusion  # noqa: F401,E402
 
 from . import evaluate  # noqa: F401,E402
 
