@@ -9,10 +9,10 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 SO = os.path.join(CSRC, 'libccsp_hip.so')
-SOURCES = ['ccsp_hip.hip', 'ccsp_philox.h', 'ccsp_plan.h', 'ccsp_energy_pre.h', 'ccsp_energy.h', 'ccsp_bf16x3.h', 'ccsp_f16x2.h',
+SOURCES = ['ccsp_hip.hip', 'ccsp_philox.h', 'ccsp_plan.h', 'ccsp_energy_pre.h', 'ccsp_energy.h', 'ccsp_bf16x3.h', 'ccsp_f16x2.h', 'ccsp_fused.h',
            'ccsp_struct.h', 'ccsp_hmc.h', os.path.join('..', '..', 'include', 'ccsp.h')]
 
-K_COUNT = 10          # CCSP_K_COUNT of include/ccsp.h
+K_COUNT = 11          # CCSP_K_COUNT of include/ccsp.h
 SAMPLERS = {False: 0, None: 0, 'NONE': 0, 'ULA': 1, 'ULA+': 2, 'MALA': 3, 'HMC': 4}
 SCHEDULE_KEYS = ['betas', 'alphas_cumprod', 'alphas_cumprod_prev', 'sqrt_recip_alphas_cumprod',
                  'sqrt_recipm1_alphas_cumprod', 'posterior_log_variance_clipped', 'posterior_mean_coef1',
@@ -119,6 +119,7 @@ def lib():
     L.ccsp_compose_energy_grad.argtypes = [vp, vp, vp, vp, C.POINTER(Compose), vp, i32, vp, vp, vp]
     L.ccsp_compose_chain_run.argtypes = [vp, vp, vp, vp, C.POINTER(Compose), i32, C.POINTER(Noise), vp, i32, i32, i32, vp, vp]
     L.ccsp_plan_host.argtypes = [i32, i32, i32] + [vp] * 14
+    L.ccsp_plan_fused_host.argtypes = [i32, i32, i32] + [vp] * 6
     _lib = L
     return L
 
@@ -157,3 +158,21 @@ def plan_host(n_nodes, n_types, edge_index, edge_attr):
     out = {n: a[:t].copy() for n, a, t in zip(names, arrs, trims)}
     out.update(E_act=e_act, R=rows, n_tiles=tiles)
     return out
+
+
+def plan_fused_host(n_nodes, n_types, edge_index, edge_attr):
+    """host-only fused tiles of the one-launch evaluation kernel (include/ccsp.h ccsp_plan_fused_host); numpy in, dict out"""
+    import numpy as np
+    L = lib()
+    ei = np.ascontiguousarray(edge_index, dtype=np.int64).reshape(2, -1)
+    ea = np.ascontiguousarray(edge_attr, dtype=np.float32)
+    E = ei.shape[1]
+    n = C.c_int32()
+    tiles = np.zeros((max(E, 1), 4), dtype=np.int32)
+    rows = np.zeros((max(E, 1), 128), dtype=np.int32)
+    e_lu = np.zeros(max(E, 1), dtype=np.uint16)
+    check(L.ccsp_plan_fused_host(n_nodes, E, n_types, ei.ctypes.data, ea.ctypes.data, C.byref(n), tiles.ctypes.data,
+                                 rows.ctypes.data, e_lu.ctypes.data))
+    nt = n.value
+    e_act = int(tiles[:nt, 2].sum())
+    return dict(n_tiles=nt, tiles=tiles[:nt].copy(), rows=rows[:nt].copy(), e_lu=e_lu[:e_act].copy())

@@ -1,0 +1,416 @@
+// k_eval_fused: one evaluation of the per-type edge MLP + pose decoder (networks/denoise_fn.py:313-371) as ONE launch in which the
+// pre-activation rows U never leave the compute unit (round 4).  The two-kernel form (k_rowgemm_h2 -> U in memory -> k_edge_h2)
+// moves 123 of its 159 MB per C2 evaluation writing U and gathering it back; here a workgroup owns a FUSED TILE
+//     (constraint type t, a run of that type's sorted edges whose distinct U rows fit 32 per slot, output half h)
+// and does, without leaving the CU:
+//   phase 1  U_h[r, :] = 2^-(e_r + e_w) pemb[node(r)] . Wp[t, slot(r)][h H : (h+1) H, :]^T + base[r, h H : (h+1) H] (+ tau, slot 0)
+//            for the tile's <= 64 rows (LDS rows 0..31 = slot 0, 32..63 = slot 1) into a 64 x 256 fp32 LDS tile.  The pose-embedding
+//            planes of the 64 rows are staged once (LDS-DMA, 64 KB); the weight fragments come STRAIGHT from global memory in
+//            v_mfma_f32_32x32x16_f16 operand order (k_pack_wp_frag: every wave-load is 1 KB contiguous, no LDS staging, no
+//            barrier in the K loop), four k-steps ahead with counted waits; `base` is DMA-ed into the U tile and the
+//            accumulators are added in place.
+//   phase 2  the tile's <= 128 edges: A[e, :] = split(2^x SiLU(U_h[lu0(e)] + U_h[lu1(e)])) built from the LDS tile (16 lanes per row:
+//            conflict-free b128 gathers whatever the rows), decoder layer 1 on the f16 pipe with fragment-ordered weights from
+//            global memory, bias + SiLU, layer 2 on the VALU, outputs to the same CSR slots as k_edge_h2.
+// Same operands, same exponents (row maxima of U_h taken from the tile), same MFMA order per accumulator and the same epilogue
+// arithmetic as k_rowgemm_h2 + k_edge_h2<false, 1, 0>: the edge outputs are BITWISE those of the two-kernel path, so the node
+// kernel, the summation order and every parity bar are untouched (tests/test_hip_parity.py::test_fused_eval_is_bitwise_identical).
+// What it costs: a tile streams both slots' weight halves (512 KB of planes) for at most 64 rows -- 2.25x the operand bytes of a
+// 128 x 128 row-GEMM tile per row -- through the CU's L2 port; what it saves: U, umax and one launch boundary.
+// Included inside the anonymous namespace of ccsp_hip.hip, after ccsp_f16x2.h.
+#pragma once
+
+constexpr int FZ_RS = 32;                     // U rows per slot of a tile
+constexpr int FZ_ME = 128;                    // edges per tile (four 32-row MFMA tiles)
+constexpr int FZ_D = 4;                       // k-steps of weight fragments in flight per wave (phase 1)
+constexpr int FZ_APL = 64 * H2_BK;            // fp16 elements per plane of one K chunk of the staged A rows
+constexpr int FZ_APL2 = FZ_ME * H2_BK;        // ... of one 32-wide sub-stage of the decoder's A operand
+constexpr int FZ_S1_LD = 132;
+constexpr int FZ_UT_BYTES = 64 * 256 * 4;
+constexpr int FZ_R2_BYTES = FZ_ME * FZ_S1_LD * 4;                  // 67 584 >= 65 536 (A planes of phase 1; the two A stages of phase 2)
+constexpr int FZ_LDS_BYTES = FZ_UT_BYTES + FZ_R2_BYTES + 8 * 128 * 4 + 64 * 4 + 64 * 4 + FZ_ME * 4;
+
+struct FusedArgs {
+    const int4* tiles;                // {type, e0, ne, -}
+    const int* rows;                  // [n_tiles][128]: [0..63] node (pose-embedding row) of LDS row i, [64..127] U row (row of base)
+    const unsigned short* e_lu;       // [E_act] LDS rows of the edge's two operands: lu0 | lu1 << 8
+    const int* ent_pos;               // [2 E_act] CSR slot of (sorted edge, slot)
+    const unsigned short* A;          // pose-embedding planes [2][N][256]
+    size_t a_plane;
+    const int* a_exp;                 // [N]
+    const unsigned short* WpF;        // fragment-ordered planes of Wp (k_pack_wp_frag)
+    int w_exp;
+    const float* base;                // [R][512]
+    const float* tau_t;               // [C][512] time term + bias of this timestep
+    const unsigned short* Wd1F;       // fragment-ordered planes of pose_decoder.0.weight (k_pack_wd1_frag)
+    int wd_exp;
+    const float* bd1;
+    const float* Wd2;                 // [P][128]
+    const float* bd2;
+    float* O;
+    int P;
+};
+
+// WpH [2][n_ts][512][256] -> WpF[((((ts * 2 + h) * 4 + wq) * 16 + ks) * 4 + f)][lane][8],  f = 2 j + plane:
+// the B fragment of v_mfma_f32_32x32x16_f16 for output columns h 256 + wq 64 + j 32 + (lane & 31), k = 16 ks + 8 (lane >> 5) + 0..7
+__global__ void k_pack_wp_frag(long n16, const unsigned short* __restrict__ WpH, size_t plane_stride, unsigned short* __restrict__ out) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n16) return;
+    const int lane = (int)(idx & 63), f = (int)(idx >> 6) & 3, ks = (int)(idx >> 8) & 15, wq = (int)(idx >> 12) & 3, h = (int)(idx >> 14) & 1;
+    const long ts = idx >> 15;
+    const int col = h * 256 + wq * 64 + (f >> 1) * 32 + (lane & 31), k0 = ks * 16 + 8 * (lane >> 5);
+    const uint4 v = *reinterpret_cast<const uint4*>(WpH + (size_t)(f & 1) * plane_stride + ((size_t)ts * 512 + col) * 256 + k0);
+    *reinterpret_cast<uint4*>(out + (size_t)idx * 8) = v;
+}
+
+// Wd1H [2][128][256] -> Wd1F[((nt * 16 + ks) * 2 + plane)][lane][8]: columns nt 32 + (lane & 31), k = 16 ks + 8 (lane >> 5) + 0..7
+__global__ void k_pack_wd1_frag(const unsigned short* __restrict__ Wd1H, unsigned short* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 4 * 16 * 2 * 64) return;
+    const int lane = idx & 63, p = (idx >> 6) & 1, ks = (idx >> 7) & 15, nt = idx >> 11;
+    const int col = nt * 32 + (lane & 31), k0 = ks * 16 + 8 * (lane >> 5);
+    const uint4 v = *reinterpret_cast<const uint4*>(Wd1H + (size_t)p * 128 * 256 + (size_t)col * 256 + k0);
+    *reinterpret_cast<uint4*>(out + (size_t)idx * 8) = v;
+}
+
+// fragment loads the compiler must neither move nor wait for (see h2_ld16): byte offsets as instruction immediates
+template <int OFF>
+__device__ __forceinline__ void fz_ld_frag(half8& d, const unsigned short* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(d) : "v"(p), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void fz_ld_f32(float& d, const float* p) { asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+// s_waitcnt vmcnt(n), n known after unrolling, naming the four fragments it releases
+__device__ __forceinline__ void fz_wait4(int n, half8 (&b)[4]) {
+#define FZ_W(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) :: "memory")
+    if (n >= 16) FZ_W(16); else if (n >= 12) FZ_W(12); else if (n >= 8) FZ_W(8); else if (n >= 4) FZ_W(4); else FZ_W(0);
+#undef FZ_W
+}
+__device__ __forceinline__ void fz_wait8(half8 (&b)[8]) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) :: "memory");
+}
+// maximum over the 16 lanes of a DPP row (h2_max8 + row_mirror)
+__device__ __forceinline__ float fz_max16(float m) {
+    m = h2_max8(m);
+    return fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x140, 0xF, 0xF, true)));
+}
+
+// decoder of the tile's edges (phase 2).  MPW: 32-row MFMA tiles per wave (1: tile wave >> 2 of <= 2; 2: tiles 2 (wave >> 2) + 0 / 1
+// of <= 4); every wave takes 32 of the 128 decoder columns.
+template <int MPW>
+__device__ __forceinline__ void fz_decode(const FusedArgs& fa, unsigned char* smem, int e0, int ne, int h, const int (&lu0)[4], const int (&lu1)[4],
+                                          const int (&aexp)[4], half8 (&bc)[8], int o_slot) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nt = wave & 3, mh = wave >> 2;
+    const int MT = (ne + 31) >> 5;
+    const float* Ut = reinterpret_cast<const float*>(smem);
+    unsigned short* stg = reinterpret_cast<unsigned short*>(smem + FZ_UT_BYTES);        // two stages of [sub 2][plane 2][128][32]
+    constexpr int STAGE = 4 * FZ_APL2;
+    float* W2s = reinterpret_cast<float*>(smem + FZ_UT_BYTES + FZ_R2_BYTES);
+    const int* sE = reinterpret_cast<const int*>(smem + FZ_UT_BYTES + FZ_R2_BYTES + 8 * 128 * 4 + 64 * 4 + 64 * 4);
+    const int br = tid >> 4, lq16 = tid & 15, sub = lq16 >> 3, lq = lq16 & 7;
+    const unsigned short* bptr = fa.Wd1F + (size_t)nt * 16 * 2 * 512 + lane * 8;
+    floatx16 acc[MPW];
+#pragma unroll
+    for (int i = 0; i < MPW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    // A rows of the 64-column stage cp, pass i (edges 32 i + br): SiLU + scale + split of four columns -> both planes
+    auto build = [&](int cp, int i, const float4& ua, const float4& ub) {
+        unsigned short* As = stg + (cp & 1) * STAGE + sub * 2 * FZ_APL2;
+        const float hv[4] = {silu_fast(ua.x + ub.x), silu_fast(ua.y + ub.y), silu_fast(ua.z + ub.z), silu_fast(ua.w + ub.w)};
+        unsigned short p1[4], p2[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split2h(ldexpf(hv[e], aexp[i]), p1[e], p2[e]);
+        unsigned short* d = As + h2_off(32 * i + br, lq >> 1) + (lq & 1) * 4;
+        *reinterpret_cast<uint2*>(d) = make_uint2(p1[0] | ((unsigned)p1[1] << 16), p1[2] | ((unsigned)p1[3] << 16));
+        *reinterpret_cast<uint2*>(d + FZ_APL2) = make_uint2(p2[0] | ((unsigned)p2[1] << 16), p2[2] | ((unsigned)p2[3] << 16));
+    };
+    auto gather = [&](int cp, int i, float4& ua, float4& ub) {
+        ua = *reinterpret_cast<const float4*>(Ut + lu0[i] * 256 + cp * 64 + lq16 * 4);
+        ub = *reinterpret_cast<const float4*>(Ut + lu1[i] * 256 + cp * 64 + lq16 * 4);
+    };
+    auto ldB = [&](int cp, half8 (&b)[8]) {                       // the wave's decoder-weight fragments of stage cp: 8 KB contiguous
+        const unsigned short* p = bptr + (size_t)cp * 4 * 2 * 512;
+        fz_ld_frag<0>(b[0], p); fz_ld_frag<1024>(b[1], p); fz_ld_frag<2048>(b[2], p); fz_ld_frag<3072>(b[3], p);
+        fz_ld_frag<0>(b[4], p + 2048); fz_ld_frag<1024>(b[5], p + 2048); fz_ld_frag<2048>(b[6], p + 2048); fz_ld_frag<3072>(b[7], p + 2048);
+    };
+    auto mma = [&](int cp, int ks, const half8 (&b)[8]) {         // one k-step (16) of the stage: same product order as h2_kstep
+        const unsigned short* As = stg + (cp & 1) * STAGE + (ks >> 1) * 2 * FZ_APL2;
+        const int piece = (lane >> 5) + 2 * (ks & 1);
+        half8 a[MPW][2];
+#pragma unroll
+        for (int i = 0; i < MPW; ++i) {
+            const int mt = MPW == 1 ? mh : 2 * mh + i;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) a[i][p] = *reinterpret_cast<const half8*>(As + p * FZ_APL2 + h2_off(mt * 32 + (lane & 31), piece));
+        }
+        constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int i = 0; i < MPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][PA[q]], b[2 * ks + PB[q]], acc[i], 0, 0, 0);
+    };
+    const bool wave_has_tile = (MPW == 1 ? mh : 2 * mh) < MT;     // (wave-uniform)
+    {   // stage 0
+        float4 ua, ub;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < MT) { gather(0, i, ua, ub); build(0, i, ua, ub); }
+    }
+    half8 bn[8];
+    __builtin_amdgcn_sched_barrier(0);
+    fz_wait8(bc);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    CCSP_TRK(0, 10);
+#pragma unroll
+    for (int cp = 0; cp < 4; ++cp) {
+        half8 (&bcur)[8] = (cp & 1) ? bn : bc;
+        half8 (&bnxt)[8] = (cp & 1) ? bc : bn;
+        if (cp + 1 < 4) ldB(cp + 1, bnxt);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            float4 ua, ub;
+            const bool bld = cp + 1 < 4 && ks < MT;               // pass ks of the next stage rides behind this k-step's MFMAs
+            if (bld) gather(cp + 1, ks, ua, ub);
+            if (wave_has_tile) mma(cp, ks, bcur);
+            if (bld) build(cp + 1, ks, ua, ub);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (cp + 1 < 4) fz_wait8(bnxt);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    CCSP_TRK(0, 14);
+    // epilogue: 2^-(e_row + e_w) acc + bias -> SiLU -> S1 (aliases the stages: every wave is past the last barrier)
+    float* S1 = reinterpret_cast<float*>(smem + FZ_UT_BYTES);
+    if (wave_has_tile) {
+        const int col = nt * 32 + (lane & 31);
+        const float bj = fa.bd1[col];
+#pragma unroll
+        for (int i = 0; i < MPW; ++i) {
+            const int mt = MPW == 1 ? mh : 2 * mh + i;
+            if (mt < MT) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const float q = ldexpf(acc[i][r], -(sE[row] + fa.wd_exp)) + bj;
+                    S1[row * FZ_S1_LD + col] = silu_fast(q);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    CCSP_TRK(0, 15);
+    // second decoder layer: one (row, p) dot product per thread, the four chains and their sum as k_edge_h2<., ., 0> forms them
+    const int P = fa.P;
+    for (int idx = tid; idx < FZ_ME * P; idx += 512) {
+        const int row = idx & (FZ_ME - 1), p = idx >> 7;
+        if (row < ne) {
+            const float4* sr = reinterpret_cast<const float4*>(S1 + row * FZ_S1_LD);
+            const float4* wr = reinterpret_cast<const float4*>(W2s + p * 128);
+            float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;
+#pragma unroll 8
+            for (int j = 0; j < 32; ++j) {
+                const float4 sv = sr[j], wv = wr[j];
+                o0 = fmaf(sv.x, wv.x, o0); o1 = fmaf(sv.y, wv.y, o1); o2 = fmaf(sv.z, wv.z, o2); o3 = fmaf(sv.w, wv.w, o3);
+            }
+            const float o = ((o0 + o1) + (o2 + o3)) + fa.bd2[p];
+            const int slot = idx == tid ? o_slot : fa.ent_pos[2 * (e0 + row) + h];
+            fa.O[(size_t)slot * P + p] = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void k_eval_fused(FusedArgs fa) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[FZ_LDS_BYTES];
+    using gptr = const __attribute__((address_space(1))) void*;
+    using lptr = __attribute__((address_space(3))) void*;
+    float* Ut = reinterpret_cast<float*>(smem);                                           // [64][256] fp32
+    unsigned short* As = reinterpret_cast<unsigned short*>(smem + FZ_UT_BYTES);           // phase 1: [8 chunks][2 planes][64][32]
+    float* W2s = reinterpret_cast<float*>(smem + FZ_UT_BYTES + FZ_R2_BYTES);              // [8][128]
+    int* sExpA = reinterpret_cast<int*>(W2s + 8 * 128);                                   // [64] exponents of the pose-embedding rows
+    float* sMax = reinterpret_cast<float*>(sExpA + 64);                                   // [64] max |U_h| per row
+    int* sE = reinterpret_cast<int*>(sMax + 64);                                          // [128] exponents of the decoder's A rows
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = bid >> 1, h = bid & 1;
+    const int4 td = fa.tiles[tile];
+    const int type = td.x, e0 = td.y, ne = td.z;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int s = wave >> 2, wq = wave & 3;                        // phase 1: slot (row half of the tile), 64 of the half's 256 columns
+    CCSP_TRK(0, 0);
+    CCSP_TRK_RT(0, 30);
+    // --- the weight stream starts before anything else: its address needs the tile descriptor only
+    const unsigned short* bptr = fa.WpF + ((((size_t)(2 * type + s) * 2 + h) * 4 + wq) * 16) * 4 * 512 + lane * 8;
+    half8 bq[FZ_D][4];
+    auto ldB = [&](int ks, half8 (&b)[4]) {
+        const unsigned short* p = bptr + (size_t)ks * 4 * 512;
+        fz_ld_frag<0>(b[0], p); fz_ld_frag<1024>(b[1], p); fz_ld_frag<2048>(b[2], p); fz_ld_frag<3072>(b[3], p);
+    };
+#pragma unroll
+    for (int d = 0; d < FZ_D; ++d) ldB(d, bq[d]);
+    __builtin_amdgcn_sched_barrier(0);
+    // --- index loads (ordinary loads: the compiler's waits for them also cover the fragments above, which are older)
+    const int* trow = fa.rows + (size_t)tile * 128;
+    const int a_row = (wave & 3) * 16 + (lane >> 2);               // A row this lane fetches in every chunk (plane wave >> 2)
+    const int node = trow[a_row];
+    const int urow_l = trow[64 + 8 * wave + (lane & 7)];           // U rows of the eight base rows this wave fetches
+    int ur[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ur[j] = __builtin_amdgcn_readlane(urow_l, j);     // (consumed here: no compiler wait between the DMA groups below)
+    const int br = tid >> 4;
+    int lu0[4], lu1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int el = 32 * i + br;
+        el = el < ne ? el : ne - 1;
+        const unsigned int v = fa.e_lu[e0 + el];
+        lu0[i] = (int)(v & 0xffu); lu1[i] = (int)(v >> 8);
+    }
+    int o_slot;
+    {
+        int row = tid & (FZ_ME - 1);
+        row = row < ne ? row : ne - 1;
+        o_slot = fa.ent_pos[2 * (e0 + row) + h];
+    }
+    const int P = fa.P;
+    if (tid * 4 < 8 * 128) {
+        const float4 w2v = *reinterpret_cast<const float4*>(fa.Wd2 + (tid * 4 < P * 128 ? tid * 4 : 0));
+        *reinterpret_cast<float4*>(W2s + tid * 4) = w2v;
+    }
+    CCSP_TRK(0, 1);
+    // --- A planes of the 64 rows (LDS-DMA, source-side swizzle as k_rowgemm_h2 MODE 2), the row exponents, base rows into the U tile
+    {
+        const int plane = wave >> 2, rb = wave & 3;
+        const int piece = (lane & 3) ^ ((a_row >> 2) & 3);
+        const unsigned short* ga = fa.A + (size_t)plane * fa.a_plane + (size_t)node * 256 + piece * 8;
+        const int lo = __builtin_amdgcn_readfirstlane(plane * FZ_APL + rb * 16 * H2_BK);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) __builtin_amdgcn_global_load_lds((gptr)(ga + c * H2_BK), (lptr)(As + c * 2 * FZ_APL + lo), 16, 0, 0);
+    }
+    int ea;
+    h2_ld4(ea, fa.a_exp + node);
+    float tv[2];
+    {
+        const float* tp = fa.tau_t + (size_t)type * 512 + h * 256 + wq * 64 + (lane & 31);
+        fz_ld_f32(tv[0], tp);
+        fz_ld_f32(tv[1], tp + 32);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int lo = __builtin_amdgcn_readfirstlane((8 * wave + j) * 256);
+        __builtin_amdgcn_global_load_lds((gptr)(fa.base + (size_t)ur[j] * 512 + h * 256 + lane * 4), (lptr)(Ut + lo), 16, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // the A planes have landed (younger: exponent 1, tau 2, base 8); W2s is written; every wave's share is visible after the barrier
+    asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    CCSP_TRK(0, 2);
+    // --- phase 1: 32 rows (slot s) x 64 columns per wave, K = 256 in 16 k-steps; no barrier inside
+    floatx16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    half8 af[2][2];                                                // [k-step parity][plane]: the A fragments of k-step ks + 1 are read under the MFMAs of ks
+    auto ldA = [&](int ks, half8 (&a)[2]) {
+        const unsigned short* Ac = As + (ks >> 1) * 2 * FZ_APL;
+        const int piece = (lane >> 5) + 2 * (ks & 1);
+        a[1] = *reinterpret_cast<const half8*>(Ac + FZ_APL + h2_off(s * 32 + (lane & 31), piece));
+        a[0] = *reinterpret_cast<const half8*>(Ac + h2_off(s * 32 + (lane & 31), piece));
+    };
+    ldA(0, af[0]);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        half8 (&b)[4] = bq[ks % FZ_D];
+        __builtin_amdgcn_sched_barrier(0);
+        // younger than the fragments of k-step ks: those of ks + 1 .. min(ks + D - 1, 15) (the refill of this slot is issued below)
+        fz_wait4(4 * ((ks + FZ_D - 1 < 15 ? ks + FZ_D - 1 : 15) - ks), b);
+        if (ks + 1 < 16) ldA(ks + 1, af[(ks + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const half8 a0 = af[ks & 1][0], a1 = af[ks & 1][1];
+        // smallest terms first (h2_kstep): (a lo, b hi), (a hi, b lo), (a hi, b hi); b[2 j + plane]
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[0], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[2], acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[1], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[3], acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[0], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[2], acc[1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);                         // (the MFMAs have read the slot: it can be refilled)
+        if (ks + FZ_D < 16) ldB(ks + FZ_D, b);
+        if ((ks & 3) == 3) CCSP_TRK(0, 3 + (ks >> 2));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // --- the decoder's first weight fragments are requested now; exponents, tau and every base row of this wave have landed
+    half8 bc[8];
+    {
+        const unsigned short* p = fa.Wd1F + (size_t)(wave & 3) * 16 * 2 * 512 + lane * 8;
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ea), "+v"(tv[0]), "+v"(tv[1]) :: "memory");
+        fz_ld_frag<0>(bc[0], p); fz_ld_frag<1024>(bc[1], p); fz_ld_frag<2048>(bc[2], p); fz_ld_frag<3072>(bc[3], p);
+        fz_ld_frag<0>(bc[4], p + 2048); fz_ld_frag<1024>(bc[5], p + 2048); fz_ld_frag<2048>(bc[6], p + 2048); fz_ld_frag<3072>(bc[7], p + 2048);
+    }
+    if (wave < 4 && (lane & 3) == 0) sExpA[a_row] = ea;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                  // every wave's base rows are in the U tile; the row exponents are visible
+    __builtin_amdgcn_sched_barrier(0);
+    CCSP_TRK(0, 7);
+    // --- U_h = 2^-(e_row + e_w) acc + (base + tau), in place (accumulator layout: 32 consecutive columns of one row per half-wave)
+    {
+        if (s != 0) { tv[0] = 0.0f; tv[1] = 0.0f; }               // (the time term rides on slot-0 rows; slot-1 rows add +0 like k_rowgemm_h2)
+        int ex[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int4 e4 = *reinterpret_cast<const int4*>(sExpA + s * 32 + 8 * q + 4 * (lane >> 5));
+            ex[4 * q] = -(e4.x + fa.w_exp); ex[4 * q + 1] = -(e4.y + fa.w_exp); ex[4 * q + 2] = -(e4.z + fa.w_exp); ex[4 * q + 3] = -(e4.w + fa.w_exp);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float* up = Ut + (s * 32 + 4 * (lane >> 5)) * 256 + wq * 64 + j * 32 + (lane & 31);
+            float bv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bv[r] = up[((r & 3) + 8 * (r >> 2)) * 256];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) up[((r & 3) + 8 * (r >> 2)) * 256] = ldexpf(acc[j][r], ex[r]) + (bv[r] + tv[j]);
+        }
+    }
+    __syncthreads();
+    CCSP_TRK(0, 8);
+    // --- row maxima of U_h (the bound behind the decoder rows' exponents): 16 lanes per row, four 16-byte reads each
+    {
+        const int c16 = tid & 15;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int row = 32 * pass + br;
+            float m = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 v = *reinterpret_cast<const float4*>(Ut + row * 256 + k * 64 + c16 * 4);
+                m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            }
+            m = fz_max16(m);
+            if (c16 == 0) sMax[row] = m;
+        }
+    }
+    __syncthreads();
+    CCSP_TRK(0, 9);
+    int aexp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        // |SiLU(z)| <= |z| <= max|U_h[u0]| + max|U_h[u1]|   (k_edge_h2 forms the same sum from umax)
+        aexp[i] = h2_scale_exp(sMax[lu0[i]] + sMax[lu1[i]]);
+        if ((tid & 15) == 0) sE[32 * i + br] = aexp[i];
+    }
+    // --- phase 2
+    if (ne > 64) fz_decode<2>(fa, smem, e0, ne, h, lu0, lu1, aexp, bc, o_slot);
+    else fz_decode<1>(fa, smem, e0, ne, h, lu0, lu1, aexp, bc, o_slot);
+#ifdef CCSP_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    CCSP_TRK(0, 16);
+    CCSP_TRK_RT(0, 31);
+}

@@ -1292,6 +1292,7 @@ struct FuseArgs {
 #include "ccsp_energy.h"
 #include "ccsp_bf16x3.h"
 #include "ccsp_f16x2.h"
+#include "ccsp_fused.h"
 #include "ccsp_struct.h"
 #include "ccsp_hmc.h"
 
@@ -1370,6 +1371,9 @@ struct ccsp_model {
     unsigned short* WpH = nullptr;    // [2][C][2][2H][H] fp16 planes of Wp * 2^wp_exp
     unsigned short* Wd1H = nullptr;   // [2][H/2][H]      fp16 planes of pose_decoder.0.weight * 2^wd_exp
     int wp_exp = 0, wd_exp = 0;
+    unsigned short* WpF = nullptr;    // the planes of WpH in MFMA fragment order (k_pack_wp_frag): k_eval_fused reads them straight into registers
+    unsigned short* Wd1F = nullptr;   // likewise pose_decoder.0.weight (k_pack_wd1_frag)
+    int eval_fused = 0;               // CCSP_EVAL=fused: direct-mode evaluations as ONE launch with U kept in LDS (ccsp_fused.h); split: two launches
     unsigned short* WpTH = nullptr;   // [2][C][2][H][2H] fp16 planes of WpT * 2^wp_exp (energy backward; energy_wrapper models only)
     unsigned short* Wd1TH = nullptr;  // [2][H][H/2]      fp16 planes of pose_decoder.0.weight^T * 2^wd_exp
     float wd2_absmax = 0.0f;          // max |pose_decoder.2.weight| (row-exponent bound of k_edge_bwd_h2)
@@ -1434,6 +1438,12 @@ struct ccsp_graph {
     int fuse_me = 0, fuse_blocks = 0;
     unsigned int fuse_epoch = 0;
     std::vector<int> h_fuse;                  // kept alive for the async upload
+    // fused tiles of k_eval_fused (ccsp::FusedPlan)
+    int4* ft_tiles = nullptr;
+    int* ft_rows = nullptr;
+    unsigned short* ft_elu = nullptr;
+    int n_ftiles = 0;
+    ccsp::FusedPlan fplan;                    // kept alive for the async upload
     int4 *td64 = nullptr, *td128 = nullptr;   // the same tile lists as {row0, nrows, 2 type + slot, 0} records (k_rowgemm_h2: one scalar load per tile)
     std::vector<int4> h_td;                   // kept alive for the async upload
     int* urow_ts;
@@ -1491,7 +1501,7 @@ namespace {
 
 const char* const kKernelNames[CCSP_K_COUNT] = {"row GEMM (forward)", "edge decoder (forward)", "node update + pose encoder", "edge decoder backward",
                                                "row sum of g_z", "row GEMM (transpose)", "node energy backward", "energy sum", "HMC elementwise",
-                                               "StructDiffusion evaluation"};
+                                               "StructDiffusion evaluation", "fused evaluation (row GEMM + edge decoder)"};
 
 inline void prof_mark(ccsp_graph* g, hipStream_t s, int id) {
     if (!g->profile || g->kev_used >= g->kev.size()) return;
@@ -1684,6 +1694,20 @@ int launch_eval(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s, bool tabled 
     const StepRef ref{tabled ? g->d_tab : nullptr, tabled ? g->d_counter : nullptr};
     int* const cinc = tabled ? g->d_counter : nullptr;
     if constexpr (H == 256) {
+        if (m->f16x2 && m->eval_fused && !tabled && g->n_ftiles > 0 && fused == nullptr) {
+            prof_mark(g, s, CCSP_K_EVAL_FUSED);
+            FusedArgs fa;
+            fa.tiles = g->ft_tiles; fa.rows = g->ft_rows; fa.e_lu = g->ft_elu; fa.ent_pos = g->ent_pos;
+            fa.A = g->pembH; fa.a_plane = (size_t)g->N * H; fa.a_exp = g->pexp;
+            fa.WpF = m->WpF; fa.w_exp = m->wp_exp; fa.base = g->base; fa.tau_t = tau_t;
+            fa.Wd1F = m->Wd1F; fa.wd_exp = m->wd_exp; fa.bd1 = m->pd0_b; fa.Wd2 = m->pd2_w; fa.bd2 = m->pd2_b;
+            fa.O = g->O; fa.P = m->d.pose_dim;
+            hipLaunchKernelGGL(k_eval_fused, dim3(2 * g->n_ftiles), dim3(512), 0, s, fa);
+            if (did_fuse) *did_fuse = false;
+            prof_mark(g, s, -1);
+            g->evals++;
+            return 0;
+        }
         if (m->f16x2) {
             launch_rowgemm_h2(m, g, tau_t, ref, tau_stride, s);
             prof_mark(g, s, CCSP_K_EDGE);
@@ -2444,6 +2468,15 @@ int graph_build(ccsp_model* m, int N, int E, int F, const float* x, const signed
         TRY(dev_upload(reg, &td, g->h_td, s));
         g->td64 = td; g->td128 = td + p.tile_row0.size();
     }
+    if (m->f16x2 && m->WpF && p.E_act > 0) {   // fused tiles (k_eval_fused): <= 32 U rows per slot, <= 128 edges
+        ccsp::build_fused_plan(p, FZ_RS, FZ_ME, g->fplan);
+        g->n_ftiles = g->fplan.n_tiles;
+        int* ft = nullptr;
+        TRY(dev_upload(reg, &ft, g->fplan.tiles, s));
+        g->ft_tiles = reinterpret_cast<int4*>(ft);
+        TRY(dev_upload(reg, &g->ft_rows, g->fplan.rows, s));
+        TRY(dev_upload(reg, &g->ft_elu, g->fplan.e_lu, s));
+    }
     TRY(dev_alloc(reg, &g->base, (size_t)p.R * 2 * H));
     TRY(dev_alloc(reg, &g->U, (size_t)p.R * 2 * H));
     TRY(dev_alloc(reg, &g->O, (size_t)2 * p.E_act * P));
@@ -2727,6 +2760,7 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     m->valu_node_energy = getenv("CCSP_NODE_ENERGY_VALU") != nullptr;
     if (const char* e = getenv("CCSP_NODE")) { m->node_generic = strcmp(e, "generic") == 0; m->node_stream = strcmp(e, "stream") == 0; }
     if (const char* e = getenv("CCSP_FUSE_NODE")) m->fuse_node = atoi(e) != 0;
+    if (const char* e = getenv("CCSP_EVAL")) m->eval_fused = strcmp(e, "fused") == 0;
     {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -2906,6 +2940,13 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
             TRY(dev_alloc(reg, &m->Wd1H, (size_t)2 * nwd));
             hipLaunchKernelGGL(k_split2h, dim3(nblk(nwp, 256)), dim3(256), 0, s, nwp, m->Wp, m->wp_exp, m->WpH);
             hipLaunchKernelGGL(k_split2h, dim3(nblk(nwd, 256)), dim3(256), 0, s, nwd, m->pd0_w, m->wd_exp, m->Wd1H);
+            {   // the same planes in MFMA fragment order for the fused evaluation kernel (ccsp_fused.h)
+                const long n16 = (long)d->n_types * 2 * 32768;
+                TRY(dev_alloc(reg, &m->WpF, (size_t)2 * nwp));
+                TRY(dev_alloc(reg, &m->Wd1F, (size_t)2 * nwd));
+                hipLaunchKernelGGL(k_pack_wp_frag, dim3(nblk(n16, 256)), dim3(256), 0, s, n16, m->WpH, (size_t)nwp, m->WpF);
+                hipLaunchKernelGGL(k_pack_wd1_frag, dim3(nblk(4 * 16 * 2 * 64, 256)), dim3(256), 0, s, m->Wd1H, m->Wd1F);
+            }
             if (d->energy_wrapper) {    // the backward GEMMs' weights: the same tensors transposed, the same exponents
                 if (const char* e = getenv("CCSP_ENERGY_BWD")) m->energy_bwd_h2 = strcmp(e, "bf16x3") != 0;
                 if (const char* e = getenv("CCSP_MALA_REUSE")) m->mala_reuse = atoi(e) != 0;
@@ -3449,6 +3490,20 @@ int ccsp_plan_host(int32_t N, int32_t E, int32_t C, const int64_t* edge_index, c
     cp(urow_node, p.urow_node); cp(urow_ts, p.urow_ts);
     cp(tile_row0, p.tile_row0); cp(tile_nrows, p.tile_nrows); cp(tile_ts, p.tile_ts);
     cp(node_ptr, p.node_ptr); cp(node_ent, p.node_ent);
+    return 0;
+}
+
+int ccsp_plan_fused_host(int32_t N, int32_t E, int32_t C, const int64_t* edge_index, const float* edge_attr, int32_t* n_tiles,
+                         int32_t* tiles, int32_t* rows, uint16_t* e_lu) {
+    ccsp::Plan p;
+    const char* perr = "";
+    if (ccsp::build_plan(N, E, C, TILE_M, edge_index, edge_attr, p, &perr)) return fail("plan_fused_host: %s", perr);
+    ccsp::FusedPlan f;
+    ccsp::build_fused_plan(p, FZ_RS, FZ_ME, f);
+    *n_tiles = f.n_tiles;
+    if (tiles && !f.tiles.empty()) memcpy(tiles, f.tiles.data(), f.tiles.size() * sizeof(int32_t));
+    if (rows && !f.rows.empty()) memcpy(rows, f.rows.data(), f.rows.size() * sizeof(int32_t));
+    if (e_lu && !f.e_lu.empty()) memcpy(e_lu, f.e_lu.data(), f.e_lu.size() * sizeof(uint16_t));
     return 0;
 }
 

@@ -233,7 +233,7 @@ int ccsp_chain_skipped(ccsp_graph* graph, int64_t* evaluations_skipped);
  * launch of the kernels below (the first CCSP_PROFILE_MARKS marks of a chain); which = CCSP_K_*; calls = launches
  * seen, ms_mean = their mean duration, launch to next mark on the stream; name = a short label (may be NULL). */
 enum { CCSP_K_ROWGEMM = 0, CCSP_K_EDGE = 1, CCSP_K_NODE = 2, CCSP_K_EDGE_BWD = 3, CCSP_K_ROWSUM = 4, CCSP_K_ROWGEMM_T = 5,
-       CCSP_K_NODE_ENERGY = 6, CCSP_K_ENERGY_SUM = 7, CCSP_K_HMC = 8, CCSP_K_SD_EVAL = 9, CCSP_K_COUNT = 10 };
+       CCSP_K_NODE_ENERGY = 6, CCSP_K_ENERGY_SUM = 7, CCSP_K_HMC = 8, CCSP_K_SD_EVAL = 9, CCSP_K_EVAL_FUSED = 10, CCSP_K_COUNT = 11 };
 #define CCSP_PROFILE_MARKS 16384
 int ccsp_kernel_stats(ccsp_graph* graph, int32_t which, int64_t* calls, float* ms_mean, char* name, int32_t name_len);
 /* Which variants of the f16x2 evaluation kernels a ONE-lane launch on this graph runs (they are chosen by tile count, see
@@ -252,6 +252,16 @@ int ccsp_plan_host(int32_t N, int32_t E, int32_t C, const int64_t* edge_index, c
                    int32_t* counts, int32_t* e_orig, int32_t* e_type, int32_t* e_u0, int32_t* e_u1,
                    int32_t* urow_node, int32_t* urow_ts, int32_t* tile_row0, int32_t* tile_nrows,
                    int32_t* tile_ts, int32_t* node_ptr, int32_t* node_ent);
+
+/* Host-only: the FUSED TILES of the one-launch evaluation kernel (csrc/ccsp_fused.h; the same loop over constraint types and
+ * their edges, denoise_fn.py:313-371).  Every type's sorted edges are cut, in order, into runs whose distinct U rows are at most
+ * 32 per slot and whose length is at most 128 edges; a workgroup owns (tile, output half), computes the tile's U rows into LDS
+ * and decodes the tile's edges from there.  n_tiles <= E_act; tiles [n_tiles][4] = {type, first sorted edge, edges,
+ * rows slot 0 | rows slot 1 << 16}; rows [n_tiles][128] = node of local row i (i < 32: slot 0, 32 <= i < 64: slot 1; unused
+ * entries repeat the slot's first row), then the U row of local row i; e_lu [E_act] = local row of operand 0 | local row of
+ * operand 1 << 8.  Caller-sized HOST arrays (tiles [4 E], rows [128 E], e_lu [E]); any of them may be NULL. */
+int ccsp_plan_fused_host(int32_t N, int32_t E, int32_t C, const int64_t* edge_index, const float* edge_attr, int32_t* n_tiles,
+                         int32_t* tiles, int32_t* rows, uint16_t* e_lu);
 
 #ifdef __cplusplus
 }

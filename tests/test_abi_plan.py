@@ -99,6 +99,53 @@ def test_plan_host_matches_numpy(case):
         assert (got['urow_ts'][r0:r0 + nr] == ts).all() and 1 <= nr <= 64
 
 
+@pytest.mark.parametrize('case', ['qualitative', 'triangular', 'robot', 'ragged', 'shuffled'])
+def test_fused_plan_invariants(case):
+    """the fused tiles of k_eval_fused (ccsp_plan_fused_host): a partition of every type's sorted edges into runs of <= 128 edges
+    whose distinct U rows are <= 32 per slot; every edge finds its two rows at the local positions it carries; padding entries
+    are valid rows of the same slot"""
+    if case == 'qualitative':
+        b, C = worlds.qualitative_batch(40, 8, seed=3), 13
+    elif case == 'triangular':
+        b, C = worlds.triangular_batch(7, 12, seed=3), 2
+    elif case == 'robot':
+        b, C = worlds.robot_box_batch(9, 10, seed=3), 2
+    else:
+        b, C = worlds.qualitative_batch(12, 6, seed=9), 13
+        b.edge_attr = b.edge_attr.copy()
+        b.edge_attr[1] = 13.0
+        if case == 'shuffled':          # edges NOT graph by graph: rows are shared between tiles, every tile still closes
+            perm = np.random.RandomState(0).permutation(b.edge_index.shape[1])
+            b.edge_index = b.edge_index[:, perm]
+            b.edge_attr = b.edge_attr[perm]
+    N = b.x.shape[0]
+    pl = _lib.plan_host(N, C, b.edge_index, b.edge_attr)
+    f = _lib.plan_fused_host(N, C, b.edge_index, b.edge_attr)
+    assert f['tiles'][:, 2].sum() == pl['E_act'] and len(f['e_lu']) == pl['E_act']
+    k = 0
+    for (typ, e0, ne, nr), rows in zip(f['tiles'], f['rows']):
+        assert e0 == k and 1 <= ne <= 128
+        k += ne
+        nr0, nr1 = nr & 0xffff, nr >> 16
+        assert 1 <= nr0 <= 32 and 1 <= nr1 <= 32
+        assert (pl['e_type'][e0:e0 + ne] == typ).all()
+        node, urow = rows[:64], rows[64:]
+        assert (pl['urow_node'][urow] == node).all()
+        assert (pl['urow_ts'][urow[:32]] == 2 * typ).all() and (pl['urow_ts'][urow[32:]] == 2 * typ + 1).all()
+        assert len(set(urow[:nr0])) == nr0 and len(set(urow[32:32 + nr1])) == nr1
+        assert (urow[nr0:32] == urow[0]).all() and (urow[32 + nr1:] == urow[32]).all()
+        lu = f['e_lu'][e0:e0 + ne]
+        lu0, lu1 = lu & 0xff, lu >> 8
+        assert (lu0 < nr0).all() and (lu1 >= 32).all() and (lu1 < 32 + nr1).all()
+        assert (urow[lu0] == pl['e_u0'][e0:e0 + ne]).all() and (urow[lu1] == pl['e_u1'][e0:e0 + ne]).all()
+        # greedy: the tile could not have taken the next edge of its type
+        if k < pl['E_act'] and pl['e_type'][k] == typ and ne < 128:
+            n0 = pl['e_u0'][k] not in set(urow[:nr0])
+            n1 = pl['e_u1'][k] not in set(urow[32:32 + nr1])
+            assert nr0 + n0 > 32 or nr1 + n1 > 32
+    assert k == pl['E_act']
+
+
 def test_plan_edge_cases():
     # no edges at all
     p = _lib.plan_host(3, 13, np.zeros((2, 0), dtype=np.int64), np.zeros(0, dtype=np.float32))
