@@ -63,12 +63,43 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return SO
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    tmp = SO + '.tmp'
     cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-pthread',
-           '-o', SO, os.path.join(CSRC, 'ccsp_hip.hip')]
+           '-Rpass-analysis=kernel-resource-usage', '-o', tmp, os.path.join(CSRC, 'ccsp_hip.hip')]
     if verbose:
         print(' '.join(cmd))
-    subprocess.check_call(cmd)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+    if r.returncode != 0:
+        raise CcspError('hipcc failed:\n' + r.stderr[-4000:])
+    bad = check_no_scratch(r.stderr)
+    if bad:
+        os.remove(tmp)
+        raise CcspError('register spills in kernels whose prefetch loads are inline asm with hand-counted s_waitcnt (a spill or reload '
+                        'next to them reads registers that are still in flight): %s -- this compiler needs the vmcnt(0) fallbacks' % bad)
+    os.replace(tmp, SO)
     return SO
+
+
+# kernels that request operands by inline-asm loads the compiler cannot see and wait for them with hand-counted s_waitcnt
+# (csrc/ccsp_f16x2.h h2_ld16 / h2_ld_wait, csrc/ccsp_fused.h fz_ld_frag): a scratch spill there adds vector-memory operations to the
+# counts and can store a register whose load is still in flight, so the build refuses a compiler that spills in them
+GUARDED_KERNELS = ('k_rowgemm_h2', 'k_edge_h2', 'k_edge_bwd_h2', 'k_node_direct', 'k_node_energy_h2', 'k_eval_fused')
+
+
+def check_no_scratch(remarks):
+    """parse hipcc -Rpass-analysis=kernel-resource-usage output; returns {kernel: scratch bytes per lane} of guarded kernels that spill"""
+    import re
+    bad = {}
+    name = None
+    for line in remarks.splitlines():
+        m = re.search(r'Function Name: (\S+)', line)
+        if m:
+            name = m.group(1)
+            continue
+        m = re.search(r'ScratchSize \[bytes/lane\]: (\d+)', line)
+        if m and name and int(m.group(1)) > 0 and any(k in name for k in GUARDED_KERNELS):
+            bad[name] = int(m.group(1))
+    return bad
 
 
 _lib = None

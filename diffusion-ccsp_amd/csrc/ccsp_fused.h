@@ -17,6 +17,12 @@
 // kernel, the summation order and every parity bar are untouched (tests/test_hip_parity.py::test_fused_eval_is_bitwise_identical).
 // What it costs: a tile streams both slots' weight halves (512 KB of planes) for at most 64 rows -- 2.25x the operand bytes of a
 // 128 x 128 row-GEMM tile per row -- through the CU's L2 port; what it saves: U, umax and one launch boundary.
+// Round 4, second form: the launch is PERSISTENT -- one 512-thread workgroup per compute unit (the LDS of a tile admits one) walks a
+// cost-sorted list of (tile, half) items with stride gridDim -- and software-pipelined across items: nothing else is resident on
+// the CU to cover a tile's dependent prologue (descriptor -> row indices -> pose-embedding planes: 7 k of the first form's 32 k
+// cycles per tile, phase trace in profiles/r04_findings.md), so the NEXT item's indices are requested under the decoder's K loop and
+// its embedding planes and first weight fragments under the decoder's epilogue; the decoder's own weight fragments (32 KB per wave) are
+// requested two 64-wide stages ahead through a ring of three register buffers (the first two are the then idle phase-1 ring).
 // Included inside the anonymous namespace of ccsp_hip.hip, after ccsp_f16x2.h.
 #pragma once
 
@@ -25,12 +31,14 @@ constexpr int FZ_ME = 128;                    // edges per tile (four 32-row MFM
 constexpr int FZ_D = 4;                       // k-steps of weight fragments in flight per wave (phase 1)
 constexpr int FZ_APL = 64 * H2_BK;            // fp16 elements per plane of one K chunk of the staged A rows
 constexpr int FZ_APL2 = FZ_ME * H2_BK;        // ... of one 32-wide sub-stage of the decoder's A operand
-constexpr int FZ_S1_LD = 132;
-constexpr int FZ_UT_BYTES = 64 * 256 * 4;
-constexpr int FZ_R2_BYTES = FZ_ME * FZ_S1_LD * 4;                  // 67 584 >= 65 536 (A planes of phase 1; the two A stages of phase 2)
-constexpr int FZ_LDS_BYTES = FZ_UT_BYTES + FZ_R2_BYTES + 8 * 128 * 4 + 64 * 4 + 64 * 4 + FZ_ME * 4;
+constexpr int FZ_W2_LD = 132;                 // row stride of the staged second-layer weight: four rows read by one b128 group hit different banks
+constexpr int FZ_UT_BYTES = 64 * 256 * 4;     // the U tile [64][256] fp32; after the decoder's K loop the S1 tile [128][128] (XOR-swizzled quads)
+constexpr int FZ_R2_BYTES = 64 * 256 * 2 * 2; // A planes of phase 1 [8 chunks][2 planes][64][32]; the two A stages of phase 2
+constexpr int FZ_LDS_BYTES = FZ_UT_BYTES + FZ_R2_BYTES + 8 * FZ_W2_LD * 4 + 8 * 4 + 64 * 4 + 64 * 4 + FZ_ME * 4;
 
 struct FusedArgs {
+    const int* order;                 // [n_items] work list: 2 tile + half, most expensive first
+    int n_items;
     const int4* tiles;                // {type, e0, ne, -}
     const int* rows;                  // [n_tiles][128]: [0..63] node (pose-embedding row) of LDS row i, [64..127] U row (row of base)
     const unsigned short* e_lu;       // [E_act] LDS rows of the edge's two operands: lu0 | lu1 << 8
@@ -94,26 +102,59 @@ __device__ __forceinline__ float fz_max16(float m) {
     return fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x140, 0xF, 0xF, true)));
 }
 
+// everything of one (tile, half) item that is read from the index tables: requested one item ahead
+struct FzItem {
+    int type, e0, ne, h;
+    int node;                         // pose-embedding row this lane fetches (A planes)
+    int ur[8];                        // U rows (rows of base) of the eight tile rows this wave fetches (wave-uniform)
+    unsigned int lu[2];               // tile rows of the two operands of the edges this thread builds: pass i (edges 32 i + tid / 16) in
+                                      // bits 16 (i & 1) .. + 15 of lu[i >> 1] as row 0 | row 1 << 8 (kept packed: the NEXT item's copy is live
+                                      // through the whole decoder loop)
+    int o_slot;                       // CSR slot of the output row this thread stores
+};
+
+__device__ __forceinline__ void fz_load_item(const FusedArgs& fa, int tid, int wave, int item, FzItem& it) {
+    const int lane = tid & 63;
+    const int w = fa.order[item];
+    const int tile = w >> 1;
+    const int4 td = fa.tiles[tile];
+    it.type = td.x; it.e0 = td.y; it.ne = td.z; it.h = w & 1;
+    const int* trow = fa.rows + (size_t)tile * 128;
+    it.node = trow[(wave & 3) * 16 + (lane >> 2)];
+    const int urow_l = trow[64 + 8 * wave + (lane & 7)];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) it.ur[j] = __builtin_amdgcn_readlane(urow_l, j);
+    const int br = tid >> 4;
+    it.lu[0] = 0u; it.lu[1] = 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int el = 32 * i + br;
+        el = el < it.ne ? el : it.ne - 1;
+        it.lu[i >> 1] |= (unsigned int)fa.e_lu[it.e0 + el] << (16 * (i & 1));
+    }
+    int row = tid >> 2;
+    row = row < it.ne ? row : it.ne - 1;
+    it.o_slot = fa.ent_pos[2 * (it.e0 + row) + it.h];
+}
+
+// S1 tile [128][128] fp32 in the U tile's LDS: the 16-byte quad q of row r lives at quad q ^ (r & 31) -- rows read one per lane
+// (second layer) and 32 consecutive columns of a row written per half-wave (accumulator layout) are both conflict-free
+__device__ __forceinline__ int fz_s1_off(int row, int col) { return row * 128 + ((((col >> 2) ^ (row & 31))) << 2) + (col & 3); }
+
 // decoder of the tile's edges (phase 2).  MPW: 32-row MFMA tiles per wave (1: tile wave >> 2 of <= 2; 2: tiles 2 (wave >> 2) + 0 / 1
-// of <= 4); every wave takes 32 of the 128 decoder columns.
+// of <= 4); every wave takes 32 of the 128 decoder columns.  The wave's weight fragments (8 per 64-wide stage) go through a ring of three
+// register buffers, two stages ahead: bq[0..7] / bq[8..15] hold stages 0 / 1, requested by the caller under the U epilogue (16 loads
+// that may still be in flight); stage 2 is requested here into b3, stage 3 into bq[0..7] once stage 0 has been multiplied.
 template <int MPW>
-__device__ __forceinline__ void fz_decode(const FusedArgs& fa, unsigned char* smem, int e0, int ne, int h, const int (&lu0)[4], const int (&lu1)[4],
-                                          const int (&aexp)[4], half8 (&bc)[8], int o_slot) {
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int nt = wave & 3, mh = wave >> 2;
+__device__ __forceinline__ void fz_decode_loop(int tid, int wave, const unsigned short* wd1f_wave, unsigned char* smem, int ne, const int (&lu0)[4],
+                                               const int (&lu1)[4], const int (&aexp)[4], half8 (&bq)[16], floatx16 (&acc)[2]) {
+    const int lane = tid & 63;
+    const int mh = wave >> 2;
     const int MT = (ne + 31) >> 5;
     const float* Ut = reinterpret_cast<const float*>(smem);
     unsigned short* stg = reinterpret_cast<unsigned short*>(smem + FZ_UT_BYTES);        // two stages of [sub 2][plane 2][128][32]
     constexpr int STAGE = 4 * FZ_APL2;
-    float* W2s = reinterpret_cast<float*>(smem + FZ_UT_BYTES + FZ_R2_BYTES);
-    const int* sE = reinterpret_cast<const int*>(smem + FZ_UT_BYTES + FZ_R2_BYTES + 8 * 128 * 4 + 64 * 4 + 64 * 4);
     const int br = tid >> 4, lq16 = tid & 15, sub = lq16 >> 3, lq = lq16 & 7;
-    const unsigned short* bptr = fa.Wd1F + (size_t)nt * 16 * 2 * 512 + lane * 8;
-    floatx16 acc[MPW];
-#pragma unroll
-    for (int i = 0; i < MPW; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
     // A rows of the 64-column stage cp, pass i (edges 32 i + br): SiLU + scale + split of four columns -> both planes
     auto build = [&](int cp, int i, const float4& ua, const float4& ub) {
         unsigned short* As = stg + (cp & 1) * STAGE + sub * 2 * FZ_APL2;
@@ -129,12 +170,7 @@ __device__ __forceinline__ void fz_decode(const FusedArgs& fa, unsigned char* sm
         ua = *reinterpret_cast<const float4*>(Ut + lu0[i] * 256 + cp * 64 + lq16 * 4);
         ub = *reinterpret_cast<const float4*>(Ut + lu1[i] * 256 + cp * 64 + lq16 * 4);
     };
-    auto ldB = [&](int cp, half8 (&b)[8]) {                       // the wave's decoder-weight fragments of stage cp: 8 KB contiguous
-        const unsigned short* p = bptr + (size_t)cp * 4 * 2 * 512;
-        fz_ld_frag<0>(b[0], p); fz_ld_frag<1024>(b[1], p); fz_ld_frag<2048>(b[2], p); fz_ld_frag<3072>(b[3], p);
-        fz_ld_frag<0>(b[4], p + 2048); fz_ld_frag<1024>(b[5], p + 2048); fz_ld_frag<2048>(b[6], p + 2048); fz_ld_frag<3072>(b[7], p + 2048);
-    };
-    auto mma = [&](int cp, int ks, const half8 (&b)[8]) {         // one k-step (16) of the stage: same product order as h2_kstep
+    auto mma = [&](int cp, int ks, const half8* b /*8 fragments of the stage: [k-step][plane]*/) {      // same product order as h2_kstep
         const unsigned short* As = stg + (cp & 1) * STAGE + (ks >> 1) * 2 * FZ_APL2;
         const int piece = (lane >> 5) + 2 * (ks & 1);
         half8 a[MPW][2];
@@ -151,77 +187,45 @@ __device__ __forceinline__ void fz_decode(const FusedArgs& fa, unsigned char* sm
             for (int i = 0; i < MPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][PA[q]], b[2 * ks + PB[q]], acc[i], 0, 0, 0);
     };
     const bool wave_has_tile = (MPW == 1 ? mh : 2 * mh) < MT;     // (wave-uniform)
+    half8 b3[8];
+    auto ldW = [&](int cp, half8* b) {                            // the wave's eight fragments of stage cp: 8 KB contiguous
+        const unsigned short* p = wd1f_wave + (size_t)cp * 4 * 2 * 512;
+        fz_ld_frag<0>(b[0], p); fz_ld_frag<1024>(b[1], p); fz_ld_frag<2048>(b[2], p); fz_ld_frag<3072>(b[3], p);
+        fz_ld_frag<0>(b[4], p + 2048); fz_ld_frag<1024>(b[5], p + 2048); fz_ld_frag<2048>(b[6], p + 2048); fz_ld_frag<3072>(b[7], p + 2048);
+    };
+    ldW(2, b3);
+    __builtin_amdgcn_sched_barrier(0);
     {   // stage 0
         float4 ua, ub;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (i < MT) { gather(0, i, ua, ub); build(0, i, ua, ub); }
     }
-    half8 bn[8];
-    __builtin_amdgcn_sched_barrier(0);
-    fz_wait8(bc);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // stage 0's fragments have landed (younger: stage 1's eight, the caller's index loads of the next item, stage 2's eight)
+    asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]), "+v"(bq[4]), "+v"(bq[5]), "+v"(bq[6]), "+v"(bq[7]) :: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     CCSP_TRK(0, 10);
 #pragma unroll
     for (int cp = 0; cp < 4; ++cp) {
-        half8 (&bcur)[8] = (cp & 1) ? bn : bc;
-        half8 (&bnxt)[8] = (cp & 1) ? bc : bn;
-        if (cp + 1 < 4) ldB(cp + 1, bnxt);
-        __builtin_amdgcn_sched_barrier(0);
+        half8* bw = cp == 1 ? bq + 8 : (cp == 2 ? b3 : bq);
+        if (cp == 1) { ldW(3, bq); __builtin_amdgcn_sched_barrier(0); }      // (stage 0's MFMAs have been issued: its buffer is refilled)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             float4 ua, ub;
             const bool bld = cp + 1 < 4 && ks < MT;               // pass ks of the next stage rides behind this k-step's MFMAs
             if (bld) gather(cp + 1, ks, ua, ub);
-            if (wave_has_tile) mma(cp, ks, bcur);
+            if (wave_has_tile) mma(cp, ks, bw);
             if (bld) build(cp + 1, ks, ua, ub);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (cp + 1 < 4) fz_wait8(bnxt);
+        // the next stage's fragments have landed; younger at this point: after stage 0 the eight of stage 2, after stage 1 the eight of stage 3
+        if (cp == 0) asm volatile("s_waitcnt vmcnt(8)" : "+v"(bq[8]), "+v"(bq[9]), "+v"(bq[10]), "+v"(bq[11]), "+v"(bq[12]), "+v"(bq[13]), "+v"(bq[14]), "+v"(bq[15]) :: "memory");
+        if (cp == 1) asm volatile("s_waitcnt vmcnt(8)" : "+v"(b3[0]), "+v"(b3[1]), "+v"(b3[2]), "+v"(b3[3]), "+v"(b3[4]), "+v"(b3[5]), "+v"(b3[6]), "+v"(b3[7]) :: "memory");
+        if (cp == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]), "+v"(bq[4]), "+v"(bq[5]), "+v"(bq[6]), "+v"(bq[7]) :: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-    }
-    CCSP_TRK(0, 14);
-    // epilogue: 2^-(e_row + e_w) acc + bias -> SiLU -> S1 (aliases the stages: every wave is past the last barrier)
-    float* S1 = reinterpret_cast<float*>(smem + FZ_UT_BYTES);
-    if (wave_has_tile) {
-        const int col = nt * 32 + (lane & 31);
-        const float bj = fa.bd1[col];
-#pragma unroll
-        for (int i = 0; i < MPW; ++i) {
-            const int mt = MPW == 1 ? mh : 2 * mh + i;
-            if (mt < MT) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    const float q = ldexpf(acc[i][r], -(sE[row] + fa.wd_exp)) + bj;
-                    S1[row * FZ_S1_LD + col] = silu_fast(q);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    CCSP_TRK(0, 15);
-    // second decoder layer: one (row, p) dot product per thread, the four chains and their sum as k_edge_h2<., ., 0> forms them
-    const int P = fa.P;
-    for (int idx = tid; idx < FZ_ME * P; idx += 512) {
-        const int row = idx & (FZ_ME - 1), p = idx >> 7;
-        if (row < ne) {
-            const float4* sr = reinterpret_cast<const float4*>(S1 + row * FZ_S1_LD);
-            const float4* wr = reinterpret_cast<const float4*>(W2s + p * 128);
-            float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;
-#pragma unroll 8
-            for (int j = 0; j < 32; ++j) {
-                const float4 sv = sr[j], wv = wr[j];
-                o0 = fmaf(sv.x, wv.x, o0); o1 = fmaf(sv.y, wv.y, o1); o2 = fmaf(sv.z, wv.z, o2); o3 = fmaf(sv.w, wv.w, o3);
-            }
-            const float o = ((o0 + o1) + (o2 + o3)) + fa.bd2[p];
-            const int slot = idx == tid ? o_slot : fa.ent_pos[2 * (e0 + row) + h];
-            fa.O[(size_t)slot * P + p] = o;
-        }
     }
 }
 
@@ -229,188 +233,248 @@ __global__ __launch_bounds__(512, 2) void k_eval_fused(FusedArgs fa) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[FZ_LDS_BYTES];
     using gptr = const __attribute__((address_space(1))) void*;
     using lptr = __attribute__((address_space(3))) void*;
-    float* Ut = reinterpret_cast<float*>(smem);                                           // [64][256] fp32
+    float* Ut = reinterpret_cast<float*>(smem);                                           // [64][256] fp32; S1 after the decoder's K loop
     unsigned short* As = reinterpret_cast<unsigned short*>(smem + FZ_UT_BYTES);           // phase 1: [8 chunks][2 planes][64][32]
-    float* W2s = reinterpret_cast<float*>(smem + FZ_UT_BYTES + FZ_R2_BYTES);              // [8][128]
-    int* sExpA = reinterpret_cast<int*>(W2s + 8 * 128);                                   // [64] exponents of the pose-embedding rows
+    float* W2s = reinterpret_cast<float*>(smem + FZ_UT_BYTES + FZ_R2_BYTES);              // [8][FZ_W2_LD]
+    float* sB2 = W2s + 8 * FZ_W2_LD;                                                      // [8] second-layer bias
+    int* sExpA = reinterpret_cast<int*>(sB2 + 8);                                         // [64] exponents of the pose-embedding rows
     float* sMax = reinterpret_cast<float*>(sExpA + 64);                                   // [64] max |U_h| per row
     int* sE = reinterpret_cast<int*>(sMax + 64);                                          // [128] exponents of the decoder's A rows
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile = bid >> 1, h = bid & 1;
-    const int4 td = fa.tiles[tile];
-    const int type = td.x, e0 = td.y, ne = td.z;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int s = wave >> 2, wq = wave & 3;                        // phase 1: slot (row half of the tile), 64 of the half's 256 columns
-    CCSP_TRK(0, 0);
+    const int tid0 = threadIdx.x;
+    const int P = fa.P;
     CCSP_TRK_RT(0, 30);
-    // --- the weight stream starts before anything else: its address needs the tile descriptor only
-    const unsigned short* bptr = fa.WpF + ((((size_t)(2 * type + s) * 2 + h) * 4 + wq) * 16) * 4 * 512 + lane * 8;
-    half8 bq[FZ_D][4];
-    auto ldB = [&](int ks, half8 (&b)[4]) {
-        const unsigned short* p = bptr + (size_t)ks * 4 * 512;
+    // --- once per launch: second-layer weight and biases
+    const float bj = fa.bd1[((tid0 >> 6) & 3) * 32 + (tid0 & 31)];
+    for (int i = tid0; i < 8 * 128; i += 512) W2s[(i >> 7) * FZ_W2_LD + (i & 127)] = i < P * 128 ? fa.Wd2[i < P * 128 ? i : 0] : 0.0f;
+    if (tid0 < 8) sB2[tid0] = tid0 < P ? fa.bd2[tid0 < P ? tid0 : 0] : 0.0f;
+    half8 bq[16];                                                  // phase 1: ring of FZ_D k-steps x 4 fragments; phase 2: the first half of the decoder weight
+    auto ldB = [&](int tid, const FzItem& it, int ks, half8* b) {
+        const int wave = tid >> 6, lane = tid & 63;
+        const unsigned short* p = fa.WpF + ((((size_t)(2 * it.type + (wave >> 2)) * 2 + it.h) * 4 + (wave & 3)) * 16 + ks) * 4 * 512 + lane * 8;
         fz_ld_frag<0>(b[0], p); fz_ld_frag<1024>(b[1], p); fz_ld_frag<2048>(b[2], p); fz_ld_frag<3072>(b[3], p);
     };
-#pragma unroll
-    for (int d = 0; d < FZ_D; ++d) ldB(d, bq[d]);
-    __builtin_amdgcn_sched_barrier(0);
-    // --- index loads (ordinary loads: the compiler's waits for them also cover the fragments above, which are older)
-    const int* trow = fa.rows + (size_t)tile * 128;
-    const int a_row = (wave & 3) * 16 + (lane >> 2);               // A row this lane fetches in every chunk (plane wave >> 2)
-    const int node = trow[a_row];
-    const int urow_l = trow[64 + 8 * wave + (lane & 7)];           // U rows of the eight base rows this wave fetches
-    int ur[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ur[j] = __builtin_amdgcn_readlane(urow_l, j);     // (consumed here: no compiler wait between the DMA groups below)
-    const int br = tid >> 4;
-    int lu0[4], lu1[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int el = 32 * i + br;
-        el = el < ne ? el : ne - 1;
-        const unsigned int v = fa.e_lu[e0 + el];
-        lu0[i] = (int)(v & 0xffu); lu1[i] = (int)(v >> 8);
-    }
-    int o_slot;
-    {
-        int row = tid & (FZ_ME - 1);
-        row = row < ne ? row : ne - 1;
-        o_slot = fa.ent_pos[2 * (e0 + row) + h];
-    }
-    const int P = fa.P;
-    if (tid * 4 < 8 * 128) {
-        const float4 w2v = *reinterpret_cast<const float4*>(fa.Wd2 + (tid * 4 < P * 128 ? tid * 4 : 0));
-        *reinterpret_cast<float4*>(W2s + tid * 4) = w2v;
-    }
-    CCSP_TRK(0, 1);
-    // --- A planes of the 64 rows (LDS-DMA, source-side swizzle as k_rowgemm_h2 MODE 2), the row exponents, base rows into the U tile
-    {
+    auto dmaA = [&](int tid, const FzItem& it) {                   // A planes of the 64 rows (LDS-DMA, source-side swizzle as k_rowgemm_h2 MODE 2)
+        const int wave = tid >> 6, lane = tid & 63;
+        const int a_row = (wave & 3) * 16 + (lane >> 2);
         const int plane = wave >> 2, rb = wave & 3;
         const int piece = (lane & 3) ^ ((a_row >> 2) & 3);
-        const unsigned short* ga = fa.A + (size_t)plane * fa.a_plane + (size_t)node * 256 + piece * 8;
+        const unsigned short* ga = fa.A + (size_t)plane * fa.a_plane + (size_t)it.node * 256 + piece * 8;
         const int lo = __builtin_amdgcn_readfirstlane(plane * FZ_APL + rb * 16 * H2_BK);
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < 8; ++c) __builtin_amdgcn_global_load_lds((gptr)(ga + c * H2_BK), (lptr)(As + c * 2 * FZ_APL + lo), 16, 0, 0);
-    }
-    int ea;
-    h2_ld4(ea, fa.a_exp + node);
-    float tv[2];
-    {
-        const float* tp = fa.tau_t + (size_t)type * 512 + h * 256 + wq * 64 + (lane & 31);
-        fz_ld_f32(tv[0], tp);
-        fz_ld_f32(tv[1], tp + 32);
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int lo = __builtin_amdgcn_readfirstlane((8 * wave + j) * 256);
-        __builtin_amdgcn_global_load_lds((gptr)(fa.base + (size_t)ur[j] * 512 + h * 256 + lane * 4), (lptr)(Ut + lo), 16, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // the A planes have landed (younger: exponent 1, tau 2, base 8); W2s is written; every wave's share is visible after the barrier
-    asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    CCSP_TRK(0, 2);
-    // --- phase 1: 32 rows (slot s) x 64 columns per wave, K = 256 in 16 k-steps; no barrier inside
-    floatx16 acc[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
-    half8 af[2][2];                                                // [k-step parity][plane]: the A fragments of k-step ks + 1 are read under the MFMAs of ks
-    auto ldA = [&](int ks, half8 (&a)[2]) {
-        const unsigned short* Ac = As + (ks >> 1) * 2 * FZ_APL;
-        const int piece = (lane >> 5) + 2 * (ks & 1);
-        a[1] = *reinterpret_cast<const half8*>(Ac + FZ_APL + h2_off(s * 32 + (lane & 31), piece));
-        a[0] = *reinterpret_cast<const half8*>(Ac + h2_off(s * 32 + (lane & 31), piece));
     };
-    ldA(0, af[0]);
+    FzItem cur, nxt;
+    int item = blockIdx.x;
+    fz_load_item(fa, tid0, tid0 >> 6, item, cur);
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-        half8 (&b)[4] = bq[ks % FZ_D];
-        __builtin_amdgcn_sched_barrier(0);
-        // younger than the fragments of k-step ks: those of ks + 1 .. min(ks + D - 1, 15) (the refill of this slot is issued below)
-        fz_wait4(4 * ((ks + FZ_D - 1 < 15 ? ks + FZ_D - 1 : 15) - ks), b);
-        if (ks + 1 < 16) ldA(ks + 1, af[(ks + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
-        const half8 a0 = af[ks & 1][0], a1 = af[ks & 1][1];
-        // smallest terms first (h2_kstep): (a lo, b hi), (a hi, b lo), (a hi, b hi); b[2 j + plane]
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[0], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[2], acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[1], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[3], acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[0], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[2], acc[1], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);                         // (the MFMAs have read the slot: it can be refilled)
-        if (ks + FZ_D < 16) ldB(ks + FZ_D, b);
-        if ((ks & 3) == 3) CCSP_TRK(0, 3 + (ks >> 2));
-    }
+    for (int d = 0; d < FZ_D; ++d) ldB(tid0, cur, d, bq + 4 * d);
+    dmaA(tid0, cur);
     __builtin_amdgcn_sched_barrier(0);
-    // --- the decoder's first weight fragments are requested now; exponents, tau and every base row of this wave have landed
-    half8 bc[8];
-    {
-        const unsigned short* p = fa.Wd1F + (size_t)(wave & 3) * 16 * 2 * 512 + lane * 8;
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ea), "+v"(tv[0]), "+v"(tv[1]) :: "memory");
-        fz_ld_frag<0>(bc[0], p); fz_ld_frag<1024>(bc[1], p); fz_ld_frag<2048>(bc[2], p); fz_ld_frag<3072>(bc[3], p);
-        fz_ld_frag<0>(bc[4], p + 2048); fz_ld_frag<1024>(bc[5], p + 2048); fz_ld_frag<2048>(bc[6], p + 2048); fz_ld_frag<3072>(bc[7], p + 2048);
-    }
-    if (wave < 4 && (lane & 3) == 0) sExpA[a_row] = ea;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                  // every wave's base rows are in the U tile; the row exponents are visible
-    __builtin_amdgcn_sched_barrier(0);
-    CCSP_TRK(0, 7);
-    // --- U_h = 2^-(e_row + e_w) acc + (base + tau), in place (accumulator layout: 32 consecutive columns of one row per half-wave)
-    {
-        if (s != 0) { tv[0] = 0.0f; tv[1] = 0.0f; }               // (the time term rides on slot-0 rows; slot-1 rows add +0 like k_rowgemm_h2)
-        int ex[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int4 e4 = *reinterpret_cast<const int4*>(sExpA + s * 32 + 8 * q + 4 * (lane >> 5));
-            ex[4 * q] = -(e4.x + fa.w_exp); ex[4 * q + 1] = -(e4.y + fa.w_exp); ex[4 * q + 2] = -(e4.z + fa.w_exp); ex[4 * q + 3] = -(e4.w + fa.w_exp);
+    for (;;) {
+        // (the thread index is laundered once per item: everything derived from it -- dozens of per-lane LDS and global offsets -- would
+        // otherwise be hoisted out of this loop and spilled: 210 scratch registers in the first persistent build)
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int s = wave >> 2, wq = wave & 3;                    // phase 1: slot (row half of the tile), 64 of the half's 256 columns
+        const int nt = wave & 3, mh = wave >> 2;                   // phase 2: 32 of the 128 decoder columns, row half
+        const int a_row = (wave & 3) * 16 + (lane >> 2);           // A row this lane fetches in every chunk (plane wave >> 2)
+        const unsigned short* wd1f_wave = fa.Wd1F + (size_t)nt * 16 * 2 * 512 + lane * 8;      // this wave's 32 decoder columns
+        // the item's A planes and first fragments have landed, the previous item's stores are acknowledged (a store among counted
+        // loads would break the counting: loads and stores return out of order), every wave is done with the previous S1 tile
+        CCSP_TRK(0, 0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        CCSP_TRK(0, 2);
+        int ea;
+        h2_ld4(ea, fa.a_exp + cur.node);
+        float tv[2];
+        {
+            const float* tp = fa.tau_t + (size_t)cur.type * 512 + cur.h * 256 + wq * 64 + (lane & 31);
+            fz_ld_f32(tv[0], tp);
+            fz_ld_f32(tv[1], tp + 32);
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float* up = Ut + (s * 32 + 4 * (lane >> 5)) * 256 + wq * 64 + j * 32 + (lane & 31);
-            float bv[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) bv[r] = up[((r & 3) + 8 * (r >> 2)) * 256];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) up[((r & 3) + 8 * (r >> 2)) * 256] = ldexpf(acc[j][r], ex[r]) + (bv[r] + tv[j]);
+        for (int j = 0; j < 8; ++j) {
+            const int lo = __builtin_amdgcn_readfirstlane((8 * wave + j) * 256);
+            __builtin_amdgcn_global_load_lds((gptr)(fa.base + (size_t)cur.ur[j] * 512 + cur.h * 256 + lane * 4), (lptr)(Ut + lo), 16, 0, 0);
         }
-    }
-    __syncthreads();
-    CCSP_TRK(0, 8);
-    // --- row maxima of U_h (the bound behind the decoder rows' exponents): 16 lanes per row, four 16-byte reads each
-    {
-        const int c16 = tid & 15;
+        __builtin_amdgcn_sched_barrier(0);
+        // --- phase 1: 32 rows (slot s) x 64 columns per wave, K = 256 in 16 k-steps; no barrier inside
+        floatx16 acc[2];
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            const int row = 32 * pass + br;
-            float m = 0.0f;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float4 v = *reinterpret_cast<const float4*>(Ut + row * 256 + k * 64 + c16 * 4);
-                m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+        half8 af[2][2];                                            // [k-step parity][plane]: the A fragments of k-step ks + 1 are read under the MFMAs of ks
+        auto ldA = [&](int ks, half8 (&a)[2]) {
+            const unsigned short* Ac = As + (ks >> 1) * 2 * FZ_APL;
+            const int piece = (lane >> 5) + 2 * (ks & 1);
+            a[1] = *reinterpret_cast<const half8*>(Ac + FZ_APL + h2_off(s * 32 + (lane & 31), piece));
+            a[0] = *reinterpret_cast<const half8*>(Ac + h2_off(s * 32 + (lane & 31), piece));
+        };
+        ldA(0, af[0]);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            half8* b = bq + 4 * (ks % FZ_D);
+            __builtin_amdgcn_sched_barrier(0);
+            // younger than the fragments of k-step ks: those of ks + 1 .. min(ks + D - 1, 15) (the refill of this slot is issued below);
+            // the exponent, tau and base requests above are OLDER than every fragment requested inside the loop
+            {
+                const int n = 4 * ((ks + FZ_D - 1 < 15 ? ks + FZ_D - 1 : 15) - ks);
+#define FZ_W(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) :: "memory")
+                if (n >= 12) FZ_W(12); else if (n >= 8) FZ_W(8); else if (n >= 4) FZ_W(4); else FZ_W(0);
+#undef FZ_W
             }
-            m = fz_max16(m);
-            if (c16 == 0) sMax[row] = m;
+            if (ks + 1 < 16) ldA(ks + 1, af[(ks + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const half8 a0 = af[ks & 1][0], a1 = af[ks & 1][1];
+            // smallest terms first (h2_kstep): (a lo, b hi), (a hi, b lo), (a hi, b hi); b[2 j + plane]
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[2], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[1], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[3], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[2], acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);                     // (the MFMAs have read the slot: it can be refilled)
+            if (ks + FZ_D < 16) ldB(tid, cur, ks + FZ_D, b);
+            if ((ks & 3) == 3) CCSP_TRK(0, 3 + (ks >> 2));
         }
-    }
-    __syncthreads();
-    CCSP_TRK(0, 9);
-    int aexp[4];
+        __builtin_amdgcn_sched_barrier(0);
+        // --- exponents, tau and every base row of this wave have landed; the first half of the decoder weight is requested into the ring
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ea), "+v"(tv[0]), "+v"(tv[1]) :: "memory");
+        {
+            const unsigned short* p = wd1f_wave;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        // |SiLU(z)| <= |z| <= max|U_h[u0]| + max|U_h[u1]|   (k_edge_h2 forms the same sum from umax)
-        aexp[i] = h2_scale_exp(sMax[lu0[i]] + sMax[lu1[i]]);
-        if ((tid & 15) == 0) sE[32 * i + br] = aexp[i];
+            for (int g = 0; g < 4; ++g) {
+                fz_ld_frag<0>(bq[4 * g], p + g * 2048); fz_ld_frag<1024>(bq[4 * g + 1], p + g * 2048);
+                fz_ld_frag<2048>(bq[4 * g + 2], p + g * 2048); fz_ld_frag<3072>(bq[4 * g + 3], p + g * 2048);
+            }
+        }
+        if (wave < 4 && (lane & 3) == 0) sExpA[a_row] = ea;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                              // every wave's base rows are in the U tile; the row exponents are visible
+        __builtin_amdgcn_sched_barrier(0);
+        CCSP_TRK(0, 7);
+        // --- U_h = 2^-(e_row + e_w) acc + (base + tau), in place (accumulator layout: 32 consecutive columns of one row per half-wave)
+        {
+            if (s != 0) { tv[0] = 0.0f; tv[1] = 0.0f; }           // (the time term rides on slot-0 rows; slot-1 rows add +0 like k_rowgemm_h2)
+            int ex[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int4 e4 = *reinterpret_cast<const int4*>(sExpA + s * 32 + 8 * q + 4 * (lane >> 5));
+                ex[4 * q] = -(e4.x + fa.w_exp); ex[4 * q + 1] = -(e4.y + fa.w_exp); ex[4 * q + 2] = -(e4.z + fa.w_exp); ex[4 * q + 3] = -(e4.w + fa.w_exp);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float* up = Ut + (s * 32 + 4 * (lane >> 5)) * 256 + wq * 64 + j * 32 + (lane & 31);
+                float bv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bv[r] = up[((r & 3) + 8 * (r >> 2)) * 256];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) up[((r & 3) + 8 * (r >> 2)) * 256] = ldexpf(acc[j][r], ex[r]) + (bv[r] + tv[j]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        CCSP_TRK(0, 8);
+        // --- row maxima of U_h (the bound behind the decoder rows' exponents): 16 lanes per row, four 16-byte reads each
+        {
+            const int c16 = tid & 15, br = tid >> 4;
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const int row = 32 * pass + br;
+                float m = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float4 v = *reinterpret_cast<const float4*>(Ut + row * 256 + k * 64 + c16 * 4);
+                    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                }
+                m = fz_max16(m);
+                if (c16 == 0) sMax[row] = m;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        CCSP_TRK(0, 9);
+        int aexp[4], lu0[4], lu1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            lu0[i] = (int)((cur.lu[i >> 1] >> (16 * (i & 1))) & 0xffu);
+            lu1[i] = (int)((cur.lu[i >> 1] >> (16 * (i & 1) + 8)) & 0xffu);
+            // |SiLU(z)| <= |z| <= max|U_h[u0]| + max|U_h[u1]|   (k_edge_h2 forms the same sum from umax)
+            aexp[i] = h2_scale_exp(sMax[lu0[i]] + sMax[lu1[i]]);
+            if ((tid & 15) == 0) sE[32 * i + (tid >> 4)] = aexp[i];
+        }
+        // --- the next item's indices are requested now and used after the decoder's K loop
+        const bool more = item + (int)gridDim.x < fa.n_items;      // (uniform)
+        if (more) fz_load_item(fa, tid, wave, item + gridDim.x, nxt);
+        // --- phase 2: decoder layer 1 over the tile's edges
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+        const int ne = cur.ne, MT = (ne + 31) >> 5;
+        if (ne > 64) fz_decode_loop<2>(tid, wave, wd1f_wave, smem, ne, lu0, lu1, aexp, bq, acc);
+        else fz_decode_loop<1>(tid, wave, wd1f_wave, smem, ne, lu0, lu1, aexp, bq, acc);
+        CCSP_TRK(0, 14);
+        // --- every wave is past the last stage barrier: the stages (A region) and the U tile are free.  The next item's first weight
+        //     fragments and its A planes are requested under this item's epilogue
+        if (more) {
+#pragma unroll
+            for (int d = 0; d < FZ_D; ++d) ldB(tid, nxt, d, bq + 4 * d);
+            dmaA(tid, nxt);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // epilogue: 2^-(e_row + e_w) acc + bias -> SiLU -> S1 (in the U tile's LDS, swizzled)
+        float* S1 = Ut;
+        {
+            const int MPW = ne > 64 ? 2 : 1;
+            const int col = nt * 32 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int mt = MPW == 1 ? mh : 2 * mh + i;
+                if (i < MPW && mt < MT) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        const float q = ldexpf(acc[i][r], -(sE[row] + fa.wd_exp)) + bj;
+                        S1[fz_s1_off(row, col)] = silu_fast(q);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        CCSP_TRK(0, 15);
+        // second decoder layer: one (row, p) dot product per thread (four lanes per row), the four chains and their sum as
+        // k_edge_h2<., ., 0> forms them
+        for (int pass = 0; pass < (P > 4 ? 2 : 1); ++pass) {
+            const int row = pass == 0 ? tid >> 2 : tid & 127, p = pass == 0 ? tid & 3 : 4 + (tid >> 7);
+            if (row < ne && p < P) {
+                const float* sr = S1 + row * 128;
+                const float4* wr = reinterpret_cast<const float4*>(W2s + p * FZ_W2_LD);
+                const int sw = row & 31;
+                float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;
+#pragma unroll 8
+                for (int j = 0; j < 32; ++j) {
+                    const float4 sv = *reinterpret_cast<const float4*>(sr + ((j ^ sw) << 2)), wv = wr[j];
+                    o0 = fmaf(sv.x, wv.x, o0); o1 = fmaf(sv.y, wv.y, o1); o2 = fmaf(sv.z, wv.z, o2); o3 = fmaf(sv.w, wv.w, o3);
+                }
+                const float o = ((o0 + o1) + (o2 + o3)) + sB2[p];
+                const int slot = pass == 0 ? cur.o_slot : fa.ent_pos[2 * (cur.e0 + row) + cur.h];
+                fa.O[(size_t)slot * P + p] = o;
+            }
+        }
+        CCSP_TRK(0, 16);
+        if (!more) break;
+        item += gridDim.x;
+        cur = nxt;
     }
-    // --- phase 2
-    if (ne > 64) fz_decode<2>(fa, smem, e0, ne, h, lu0, lu1, aexp, bc, o_slot);
-    else fz_decode<1>(fa, smem, e0, ne, h, lu0, lu1, aexp, bc, o_slot);
 #ifdef CCSP_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-    CCSP_TRK(0, 16);
     CCSP_TRK_RT(0, 31);
 }

@@ -1442,6 +1442,8 @@ struct ccsp_graph {
     int4* ft_tiles = nullptr;
     int* ft_rows = nullptr;
     unsigned short* ft_elu = nullptr;
+    int* ft_order = nullptr;                  // work list of the persistent launch: 2 tile + half, most expensive first
+    std::vector<int> h_forder;
     int n_ftiles = 0;
     ccsp::FusedPlan fplan;                    // kept alive for the async upload
     int4 *td64 = nullptr, *td128 = nullptr;   // the same tile lists as {row0, nrows, 2 type + slot, 0} records (k_rowgemm_h2: one scalar load per tile)
@@ -1697,12 +1699,13 @@ int launch_eval(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s, bool tabled 
         if (m->f16x2 && m->eval_fused && !tabled && g->n_ftiles > 0 && fused == nullptr) {
             prof_mark(g, s, CCSP_K_EVAL_FUSED);
             FusedArgs fa;
+            fa.order = g->ft_order; fa.n_items = 2 * g->n_ftiles;
             fa.tiles = g->ft_tiles; fa.rows = g->ft_rows; fa.e_lu = g->ft_elu; fa.ent_pos = g->ent_pos;
             fa.A = g->pembH; fa.a_plane = (size_t)g->N * H; fa.a_exp = g->pexp;
             fa.WpF = m->WpF; fa.w_exp = m->wp_exp; fa.base = g->base; fa.tau_t = tau_t;
             fa.Wd1F = m->Wd1F; fa.wd_exp = m->wd_exp; fa.bd1 = m->pd0_b; fa.Wd2 = m->pd2_w; fa.bd2 = m->pd2_b;
             fa.O = g->O; fa.P = m->d.pose_dim;
-            hipLaunchKernelGGL(k_eval_fused, dim3(2 * g->n_ftiles), dim3(512), 0, s, fa);
+            hipLaunchKernelGGL(k_eval_fused, dim3(fa.n_items < m->ncu ? fa.n_items : m->ncu), dim3(512), 0, s, fa);
             if (did_fuse) *did_fuse = false;
             prof_mark(g, s, -1);
             g->evals++;
@@ -2476,6 +2479,15 @@ int graph_build(ccsp_model* m, int N, int E, int F, const float* x, const signed
         g->ft_tiles = reinterpret_cast<int4*>(ft);
         TRY(dev_upload(reg, &g->ft_rows, g->fplan.rows, s));
         TRY(dev_upload(reg, &g->ft_elu, g->fplan.e_lu, s));
+        {   // items by decreasing cost (matrix-pipe time: the row GEMM of a tile is constant, the decoder grows with the 32-edge blocks);
+            // a stable sort keeps a type's tiles together (they stream the same weights through the XCDs' L2s)
+            std::vector<int> key(g->n_ftiles);
+            for (int i = 0; i < g->n_ftiles; ++i) key[i] = (g->fplan.tiles[4 * i + 2] + 31) / 32;
+            g->h_forder.resize((size_t)2 * g->n_ftiles);
+            for (int i = 0; i < 2 * g->n_ftiles; ++i) g->h_forder[i] = i;
+            std::stable_sort(g->h_forder.begin(), g->h_forder.end(), [&](int a, int b) { return key[a >> 1] > key[b >> 1]; });
+            TRY(dev_upload(reg, &g->ft_order, g->h_forder, s));
+        }
     }
     TRY(dev_alloc(reg, &g->base, (size_t)p.R * 2 * H));
     TRY(dev_alloc(reg, &g->U, (size_t)p.R * 2 * H));
