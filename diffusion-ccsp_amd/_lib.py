@@ -150,7 +150,7 @@ def lib():
     L.ccsp_compose_energy_grad.argtypes = [vp, vp, vp, vp, C.POINTER(Compose), vp, i32, vp, vp, vp]
     L.ccsp_compose_chain_run.argtypes = [vp, vp, vp, vp, C.POINTER(Compose), i32, C.POINTER(Noise), vp, i32, i32, i32, vp, vp]
     L.ccsp_plan_host.argtypes = [i32, i32, i32] + [vp] * 14
-    L.ccsp_plan_fused_host.argtypes = [i32, i32, i32] + [vp] * 6
+    L.ccsp_plan_fused_host.argtypes = [i32, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp]
     _lib = L
     return L
 
@@ -191,7 +191,7 @@ def plan_host(n_nodes, n_types, edge_index, edge_attr):
     return out
 
 
-def plan_fused_host(n_nodes, n_types, edge_index, edge_attr):
+def plan_fused_host(n_nodes, n_types, edge_index, edge_attr, rows_per_slot=28, max_edges=112):
     """host-only fused tiles of the one-launch evaluation kernel (include/ccsp.h ccsp_plan_fused_host); numpy in, dict out"""
     import numpy as np
     L = lib()
@@ -202,7 +202,7 @@ def plan_fused_host(n_nodes, n_types, edge_index, edge_attr):
     tiles = np.zeros((max(E, 1), 4), dtype=np.int32)
     rows = np.zeros((max(E, 1), 128), dtype=np.int32)
     e_lu = np.zeros(max(E, 1), dtype=np.uint16)
-    check(L.ccsp_plan_fused_host(n_nodes, E, n_types, ei.ctypes.data, ea.ctypes.data, C.byref(n), tiles.ctypes.data,
+    check(L.ccsp_plan_fused_host(n_nodes, E, n_types, ei.ctypes.data, ea.ctypes.data, rows_per_slot, max_edges, C.byref(n), tiles.ctypes.data,
                                  rows.ctypes.data, e_lu.ctypes.data))
     nt = n.value
     e_act = int(tiles[:nt, 2].sum())

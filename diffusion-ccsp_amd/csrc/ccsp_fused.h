@@ -478,3 +478,356 @@ __global__ __launch_bounds__(512, 2) void k_eval_fused(FusedArgs fa) {
 #endif
     CCSP_TRK_RT(0, 31);
 }
+
+// ------------------------------------------------------------------------------------------
+// k_eval_fused4 -- third form (the default of CCSP_EVAL=fused): TWO 256-thread workgroups per compute unit.
+// What the first two forms measured (profiles/r04_findings.md): a tile's time is the SUM of a phase bound by the CU's L2 port (the
+// weight stream of the row GEMM: 512 KB per tile, 42-53 B/clk/CU against 64 peak, matrix pipe half idle) and of phases that move
+// nothing through that port (U epilogue, row maxima, the decoder's SiLU / split on the VALU, its MFMAs, the second layer) -- and one
+// workgroup per CU runs them one after the other.  With two independent workgroups on a CU the hardware overlaps one tile's weight
+// stream with the other tile's decoder.  That needs a tile in <= 80 KB of LDS and 4 waves per workgroup (<= 256 VGPRs at two waves per
+// SIMD): 28 U rows per slot (56 KB U tile; the pose-embedding planes of phase 1 use the same bytes plus the decoder's 16 KB stage,
+// the S1 tile of the epilogue the same bytes again), <= 112 edges, decoder K chunks of 32 through ONE stage whose next contents are
+// built in registers under the current chunk's MFMAs.  Phase 1: wave = (slot, column half), 32 x 128 per wave, fragments from the
+// same k_pack_wp_frag layout (two 4 KB runs per k-step), three k-steps ahead.  Same operands, exponents, MFMA order and epilogue
+// arithmetic as the other forms: bitwise the edge outputs of the two-launch path.
+// ------------------------------------------------------------------------------------------
+constexpr int F4_RS = 28;                     // U rows per slot of a tile (A rows are padded to the 32-row MFMA tile)
+constexpr int F4_ME = 112;                    // edges per tile
+constexpr int F4_D = 3;                       // k-steps of weight fragments in flight per wave (phase 1): 3 x 8 KB
+constexpr int F4_UT_BYTES = 2 * F4_RS * 256 * 4;                   // 57 344: U tile [56][256]; S1 tile [112][128] (swizzled quads)
+constexpr int F4_STG_BYTES = 2 * 128 * H2_BK * 2;                  // 16 384: the decoder's A stage [2 planes][128][32]
+constexpr int F4_LDS_BYTES = F4_UT_BYTES + F4_STG_BYTES + 8 * FZ_W2_LD * 4 + 8 * 4 + 64 * 4 + 64 * 4 + 128 * 4;
+static_assert(F4_UT_BYTES + F4_STG_BYTES >= 8 * 2 * FZ_APL * 2, "the pose-embedding planes of phase 1 span the U tile and the stage");
+static_assert(F4_LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+
+template <int N>
+__device__ __forceinline__ void f4_wait8(half8* b) {
+    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void f4_wait4(half8* b) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
+}
+
+__global__ __launch_bounds__(256, 2) void k_eval_fused4(FusedArgs fa) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[F4_LDS_BYTES];
+    using gptr = const __attribute__((address_space(1))) void*;
+    using lptr = __attribute__((address_space(3))) void*;
+    float* Ut = reinterpret_cast<float*>(smem);                                           // [56][256] fp32; S1 after the decoder's K loop
+    unsigned short* As = reinterpret_cast<unsigned short*>(smem);                         // phase 1: [8 chunks][2 planes][64][32] (over Ut and the stage)
+    unsigned short* stg = reinterpret_cast<unsigned short*>(smem + F4_UT_BYTES);          // phase 2: [2 planes][128][32]
+    float* W2s = reinterpret_cast<float*>(smem + F4_UT_BYTES + F4_STG_BYTES);             // [8][FZ_W2_LD]
+    float* sB2 = W2s + 8 * FZ_W2_LD;
+    int* sExpA = reinterpret_cast<int*>(sB2 + 8);                                         // [64] exponents of the pose-embedding rows (A row order)
+    float* sMax = reinterpret_cast<float*>(sExpA + 64);                                   // [64] max |U_h| per tile row
+    int* sE = reinterpret_cast<int*>(sMax + 64);                                          // [128] exponents of the decoder's A rows
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int s = wave >> 1, ch = wave & 1;                        // phase 1: slot, column half (128 of the half's 256 columns)
+    const int P = fa.P;
+    CCSP_TRK(0, 0);
+    CCSP_TRK_RT(0, 30);
+    const int w = fa.order[blockIdx.x];
+    const int tile = w >> 1, h = w & 1;
+    const int4 td = fa.tiles[tile];
+    const int type = td.x, e0 = td.y, ne = td.z;
+    const int MT = (ne + 31) >> 5;
+    // --- the weight stream starts first: two runs of four fragments per k-step (column groups 2 ch and 2 ch + 1 of k_pack_wp_frag)
+    const unsigned short* bptr = fa.WpF + ((((size_t)(2 * type + s) * 2 + h) * 4 + 2 * ch) * 16) * 4 * 512 + lane * 8;
+    half8 bq[F4_D * 8];
+    auto ldB = [&](int ks, half8* b) {
+        const unsigned short* p0 = bptr + (size_t)ks * 4 * 512;
+        const unsigned short* p1 = p0 + (size_t)16 * 4 * 512;
+        fz_ld_frag<0>(b[0], p0); fz_ld_frag<1024>(b[1], p0); fz_ld_frag<2048>(b[2], p0); fz_ld_frag<3072>(b[3], p0);
+        fz_ld_frag<0>(b[4], p1); fz_ld_frag<1024>(b[5], p1); fz_ld_frag<2048>(b[6], p1); fz_ld_frag<3072>(b[7], p1);
+    };
+#pragma unroll
+    for (int d = 0; d < F4_D; ++d) ldB(d, bq + 8 * d);
+    __builtin_amdgcn_sched_barrier(0);
+    // --- index loads (ordinary loads; the compiler's waits for them also cover the fragments above, which are older)
+    const int* trow = fa.rows + (size_t)tile * 128;
+    const int a_row0 = (2 * (wave & 1)) * 16 + (lane >> 2);        // A rows this lane fetches in every chunk: a_row0, a_row0 + 16 (plane wave >> 1)
+    const int node0 = trow[a_row0], node1 = trow[a_row0 + 16];
+    const int urow_l = trow[64 + 14 * wave + (lane < 14 ? lane : 13)];       // U rows of the fourteen tile rows whose base this wave fetches
+    int ur[14];
+#pragma unroll
+    for (int j = 0; j < 14; ++j) ur[j] = __builtin_amdgcn_readlane(urow_l, j);
+    const int br = tid >> 3, lq = tid & 7;                         // decoder A producer: edges 32 i + br, fp32 columns 4 lq .. + 3 of the chunk
+    int lu0[4], lu1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int el = 32 * i + br;
+        el = el < ne ? el : ne - 1;
+        const unsigned int v = fa.e_lu[e0 + el];
+        lu0[i] = (int)(v & 0xffu); lu1[i] = (int)(v >> 8);
+    }
+    int o_slot[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int row = 64 * i + (tid >> 2);
+        row = row < ne ? row : ne - 1;
+        o_slot[i] = fa.ent_pos[2 * (e0 + row) + h];
+    }
+    const float bj = fa.bd1[wave * 32 + (lane & 31)];
+    for (int i = tid; i < 8 * 128; i += 256) W2s[(i >> 7) * FZ_W2_LD + (i & 127)] = i < P * 128 ? fa.Wd2[i < P * 128 ? i : 0] : 0.0f;
+    if (tid < 8) sB2[tid] = tid < P ? fa.bd2[tid < P ? tid : 0] : 0.0f;
+    CCSP_TRK(0, 1);
+    // --- A planes of the 64 rows (LDS-DMA, source-side swizzle as k_rowgemm_h2 MODE 2): wave = (plane, two 16-row blocks)
+    {
+        const int plane = wave >> 1;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int row = a_row0 + 16 * q;
+            const int piece = (lane & 3) ^ ((row >> 2) & 3);
+            const unsigned short* ga = fa.A + (size_t)plane * fa.a_plane + (size_t)(q ? node1 : node0) * 256 + piece * 8;
+            const int lo = __builtin_amdgcn_readfirstlane(plane * FZ_APL + (2 * (wave & 1) + q) * 16 * H2_BK);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) __builtin_amdgcn_global_load_lds((gptr)(ga + c * H2_BK), (lptr)(As + c * 2 * FZ_APL + lo), 16, 0, 0);
+        }
+    }
+    int ea0, ea1;
+    h2_ld4(ea0, fa.a_exp + node0);
+    h2_ld4(ea1, fa.a_exp + node1);
+    float tv[4];
+    {
+        const float* tp = fa.tau_t + (size_t)type * 512 + h * 256 + ch * 128 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fz_ld_f32(tv[j], tp + 32 * j);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // the A planes have landed (younger: exponents 2, tau 4); W2s / sB2 are written; every wave's share is visible after the barrier
+    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    CCSP_TRK(0, 2);
+    // --- phase 1: 32 rows (slot s) x 128 columns per wave, K = 256 in 16 k-steps; no barrier inside
+    floatx16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    {
+        half8 af[2][2];                                            // [k-step parity][plane]
+        auto ldA = [&](int ks, half8 (&a)[2]) {
+            const unsigned short* Ac = As + (ks >> 1) * 2 * FZ_APL;
+            const int piece = (lane >> 5) + 2 * (ks & 1);
+            a[1] = *reinterpret_cast<const half8*>(Ac + FZ_APL + h2_off(s * 32 + (lane & 31), piece));
+            a[0] = *reinterpret_cast<const half8*>(Ac + h2_off(s * 32 + (lane & 31), piece));
+        };
+        ldA(0, af[0]);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            half8* b = bq + 8 * (ks % F4_D);
+            __builtin_amdgcn_sched_barrier(0);
+            // younger than the fragments of k-step ks: those of ks + 1 .. min(ks + D - 1, 15); the exponent / tau requests are older than
+            // every fragment requested inside the loop
+            {
+                const int n = 8 * ((ks + F4_D - 1 < 15 ? ks + F4_D - 1 : 15) - ks);
+                if (n >= 16) f4_wait8<16>(b); else if (n >= 8) f4_wait8<8>(b); else f4_wait8<0>(b);
+            }
+            if (ks + 1 < 16) ldA(ks + 1, af[(ks + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const half8 a0 = af[ks & 1][0], a1 = af[ks & 1][1];
+            // smallest terms first (h2_kstep): (a lo, b hi), (a hi, b lo), (a hi, b hi); b[4 (j >> 1) + 2 (j & 1) + plane]
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[4 * (j >> 1) + 2 * (j & 1)], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[4 * (j >> 1) + 2 * (j & 1) + 1], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[4 * (j >> 1) + 2 * (j & 1)], acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);                     // (the MFMAs have read the slot: it can be refilled)
+            if (ks + F4_D < 16) ldB(ks + F4_D, b);
+            if ((ks & 3) == 3) CCSP_TRK(0, 3 + (ks >> 2));
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ea0), "+v"(ea1), "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]) :: "memory");
+    if ((wave >> 1) == 0 && (lane & 3) == 0) { sExpA[a_row0] = ea0; sExpA[a_row0 + 16] = ea1; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                  // every wave is done reading the A planes: the U tile's bytes are free
+    __builtin_amdgcn_sched_barrier(0);
+    // --- base rows into the U tile (LDS-DMA), the decoder's first weight fragments behind them
+    const unsigned short* wd1f_wave = fa.Wd1F + (size_t)wave * 16 * 2 * 512 + lane * 8;      // this wave's 32 decoder columns
+    half8 bw[12];                                                  // ring of three K chunks x 4 fragments ([k-step][plane])
+    auto ldW = [&](int c, half8* b) {
+        const unsigned short* p = wd1f_wave + (size_t)c * 2 * 2 * 512;
+        fz_ld_frag<0>(b[0], p); fz_ld_frag<1024>(b[1], p); fz_ld_frag<2048>(b[2], p); fz_ld_frag<3072>(b[3], p);
+    };
+#pragma unroll
+    for (int j = 0; j < 14; ++j) {
+        const int lo = __builtin_amdgcn_readfirstlane((14 * wave + j) * 256);
+        __builtin_amdgcn_global_load_lds((gptr)(fa.base + (size_t)ur[j] * 512 + h * 256 + lane * 4), (lptr)(Ut + lo), 16, 0, 0);
+    }
+    ldW(0, bw); ldW(1, bw + 4); ldW(2, bw + 8);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");             // the base rows (older than the twelve weight fragments) have landed
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    CCSP_TRK(0, 7);
+    // --- U_h = 2^-(e_row + e_w) acc + (base + tau), in place (accumulator layout); A rows 28..31 of the MFMA tile are padding
+    {
+        if (s != 0) { tv[0] = 0.0f; tv[1] = 0.0f; tv[2] = 0.0f; tv[3] = 0.0f; }      // (the time term rides on slot-0 rows; slot-1 rows add +0)
+        int ex[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int4 e4 = *reinterpret_cast<const int4*>(sExpA + s * 32 + 8 * q + 4 * (lane >> 5));
+            ex[4 * q] = -(e4.x + fa.w_exp); ex[4 * q + 1] = -(e4.y + fa.w_exp); ex[4 * q + 2] = -(e4.z + fa.w_exp); ex[4 * q + 3] = -(e4.w + fa.w_exp);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float* up = Ut + (s * F4_RS + 4 * (lane >> 5)) * 256 + ch * 128 + j * 32 + (lane & 31);
+            float bv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2);
+                bv[r] = (r < 12 || lane < 32) ? up[rr * 256] : 0.0f;                   // (rows 28..31: r >= 12 in the upper half-wave)
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2);
+                if (r < 12 || lane < 32) up[rr * 256] = ldexpf(acc[j][r], ex[r]) + (bv[r] + tv[j]);
+            }
+        }
+    }
+    __syncthreads();
+    CCSP_TRK(0, 8);
+    // --- row maxima of U_h: 16 lanes per row, four 16-byte reads each; 16 rows per pass
+    {
+        const int c16 = tid & 15, r16 = tid >> 4;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int row = 16 * pass + r16;
+            float m = 0.0f;
+            if (row < 2 * F4_RS) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float4 v = *reinterpret_cast<const float4*>(Ut + row * 256 + k * 64 + c16 * 4);
+                    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                }
+            }
+            m = fz_max16(m);
+            if (c16 == 0 && row < 2 * F4_RS) sMax[row] = m;
+        }
+    }
+    __syncthreads();
+    CCSP_TRK(0, 9);
+    int aexp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        // |SiLU(z)| <= |z| <= max|U_h[u0]| + max|U_h[u1]|   (k_edge_h2 forms the same sum from umax)
+        aexp[i] = h2_scale_exp(sMax[lu0[i]] + sMax[lu1[i]]);
+        if (lq == 0) sE[32 * i + br] = aexp[i];
+    }
+    // --- phase 2: decoder layer 1, K = 256 in eight chunks of 32 through one stage; wave = 32 of the 128 decoder columns, all row tiles
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    uint2 pb[4][2];                                                // the next chunk's A rows of this thread, both planes: built under the MFMAs
+    auto prebuild = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < MT) {
+                const float4 ua = *reinterpret_cast<const float4*>(Ut + lu0[i] * 256 + c * H2_BK + lq * 4);
+                const float4 ub = *reinterpret_cast<const float4*>(Ut + lu1[i] * 256 + c * H2_BK + lq * 4);
+                const float hv[4] = {silu_fast(ua.x + ub.x), silu_fast(ua.y + ub.y), silu_fast(ua.z + ub.z), silu_fast(ua.w + ub.w)};
+                unsigned short p1[4], p2[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split2h(ldexpf(hv[e], aexp[i]), p1[e], p2[e]);
+                pb[i][0] = make_uint2(p1[0] | ((unsigned)p1[1] << 16), p1[2] | ((unsigned)p1[3] << 16));
+                pb[i][1] = make_uint2(p2[0] | ((unsigned)p2[1] << 16), p2[2] | ((unsigned)p2[3] << 16));
+            }
+        }
+    };
+    prebuild(0);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        half8* b = bw + 4 * (c % 3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < MT) {
+                unsigned short* d = stg + h2_off(32 * i + br, lq >> 1) + (lq & 1) * 4;
+                *reinterpret_cast<uint2*>(d) = pb[i][0];
+                *reinterpret_cast<uint2*>(d + 128 * H2_BK) = pb[i][1];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // this chunk's weight fragments have landed (younger: the chunks c + 1, c + 2 of the ring)
+        {
+            const int n = 4 * ((c + 2 < 7 ? c + 2 : 7) - c);
+            if (n >= 8) f4_wait4<8>(b); else if (n >= 4) f4_wait4<4>(b); else f4_wait4<0>(b);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                              // the stage holds chunk c
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int piece = (lane >> 5) + 2 * ks;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i < MT) {
+                    const half8 a0 = *reinterpret_cast<const half8*>(stg + h2_off(i * 32 + (lane & 31), piece));
+                    const half8 a1 = *reinterpret_cast<const half8*>(stg + 128 * H2_BK + h2_off(i * 32 + (lane & 31), piece));
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[2 * ks], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[2 * ks + 1], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[2 * ks], acc[i], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 3 < 8) ldW(c + 3, b);
+        if (c + 1 < 8) prebuild(c + 1);                            // (VALU + LDS reads of the U tile, in the shadow of the MFMAs just issued)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                              // every wave is done reading the stage
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    CCSP_TRK(0, 14);
+    // --- epilogue: 2^-(e_row + e_w) acc + bias -> SiLU -> S1 (in the U tile's LDS, swizzled quads)
+    float* S1 = Ut;
+    {
+        const int col = wave * 32 + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < MT) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (row < F4_ME) {
+                        const float q = ldexpf(acc[i][r], -(sE[row] + fa.wd_exp)) + bj;
+                        S1[fz_s1_off(row, col)] = silu_fast(q);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    CCSP_TRK(0, 15);
+    // second decoder layer: one (row, p) dot product per thread (four lanes per row), chains and sum as k_edge_h2<., ., 0> forms them
+    auto layer2 = [&](int row, int p, int slot) {
+        const float* sr = S1 + row * 128;
+        const float4* wr = reinterpret_cast<const float4*>(W2s + p * FZ_W2_LD);
+        const int sw = row & 31;
+        float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;
+#pragma unroll 8
+        for (int j = 0; j < 32; ++j) {
+            const float4 sv = *reinterpret_cast<const float4*>(sr + ((j ^ sw) << 2)), wv = wr[j];
+            o0 = fmaf(sv.x, wv.x, o0); o1 = fmaf(sv.y, wv.y, o1); o2 = fmaf(sv.z, wv.z, o2); o3 = fmaf(sv.w, wv.w, o3);
+        }
+        fa.O[(size_t)slot * P + p] = ((o0 + o1) + (o2 + o3)) + sB2[p];
+    };
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 64 * i + (tid >> 2), p = tid & 3;
+        if (row < ne && p < P) layer2(row, p, o_slot[i]);
+    }
+    for (int p0 = 4; p0 < P; p0 += 2) {                            // pose_dim > 4 (robot: 5): rows tid & 127, components p0 + (tid >> 7)
+        const int row = tid & 127, p = p0 + (tid >> 7);
+        if (row < ne && p < P) layer2(row, p, fa.ent_pos[2 * (e0 + row) + h]);
+    }
+#ifdef CCSP_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    CCSP_TRK(0, 16);
+    CCSP_TRK_RT(0, 31);
+}

@@ -1373,7 +1373,8 @@ struct ccsp_model {
     int wp_exp = 0, wd_exp = 0;
     unsigned short* WpF = nullptr;    // the planes of WpH in MFMA fragment order (k_pack_wp_frag): k_eval_fused reads them straight into registers
     unsigned short* Wd1F = nullptr;   // likewise pose_decoder.0.weight (k_pack_wd1_frag)
-    int eval_fused = 0;               // CCSP_EVAL=fused: direct-mode evaluations as ONE launch with U kept in LDS (ccsp_fused.h); split: two launches
+    int eval_fused = 0;               // CCSP_EVAL=fused: direct-mode evaluations as ONE launch with U kept in LDS (ccsp_fused.h: 1 = k_eval_fused4, two
+                                      // 256-thread workgroups per CU; 2 = CCSP_EVAL=fused8, the persistent 512-thread form); split: two launches
     unsigned short* WpTH = nullptr;   // [2][C][2][H][2H] fp16 planes of WpT * 2^wp_exp (energy backward; energy_wrapper models only)
     unsigned short* Wd1TH = nullptr;  // [2][H][H/2]      fp16 planes of pose_decoder.0.weight^T * 2^wd_exp
     float wd2_absmax = 0.0f;          // max |pose_decoder.2.weight| (row-exponent bound of k_edge_bwd_h2)
@@ -1705,7 +1706,8 @@ int launch_eval(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s, bool tabled 
             fa.WpF = m->WpF; fa.w_exp = m->wp_exp; fa.base = g->base; fa.tau_t = tau_t;
             fa.Wd1F = m->Wd1F; fa.wd_exp = m->wd_exp; fa.bd1 = m->pd0_b; fa.Wd2 = m->pd2_w; fa.bd2 = m->pd2_b;
             fa.O = g->O; fa.P = m->d.pose_dim;
-            hipLaunchKernelGGL(k_eval_fused, dim3(fa.n_items < m->ncu ? fa.n_items : m->ncu), dim3(512), 0, s, fa);
+            if (m->eval_fused == 1) hipLaunchKernelGGL(k_eval_fused4, dim3(fa.n_items), dim3(256), 0, s, fa);
+            else hipLaunchKernelGGL(k_eval_fused, dim3(fa.n_items < m->ncu ? fa.n_items : m->ncu), dim3(512), 0, s, fa);
             if (did_fuse) *did_fuse = false;
             prof_mark(g, s, -1);
             g->evals++;
@@ -2471,8 +2473,8 @@ int graph_build(ccsp_model* m, int N, int E, int F, const float* x, const signed
         TRY(dev_upload(reg, &td, g->h_td, s));
         g->td64 = td; g->td128 = td + p.tile_row0.size();
     }
-    if (m->f16x2 && m->WpF && p.E_act > 0) {   // fused tiles (k_eval_fused): <= 32 U rows per slot, <= 128 edges
-        ccsp::build_fused_plan(p, FZ_RS, FZ_ME, g->fplan);
+    if (m->f16x2 && m->WpF && m->eval_fused && p.E_act > 0) {   // fused tiles: <= 28 (32) U rows per slot, <= 112 (128) edges
+        ccsp::build_fused_plan(p, m->eval_fused == 1 ? F4_RS : FZ_RS, m->eval_fused == 1 ? F4_ME : FZ_ME, g->fplan);
         g->n_ftiles = g->fplan.n_tiles;
         int* ft = nullptr;
         TRY(dev_upload(reg, &ft, g->fplan.tiles, s));
@@ -2772,7 +2774,7 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     m->valu_node_energy = getenv("CCSP_NODE_ENERGY_VALU") != nullptr;
     if (const char* e = getenv("CCSP_NODE")) { m->node_generic = strcmp(e, "generic") == 0; m->node_stream = strcmp(e, "stream") == 0; }
     if (const char* e = getenv("CCSP_FUSE_NODE")) m->fuse_node = atoi(e) != 0;
-    if (const char* e = getenv("CCSP_EVAL")) m->eval_fused = strcmp(e, "fused") == 0;
+    if (const char* e = getenv("CCSP_EVAL")) m->eval_fused = strcmp(e, "fused") == 0 ? 1 : (strcmp(e, "fused8") == 0 ? 2 : 0);
     {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -3505,13 +3507,14 @@ int ccsp_plan_host(int32_t N, int32_t E, int32_t C, const int64_t* edge_index, c
     return 0;
 }
 
-int ccsp_plan_fused_host(int32_t N, int32_t E, int32_t C, const int64_t* edge_index, const float* edge_attr, int32_t* n_tiles,
-                         int32_t* tiles, int32_t* rows, uint16_t* e_lu) {
+int ccsp_plan_fused_host(int32_t N, int32_t E, int32_t C, const int64_t* edge_index, const float* edge_attr, int32_t rows_per_slot,
+                         int32_t max_edges, int32_t* n_tiles, int32_t* tiles, int32_t* rows, uint16_t* e_lu) {
+    if (rows_per_slot < 1 || rows_per_slot > 32 || max_edges < 1 || max_edges > 128) return fail("plan_fused_host: rows_per_slot in 1..32, max_edges in 1..128");
     ccsp::Plan p;
     const char* perr = "";
     if (ccsp::build_plan(N, E, C, TILE_M, edge_index, edge_attr, p, &perr)) return fail("plan_fused_host: %s", perr);
     ccsp::FusedPlan f;
-    ccsp::build_fused_plan(p, FZ_RS, FZ_ME, f);
+    ccsp::build_fused_plan(p, rows_per_slot, max_edges, f);
     *n_tiles = f.n_tiles;
     if (tiles && !f.tiles.empty()) memcpy(tiles, f.tiles.data(), f.tiles.size() * sizeof(int32_t));
     if (rows && !f.rows.empty()) memcpy(rows, f.rows.data(), f.rows.size() * sizeof(int32_t));

@@ -115,16 +115,18 @@ inline int build_plan(int N, int E, int C, int tile_m, const int64_t* ei /*[2,E]
     return 0;
 }
 
-// Fused tiles of k_eval_fused (ccsp_fused.h): every type's sorted edges are cut, in order, into runs whose DISTINCT U rows are at
-// most `rows_per_slot` per slot and whose length is at most `max_edges`.  A tile carries its own row list (64 entries: slot-0 rows
-// first, slot-1 rows from entry rows_per_slot on; unused entries repeat the slot's first row so that every address is valid) and
-// every edge the positions of its two rows inside the tile.  A U row that edges of two tiles share is evaluated by both (collated
-// graphs come graph by graph, so in practice a row belongs to one tile).
+// Fused tiles of the one-launch evaluation kernels (ccsp_fused.h): every type's sorted edges are cut, in order, into runs whose
+// DISTINCT U rows are at most `rows_per_slot` per slot and whose length is at most `max_edges`.  A tile carries its own row list and
+// every edge the positions of its two rows inside the tile's U rows (slot-0 rows first, slot-1 rows from position rows_per_slot on).
+// rows [n_tiles][128]: entries 0..63 = node (pose-embedding row) of A row i, slot 0 at 0.., slot 1 at 32.. (the MFMA row tiles);
+// entries 64..127 = U row (row of `base`) of tile row j, j < 2 rows_per_slot.  Unused entries repeat the slot's first row so that every
+// address is valid.  A U row that edges of two tiles share is evaluated by both (collated graphs come graph by graph, so in practice
+// a row belongs to one tile).
 struct FusedPlan {
     int n_tiles = 0;
     std::vector<int32_t> tiles;       // [n_tiles][4]  {type, first sorted edge, edges, rows slot 0 | rows slot 1 << 16}
-    std::vector<int32_t> rows;        // [n_tiles][4 * rows_per_slot]  node of local row i (2 * rows_per_slot entries), then its U row
-    std::vector<uint16_t> e_lu;       // [E_act]  local row of operand 0 | local row of operand 1 << 8
+    std::vector<int32_t> rows;        // [n_tiles][128]
+    std::vector<uint16_t> e_lu;       // [E_act]  tile row of operand 0 | tile row of operand 1 << 8
 };
 
 inline void build_fused_plan(const Plan& p, int rows_per_slot, int max_edges, FusedPlan& f) {
@@ -139,7 +141,9 @@ inline void build_fused_plan(const Plan& p, int rows_per_slot, int max_edges, Fu
         const int e0 = k;
         for (; k < p.E_act && p.e_type[k] == type && k - e0 < max_edges; ++k) {
             const int u0 = p.e_u0[k], u1 = p.e_u1[k];
-            const bool n0 = stamp[u0] != tile, n1 = stamp[u1] != tile;
+            const bool n0 = stamp[u0] != tile;
+            // (a self loop puts one node into both slots: two different U rows, so the two tests never see the same row)
+            const bool n1 = stamp[u1] != tile;
             if ((int)r0.size() + (n0 ? 1 : 0) > RS || (int)r1.size() + (n1 ? 1 : 0) > RS) break;
             if (n0) { stamp[u0] = tile; loc[u0] = (int)r0.size(); r0.push_back(u0); }
             if (n1) { stamp[u1] = tile; loc[u1] = RS + (int)r1.size(); r1.push_back(u1); }
@@ -148,13 +152,14 @@ inline void build_fused_plan(const Plan& p, int rows_per_slot, int max_edges, Fu
         f.tiles.push_back(type); f.tiles.push_back(e0); f.tiles.push_back(k - e0);
         f.tiles.push_back((int32_t)r0.size() | ((int32_t)r1.size() << 16));
         const size_t base = f.rows.size();
-        f.rows.resize(base + 4 * RS);
-        for (int i = 0; i < RS; ++i) {
-            const int a = r0[i < (int)r0.size() ? i : 0], b = r1[i < (int)r1.size() ? i : 0];
-            f.rows[base + i] = p.urow_node[a];
-            f.rows[base + RS + i] = p.urow_node[b];
-            f.rows[base + 2 * RS + i] = a;
-            f.rows[base + 3 * RS + i] = b;
+        f.rows.resize(base + 128);
+        for (int i = 0; i < 32; ++i) {
+            f.rows[base + i] = p.urow_node[r0[i < (int)r0.size() ? i : 0]];
+            f.rows[base + 32 + i] = p.urow_node[r1[i < (int)r1.size() ? i : 0]];
+        }
+        for (int j = 0; j < 64; ++j) {
+            const int a = j < RS ? r0[j < (int)r0.size() ? j : 0] : r1[j - RS < (int)r1.size() ? j - RS : 0];
+            f.rows[base + 64 + j] = a;
         }
     }
 }

@@ -253,15 +253,16 @@ int ccsp_plan_host(int32_t N, int32_t E, int32_t C, const int64_t* edge_index, c
                    int32_t* urow_node, int32_t* urow_ts, int32_t* tile_row0, int32_t* tile_nrows,
                    int32_t* tile_ts, int32_t* node_ptr, int32_t* node_ent);
 
-/* Host-only: the FUSED TILES of the one-launch evaluation kernel (csrc/ccsp_fused.h; the same loop over constraint types and
+/* Host-only: the FUSED TILES of the one-launch evaluation kernels (csrc/ccsp_fused.h; the same loop over constraint types and
  * their edges, denoise_fn.py:313-371).  Every type's sorted edges are cut, in order, into runs whose distinct U rows are at most
- * 32 per slot and whose length is at most 128 edges; a workgroup owns (tile, output half), computes the tile's U rows into LDS
- * and decodes the tile's edges from there.  n_tiles <= E_act; tiles [n_tiles][4] = {type, first sorted edge, edges,
- * rows slot 0 | rows slot 1 << 16}; rows [n_tiles][128] = node of local row i (i < 32: slot 0, 32 <= i < 64: slot 1; unused
- * entries repeat the slot's first row), then the U row of local row i; e_lu [E_act] = local row of operand 0 | local row of
- * operand 1 << 8.  Caller-sized HOST arrays (tiles [4 E], rows [128 E], e_lu [E]); any of them may be NULL. */
-int ccsp_plan_fused_host(int32_t N, int32_t E, int32_t C, const int64_t* edge_index, const float* edge_attr, int32_t* n_tiles,
-                         int32_t* tiles, int32_t* rows, uint16_t* e_lu);
+ * rows_per_slot (<= 32; the kernels use 28 or 32) per slot and whose length is at most max_edges (<= 128; 112 or 128); a workgroup
+ * owns (tile, output half), computes the tile's U rows into LDS and decodes the tile's edges from there.  n_tiles <= E_act;
+ * tiles [n_tiles][4] = {type, first sorted edge, edges, rows slot 0 | rows slot 1 << 16}; rows [n_tiles][128]: entries 0..63 =
+ * node of A row i (slot 0 at 0.., slot 1 at 32..), entries 64..127 = U row of tile row j (slot 0 at 0.., slot 1 at
+ * rows_per_slot..); unused entries repeat the slot's first row; e_lu [E_act] = tile row of operand 0 | tile row of operand 1 << 8.
+ * Caller-sized HOST arrays (tiles [4 E], rows [128 E], e_lu [E]); any of them may be NULL. */
+int ccsp_plan_fused_host(int32_t N, int32_t E, int32_t C, const int64_t* edge_index, const float* edge_attr, int32_t rows_per_slot,
+                         int32_t max_edges, int32_t* n_tiles, int32_t* tiles, int32_t* rows, uint16_t* e_lu);
 
 #ifdef __cplusplus
 }

@@ -99,11 +99,13 @@ def test_plan_host_matches_numpy(case):
         assert (got['urow_ts'][r0:r0 + nr] == ts).all() and 1 <= nr <= 64
 
 
+@pytest.mark.parametrize('shape', [(28, 112), (32, 128)])
 @pytest.mark.parametrize('case', ['qualitative', 'triangular', 'robot', 'ragged', 'shuffled'])
-def test_fused_plan_invariants(case):
-    """the fused tiles of k_eval_fused (ccsp_plan_fused_host): a partition of every type's sorted edges into runs of <= 128 edges
-    whose distinct U rows are <= 32 per slot; every edge finds its two rows at the local positions it carries; padding entries
-    are valid rows of the same slot"""
+def test_fused_plan_invariants(case, shape):
+    """the fused tiles of the one-launch evaluation kernels (ccsp_plan_fused_host): a partition of every type's sorted edges into runs
+    of <= ME edges whose distinct U rows are <= RS per slot; every edge finds its two rows at the positions it carries; padding
+    entries are valid rows of the same slot"""
+    RS, ME = shape
     if case == 'qualitative':
         b, C = worlds.qualitative_batch(40, 8, seed=3), 13
     elif case == 'triangular':
@@ -120,29 +122,31 @@ def test_fused_plan_invariants(case):
             b.edge_attr = b.edge_attr[perm]
     N = b.x.shape[0]
     pl = _lib.plan_host(N, C, b.edge_index, b.edge_attr)
-    f = _lib.plan_fused_host(N, C, b.edge_index, b.edge_attr)
+    f = _lib.plan_fused_host(N, C, b.edge_index, b.edge_attr, RS, ME)
     assert f['tiles'][:, 2].sum() == pl['E_act'] and len(f['e_lu']) == pl['E_act']
     k = 0
     for (typ, e0, ne, nr), rows in zip(f['tiles'], f['rows']):
-        assert e0 == k and 1 <= ne <= 128
+        assert e0 == k and 1 <= ne <= ME
         k += ne
         nr0, nr1 = nr & 0xffff, nr >> 16
-        assert 1 <= nr0 <= 32 and 1 <= nr1 <= 32
+        assert 1 <= nr0 <= RS and 1 <= nr1 <= RS
         assert (pl['e_type'][e0:e0 + ne] == typ).all()
         node, urow = rows[:64], rows[64:]
-        assert (pl['urow_node'][urow] == node).all()
-        assert (pl['urow_ts'][urow[:32]] == 2 * typ).all() and (pl['urow_ts'][urow[32:]] == 2 * typ + 1).all()
-        assert len(set(urow[:nr0])) == nr0 and len(set(urow[32:32 + nr1])) == nr1
-        assert (urow[nr0:32] == urow[0]).all() and (urow[32 + nr1:] == urow[32]).all()
+        # A rows (slot 0 at 0, slot 1 at 32) and tile rows (slot 1 at RS) name the same U rows
+        assert (pl['urow_node'][urow[:nr0]] == node[:nr0]).all() and (pl['urow_node'][urow[RS:RS + nr1]] == node[32:32 + nr1]).all()
+        assert (node[nr0:32] == node[0]).all() and (node[32 + nr1:] == node[32]).all()
+        assert (pl['urow_ts'][urow[:RS]] == 2 * typ).all() and (pl['urow_ts'][urow[RS:]] == 2 * typ + 1).all()
+        assert len(set(urow[:nr0])) == nr0 and len(set(urow[RS:RS + nr1])) == nr1
+        assert (urow[nr0:RS] == urow[0]).all() and (urow[RS + nr1:] == urow[RS]).all()
         lu = f['e_lu'][e0:e0 + ne]
         lu0, lu1 = lu & 0xff, lu >> 8
-        assert (lu0 < nr0).all() and (lu1 >= 32).all() and (lu1 < 32 + nr1).all()
+        assert (lu0 < nr0).all() and (lu1 >= RS).all() and (lu1 < RS + nr1).all()
         assert (urow[lu0] == pl['e_u0'][e0:e0 + ne]).all() and (urow[lu1] == pl['e_u1'][e0:e0 + ne]).all()
         # greedy: the tile could not have taken the next edge of its type
-        if k < pl['E_act'] and pl['e_type'][k] == typ and ne < 128:
+        if k < pl['E_act'] and pl['e_type'][k] == typ and ne < ME:
             n0 = pl['e_u0'][k] not in set(urow[:nr0])
-            n1 = pl['e_u1'][k] not in set(urow[32:32 + nr1])
-            assert nr0 + n0 > 32 or nr1 + n1 > 32
+            n1 = pl['e_u1'][k] not in set(urow[RS:RS + nr1])
+            assert nr0 + n0 > RS or nr1 + n1 > RS
     assert k == pl['E_act']
 
 
