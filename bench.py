@@ -231,6 +231,66 @@ def algorithmic_bytes(n_nodes, n_types_present, H, P, grasp):
     return n_types_present * per_type + shared + 3 * n_nodes * P * 4
 
 
+def working_set_bytes(n_nodes, E_act, R, H, P, types_present, energy):
+    """bytes one evaluation reads or writes at least once (f16x2 kernels): the chain-constant row terms `base`, the pre-activation
+    rows U and their maxima, the pose-embedding planes, the edge outputs, the fp16 planes of the present types' pose slices and of the
+    decoder; energy mode adds Q, GZ, the row sums and their planes, the transposed weights"""
+    ws = 2 * R * 2 * H * 4 + R * 8 * 4 + 2 * n_nodes * H * 2 + 2 * E_act * P * 4 + types_present * 2 * 2 * 2 * H * H * 2 + 2 * (H // 2) * H * 2
+    if energy:
+        ws += 2 * E_act * (H // 2) * 4 + E_act * 2 * H * 4 + R * 2 * H * 4 + 2 * R * 2 * H * 2 + R * H * 4 + types_present * 2 * 2 * 2 * H * H * 2
+    return ws
+
+
+def throughput_regime(gd, cfg, worlds, dev, args, graphs=1024):
+    """the same chain on a batch whose `base` + U (2 x 160 MB) exceed the Infinity Cache: there the fabric-side bytes ARE HBM bytes.
+    One profiled chain (kernel durations) + two live --pmc passes on the same batch size -> us per evaluation, HBM-side TB/s of
+    the evaluation and of the dominant kernel, its matrix-pipe fraction"""
+    import gc
+    batch_np = getattr(worlds, cfg['batch'])(graphs, cfg['n_objects'], seed=5)
+    b = batch_np.to_torch(dev)
+    gd.profile(b, True)
+    gd.sample(b, seed=78)
+    ks = gd.kernel_stats()
+    st = gd.chain_stats()
+    gd.profile(b, False)
+    del b
+    gc.collect()
+    from diffusion_ccsp_amd import _lib
+    plan = _lib.plan_host(batch_np.x.shape[0], cfg['n_types'], batch_np.edge_index, batch_np.edge_attr)
+    R, E_act, N = plan['R'], plan['E_act'], batch_np.x.shape[0]
+    P = worlds.MODE_DIMS[cfg['mode']][-1][0]
+    out = {'graphs': graphs, 'nodes': N, 'edges': E_act, 'u_rows': R,
+           'working_set_bytes': working_set_bytes(N, E_act, R, HIDDEN, P, cfg['n_types'], cfg['energy'])}
+    timed = sum(ms * calls for calls, ms in ks.values())
+    n_eval = ks.get('row GEMM (forward)', (0, 0.0))[0]
+    out['us_per_evaluation'] = 1e3 * timed / n_eval if n_eval else None
+    out['chain_ms_event'] = st['ms_total']
+    out['kernels'] = {label: {'us_mean': 1e3 * ms, 'calls_timed': calls} for label, (calls, ms) in ks.items()}
+    row = ks.get('row GEMM (forward)')
+    if row:
+        w = executed_work('row GEMM (forward)', N, E_act, R, HIDDEN, 'f16x2')
+        out['row_gemm_frac_mfma'] = w[1] * w[0] / (row[1] * 1e-3) / 1e12 / PEAKS[w[2]]
+    if not args.no_live_pmc:
+        syms = ['k_rowgemm_h2<256, 512', 'k_edge_h2', 'k_node_direct']
+        traffic, stamp = pmc_traffic_live('c2', graphs, syms)
+        if traffic:
+            tot = sum(t['bytes'] for t in traffic.values())
+            out['hbm_side_bytes_per_evaluation'] = tot
+            out['traffic_source'] = stamp
+            if out['us_per_evaluation']:
+                out['hbm_side_tb_per_s'] = tot / (out['us_per_evaluation'] * 1e-6) / 1e12
+                out['frac_of_8_tb_per_s'] = out['hbm_side_tb_per_s'] / 8.0
+            tr = traffic.get('k_rowgemm_h2<256, 512')
+            if tr and row:
+                out['row_gemm_bytes_per_launch'] = tr['bytes']
+                out['row_gemm_tb_per_s'] = tr['bytes'] / (row[1] * 1e-3) / 1e12
+        else:
+            out['traffic_source'] = stamp
+    out['note'] = ('%d graphs in one lane: base + U = %.0f MB do not fit the 256 MiB Infinity Cache, so 2 x FETCH_SIZE + WRITE_SIZE is HBM traffic here; '
+                   'the configuration\'s own 256 graphs per GPU sit below that (roofline.bound = fabric / mfma)' % (graphs, 2 * R * 2 * HIDDEN * 4 / 1e6))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -241,6 +301,11 @@ def main():
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
                     help='weak: the configuration\'s shard on every GPU (C3 at N = 8).  strong: C3 proper -- 2048 graphs in total (8 shards '
                          'of the configuration), split over the N ranks')
+    ap.add_argument('--samples-per-step', type=int, default=S_LANGEVIN,
+                    help='Langevin steps per timestep.  Default 10 = GaussianDiffusion\'s and get_args\' default (train_utils.py:89), the setting SURVEY 8 '
+                         'and BASELINE.json quote (11 000 evaluations per sample); 3 = what the reference\'s documented command line passes '
+                         '(train_ddpm.py:31-35, README.md:96-100)')
+    ap.add_argument('--no-throughput-regime', action='store_true', help='skip the 1024-graph sub-block of the roofline (c2)')
     ap.add_argument('--no-live-pmc', action='store_true', help='do not run the rocprofv3 --pmc passes (roofline.traffic from profiles/ instead)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -251,6 +316,7 @@ def main():
     args = ap.parse_args()
     cname = 'c2' if args.config == 'c3' else args.config
     cfg = CONFIGS[cname]
+    S = args.samples_per_step
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -291,7 +357,7 @@ def main():
     sd = sharding.broadcast_state_dict(sd, den.shapes(), dev, dist)
     den.load_state_dict(sd)
     fn = ComposedEBMDenoiseFn(den) if energy else den
-    gd = GaussianDiffusion(fn, timesteps=T_STEPS, EBM=cfg['EBM'], samples_per_step=S_LANGEVIN)
+    gd = GaussianDiffusion(fn, timesteps=T_STEPS, EBM=cfg['EBM'], samples_per_step=S)
     if args.mala_global_batch and dist is not None and cfg['EBM'] == 'MALA':
         sharding.enable_global_batch_energy(gd, dist)
     base = batch_np.to_torch(dev)
@@ -325,7 +391,7 @@ def main():
     nan_graphs = len(set(batch_np.batch[(~torch.isfinite(x).all(dim=1)).cpu().numpy()].tolist()))
     samples = world * B * args.steps
     value = samples / elapsed
-    evals_per_chain = T_STEPS * (1 + (2 if cfg['EBM'] == 'MALA' else 1) * S_LANGEVIN)
+    evals_per_chain = T_STEPS * (1 + (2 if cfg['EBM'] == 'MALA' else 1) * S)
 
     rec = {
         'metric': 'solved samples/sec, T=1000 %s, %s (%s)' %
@@ -340,7 +406,9 @@ def main():
         'dtype': {'f16x2': 'f32 (f16x2 split operands: 3 fp16 MFMA products per fp32 product, fp32 accumulate)',
                   'bf16x3': 'f32 (bf16x3 split operands: 6 bf16 MFMA products per fp32 product, fp32 accumulate)'}.get(os.environ.get('CCSP_MMA', 'f16x2'), 'f32'),
         'data': 'synthetic',
-        'config': {'workload': '%s, %d graphs per GPU, hidden_dim %d' % (cfg['label'], B, HIDDEN),
+        'config': {'workload': '%s, %d graphs per GPU, hidden_dim %d' % (cfg['label'] if S == S_LANGEVIN else cfg['label'].replace('S=10', 'S=%d (NOT the headline setting: '
+                               'the reference\'s documented command line, train_ddpm.py:31-35)' % S), B, HIDDEN),
+                   'samples_per_step': S,
                    'name': args.config, 'graphs_per_gpu': B, 'nodes_per_gpu': n_nodes, 'edges_per_gpu': n_edges,
                    'evaluations_per_chain': evals_per_chain,
                    'parallelism': 'independent graph shards x%d, RCCL weight broadcast + final gather only' % world +
@@ -370,7 +438,7 @@ def main():
             den0 = ConstraintDiffuser(dims=worlds.MODE_DIMS[cfg['mode']], hidden_dim=HIDDEN, input_mode=cfg['mode'], EBM=cfg['EBM'],
                                       energy_wrapper=cfg['energy'], device=dev, verbose=False)
             den0.load_state_dict(sd)
-            gd0 = GaussianDiffusion(ComposedEBMDenoiseFn(den0) if cfg['energy'] else den0, timesteps=T_STEPS, EBM=cfg['EBM'], samples_per_step=S_LANGEVIN)
+            gd0 = GaussianDiffusion(ComposedEBMDenoiseFn(den0) if cfg['energy'] else den0, timesteps=T_STEPS, EBM=cfg['EBM'], samples_per_step=S)
             os.environ['CCSP_MALA_REUSE'] = '1'
             gd0.sample(base.clone(), seed=999)
             torch.cuda.synchronize()
@@ -465,19 +533,29 @@ def main():
         # evaluations seen by the profiler = launches of the forward row GEMM
         n_eval_timed = ks.get('row GEMM (forward)', (0, 0.0))[0]
         us_eval = timed / n_eval_timed if n_eval_timed else None
+        types_present = int(len(set(np.asarray(batch_np.edge_attr).astype(np.int64).tolist()) & set(range(cfg['n_types']))))
         frac_mfma = dom['frac']
         frac_bytes = dom.get('frac_bytes')
         by_bytes = frac_bytes is not None and frac_bytes > frac_mfma
         eval_labels = [k for k in kernels if k['kernel'] not in ('energy sum', 'HMC elementwise')]
         fabric_eval = sum(k['fabric_bytes_per_launch'] for k in eval_labels) if eval_labels and all('fabric_bytes_per_launch' in k for k in eval_labels) else None
-        types_present = int(len(set(np.asarray(batch_np.edge_attr).astype(np.int64).tolist()) & set(range(cfg['n_types']))))
         alg_bytes = algorithmic_bytes(n_nodes, types_present, HIDDEN, P, grasp)
+        # what one evaluation touches: if it fits the 256 MiB Infinity Cache the fabric-side bytes (L2 misses, Infinity-Cache hits
+        # included) are NOT HBM bytes and the byte fraction is a fabric-side figure, not an HBM roofline
+        ws = working_set_bytes(n_nodes, E_act, R, HIDDEN, P, types_present, energy)
+        in_cache = ws < 256 * 1024 * 1024
+        hbm_bound = by_bytes and not in_cache
         rec['roofline'] = {
-            'bound': 'hbm' if by_bytes else 'mfma',
-            'achieved': (dom['fabric_bytes_per_launch'] / (dom['us_mean'] * 1e-6) / 1e9) if by_bytes else dom['pipe_tflops'],
-            'peak': 8000.0 if by_bytes else dom['pipe_peak_tflops'], 'unit': 'GB/s' if by_bytes else 'TFLOP/s',
-            'frac': frac_bytes if by_bytes else frac_mfma,
+            'bound': 'hbm' if hbm_bound else ('fabric' if by_bytes else 'mfma'),
+            'achieved': (dom['fabric_bytes_per_launch'] / (dom['us_mean'] * 1e-6) / 1e9) if hbm_bound else dom['pipe_tflops'],
+            'peak': 8000.0 if hbm_bound else dom['pipe_peak_tflops'], 'unit': 'GB/s' if hbm_bound else 'TFLOP/s',
+            'frac': frac_bytes if hbm_bound else frac_mfma,
             'frac_mfma': frac_mfma, 'frac_bytes': frac_bytes,
+            'working_set_bytes': ws, 'working_set_fits_infinity_cache': in_cache,
+            'bound_note': 'bound = "fabric": the dominant kernel\'s fabric-side bytes / duration / 8 TB/s (frac_bytes) exceed its matrix-pipe fraction, but one '
+                          'evaluation\'s working set fits the 256 MiB Infinity Cache, so those bytes are L2 misses served on the die, not HBM traffic: '
+                          'achieved / peak / frac are the MATRIX-PIPE figures (frac = frac_mfma).  bound = "hbm" only when the working set exceeds the '
+                          'Infinity Cache (see throughput_regime); "mfma" when the pipe fraction is the larger one',
             'traffic': dom.get('fabric_bytes_per_launch'), 'traffic_source': stamp,
             'fabric_bytes_per_evaluation': fabric_eval, 'algorithmic_bytes_per_evaluation': alg_bytes,
             'wasted_traffic_ratio': (fabric_eval / alg_bytes) if fabric_eval else None,
@@ -485,7 +563,7 @@ def main():
             'note': 'the dominant kernel priced twice: frac_mfma = flops it EXECUTES on the %s matrix pipe (%d MFMA products per fp32 product after '
                     'the row factorisation) / its mean launch duration (HIP events on the chain stream, launch to next mark) / the dense %s peak; '
                     'frac_bytes = its fabric-side bytes (2 x FETCH_SIZE + WRITE_SIZE: Infinity-Cache hits included, an upper bound on HBM bytes) / '
-                    'the same duration / 8 TB/s.  `bound`, `achieved`, `peak`, `frac` are those of the larger fraction' %
+                    'the same duration / 8 TB/s' %
                     (dom['pipe'], dom['products_per_fp32_product'], dom['pipe']),
             'frac_fp32_equiv': dom['executed_flops_fp32_equiv'] / (dom['us_mean'] * 1e-6) / 1e12 / PEAKS['f32'],
             'kernels': kernels,
@@ -500,15 +578,22 @@ def main():
             'chain_ms_event': st['ms_total'], 'chain_evals': st['evals'],
             'profile_note': 'the profiled chain runs as one lane with an event per launch; its ms is not the timed value above',
         }
+        if cname == 'c2' and world == 1 and mma == 'f16x2' and not args.no_throughput_regime and not args.graphs_per_gpu:
+            try:
+                rec['roofline']['throughput_regime'] = throughput_regime(gd, cfg, worlds, dev, args)
+            except Exception as e:               # noqa: a sub-block must not take the benchmark line down
+                rec['roofline']['throughput_regime'] = {'error': str(e)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, 'oracle'))
         import torch_proxy                              # the checker / baseline port, never the product path
         cpu_batch = batch_np.to_torch('cpu')
         cpu_batch.num_graphs = B
-        r = torch_proxy.time_baseline(load_weights(wpath), dims, HIDDEN, cfg['n_types'], cpu_batch, T=T_STEPS, S=S_LANGEVIN,
+        r = torch_proxy.time_baseline(load_weights(wpath), dims, HIDDEN, cfg['n_types'], cpu_batch, T=T_STEPS, S=S,
                                       n_timesteps=3, budget_s=25.0, sampler=cfg['EBM'])
-        rec['cpu_baseline'] = {'value': r['samples_per_s'], 'unit': 'samples/s', 'cores': r['cores'], 'kind': 'port',
+        rec['cpu_baseline'] = {'value': r['samples_per_s'], 'unit': 'samples/s', 'cores': os.cpu_count(), 'threads_used': r['cores'], 'kind': 'port',
+                               'cores_note': 'cores = host cores of this box (os.cpu_count()); threads_used = the PyTorch thread count the value was taken at, '
+                                             'the fastest of sec_per_eval_by_threads (these small matrices do not scale to every core)',
                                'sample': r['sample'], 'sec_per_timestep': r['sec_per_timestep'],
                                'sec_per_eval_by_threads': r['sec_per_eval_by_threads'],
                                'speedup_gpu_over_cpu': value / r['samples_per_s']}
