@@ -418,6 +418,21 @@ def main():
                    'outputs_finite': finite, 'graphs_with_nonfinite_poses': nan_graphs},
     }
 
+    replica_value = None
+    if args.mala_global_batch and dist is not None and cfg['EBM'] == 'MALA':
+        # the same shards WITHOUT the coupling (replica semantics: each shard its own reference batch, no collective in the chain),
+        # timed the same way on every rank, so that the line shows what the 10 000 two-float all-reduces per chain cost
+        sharding.enable_global_batch_energy(gd, None)
+        one_step(0)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        one_step(args.warmup + args.steps)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        tt = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        replica_value = world * B / float(tt.item())
+        sharding.enable_global_batch_energy(gd, dist)
+
     if cfg['EBM'] == 'MALA' and rank == 0:
         # MALA: the gradient evaluation of an inner step whose predecessor accepted no node is skipped on the device (exact: the
         # state has not moved; include/ccsp.h, ccsp_chain_skipped).  Report what that was worth: the acceptance of the last timed
@@ -433,6 +448,11 @@ def main():
                                '(test_mala_rejected_step_reuse_is_bitwise_identical); the gain is workload-dependent (acceptance rate).  The profiled chain of the '
                                'roofline block recomputes every evaluation (kernels timed at full work).'}
         rec['mean_acceptance_rate'] = rec['mala']['mean_acceptance_rate']
+        if replica_value is not None:
+            rec['mala']['value_global_batch'] = value
+            rec['mala']['value_replica_semantics'] = replica_value
+            rec['mala']['global_batch_reduction'] = ('ncclAllReduce(sum, 2 floats) per inner step, enqueued by the library on the chain stream '
+                                                     '(ccsp_model_set_energy_allreduce; communicator of its own over the %d ranks)' % world)
         if reuse_on and dist is None:
             os.environ['CCSP_MALA_REUSE'] = '0'
             den0 = ConstraintDiffuser(dims=worlds.MODE_DIMS[cfg['mode']], hidden_dim=HIDDEN, input_mode=cfg['mode'], EBM=cfg['EBM'],

@@ -65,7 +65,7 @@ def build(force=False, verbose=False):
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     tmp = SO + '.tmp'
     cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-pthread',
-           '-Rpass-analysis=kernel-resource-usage', '-o', tmp, os.path.join(CSRC, 'ccsp_hip.hip')]
+           '-Rpass-analysis=kernel-resource-usage', '-o', tmp, os.path.join(CSRC, 'ccsp_hip.hip'), '-ldl']
     if verbose:
         print(' '.join(cmd))
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
@@ -143,6 +143,10 @@ def lib():
     L.ccsp_profile_enable.argtypes = [vp, i32]
     L.ccsp_chain_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.ccsp_model_set_energy_hook.argtypes = [vp, vp, vp]
+    L.ccsp_model_set_energy_allreduce.argtypes = [vp, vp]
+    L.ccsp_rccl_unique_id.argtypes = [vp]
+    L.ccsp_rccl_comm_create.argtypes = [i32, i32, vp, C.POINTER(vp)]
+    L.ccsp_rccl_comm_destroy.argtypes = [vp]
     L.ccsp_kernel_stats.argtypes = [vp, i32, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.c_char_p, i32]
     L.ccsp_chain_skipped.argtypes = [vp, C.POINTER(C.c_int64)]
     L.ccsp_graph_variant.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]

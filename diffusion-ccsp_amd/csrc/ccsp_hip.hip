@@ -19,6 +19,7 @@
 #include <string>
 #include <algorithm>
 #include <thread>
+#include <dlfcn.h>
 #include <type_traits>
 #include <vector>
 
@@ -1338,6 +1339,41 @@ struct StreamBuf {
 // host objects
 // ==========================================================================================
 
+// RCCL, bound at run time (dlopen): the library has no link-time dependency on it, and a process that already carries an RCCL
+// (PyTorch-ROCm ships one) gets that same instance.  Only what the MALA global-batch reduction needs.
+namespace {
+struct RcclId { char internal[128]; };        // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128), passed by value
+struct RcclApi {
+    void* lib = nullptr;
+    int (*get_unique_id)(RcclId*) = nullptr;
+    int (*comm_init_rank)(void**, int, RcclId, int) = nullptr;
+    int (*comm_destroy)(void*) = nullptr;
+    int (*all_reduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*error_string)(int) = nullptr;
+};
+RcclApi* rccl_api() {
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return api.lib ? &api : nullptr;
+    tried = true;
+    const char* names[] = {getenv("CCSP_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* n : names) {
+        if (!n || !*n) continue;
+        api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (api.lib) break;
+    }
+    if (!api.lib) return nullptr;
+    api.get_unique_id = (int (*)(RcclId*))dlsym(api.lib, "ncclGetUniqueId");
+    api.comm_init_rank = (int (*)(void**, int, RcclId, int))dlsym(api.lib, "ncclCommInitRank");
+    api.comm_destroy = (int (*)(void*))dlsym(api.lib, "ncclCommDestroy");
+    api.all_reduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(api.lib, "ncclAllReduce");
+    api.error_string = (const char* (*)(int))dlsym(api.lib, "ncclGetErrorString");
+    if (!api.get_unique_id || !api.comm_init_rank || !api.comm_destroy || !api.all_reduce) { dlclose(api.lib); api.lib = nullptr; return nullptr; }
+    return &api;
+}
+const char* rccl_err(RcclApi* a, int rc) { return a && a->error_string ? a->error_string(rc) : "?"; }
+}  // namespace
+
 struct ccsp_model {
     ccsp_model_desc d;
     int K_in;
@@ -1394,6 +1430,7 @@ struct ccsp_model {
     int ncu = 256;          // compute units of the device (residency-based kernel selection)
     ccsp_energy_hook energy_hook = nullptr;   // MALA global-batch mode (ccsp_model_set_energy_hook)
     void* energy_hook_ctx = nullptr;
+    void* rccl_comm = nullptr;                // ccsp_model_set_energy_allreduce: the pair is all-reduced by ncclAllReduce on the chain's stream
     int row_mode = -1, edge_mt = -1;  // CCSP_ROW_MODE / CCSP_EDGE_MT: force a variant of the f16x2 kernels (-1: by tile count)
     int edge_small = -1;              // CCSP_EDGE_SMALL=1 / 0: always / never the 16-edge-tile kernel k_edge_h2s (-1: by tile count)
     // StructDiffusion baseline (model_kind 1): transformer weights as given ([out, in] row-major)
@@ -2172,7 +2209,7 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
                         !g->profile;        // (a profiled chain times every kernel at full work)
             // with a shard hook the kernels write the shard's own energies to Escal[2..3]; a copy of them goes through the hook
             // (Escal[0..1], reduced in place) every inner step, so a skipped evaluation leaves the LOCAL E(x) standing
-            const bool hook = sampler == CCSP_SAMPLER_MALA && m->energy_hook != nullptr;
+            const bool hook = sampler == CCSP_SAMPLER_MALA && (m->energy_hook != nullptr || m->rccl_comm != nullptr);
             float* E_xl = hook ? g->Escal + 2 : E_x;
             float* E_hatl = hook ? g->Escal + 3 : E_hat;
             for (int e = 1; e <= S; ++e) {
@@ -2192,13 +2229,17 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
                 a.changed = reuse ? g->mala_changed : nullptr;
                 launch_node<H>(m, g, a, s);                                   // x_hat, and its pose embedding
                 // without a shard hook the accept kernel sums the proposal's energy partials itself (no k_energy_sum launch)
-                const bool fold_sum = m->energy_hook == nullptr && g->plan.E_act > 0;
+                const bool fold_sum = !hook && g->plan.E_act > 0;
                 if (launch_eval_energy<H>(m, g, t, g->xhat, false, fold_sum ? (float*)nullptr : E_hatl, s)) return 1;
                 // global-batch mode: E(x), E(x_hat) of this shard -> sums over all shards (the reference's energies are
                 // one scalar for the WHOLE batch, ddpm.py:1026-1038); the hook enqueues the reduction on the chain's stream
                 if (hook) {
                     HIP_TRY(hipMemcpyAsync(g->Escal, g->Escal + 2, 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
-                    if (m->energy_hook(m->energy_hook_ctx, g->Escal, (void*)s)) return fail("chain_run: the energy hook failed");
+                    if (m->rccl_comm) {      // {E(x), E(x_hat)} of this shard -> sums over the communicator's ranks, enqueued on the chain's own stream
+                        RcclApi* ra = rccl_api();
+                        const int rc = ra ? ra->all_reduce(g->Escal, g->Escal, 2, 7 /*ncclFloat32*/, 0 /*ncclSum*/, m->rccl_comm, s) : -1;
+                        if (rc != 0) return fail("chain_run: ncclAllReduce of the batch energies failed: %s", rccl_err(ra, rc));
+                    } else if (m->energy_hook(m->energy_hook_ctx, g->Escal, (void*)s)) return fail("chain_run: the energy hook failed");
                 }
                 NodeArgs b = node_args(m, g);
                 b.src = 1; b.eps_buf = g->eps; b.do_encode = 1; b.xhat = g->xhat; b.step = STEP_MALA_ACCEPT;
@@ -2997,6 +3038,44 @@ int ccsp_model_set_energy_hook(ccsp_model* m, ccsp_energy_hook hook, void* ctx) 
     m->energy_hook = hook;
     m->energy_hook_ctx = ctx;
     return 0;
+}
+
+int ccsp_model_set_energy_allreduce(ccsp_model* m, void* comm) {
+    if (!m) return fail("model_set_energy_allreduce: null model");
+    if (comm && !rccl_api()) return fail("model_set_energy_allreduce: librccl.so could not be loaded (set CCSP_RCCL_LIB)");
+    m->rccl_comm = comm;
+    return 0;
+}
+
+int ccsp_rccl_unique_id(void* id) {
+    RcclApi* ra = rccl_api();
+    if (!ra) return fail("rccl_unique_id: librccl.so could not be loaded (set CCSP_RCCL_LIB)");
+    if (!id) return fail("rccl_unique_id: null argument");
+    RcclId u;
+    const int rc = ra->get_unique_id(&u);
+    if (rc != 0) return fail("ncclGetUniqueId failed: %s", rccl_err(ra, rc));
+    memcpy(id, &u, sizeof(u));
+    return 0;
+}
+
+int ccsp_rccl_comm_create(int32_t n_ranks, int32_t rank, const void* id, void** comm) {
+    RcclApi* ra = rccl_api();
+    if (!ra) return fail("rccl_comm_create: librccl.so could not be loaded (set CCSP_RCCL_LIB)");
+    if (!id || !comm || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail("rccl_comm_create: bad argument");
+    RcclId u;
+    memcpy(&u, id, sizeof(u));
+    void* c = nullptr;
+    const int rc = ra->comm_init_rank(&c, n_ranks, u, rank);
+    if (rc != 0) return fail("ncclCommInitRank(%d of %d) failed: %s", rank, n_ranks, rccl_err(ra, rc));
+    *comm = c;
+    return 0;
+}
+
+int ccsp_rccl_comm_destroy(void* comm) {
+    RcclApi* ra = rccl_api();
+    if (!ra || !comm) return 0;
+    const int rc = ra->comm_destroy(comm);
+    return rc == 0 ? 0 : fail("ncclCommDestroy failed: %s", rccl_err(ra, rc));
 }
 
 int ccsp_time_embedding(ccsp_model* m, int32_t t, float* out, void* stream) {

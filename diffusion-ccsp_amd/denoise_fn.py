@@ -135,6 +135,7 @@ class ConstraintDiffuser(object):
         self._params = None       # name -> device tensor
         self._h = None
         self._energy_hook = None  # (ctypes trampoline, views) of the MALA shard hook: re-installed on every new native model
+        self._energy_comm = None  # ncclComm_t of the in-library reduction (sharding.enable_global_batch_energy, native form)
         self._generation = 0      # bumped for every native model created: handles are compared by this, not by address
         self._graphs = {}                     # id(batch) -> (weakref to the batch, content key, _Graph)
         self._live_graphs = weakref.WeakSet()  # every _Graph built on the current native model, wherever it is referenced
@@ -358,6 +359,9 @@ class ConstraintDiffuser(object):
             # MALA global-batch mode (sharding.enable_global_batch_energy): the hook lives on the native model, which was just
             # re-created (weights reloaded, or another `timesteps` bound) -- without it the shards would silently decouple
             _lib.check(L.ccsp_model_set_energy_hook(h, C.cast(hook[0], C.c_void_p), None))
+        comm = getattr(self, '_energy_comm', None)
+        if comm:                                  # the native form of the same coupling (ccsp_model_set_energy_allreduce)
+            _lib.check(L.ccsp_model_set_energy_allreduce(h, C.c_void_p(comm)))
         return h
 
     def _graph(self, batch):

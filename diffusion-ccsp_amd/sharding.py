@@ -116,17 +116,54 @@ class _DevicePair(object):
         self.__cuda_array_interface__ = {'shape': (2,), 'typestr': '<f4', 'data': (int(ptr), False), 'version': 2}
 
 
-def enable_global_batch_energy(gd, dist):
-    """MALA global-batch mode on the HIP path (ccsp_model_set_energy_hook): every inner step's shard energies are summed
-    over the ranks of `dist` on the chain's stream before the accept test -- ``ncclAllReduce(sum, 2 floats)`` over
-    RCCL/xGMI.  The hook is kept on the denoiser and re-installed whenever its native model is re-created (weights reloaded,
-    another ``timesteps`` bound).  ``dist=None`` removes it.  The per-timestep acceptance rates a rank reads back remain those of its own shard."""
+def _native_comm(dist, device):
+    """an RCCL communicator of the library's own over the ranks of `dist` (ccsp_rccl_comm_create): rank 0 draws the unique id, the
+    process group carries its 128 bytes to the other ranks, every rank joins.  -> ncclComm_t as int"""
+    import ctypes as C
     from . import _lib
+    L = _lib.lib()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    buf = C.create_string_buffer(128)
+    if rank == 0:
+        _lib.check(L.ccsp_rccl_unique_id(buf))
+    box = [bytes(buf.raw)]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    comm = C.c_void_p()
+    with torch.cuda.device(device):
+        _lib.check(L.ccsp_rccl_comm_create(world, rank, box[0], C.byref(comm)))
+    return comm.value
+
+
+def enable_global_batch_energy(gd, dist, native=None):
+    """MALA global-batch mode on the HIP path: every inner step's shard energies {E(x), E(x_hat)} are summed over the ranks of `dist`
+    on the chain's stream before the accept test (the reference's energies are one scalar for the whole batch, ddpm.py:1026-1038).
+    native (default: when the backend is nccl = RCCL): ``ncclAllReduce(sum, 2 floats)`` enqueued by the LIBRARY on a communicator
+    of its own (ccsp_model_set_energy_allreduce) -- no Python in the chain.  Otherwise a ctypes hook that calls ``dist.all_reduce``
+    (ccsp_model_set_energy_hook; the gloo tests).  Kept on the denoiser and re-installed whenever its native model is
+    re-created (weights reloaded, another ``timesteps`` bound).  ``dist=None`` removes it.  The per-timestep acceptance rates a rank
+    reads back remain those of its own shard."""
+    from . import _lib
+    import ctypes as C
     core = gd._core()
     h = gd._handle()
+    L = _lib.lib()
     if dist is None:
-        _lib.check(_lib.lib().ccsp_model_set_energy_hook(h, None, None))
+        _lib.check(L.ccsp_model_set_energy_hook(h, None, None))
+        _lib.check(L.ccsp_model_set_energy_allreduce(h, None))
+        old = getattr(core, '_energy_comm', None)
+        if old:
+            L.ccsp_rccl_comm_destroy(C.c_void_p(old))
         core._energy_hook = None
+        core._energy_comm = None
+        return
+    if native is None:
+        native = getattr(dist, 'get_backend', lambda: '')() == 'nccl'
+    if native:
+        comm = getattr(core, '_energy_comm', None) or _native_comm(dist, core.device)
+        core._energy_comm = comm
+        core._energy_hook = None
+        _lib.check(L.ccsp_model_set_energy_allreduce(h, C.c_void_p(comm)))
         return
     views = {}
 
@@ -141,5 +178,4 @@ def enable_global_batch_energy(gd, dist):
             return 1
     cb = _lib.ENERGY_HOOK(hook)
     core._energy_hook = (cb, views)         # keep the trampoline alive as long as the model
-    import ctypes as C
-    _lib.check(_lib.lib().ccsp_model_set_energy_hook(h, C.cast(cb, C.c_void_p), None))
+    _lib.check(L.ccsp_model_set_energy_hook(h, C.cast(cb, C.c_void_p), None))

@@ -215,6 +215,19 @@ int ccsp_compose_chain_run(ccsp_model* first, ccsp_graph* graph_first, ccsp_mode
  * (e.g. an RCCL all_reduce) and returns 0.  NULL removes the hook (replica semantics: each shard is its own batch). */
 typedef int (*ccsp_energy_hook)(void* ctx, float* pair, void* stream);
 int ccsp_model_set_energy_hook(ccsp_model* model, ccsp_energy_hook hook, void* ctx);
+/* The same reduction inside the library: with a communicator installed, every MALA inner step enqueues
+ * ncclAllReduce(pair, pair, 2, ncclFloat32, ncclSum, comm, stream) on the chain's own stream between the energy evaluation at the
+ * proposal and the accept step -- no callback, no host round trip (the Python trampoline of round 3 cost 10 % of a C4 chain with
+ * ONE rank).  RCCL is bound at run time (dlopen "librccl.so", or CCSP_RCCL_LIB): a process that already carries an RCCL
+ * (PyTorch-ROCm) gets that instance.  comm = an ncclComm_t; NULL removes it; a communicator takes precedence over a hook.
+ * ccsp_rccl_unique_id / ccsp_rccl_comm_create / ccsp_rccl_comm_destroy wrap ncclGetUniqueId / ncclCommInitRank (on the calling
+ * thread's current device; collective over the n_ranks callers) / ncclCommDestroy for hosts that have no communicator of their
+ * own: rank 0 draws the 128-byte id, sends it to the other ranks by any means, every rank creates its communicator. */
+#define CCSP_RCCL_ID_BYTES 128
+int ccsp_model_set_energy_allreduce(ccsp_model* model, void* comm);
+int ccsp_rccl_unique_id(void* id /* host, CCSP_RCCL_ID_BYTES */);
+int ccsp_rccl_comm_create(int32_t n_ranks, int32_t rank, const void* id, void** comm);
+int ccsp_rccl_comm_destroy(void* comm);
 
 /* Kernel-level timing of the most recent ccsp_chain_run on this graph, measured with HIP events
  * on the chain's stream (bench.py's roofline block).  evals = network evaluations executed,

@@ -134,3 +134,44 @@ def test_mala_energy_hook_is_called_on_the_chain_stream(device):
     assert big.calls == 8 * 3 and not np.array_equal(other, base)
     sharding.enable_global_batch_energy(gd, None)
     assert np.array_equal(gd.p_sample_segment(b, x0, 400, 393, seed=5).cpu().numpy(), base)
+
+
+@pytest.mark.gpu
+def test_mala_native_rccl_allreduce_one_rank(device):
+    """ccsp_model_set_energy_allreduce through sharding.enable_global_batch_energy(native): the library itself enqueues
+    ncclAllReduce(sum, 2 floats) on the chain's stream between the proposal's energy evaluation and the accept step, on an RCCL
+    communicator of its own (ccsp_rccl_unique_id / ccsp_rccl_comm_create; RCCL bound by dlopen).  One rank: the sum over the
+    communicator is the shard's own pair, so the chain must be bit-equal to the hook-free one -- and the reduction must really
+    run (rejected-step reuse keeps the shard's local energies apart from the reduced pair); removing it restores the plain path."""
+    import torch.distributed as dist
+    from diffusion_ccsp_amd import ComposedEBMDenoiseFn, ConstraintDiffuser, GaussianDiffusion, sharding
+    den = ConstraintDiffuser(dims=worlds.MODE_DIMS['diffuse_pairwise'], hidden_dim=256, input_mode='diffuse_pairwise', EBM='MALA',
+                             energy_wrapper=True, device=device, verbose=False)
+    den.load_state_dict(weights('weights_diffuse_pairwise_h256_energy.npz'))
+    gd = GaussianDiffusion(ComposedEBMDenoiseFn(den), timesteps=1000, EBM='MALA', samples_per_step=3)
+    b = worlds.triangular_batch(6, 12, seed=19).to_torch()
+    x0 = torch.zeros(b.x.shape[0], 4)
+    base = gd.p_sample_segment(b, x0, 400, 380, seed=5).cpu().numpy()
+    created = not dist.is_initialized()
+    if created:
+        import socket
+        sk = socket.socket()
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1, device_id=device)
+    try:
+        sharding.enable_global_batch_energy(gd, dist)
+        assert gd._core()._energy_comm and gd._core()._energy_hook is None
+        same = gd.p_sample_segment(b, x0, 400, 380, seed=5).cpu().numpy()
+        assert np.array_equal(same, base)
+        # the communicator survives a re-creation of the native model (another chain length bound to the same denoiser)
+        gd2 = GaussianDiffusion(ComposedEBMDenoiseFn(den), timesteps=200, EBM='MALA', samples_per_step=2)
+        gd2.p_sample_segment(b, x0, 100, 95, seed=5)
+        assert np.array_equal(gd.p_sample_segment(b, x0, 400, 380, seed=5).cpu().numpy(), base)
+        sharding.enable_global_batch_energy(gd, None)
+        assert gd._core()._energy_comm is None
+        assert np.array_equal(gd.p_sample_segment(b, x0, 400, 380, seed=5).cpu().numpy(), base)
+    finally:
+        if created:
+            dist.destroy_process_group()

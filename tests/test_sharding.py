@@ -35,7 +35,7 @@ def _worker(rank, world, port, q):
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.set_num_threads(2)
-    batch = worlds.qualitative_batch(5, 4, seed=8)            # 5 graphs -> uneven shards (3 + 2)
+    batch = worlds.qualitative_batch(5, 4, seed=8)            # 5 graphs -> uneven shards (3 + 2; 2 + 1 + 1 + 1 over four ranks)
     # weights travel from rank 0 only
     from conftest import weights
     W = weights('weights_qualitative_h64.npz') if rank == 0 else None
@@ -61,8 +61,13 @@ def test_shard_bounds_and_batches():
     assert np.array_equal(np.concatenate([s0.x, s1.x]), b.x)
 
 
-def test_world_size_2_gloo_matches_unsharded():
-    world, port = 2, _free_port()
+import pytest
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_world_size_n_gloo_matches_unsharded(world):
+    """uneven shards (5 graphs over 2 or 4 ranks): the padded all_gather of gather_poses(sizes=...) puts every shard's rows back in place"""
+    port = _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
@@ -123,8 +128,8 @@ def _mala_worker(rank, world, port, q, global_batch):
     dist.destroy_process_group()
 
 
-def _run_mala(global_batch):
-    world, port = 2, _free_port()
+def _run_mala(global_batch, world=2):
+    port = _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     procs = [ctx.Process(target=_mala_worker, args=(r, world, port, q, global_batch)) for r in range(world)]
@@ -157,3 +162,52 @@ def test_mala_global_batch_world_size_2_matches_unsharded():
         sub, r0 = sharding.shard_batch(batch, r, 2)
         parts.append(_mala_model().graph(sub.to_torch()).chain('MALA', seed=23, row_offset=r0, x=x0[r0:r0 + sub.x.shape[0]], t_first=300, t_last=293))
     assert np.array_equal(replica[0][1], np.concatenate(parts))
+
+
+def test_mala_global_batch_world_size_4_uneven_shards():
+    """four ranks, five graphs (2 + 1 + 1 + 1): the all-reduced energies make every rank's shard follow the unsharded chain"""
+    b = worlds.triangular_batch(5, 6, seed=19)
+    x0 = (np.random.default_rng(4).standard_normal((b.x.shape[0], 4)) * 0.3).astype(np.float32)
+    mk = b.mask.astype(bool)
+    x0[mk] = b.x[mk][:, 3:7]
+    want = _mala_model().graph(b.to_torch()).chain('MALA', seed=23, x=x0, t_first=300, t_last=296)
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_mala_worker4, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=900) for _ in range(4)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, x, calls in got:
+        assert calls == 5 * 3 and np.array_equal(x, want), rank
+
+
+def _mala_worker4(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    m = _mala_model()
+    calls = [0]
+
+    def hook(pair):
+        t = torch.from_numpy(pair)
+        dist.all_reduce(t)
+        calls[0] += 1
+    m.set_energy_hook(hook)
+    b = worlds.triangular_batch(5, 6, seed=19)
+    x0 = (np.random.default_rng(4).standard_normal((b.x.shape[0], 4)) * 0.3).astype(np.float32)
+    mk = b.mask.astype(bool)
+    x0[mk] = b.x[mk][:, 3:7]
+
+    def fn(sub, seed, row_offset):
+        xs = x0[row_offset:row_offset + sub.x.shape[0]]
+        return torch.from_numpy(m.graph(sub.to_torch()).chain('MALA', seed=seed, row_offset=row_offset, x=xs, t_first=300, t_last=296))
+    x = sharding.sample_sharded(fn, b, dist, seed=23)
+    q.put((rank, x.numpy(), calls[0]))
+    dist.barrier()
+    dist.destroy_process_group()
