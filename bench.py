@@ -291,12 +291,119 @@ def throughput_regime(gd, cfg, worlds, dev, args, graphs=1024):
     return out
 
 
+def sd_main(args):
+    """--config sd: the StructDiffusion transformer baseline (denoise_fn.py:391-451, transformer.py:43-82) on 256 graphs x 7
+    objects (8-token sequences), T=1000 ULA S=10, hidden_dim 256 (transformer width 512, 4 blocks, 2 heads).  Not a BASELINE.json
+    configuration: the place north_star attaches "MFMA for the dense transformer linear layers" to.  Random-init weights (nn.Linear
+    default init; the reference ships no checkpoint and timing is value-independent).  Graphs are independent: N ranks = N replicas of
+    the shard, no collective in the chain."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP path has no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1 or args.force_dist:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    from diffusion_ccsp_amd import ConstraintDiffuser, GaussianDiffusion, device_info, worlds
+    B = args.graphs_per_gpu or 256
+    S = args.samples_per_step
+    dims = worlds.MODE_DIMS['qualitative']
+    den = ConstraintDiffuser(dims=dims, hidden_dim=HIDDEN, input_mode='qualitative', EBM='ULA', device=dev, verbose=False, model='StructDiffusion')
+    den.reset_parameters(0)
+    gd = GaussianDiffusion(den, timesteps=T_STEPS, EBM='ULA', samples_per_step=S)
+    batch_np = worlds.qualitative_batch(B, 7, seed=5 + rank)
+    n_nodes = batch_np.x.shape[0]
+    base = batch_np.to_torch(dev)
+
+    def one_step(k):
+        return gd.sample(base.clone(), seed=1000 + k, row_offset=rank * n_nodes)
+    for k in range(args.warmup):
+        one_step(k)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        x = one_step(args.warmup + k)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = world * B * args.steps / elapsed
+    M, Wd = 8 * B, 2 * HIDDEN
+    mma = os.environ.get('CCSP_MMA', 'f16x2')
+    prods, pipe = (3, 'f16') if mma == 'f16x2' else (1, 'f32')
+    flops_eval = 4 * 2.0 * M * 12 * Wd * Wd                      # per block: in_proj 3 Wd^2, out_proj Wd^2, c_fc 4 Wd^2, c_proj 4 Wd^2 per token
+    rec = {'metric': 'samples/sec, T=1000 ULA, StructDiffusion transformer baseline, 7-obj (all chains per second; not a BASELINE.json configuration)',
+           'value': value, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+           'dtype': 'f32 (f16x2 split operands: 3 fp16 MFMA products per fp32 product, fp32 accumulate)' if mma == 'f16x2' else 'f32',
+           'data': 'synthetic (random-init weights: nn.Linear default init)',
+           'config': {'workload': 'StructDiffusion baseline (denoise_fn.py:391-451): %d graphs x 7 objects per GPU, 8-token sequences, width %d, 4 blocks, 2 heads, '
+                                  'T=1000 ULA S=%d' % (B, Wd, S), 'name': 'sd', 'graphs_per_gpu': B, 'nodes_per_gpu': n_nodes, 'token_rows': M,
+                      'evaluations_per_chain': T_STEPS * (1 + S), 'samples_per_step': S, 'gemm_mode': mma,
+                      'parallelism': 'independent replicas x%d (graphs are independent; no collective)' % world,
+                      'outputs_finite': bool(torch.isfinite(x).all().item())}}
+    if rank == 0 and not args.no_roofline:
+        b = base.clone()
+        gd.profile(b, True)
+        gd.sample(b, seed=77)
+        ks = gd.kernel_stats()
+        ev = ks.get('StructDiffusion evaluation')
+        if ev:
+            us = 1e3 * ev[1]
+            rec['roofline'] = {'bound': 'mfma', 'achieved': prods * flops_eval / (us * 1e-6) / 1e12, 'peak': PEAKS[pipe], 'unit': 'TFLOP/s',
+                               'frac': prods * flops_eval / (us * 1e-6) / 1e12 / PEAKS[pipe], 'traffic': None,
+                               'kernel': 'one whole evaluation (30 launches: embed, 4 x [ln_1, in_proj, attention, out_proj, c_fc, c_proj, ln_2], decode); '
+                                         'per-kernel durations: profiles/r04_kernel_stats_sd.csv',
+                               'us_per_evaluation': us, 'calls_timed': ev[0], 'executed_flops_fp32_equiv_per_evaluation': flops_eval,
+                               'products_per_fp32_product': prods, 'pipe': pipe,
+                               'frac_fp32_equiv': flops_eval / (us * 1e-6) / 1e12 / PEAKS['f32'],
+                               'note': 'flops of the four GEMMs of the four blocks (attention scores, LayerNorms, decoder not counted) x MFMA products per fp32 product / '
+                                       'the mean duration of a whole evaluation (HIP events on the chain stream) / the dense peak of the pipe'}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+        import oracle                                   # the checker as CPU baseline (never the product path)
+        nb = 16
+        small = worlds.qualitative_batch(nb, 7, seed=5)
+        om = oracle.OracleModel({k: v.cpu().numpy() for k, v in den.state_dict().items()}, dims, HIDDEN, 13, timesteps=T_STEPS, samples_per_step=S, model='StructDiffusion')
+        og = om.graph(small.to_torch())
+        poses = (np.random.default_rng(1).standard_normal((small.x.shape[0], 4)) * 0.7).astype(np.float32)
+        og.denoise(poses, 500)
+        n_ev, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < 10.0:
+            og.denoise(poses, 500 - n_ev % 400)
+            n_ev += 1
+        dt = (time.perf_counter() - t1) / n_ev
+        rec['cpu_baseline'] = {'value': nb / (dt * T_STEPS * (1 + S)), 'unit': 'samples/s', 'cores': os.cpu_count(), 'threads_used': 1, 'kind': 'port',
+                               'sample': '%d single evaluations of a %d-graph batch by the C oracle (oracle/ccsp_oracle.c, one thread), extrapolated x %d evaluations per chain'
+                                         % (n_ev, nb, T_STEPS * (1 + S)), 'sec_per_evaluation_per_graph': dt / nb}
+    if rank == 0:
+        rec['device'] = device_info()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(rec), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--config', default='c2', choices=sorted(CONFIGS) + ['c3'])
+    ap.add_argument('--config', default='c2', choices=sorted(CONFIGS) + ['c3', 'sd'])
     ap.add_argument('--graphs-per-gpu', type=int, default=0, help='override the configuration\'s per-GPU shard size')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
                     help='weak: the configuration\'s shard on every GPU (C3 at N = 8).  strong: C3 proper -- 2048 graphs in total (8 shards '
@@ -314,6 +421,8 @@ def main():
     ap.add_argument('--mala-global-batch', action='store_true',
                     help='c4 with N > 1: couple the shards through the reference\'s batch-scalar energies (2-float all_reduce per inner step)')
     args = ap.parse_args()
+    if args.config == 'sd':
+        return sd_main(args)
     cname = 'c2' if args.config == 'c3' else args.config
     cfg = CONFIGS[cname]
     S = args.samples_per_step

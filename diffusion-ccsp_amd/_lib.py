@@ -83,7 +83,7 @@ def build(force=False, verbose=False):
 # kernels that request operands by inline-asm loads the compiler cannot see and wait for them with hand-counted s_waitcnt
 # (csrc/ccsp_f16x2.h h2_ld16 / h2_ld_wait, csrc/ccsp_fused.h fz_ld_frag): a scratch spill there adds vector-memory operations to the
 # counts and can store a register whose load is still in flight, so the build refuses a compiler that spills in them
-GUARDED_KERNELS = ('k_rowgemm_h2', 'k_edge_h2', 'k_edge_bwd_h2', 'k_node_direct', 'k_node_energy_h2', 'k_eval_fused')
+GUARDED_KERNELS = ('k_rowgemm_h2', 'k_edge_h2', 'k_edge_bwd_h2', 'k_node_direct', 'k_node_energy_h2', 'k_eval_fused', 'k_sd_gemm_h2')
 
 
 def check_no_scratch(remarks):

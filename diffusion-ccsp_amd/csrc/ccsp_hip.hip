@@ -1434,7 +1434,12 @@ struct ccsp_model {
     int row_mode = -1, edge_mt = -1;  // CCSP_ROW_MODE / CCSP_EDGE_MT: force a variant of the f16x2 kernels (-1: by tile count)
     int edge_small = -1;              // CCSP_EDGE_SMALL=1 / 0: always / never the 16-edge-tile kernel k_edge_h2s (-1: by tile count)
     // StructDiffusion baseline (model_kind 1): transformer weights as given ([out, in] row-major)
-    struct SdLayer { float *in_w, *in_b, *out_w, *out_b, *ln1_g, *ln1_b, *fc_w, *fc_b, *proj_w, *proj_b, *ln2_g, *ln2_b; };
+    struct SdLayer {
+        float *in_w, *in_b, *out_w, *out_b, *ln1_g, *ln1_b, *fc_w, *fc_b, *proj_w, *proj_b, *ln2_g, *ln2_b;
+        unsigned short *in_wH = nullptr, *out_wH = nullptr, *fc_wH = nullptr, *proj_wH = nullptr;    // fp16 planes [2][N][K] * 2^exp (k_sd_gemm_h2)
+        int in_e = 0, out_e = 0, fc_e = 0, proj_e = 0;
+    };
+    int sd_h2 = 0;         // 1: the transformer's GEMMs on the f16 pipe (f16x2; Wd a multiple of 128, CCSP_MMA unset or f16x2)
     int Wd = 0;            // transformer width: 2H, or 3H with a grasp group
     float *lnpre_g = nullptr, *lnpre_b = nullptr, *lnpost_g = nullptr, *lnpost_b = nullptr;
     float* sd_pe = nullptr;   // [8][Wd] positional-encoding rows (transformer.py:22-28)
@@ -1516,6 +1521,7 @@ struct ccsp_graph {
     int *tok_node = nullptr, *tok_pos = nullptr, *node_tok = nullptr, *mask_from = nullptr;
     float *gemb = nullptr, *remb = nullptr;
     float *sdX = nullptr, *sdY = nullptr, *sdQKV = nullptr, *sdA = nullptr, *sdF = nullptr;
+    unsigned int* sdMax = nullptr;     // [4][M] bits of the row maxima of sdY (ln_1 output), sdA, sdX (after out_proj), sdF: the f16x2 GEMMs' row exponents
     // hipGraph mode (small batches): step table, header, counter and the instantiated per-S graphs
     StepEntry* d_tab = nullptr;
     ChainHeader* d_hdr = nullptr;
@@ -1858,6 +1864,26 @@ void sd_gemm(int M, int K, int N, const float* A, const float* W, const float* b
         hipLaunchKernelGGL((k_sd_gemm<1, EPI>), dim3(rt * (N / 64)), dim3(256), 0, s, M, K, N, A, W, b, Cm);
 }
 
+constexpr int SD_KSPLIT = 4;       // most K slices of the c_proj GEMM (sdY holds that many partial products); used: 2 (r04 A/B: 453 us per evaluation against 473 with 4, 477 with 1)
+
+// returns the number of K slices written (1: Cm is the result; > 1: partial products [slices][M][N], summed by the LayerNorm kernel that reads them)
+template <int EPI>
+int sd_gemm_h2(const ccsp_model* m, int M, int K, int N, const float* A, const unsigned int* amax, const unsigned short* WH, int w_exp, const float* b, float* Cm,
+               unsigned int* cmax, hipStream_t s, bool may_split = false) {
+    // 64-column tiles when the 128-column tile list would not give every CU two workgroups (the N = Wd GEMMs of a 256-graph batch)
+    static const int force_tn = getenv("CCSP_SD_TN") ? atoi(getenv("CCSP_SD_TN")) : 0;
+    static const int force_ks = getenv("CCSP_SD_KSPLIT") ? atoi(getenv("CCSP_SD_KSPLIT")) : -1;
+    const bool tn64 = force_tn ? force_tn == 64 : (long)nblk(M, 64) * (N / 128) < 2L * m->ncu;
+    int ks = 1;
+    if (may_split && EPI == SD_EPI_BIAS && cmax == nullptr && K % (64 * SD_KSPLIT) == 0 && (long)nblk(M, 64) * (N / 64) < 2L * m->ncu) ks = 2;
+    if (may_split && force_ks >= 1 && K % (64 * force_ks) == 0 && force_ks <= SD_KSPLIT) ks = force_ks;
+    if (tn64)
+        hipLaunchKernelGGL((k_sd_gemm_h2<EPI, 64>), dim3(nblk(M, 64) * (N / 64), ks), dim3(256), 0, s, M, K, N, A, amax, WH, (size_t)N * K, w_exp, b, Cm, cmax);
+    else
+        hipLaunchKernelGGL((k_sd_gemm_h2<EPI, 128>), dim3(nblk(M, 64) * (N / 128), ks), dim3(256), 0, s, M, K, N, A, amax, WH, (size_t)N * K, w_exp, b, Cm, cmax);
+    return ks;
+}
+
 // one evaluation of the transformer at the poses whose embeddings are in g->pemb; result -> g->eps
 template <int H>
 int launch_eval_sd(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s) {
@@ -1866,15 +1892,33 @@ int launch_eval_sd(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s) {
     prof_mark(g, s, CCSP_K_SD_EVAL);
     hipLaunchKernelGGL(k_sd_embed, dim3(nblk(M, 4)), dim3(256), 0, s, M, H, Wd, m->d.grasp_dim > 0 ? 1 : 0, g->tok_node, g->tok_pos, g->gemb,
                        g->remb, g->pemb, m->temb + (size_t)t * H, m->sd_pe, m->lnpre_g, m->lnpre_b, g->sdX);
+    unsigned int* const nomax = nullptr;
+    unsigned int *mY = g->sdMax, *mA = g->sdMax + M, *mX = g->sdMax + 2 * (size_t)M, *mF = g->sdMax + 3 * (size_t)M;
     for (int l = 0; l < SD_LAYERS; ++l) {
         const ccsp_model::SdLayer& w = m->sd[l];
-        hipLaunchKernelGGL(k_sd_ln<0>, dim3(nblk(M, 4)), dim3(256), 0, s, M, Wd, g->sdX, w.ln1_g, w.ln1_b, g->sdY);
+        if (m->sd_h2) {
+            // row maxima travel with the activations: ln_1 stores those of its output and clears the three buffers this block accumulates
+            // (from the second block on, ln_1 ran fused behind the previous block's ln_2: k_sd_ln2ln1)
+            if (l == 0) hipLaunchKernelGGL(k_sd_ln<0>, dim3(nblk(M, 4)), dim3(256), 0, s, M, Wd, g->sdX, w.ln1_g, w.ln1_b, g->sdY, mY, mA, mX, mF, 1);
+            sd_gemm_h2<SD_EPI_BIAS>(m, M, Wd, 3 * Wd, g->sdY, mY, w.in_wH, w.in_e, w.in_b, g->sdQKV, nomax, s);
+            hipLaunchKernelGGL(k_sd_attn, dim3(g->sd_B * SD_HEADS), dim3(256), 0, s, Wd, g->sdQKV, g->mask_from, g->sdA, mA);
+            sd_gemm_h2<SD_EPI_RESID>(m, M, Wd, Wd, g->sdA, mA, w.out_wH, w.out_e, w.out_b, g->sdX, mX, s);
+            sd_gemm_h2<SD_EPI_QGELU>(m, M, Wd, 4 * Wd, g->sdX, mX, w.fc_wH, w.fc_e, w.fc_b, g->sdF, mF, s);
+            const int parts = sd_gemm_h2<SD_EPI_BIAS>(m, M, 4 * Wd, Wd, g->sdF, mF, w.proj_wH, w.proj_e, w.proj_b, g->sdY, nomax, s, true);
+            if (l + 1 < SD_LAYERS)
+                hipLaunchKernelGGL(k_sd_ln2ln1, dim3(nblk(M, 4)), dim3(256), 0, s, M, Wd, g->sdX, w.ln2_g, w.ln2_b, m->sd[l + 1].ln1_g, m->sd[l + 1].ln1_b, g->sdY,
+                                   mY, mA, mX, mF, parts);
+            else
+                hipLaunchKernelGGL(k_sd_ln<1>, dim3(nblk(M, 4)), dim3(256), 0, s, M, Wd, g->sdY, w.ln2_g, w.ln2_b, g->sdX, nomax, nomax, nomax, nomax, parts);
+            continue;
+        }
+        hipLaunchKernelGGL(k_sd_ln<0>, dim3(nblk(M, 4)), dim3(256), 0, s, M, Wd, g->sdX, w.ln1_g, w.ln1_b, g->sdY, nomax, nomax, nomax, nomax, 1);
         sd_gemm<SD_EPI_BIAS>(M, Wd, 3 * Wd, g->sdY, w.in_w, w.in_b, g->sdQKV, s);
-        hipLaunchKernelGGL(k_sd_attn, dim3(g->sd_B * SD_HEADS), dim3(256), 0, s, Wd, g->sdQKV, g->mask_from, g->sdA);
+        hipLaunchKernelGGL(k_sd_attn, dim3(g->sd_B * SD_HEADS), dim3(256), 0, s, Wd, g->sdQKV, g->mask_from, g->sdA, nomax);
         sd_gemm<SD_EPI_RESID>(M, Wd, Wd, g->sdA, w.out_w, w.out_b, g->sdX, s);
         sd_gemm<SD_EPI_QGELU>(M, Wd, 4 * Wd, g->sdX, w.fc_w, w.fc_b, g->sdF, s);
         sd_gemm<SD_EPI_BIAS>(M, 4 * Wd, Wd, g->sdF, w.proj_w, w.proj_b, g->sdY, s);
-        hipLaunchKernelGGL(k_sd_ln<1>, dim3(nblk(M, 4)), dim3(256), 0, s, M, Wd, g->sdY, w.ln2_g, w.ln2_b, g->sdX);
+        hipLaunchKernelGGL(k_sd_ln<1>, dim3(nblk(M, 4)), dim3(256), 0, s, M, Wd, g->sdY, w.ln2_g, w.ln2_b, g->sdX, nomax, nomax, nomax, nomax, 1);
     }
     hipLaunchKernelGGL(k_sd_decode<H>, dim3(nblk(g->N, 4)), dim3(256), 0, s, g->N, Wd, P, g->F, g->node_tok, g->sdX, m->lnpost_g, m->lnpost_b,
                        m->pd0_wT, m->pd0_b, m->pd2_w, m->pd2_b, g->xfeat, g->mask, g->eps);
@@ -2893,6 +2937,37 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
             TRY(dup(&w.ln2_g, Wd)); TRY(dup(&w.ln2_b, Wd));
         }
         TRY(dup(&m->lnpost_g, Wd)); TRY(dup(&m->lnpost_b, Wd));
+        {   // f16x2 planes of the four GEMM weights of every block (one exponent per tensor)
+            const char* mma = getenv("CCSP_MMA");
+            m->sd_h2 = (Wd % 128 == 0 && (!mma || strcmp(mma, "f16x2") == 0)) ? 1 : 0;
+            if (m->sd_h2) {
+                unsigned int* mx = nullptr;
+                TRY(dev_alloc(reg, &mx, 4 * SD_LAYERS));
+                HIP_TRY(hipMemsetAsync(mx, 0, 4 * SD_LAYERS * sizeof(unsigned int), s));
+                const long n_in = (long)3 * Wd * Wd, n_out = (long)Wd * Wd, n_fc = (long)4 * Wd * Wd;
+                for (int l = 0; l < SD_LAYERS; ++l) {
+                    ccsp_model::SdLayer& w = m->sd[l];
+                    hipLaunchKernelGGL(k_absmax_bits, dim3(nblk(n_in, 256)), dim3(256), 0, s, n_in, w.in_w, mx + 4 * l);
+                    hipLaunchKernelGGL(k_absmax_bits, dim3(nblk(n_out, 256)), dim3(256), 0, s, n_out, w.out_w, mx + 4 * l + 1);
+                    hipLaunchKernelGGL(k_absmax_bits, dim3(nblk(n_fc, 256)), dim3(256), 0, s, n_fc, w.fc_w, mx + 4 * l + 2);
+                    hipLaunchKernelGGL(k_absmax_bits, dim3(nblk(n_fc, 256)), dim3(256), 0, s, n_fc, w.proj_w, mx + 4 * l + 3);
+                }
+                unsigned int h_mx[4 * SD_LAYERS];
+                HIP_TRY(hipMemcpyAsync(h_mx, mx, sizeof(h_mx), hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                auto host_exp = [](unsigned int bits) { const int be = (int)((bits >> 23) & 0xffu); return (be == 0 || be == 255) ? 0 : 140 - be; };
+                for (int l = 0; l < SD_LAYERS; ++l) {
+                    ccsp_model::SdLayer& w = m->sd[l];
+                    w.in_e = host_exp(h_mx[4 * l]); w.out_e = host_exp(h_mx[4 * l + 1]); w.fc_e = host_exp(h_mx[4 * l + 2]); w.proj_e = host_exp(h_mx[4 * l + 3]);
+                    TRY(dev_alloc(reg, &w.in_wH, (size_t)2 * n_in)); TRY(dev_alloc(reg, &w.out_wH, (size_t)2 * n_out));
+                    TRY(dev_alloc(reg, &w.fc_wH, (size_t)2 * n_fc)); TRY(dev_alloc(reg, &w.proj_wH, (size_t)2 * n_fc));
+                    hipLaunchKernelGGL(k_split2h, dim3(nblk(n_in, 256)), dim3(256), 0, s, n_in, w.in_w, w.in_e, w.in_wH);
+                    hipLaunchKernelGGL(k_split2h, dim3(nblk(n_out, 256)), dim3(256), 0, s, n_out, w.out_w, w.out_e, w.out_wH);
+                    hipLaunchKernelGGL(k_split2h, dim3(nblk(n_fc, 256)), dim3(256), 0, s, n_fc, w.fc_w, w.fc_e, w.fc_wH);
+                    hipLaunchKernelGGL(k_split2h, dim3(nblk(n_fc, 256)), dim3(256), 0, s, n_fc, w.proj_w, w.proj_e, w.proj_wH);
+                }
+            }
+        }
         // PositionalEncoding.pe rows 0..7 in fp32 like the reference buffer (transformer.py:22-28)
         std::vector<float> pe((size_t)SD_L * Wd);
         for (int pos = 0; pos < SD_L; ++pos)
@@ -3248,9 +3323,11 @@ int ccsp_graph_set_sequences(ccsp_graph* g, const int64_t* batch, const int64_t*
     const int M = B * SD_L, Wd = m->Wd;
     auto& reg = g->allocs;
     if (dev_upload(reg, &g->tok_node, tok_node, s) || dev_upload(reg, &g->tok_pos, tok_pos, s) || dev_upload(reg, &g->node_tok, node_tok, s) ||
-        dev_upload(reg, &g->mask_from, mask_from, s) || dev_alloc(reg, &g->sdX, (size_t)M * Wd) || dev_alloc(reg, &g->sdY, (size_t)M * Wd) ||
-        dev_alloc(reg, &g->sdQKV, (size_t)M * 3 * Wd) || dev_alloc(reg, &g->sdA, (size_t)M * Wd) || dev_alloc(reg, &g->sdF, (size_t)M * 4 * Wd))
+        dev_upload(reg, &g->mask_from, mask_from, s) || dev_alloc(reg, &g->sdX, (size_t)M * Wd) || dev_alloc(reg, &g->sdY, (size_t)SD_KSPLIT * M * Wd) ||
+        dev_alloc(reg, &g->sdQKV, (size_t)M * 3 * Wd) || dev_alloc(reg, &g->sdA, (size_t)M * Wd) || dev_alloc(reg, &g->sdF, (size_t)M * 4 * Wd) ||
+        dev_alloc(reg, &g->sdMax, (size_t)4 * M))
         return 1;
+    HIP_TRY(hipMemsetAsync(g->sdMax, 0, (size_t)4 * M * sizeof(unsigned int), s));
     HIP_TRY(hipStreamSynchronize(s));       // the host vectors go out of scope
     g->sd_B = B; g->sd_M = M;
     g->seq_ready = true;

@@ -4,9 +4,14 @@
 //
 // One evaluation = k_sd_embed, then per block  k_sd_ln -> k_sd_gemm(in_proj) -> k_sd_attn ->
 // k_sd_gemm(out_proj, +residual) -> k_sd_gemm(c_fc, QuickGELU) -> k_sd_gemm(c_proj) -> k_sd_ln(+residual),
-// then k_sd_decode (ln_post, last H channels, pose decoder, mask fill).  The GEMMs are fp32 MFMA 32x32x2
-// tiles through LDS (the same core as k_rowgemm); 24 M Wd^2 flops per block dominate (MFMA bound).
-// Included by ccsp_hip.hip.
+// then k_sd_decode (ln_post, last H channels, pose decoder, mask fill).  24 M Wd^2 flops per block dominate.
+// Round 4: the four GEMMs of a block run on the f16 matrix pipe with the f16x2 scheme of ccsp_f16x2.h (k_sd_gemm_h2: three fp16
+// products per fp32 product, fp32 accumulate; weights pre-split once per model with one exponent per tensor; the activation rows
+// are split on the fly with one exponent per ROW taken from the row's largest magnitude, which the producing kernel leaves behind --
+// the LayerNorm / attention kernels store it, the GEMM epilogues combine their column tiles' maxima by atomicMax on the float
+// bits, an order-independent and therefore deterministic reduction).  k_sd_gemm (fp32 MFMA 32x32x2, round 1) stays for
+// CCSP_MMA=f32 and for widths that are not a multiple of 128.
+// Included by ccsp_hip.hip, after ccsp_f16x2.h.
 #pragma once
 
 constexpr int SD_L = 8;        // max_seq_len   (denoise_fn.py:272)
@@ -118,21 +123,274 @@ __device__ __forceinline__ void ln_row(float (&v)[SD_MAXV], int Wd, int lane, co
 }
 
 // Y[r] = LN(X[r])  (ACC = 0)   or   Y[r] += LN(X[r])  (ACC = 1: x = x + ln_2(mlp(x)), transformer.py:66)
+// ymax (f16x2 path, or null): bits of max |Y[r]| for the GEMM that reads Y; z0..z2: per-row maxima the GEMM epilogues / the attention
+// kernel of THIS block accumulate by atomicMax, cleared here (their readers of the previous block are done: same stream)
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// xparts > 1: X is the sum of that many split-K partial products [xparts][M][Wd], added in order
 template <int ACC>
 __global__ __launch_bounds__(256) void k_sd_ln(int M, int Wd, const float* __restrict__ X, const float* __restrict__ gam,
-                                               const float* __restrict__ bet, float* __restrict__ Y) {
+                                               const float* __restrict__ bet, float* __restrict__ Y, unsigned int* __restrict__ ymax,
+                                               unsigned int* __restrict__ z0, unsigned int* __restrict__ z1, unsigned int* __restrict__ z2, int xparts) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
+    if (lane == 0) { if (z0) z0[row] = 0u; if (z1) z1[row] = 0u; if (z2) z2[row] = 0u; }
     float v[SD_MAXV];
 #pragma unroll
-    for (int i = 0; i < SD_MAXV; ++i) v[i] = lane + 64 * i < Wd ? X[(size_t)row * Wd + lane + 64 * i] : 0.0f;
+    for (int i = 0; i < SD_MAXV; ++i) {
+        v[i] = lane + 64 * i < Wd ? X[(size_t)row * Wd + lane + 64 * i] : 0.0f;
+        for (int k = 1; k < xparts; ++k) v[i] += lane + 64 * i < Wd ? X[((size_t)k * M + row) * Wd + lane + 64 * i] : 0.0f;
+    }
     ln_row(v, Wd, lane, gam, bet);
+    unsigned int b = 0u;                                          // largest |Y| as float bits (NaN ranks above Inf and reaches the exponent as NaN)
 #pragma unroll
     for (int i = 0; i < SD_MAXV; ++i)
         if (lane + 64 * i < Wd) {
             float* dst = Y + (size_t)row * Wd + lane + 64 * i;
-            *dst = ACC ? *dst + v[i] : v[i];
+            const float o = ACC ? *dst + v[i] : v[i];
+            *dst = o;
+            const unsigned int ob = __float_as_uint(o) & 0x7fffffffu;
+            b = b > ob ? b : ob;
         }
+    if (ymax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const unsigned int t = (unsigned int)__shfl_xor((int)b, o); b = b > t ? b : t; }
+        if (lane == 0) ymax[row] = b;
+    }
+}
+
+// x = X[r] + LN_2(Y[r]) (the end of block l, transformer.py:66) and at once Y[r] = LN_1'(x) of block l + 1: one launch and one pass
+// over the row instead of two (k_sd_ln<1> then k_sd_ln<0>); same arithmetic in the same order as the two kernels.
+__global__ __launch_bounds__(256) void k_sd_ln2ln1(int M, int Wd, float* __restrict__ X, const float* __restrict__ g2, const float* __restrict__ b2,
+                                                   const float* __restrict__ g1, const float* __restrict__ b1, float* __restrict__ Y,
+                                                   unsigned int* __restrict__ ymax, unsigned int* __restrict__ z0, unsigned int* __restrict__ z1,
+                                                   unsigned int* __restrict__ z2, int yparts) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    if (lane == 0) { if (z0) z0[row] = 0u; if (z1) z1[row] = 0u; if (z2) z2[row] = 0u; }
+    float v[SD_MAXV];
+#pragma unroll
+    for (int i = 0; i < SD_MAXV; ++i) {
+        v[i] = lane + 64 * i < Wd ? Y[(size_t)row * Wd + lane + 64 * i] : 0.0f;
+        for (int k = 1; k < yparts; ++k) v[i] += lane + 64 * i < Wd ? Y[((size_t)k * M + row) * Wd + lane + 64 * i] : 0.0f;      // split-K partials, in order
+    }
+    ln_row(v, Wd, lane, g2, b2);
+#pragma unroll
+    for (int i = 0; i < SD_MAXV; ++i)
+        if (lane + 64 * i < Wd) {
+            float* dst = X + (size_t)row * Wd + lane + 64 * i;
+            v[i] = *dst + v[i];
+            *dst = v[i];
+        }
+    ln_row(v, Wd, lane, g1, b1);
+    unsigned int b = 0u;
+#pragma unroll
+    for (int i = 0; i < SD_MAXV; ++i)
+        if (lane + 64 * i < Wd) {
+            Y[(size_t)row * Wd + lane + 64 * i] = v[i];
+            const unsigned int ob = __float_as_uint(v[i]) & 0x7fffffffu;
+            b = b > ob ? b : ob;
+        }
+    if (ymax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const unsigned int t = (unsigned int)__shfl_xor((int)b, o); b = b > t ? b : t; }
+        if (lane == 0) ymax[row] = b;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_sd_gemm_h2<EPI, TN>: C[M,N] (op)= A[M,K] . W[N,K]^T + bias on the f16 pipe (f16x2).  64 x TN tiles (TN = 128: 32 x 64 per wave;
+// TN = 64: 32 x 32 per wave -- for the N = Wd GEMMs, whose 128-wide tile list would leave half the chip empty), 4 waves as 2 x 2,
+// K chunks of 32 double-buffered through LDS, operands requested TWO chunks ahead into two register sets (with one chunk of
+// lead every iteration waited an L2 round trip: 1.5 k cycles per chunk against 0.4 k of MFMA work, first build of this round).
+// A is fp32 in memory: a row's exponent comes from amax (bits of its largest magnitude, left by the producer), the split into two
+// fp16 planes happens while the chunk is staged.  W: planes [2][N][K] scaled by 2^w_exp.  Epilogue per wave through a wave-private
+// LDS tile (rows re-read as 16-byte segments): bias, residual / QuickGELU, 16-byte stores, and -- cmax non-null -- the row maxima
+// of the result for the next GEMM (DPP maximum over the lanes of a row, one atomicMax on the float bits per row and wave).
+// K % 64 == 0, N % TN == 0; M arbitrary (rows clamped).
+// ------------------------------------------------------------------------------------------
+template <int EPI, int TN>
+__global__ __launch_bounds__(256, 2) void k_sd_gemm_h2(int M, int K, int N, const float* __restrict__ A, const unsigned int* __restrict__ amax,
+                                                       const unsigned short* __restrict__ WH, size_t w_plane, int w_exp,
+                                                       const float* __restrict__ bias, float* __restrict__ Cm, unsigned int* __restrict__ cmax) {
+    constexpr int NJ = TN / 64;                                   // 32-column MFMA tiles per wave
+    constexpr int APL = 64 * H2_BK, BPL = TN * H2_BK, STAGE = 2 * APL + 2 * BPL;
+    constexpr int NB = TN / 64;                                   // B pieces (16 bytes) per thread and plane
+    constexpr int CW_LD = 32 * NJ + 4, CW_SZ = 32 * CW_LD;        // wave-private epilogue tile [32][CW_LD] floats
+    constexpr int SMEM_US = 2 * STAGE * 2 > 4 * CW_SZ * 4 ? 2 * STAGE : 4 * CW_SZ * 2;
+    __shared__ __attribute__((aligned(16))) unsigned short smem[SMEM_US + 2 * 64];
+    int* sE = reinterpret_cast<int*>(smem + SMEM_US);
+    const int nct = N / TN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int row0 = (bid / nct) * 64, col0 = (bid % nct) * TN;
+    const int nrows = M - row0 < 64 ? M - row0 : 64;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    // split K (gridDim.y slices; EPI = BIAS only): slice y multiplies K columns [y Ks, (y + 1) Ks) and writes its partial product to
+    // Cm + y M N (the bias rides on slice 0); the LayerNorm kernel that reads the result adds the slices in order -- deterministic,
+    // and a K = 4 Wd GEMM with one 64 x 64 tile per CU becomes four times as many workgroups of a quarter of the chain
+    const int Ks = K / (int)gridDim.y, k_first = (int)blockIdx.y * Ks;
+    Cm += (size_t)blockIdx.y * M * N;
+    const int lr = tid >> 3, lq = tid & 7;                        // A producer: rows lr, lr + 32, fp32 columns 4 lq .. + 3 of the chunk
+    const float* a_ptr[2];
+    int a_exp[2], a_st[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int r = lr + 32 * i;
+        r = r < nrows ? r : nrows - 1;
+        a_ptr[i] = A + (size_t)(row0 + r) * K + k_first + lq * 4;
+        a_exp[i] = h2_scale_exp(__uint_as_float(amax[row0 + r]));
+        a_st[i] = h2_off(lr + 32 * i, lq >> 1) + (lq & 1) * 4;
+    }
+    if (lq == 0) { sE[lr] = a_exp[0]; sE[lr + 32] = a_exp[1]; }
+    const int brow = tid >> 2, bq = tid & 3;                      // B copy: rows brow (+ 64), piece bq, both planes
+    const unsigned short* b_ptr = WH + (size_t)(col0 + brow) * K + k_first + bq * 8;
+    const int b_st = h2_off(brow, bq);
+    // operand loads by inline asm, waited for by counted s_waitcnt (h2_ld16): hipcc sinks an ordinary load to its first use -- the
+    // ds_write of the NEXT trip -- which puts a memory round trip into every chunk (measured: 1.8 k cycles per chunk against 0.2 k of
+    // MFMA work, whatever the prefetch distance written in the source)
+    h2_f4 ra[2][2];                                               // [register set][row]
+    h2_f4 rb[2][2 * NB];
+    constexpr int NLD = 2 + 2 * NB;                               // loads per chunk and thread
+    auto gload = [&](int c, int set) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) h2_ld16(ra[set][i], a_ptr[i] + c * H2_BK);
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                h2_ld16(rb[set][i * 2 + p], reinterpret_cast<const float*>(b_ptr + (size_t)p * w_plane + (size_t)i * 64 * K + c * H2_BK));
+    };
+    // the set's loads have landed; `younger`: the OTHER set was requested after it and may stay in flight
+    auto gwait = [&](int set, bool younger) {
+        if (NB == 1) {
+            if (younger) asm volatile("s_waitcnt vmcnt(4)" : "+v"(ra[set][0]), "+v"(ra[set][1]), "+v"(rb[set][0]), "+v"(rb[set][1]) :: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[set][0]), "+v"(ra[set][1]), "+v"(rb[set][0]), "+v"(rb[set][1]) :: "memory");
+        } else {
+            if (younger) asm volatile("s_waitcnt vmcnt(6)" : "+v"(ra[set][0]), "+v"(ra[set][1]), "+v"(rb[set][0]), "+v"(rb[set][1]), "+v"(rb[set][2 * NB - 2]), "+v"(rb[set][2 * NB - 1]) :: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[set][0]), "+v"(ra[set][1]), "+v"(rb[set][0]), "+v"(rb[set][1]), "+v"(rb[set][2 * NB - 2]), "+v"(rb[set][2 * NB - 1]) :: "memory");
+        }
+    };
+    static_assert(NLD == 4 || NLD == 6, "the literal wait counts above");
+    auto lstore = [&](int stage, int set) {
+        unsigned short* As = smem + stage * STAGE;
+        unsigned short* Bs = As + 2 * APL;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float h[4] = {ra[set][i][0], ra[set][i][1], ra[set][i][2], ra[set][i][3]};
+            unsigned short p1[4], p2[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split2h(ldexpf(h[e], a_exp[i]), p1[e], p2[e]);
+            unsigned short* d = As + a_st[i];
+            *reinterpret_cast<uint2*>(d) = make_uint2(p1[0] | ((unsigned)p1[1] << 16), p1[2] | ((unsigned)p1[3] << 16));
+            *reinterpret_cast<uint2*>(d + APL) = make_uint2(p2[0] | ((unsigned)p2[1] << 16), p2[2] | ((unsigned)p2[3] << 16));
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) *reinterpret_cast<h2_f4*>(Bs + p * BPL + b_st + i * 64 * H2_BK) = rb[set][i * 2 + p];
+    };
+    floatx16 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    // one k-step (16) of a staged chunk: same product order per accumulator as h2_kstep
+    auto kstep = [&](const unsigned short* st, int ks) {
+        const int piece = (lane >> 5) + 2 * ks;
+        half8 a[2], b[NJ][2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            a[p] = *reinterpret_cast<const half8*>(st + p * APL + h2_off(wm * 32 + (lane & 31), piece));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) b[j][p] = *reinterpret_cast<const half8*>(st + 2 * APL + p * BPL + h2_off(wn * 32 * NJ + 32 * j + (lane & 31), piece));
+        }
+        constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[PA[q]], b[j][PB[q]], acc[j], 0, 0, 0);
+    };
+    const int nch = Ks / H2_BK;                                   // (even: the slice is a multiple of 64)
+    gload(0, 0);
+    gwait(0, false);
+    lstore(0, 0);
+    gload(1, 1);
+    if (nch > 2) gload(2, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    for (int c = 0; c < nch; c += 2) {                            // two chunks per trip: the register-set indices are constants
+        kstep(smem, 0);
+        kstep(smem, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        gwait(1, c + 2 < nch);                                    // chunk c + 1, requested two chunks ago; younger: chunk c + 2 in set 0
+        lstore(1, 1);
+        if (c + 3 < nch) gload(c + 3, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (not __syncthreads(): its fence is a vmcnt(0) that drains the prefetch)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        kstep(smem + STAGE, 0);
+        kstep(smem + STAGE, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 2 < nch) {
+            gwait(0, c + 3 < nch);                                // chunk c + 2; younger: chunk c + 3 in set 1
+            lstore(0, 0);
+            if (c + 4 < nch) gload(c + 4, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (not __syncthreads(): its fence is a vmcnt(0) that drains the prefetch)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // epilogue, one wave at a time through its private LDS tile (the stages are free: every wave is past the last barrier)
+    float* Cw = reinterpret_cast<float*>(smem) + wave * CW_SZ;
+    constexpr int LPR = 8 * NJ;                                   // lanes per row segment: 4 columns each
+    const int er = lane / LPR, eq = lane % LPR;                   // rows er + (64 / LPR) st, columns 4 eq
+    const int colw = col0 + wn * 32 * NJ;
+    float4 bv = *reinterpret_cast<const float4*>(bias + colw + 4 * eq);
+    if (blockIdx.y != 0) bv = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            Cw[rr * CW_LD + j * 32 + (lane & 31)] = acc[j][r];
+        }
+    asm volatile("" ::: "memory");                                // (compiler ordering only: one wave's LDS operations execute in order)
+    constexpr int RPP = 64 / LPR;                                 // rows per pass
+#pragma unroll
+    for (int st = 0; st < 32 / RPP; ++st) {
+        const int trow = wm * 32 + er + RPP * st;
+        const int e = -(sE[trow] + w_exp);
+        const bool live = trow < nrows;
+        float* dst = Cm + (size_t)(row0 + (live ? trow : 0)) * N + colw + 4 * eq;
+        const float4 v = *reinterpret_cast<const float4*>(Cw + (er + RPP * st) * CW_LD + 4 * eq);
+        float o[4] = {ldexpf(v.x, e) + bv.x, ldexpf(v.y, e) + bv.y, ldexpf(v.z, e) + bv.z, ldexpf(v.w, e) + bv.w};
+        if (EPI == SD_EPI_RESID) {
+            const float4 x = *reinterpret_cast<const float4*>(dst);
+            o[0] += x.x; o[1] += x.y; o[2] += x.z; o[3] += x.w;
+        }
+        if (EPI == SD_EPI_QGELU) {                                // x * sigmoid(1.702 x), transformer.py:38-40
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = o[q] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.44269504088896341f * o[q]));
+        }
+        if (live) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        if (cmax) {
+            // largest |o| of the row as float bits: integer maximum (non-negative floats order like their bits; NaN ranks above Inf)
+            unsigned int b = 0u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const unsigned int ob = __float_as_uint(o[q]) & 0x7fffffffu; b = b > ob ? b : ob; }
+            unsigned int t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)b, 0xB1, 0xF, 0xF, true); b = b > t ? b : t;        // quad_perm [1,0,3,2]
+            t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)b, 0x4E, 0xF, 0xF, true); b = b > t ? b : t;                     // quad_perm [2,3,0,1]
+            t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)b, 0x141, 0xF, 0xF, true); b = b > t ? b : t;                    // row_half_mirror: 8 lanes
+            if (LPR == 16) { t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)b, 0x140, 0xF, 0xF, true); b = b > t ? b : t; }  // row_mirror: 16 lanes
+            if (eq == 0 && live) atomicMax(cmax + row0 + trow, b);
+        }
+    }
 }
 
 // token rows: [grasp_emb] geoms_emb (poses_emb + time_emb) + pe[position] -> ln_pre; padding rows are zero
@@ -177,10 +435,12 @@ __global__ __launch_bounds__(256) void k_sd_embed(int M, int H, int Wd, int gras
 // head-major.
 constexpr int SD_DH_MAX = 384;
 __global__ __launch_bounds__(256) void k_sd_attn(int Wd, const float* __restrict__ QKV, const int* __restrict__ mask_from,
-                                                 float* __restrict__ Aout) {
+                                                 float* __restrict__ Aout, unsigned int* __restrict__ amax /*[8 B] or null: atomicMax of |Aout| per token row*/) {
     __shared__ float qkv[3][SD_L][SD_DH_MAX + 1];
     __shared__ float part[4][SD_L * SD_L];
     __shared__ float ps[SD_L][SD_L];
+    __shared__ unsigned int srow[SD_L];
+    if (threadIdx.x < SD_L) srow[threadIdx.x] = 0u;
     const int b = blockIdx.x / SD_HEADS, h = blockIdx.x % SD_HEADS;
     const int DH = Wd / SD_HEADS, tid = threadIdx.x;
     const float* base = QKV + (size_t)b * SD_L * 3 * Wd + h * DH;
@@ -223,6 +483,11 @@ __global__ __launch_bounds__(256) void k_sd_attn(int Wd, const float* __restrict
 #pragma unroll
         for (int jj = 0; jj < SD_L; ++jj) o += ps[r][jj] * qkv[2][jj][c];
         Aout[((size_t)b * SD_L + r) * Wd + h * DH + c] = o;
+        if (amax) atomicMax(&srow[r], __float_as_uint(o) & 0x7fffffffu);      // (LDS; integer maximum of the bits: order-independent, NaN on top)
+    }
+    if (amax) {
+        __syncthreads();
+        if (tid < SD_L) atomicMax(amax + (size_t)b * SD_L + tid, srow[tid]);      // (the two heads of a row, in any order)
     }
 }
 
