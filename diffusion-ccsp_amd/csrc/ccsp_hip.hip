@@ -2681,11 +2681,18 @@ __global__ void k_compose_outputs(int N, int P, int P2, int zero_col, const floa
 
 struct ComposeScratch { float *s1, *s2, *p2; };
 
-int compose_check(const ccsp_model* m1, const ccsp_graph* g1, const ccsp_model* m2, const ccsp_graph* g2, const ccsp_compose* c, const char* who) {
+int compose_energy_eval(ccsp_model* m1, ccsp_graph* g1, ccsp_model* m2, ccsp_graph* g2, const ccsp_compose* c, const float* poses_in, int t,
+                        float* p_enc, float* p_tgt, float* E12, float* grad, float* energy, hipStream_t s);
+
+// energy_ok: energy_wrapper models are accepted (their DIRECT evaluation is what forward(tag != 'EBM') returns, denoise_fn.py:535-537,
+// and what a chain evaluates when both are energy models is decided by the caller)
+int compose_check(const ccsp_model* m1, const ccsp_graph* g1, const ccsp_model* m2, const ccsp_graph* g2, const ccsp_compose* c, const char* who,
+                  bool energy_ok = false) {
     if (!m1 || !g1 || !m2 || !g2 || !c) return fail("%s: null argument", who);
     if (g1->m != m1 || g2->m != m2) return fail("%s: a graph belongs to another model", who);
     if (m1->d.model_kind != CCSP_MODEL_DIFFUSION_CCSP || m2->d.model_kind != CCSP_MODEL_DIFFUSION_CCSP) return fail("%s: both domains must be Diffusion-CCSP models", who);
-    if (m1->d.energy_wrapper || m2->d.energy_wrapper) return fail("%s: composition is built for direct-mode (non energy_wrapper) models", who);
+    if (!energy_ok && (m1->d.energy_wrapper || m2->d.energy_wrapper)) return fail("%s: composition is built for direct-mode (non energy_wrapper) models", who);
+    if (m1->d.energy_wrapper != m2->d.energy_wrapper) return fail("%s: one domain is an energy_wrapper model and the other is not", who);
     if (m2->d.pose_dim + 1 != m1->d.pose_dim) return fail("%s: the second domain's pose_dim (%d) must be the first's (%d) minus the zero column", who, m2->d.pose_dim, m1->d.pose_dim);
     if (m2->d.pose_dim < 2 || g1->F < m2->d.pose_dim - 2) return fail("%s: bad second-domain pose layout", who);
     if (c->zero_col < 0 || c->zero_col >= m1->d.pose_dim) return fail("%s: zero_col=%d out of range", who, c->zero_col);
@@ -3529,7 +3536,7 @@ int ccsp_chain_stats(ccsp_graph* g, int64_t* evals, float* ms_total, float* ms_u
 // node_ptr [N+1], node_ent [2E].  counts = {E_act, R, n_tiles}.
 int ccsp_compose_denoise(ccsp_model* m1, ccsp_graph* g1, ccsp_model* m2, ccsp_graph* g2, const ccsp_compose* c, const float* poses_in,
                          int32_t t, float* out, void* stream) {
-    if (compose_check(m1, g1, m2, g2, c, "compose_denoise")) return 1;
+    if (compose_check(m1, g1, m2, g2, c, "compose_denoise", true)) return 1;      // (energy_wrapper models: their direct output, forward(tag != 'EBM'))
     if (!poses_in || !out) return fail("compose_denoise: null argument");
     if (t < 0 || t >= m1->d.timesteps) return fail("compose_denoise: t=%d out of range", t);
     hipStream_t s = (hipStream_t)stream;
@@ -3555,10 +3562,22 @@ int ccsp_compose_energy_grad(ccsp_model* m1, ccsp_graph* g1, ccsp_model* m2, ccs
     if (t < 0 || t >= m1->d.timesteps || t >= m2->d.timesteps) return fail("compose_energy_grad: t=%d out of range", t);
     hipStream_t s = (hipStream_t)stream;
     if (energy_prepare(m1, g1, s) || energy_prepare(m2, g2, s)) return 1;
-    const int N = g1->N, P = m1->d.pose_dim, P2 = m2->d.pose_dim;
+    const int N = g1->N, P2 = m2->d.pose_dim;
     StreamBuf b1(s), b2(s), b3(s);
     if (b1.alloc((size_t)N * P2 * sizeof(float)) || b2.alloc((size_t)N * P2 * sizeof(float)) || b3.alloc(2 * sizeof(float))) return 1;
-    float *p_enc = b1.f(), *p_tgt = b2.f(), *E12 = b3.f();
+    if (compose_energy_eval(m1, g1, m2, g2, c, poses_in, t, b1.f(), b2.f(), b3.f(), grad, energy, s)) return 1;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"
+
+namespace {
+// the composed energy and its gradient at poses_in (the body of ccsp_compose_energy_grad; also one evaluation of an energy-mode
+// chain of a composed model, ccsp_compose_chain_run).  p_enc / p_tgt: [N, P2] scratch, E12: 2 floats of scratch
+int compose_energy_eval(ccsp_model* m1, ccsp_graph* g1, ccsp_model* m2, ccsp_graph* g2, const ccsp_compose* c, const float* poses_in, int t,
+                        float* p_enc, float* p_tgt, float* E12, float* grad, float* energy, hipStream_t s) {
+    const int N = g1->N, P = m1->d.pose_dim, P2 = m2->d.pose_dim;
     hipLaunchKernelGGL(k_compose_pack, dim3(nblk((long)N * P2, 256)), dim3(256), 0, s, N, P, P2, poses_in, g1->xfeat, g1->F, p_enc);
     hipLaunchKernelGGL(k_compose_targets, dim3(nblk((long)N * P2, 256)), dim3(256), 0, s, N, P, c->zero_col, poses_in, p_tgt);
     const int rc = dispatch_h(m1->d.hidden_dim, [&](auto hc) {
@@ -3575,27 +3594,40 @@ int ccsp_compose_energy_grad(ccsp_model* m1, ccsp_graph* g1, ccsp_model* m2, ccs
     if (rc) return 1;
     hipLaunchKernelGGL(k_compose_energy, dim3(1), dim3(256), 0, s, N, P, c->zero_col, poses_in, g1->eps, g2->eps,
                        g2->plan.E_act > 0 ? g2->node_ptr : (const int*)nullptr, E12, grad, energy);
-    HIP_TRY(hipGetLastError());
     return 0;
 }
+}  // namespace
+
+extern "C" {
 
 int ccsp_compose_chain_run(ccsp_model* m1, ccsp_graph* g1, ccsp_model* m2, ccsp_graph* g2, const ccsp_compose* c, int32_t sampler,
                            const ccsp_noise* nz, float* x, int32_t init, int32_t t_first, int32_t t_last, float* history, void* stream) {
-    if (compose_check(m1, g1, m2, g2, c, "compose_chain_run")) return 1;
+    if (compose_check(m1, g1, m2, g2, c, "compose_chain_run", true)) return 1;
     if (!nz || !x) return fail("compose_chain_run: null argument");
     ccsp_model* m = m1;
     ccsp_graph* g = g1;
     const int T = m->d.timesteps, P = m->d.pose_dim;
     if (sampler != CCSP_SAMPLER_NONE && sampler != CCSP_SAMPLER_ULA && sampler != CCSP_SAMPLER_ULA_PLUS)
-        return fail("compose_chain_run: sampler %d needs an energy model; composition runs the direct-mode samplers (none, ULA, ULA+)", sampler);
+        return fail("compose_chain_run: sampler %d: composed models run the ancestral / ULA / ULA+ samplers (on the denoiser output, or on the energy gradient "
+                    "when both are energy_wrapper models); MALA and HMC are not built for them", sampler);
+    // energy mode (both energy_wrapper models; ComposedEBMDenoiseFn.forward: epsilon = dE/dposes, ddpm.py:940-966 on it): every evaluation
+    // is the composed energy gradient of ccsp_compose_energy_grad
+    const bool energy = m1->d.energy_wrapper != 0;
+    if (energy) {
+        if (c->zero_col < 2) return fail("compose_chain_run: zero_col=%d (the second domain's encoder takes pose columns 0 and 1)", c->zero_col);
+        if (c->weight_first != 1.0f || c->weight_second != 1.0f) return fail("compose_chain_run: composing weights other than (1, 1) are built for the direct mode only");
+        if (m1->d.hidden_dim != m2->d.hidden_dim) return fail("compose_chain_run: the two domains differ in hidden_dim");
+    }
     if (t_first >= T || t_last < 0 || t_first < t_last - 1) return fail("compose_chain_run: bad timestep range [%d,%d]", t_first, t_last);
     if (nz->mode != CCSP_NOISE_PHILOX && nz->mode != CCSP_NOISE_INJECTED) return fail("compose_chain_run: unknown noise mode %d", nz->mode);
     if (nz->mode == CCSP_NOISE_INJECTED && !nz->normal) return fail("compose_chain_run: injected noise without a normal stream");
     hipStream_t s = (hipStream_t)stream;
     const size_t N = (size_t)g->N, NP = N * P;
-    StreamBuf b1(s), b2(s), b3(s);
-    if (b1.alloc(NP * sizeof(float)) || b2.alloc(N * m2->d.pose_dim * sizeof(float)) || b3.alloc(N * m2->d.pose_dim * sizeof(float))) return 1;
+    StreamBuf b1(s), b2(s), b3(s), b4(s);
+    if (b1.alloc(NP * sizeof(float)) || b2.alloc(N * m2->d.pose_dim * sizeof(float)) || b3.alloc(N * m2->d.pose_dim * sizeof(float)) ||
+        b4.alloc(4 * sizeof(float))) return 1;
     const ComposeScratch w{b1.f(), b2.f(), b3.f()};
+    if (energy && (energy_prepare(m1, g1, s) || energy_prepare(m2, g2, s))) return 1;
     std::vector<uint64_t> call0(T);
     {
         uint64_t k = 1;
@@ -3629,9 +3661,11 @@ int ccsp_compose_chain_run(ccsp_model* m1, ccsp_graph* g1, ccsp_model* m2, ccsp_
     for (int t = t_first; t >= t_last; --t) {
         const int S = steps_at(m, sampler, t);
         for (int e = 0; e <= S; ++e) {
-            if (compose_eval(m1, g1, m2, g2, c, nullptr, t, w, g->eps, s)) return 1;
+            if (energy) {      // gradient at the state (w.s1: the gradient; g1->eps / g2->eps hold the two domains' own gradients)
+                if (compose_energy_eval(m1, g1, m2, g2, c, g->x, t, w.s2, w.p2, b4.f(), w.s1, b4.f() + 2, s)) return 1;
+            } else if (compose_eval(m1, g1, m2, g2, c, nullptr, t, w, g->eps, s)) return 1;
             NodeArgs a = node_args(m, g);
-            a.src = 1; a.eps_buf = g->eps; a.do_encode = 1;
+            a.src = 1; a.eps_buf = energy ? w.s1 : g->eps; a.do_encode = 1;
             a.step = e == 0 ? STEP_ANCESTRAL : STEP_ULA;
             a.reset_mask = (e == S);
             a.hist = (e == S && history) ? history + (size_t)(T - t) * NP : nullptr;

@@ -189,7 +189,10 @@ class GaussianDiffusion(object):
         if getattr(core, '_second', None) is not None:
             # two composed domains (ConstraintDiffuser.compose): one evaluation per domain and evaluation, ccsp_compose_chain_run
             if self._sampler() in ('MALA', 'HMC'):
-                raise NotImplementedError('composed domains run the direct-mode samplers (EBM=False, ULA, ULA+)')
+                raise NotImplementedError('composed domains run EBM=False, ULA and ULA+ (on the denoiser output, or on the energy gradient '
+                                          'when the composed model is an energy_wrapper model); MALA / HMC are not built for them')
+            if core.energy_wrapper and tuple(core.composing_weight) != (1, 1):
+                raise NotImplementedError('the energy of composed domains is built for composing_weight (1, 1)')
             first, second = core._composed_parts()
             h = self._handle()
             g1, g2 = core._composed_graphs(batch)

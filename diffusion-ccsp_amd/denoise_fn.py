@@ -264,7 +264,11 @@ class ConstraintDiffuser(object):
         return self
 
     def _composed_parts(self):
-        """the two single-domain models of the composed forward, bound to the same number of timesteps"""
+        """the two single-domain models of the composed forward, bound to the same number of timesteps and to the same mode (the
+        second native model follows this one's energy_wrapper: forward() and GaussianDiffusion._run() both come through here)"""
+        if self._second.energy_wrapper != self.energy_wrapper:
+            self._second.energy_wrapper = self.energy_wrapper
+            self._second._drop_handle()
         self._second._bind(self.timesteps)
         self._handle()
         self._second._handle()
@@ -469,9 +473,6 @@ class ConstraintDiffuser(object):
             energy_mode = tag == 'EBM' and self.energy_wrapper
             if energy_mode and tuple(self.composing_weight) != (1, 1):
                 raise NotImplementedError('the energy of composed domains is built for composing_weight (1, 1)')
-            if self._second.energy_wrapper != self.energy_wrapper:       # the second native model follows this one's mode
-                self._second.energy_wrapper = self.energy_wrapper
-                self._second._drop_handle()
             g1, g2 = self._composed_graphs(batch)
             first, second = self, self._second
             p = poses_in.detach().to(self.device, torch.float32).contiguous()

@@ -103,8 +103,12 @@ class ComposedOracleGraph(object):
         grad[:, z] += np.float32(2) * poses[:, z] * cnt2
         return grad, float(e1) + float(e2) + float((cnt2 * poses[:, z] ** 2).sum())
 
-    def chain(self, normal, samples_per_step, sampler='ULA', history=False):
-        """full reverse chain with injected normal draws [n_calls, N, P]; sampler 'ULA' or None"""
+    def chain(self, normal, samples_per_step, sampler='ULA', history=False, energy=False, x=None, t_first=None, t_last=0):
+        """full reverse chain with injected normal draws [n_calls, N, P]; sampler 'ULA' or None.  energy: epsilon is the gradient of
+        the composed energy (ComposedEBMDenoiseFn around the energy_wrapper model, denoise_fn.py:539-548): no count normalisation,
+        no mask fill inside an evaluation.  x / t_first / t_last: run timesteps t_first..t_last from the state x (the draws keep their
+        call numbers: timestep t starts at call 1 + (T - 1 - t) (1 + S))"""
+        ev = (lambda xx, tt: self.energy_grad(xx, tt)[0]) if energy else self.denoise
         m = self.m1
         sc = m.schedule()
         T, N, P = m.T, self.N, self.P
@@ -112,24 +116,28 @@ class ComposedOracleGraph(object):
         gt = self.x[:, m.dims[-1][1]:m.dims[-1][1] + P]
         z = np.asarray(normal, dtype=np.float32)
         S = int(samples_per_step) if sampler == 'ULA' else 0
-        x = (f(0.5) * z[0]).astype(np.float32)
-        x[self.mask] = gt[self.mask]
+        if x is None:
+            x = (f(0.5) * z[0]).astype(np.float32)
+            x[self.mask] = gt[self.mask]
+            t_first = T - 1
+        else:
+            x = np.array(x, dtype=np.float32)
         hist = [x.copy()]
-        call = 1
-        for t in range(T - 1, -1, -1):
+        call = 1 + (T - 1 - int(t_first)) * (1 + S)
+        for t in range(int(t_first), int(t_last) - 1, -1):
             a_t, b_t = f(sc['sqrt_recip_alphas_cumprod'][t]), f(sc['sqrt_recipm1_alphas_cumprod'][t])
             c1, c2 = f(sc['posterior_mean_coef1'][t]), f(sc['posterior_mean_coef2'][t])
             sigma = f(np.exp(f(0.5) * f(sc['posterior_log_variance_clipped'][t]))) if t != 0 else f(0)
             kappa, ss = f(sc['kappa'][t]), f(sc['step_sizes'][t])
             std = f(np.sqrt(f(2) * ss))
             with np.errstate(all='ignore'):
-                eps = self.denoise(x, t)
+                eps = ev(x, t)
                 x0 = (a_t * x - b_t * eps).astype(np.float32)
                 mean = (c1 * x0 + c2 * x).astype(np.float32)
                 x = (mean + sigma * z[call]).astype(np.float32)
                 call += 1
                 for _ in range(S):
-                    eps = self.denoise(x, t)
+                    eps = ev(x, t)
                     grad = ((-eps) * kappa).astype(np.float32)
                     x = ((x + grad * ss).astype(np.float32) + (z[call] * std).astype(np.float32)).astype(np.float32)
                     call += 1

@@ -560,7 +560,7 @@ def gen_options():
     print('options.npz  randn calls %d  |final|max %.3g  |hist|max %.3g' % (pn.c, np.abs(rec['final']).max(), np.abs(rec['hist']).max()))
 
 
-def build_composed_reference(H, W_robot, W_qual, weight=(1, 1), T=1000, S=10, EBM='ULA'):
+def build_composed_reference(H, W_robot, W_qual, weight=(1, 1), T=1000, S=10, EBM='ULA', energy=False):
     """the reference's composed denoiser the way its code expects to be assembled (nothing in the repository does the
     assembly: pose_encoder_2 & co. are None after the constructor, denoise_fn.py:287-291): a 'robot_qualitative'
     ConstraintDiffuser holding the robot domain's weights, the qualitative model's thirteen type MLPs appended to its
@@ -576,7 +576,9 @@ def build_composed_reference(H, W_robot, W_qual, weight=(1, 1), T=1000, S=10, EB
     model.pose_encoder_2, model.geom_encoder_2 = qual.pose_encoder, qual.geom_encoder
     model.pose_decoder_2, model.time_mlp_2 = qual.pose_decoder, qual.time_mlp
     model.composing_weight = tuple(weight)
-    gd = ddpm.GaussianDiffusion(model, timesteps=T, EBM=EBM, samples_per_step=S, step_sizes='2*self.betas')
+    if energy:      # the composed model in energy mode: its forward returns (dE/dposes, E) (denoise_fn.py:539-548), wrapped like any energy model
+        model.energy_wrapper = True
+    gd = ddpm.GaussianDiffusion(dfn.ComposedEBMDenoiseFn(model) if energy else model, timesteps=T, EBM=EBM, samples_per_step=S, step_sizes='2*self.betas')
     return model, gd.eval()
 
 
@@ -649,6 +651,33 @@ def gen_composed():
                  H=np.int32(H), n_randn=np.int64(pn.c), weight=np.asarray(weight, dtype=np.float32), ref_seconds=np.float64(dt))
         np.savez_compressed(os.path.join(GOLD, name + '.npz'), **r)
         print('%-20s %6.1fs  randn calls %d  |final|max %.3f  |hist|max %.3g' % (name, dt, pn.c, np.abs(out).max(), np.abs(hist).max()), flush=True)
+
+
+def gen_composed_energy_chains():
+    """ULA on the ENERGY gradient of a composed model (ComposedEBMDenoiseFn around the 'robot_qualitative' ConstraintDiffuser with
+    energy_wrapper=True: ddpm.py:940-966 with the epsilon of denoise_fn.py:539-548), every timestep recorded"""
+    for name, H, batch, T, S, seed in (('chain_c64_ula_energy', 64, worlds.robot_qualitative_batch(2, 6, seed=55), 60, 2, 13),
+                                       ('chain_c256_ula_energy', 256, worlds.robot_qualitative_batch(2, 6, seed=56), 40, 2, 14)):
+        # hidden_dim 64: both domains' weights trained in energy mode (oracle/ref_train.py --energy); 256: the direct-mode fixtures.
+        # Either way the REFERENCE chain overflows within a few timesteps: the zero column's energy term cnt * p_z^2 alone has ULA
+        # gain |1 - 2 beta kappa 2 cnt| >> 1 at beta -> 0.999 -- the fixture pins the evaluations along that transient and the
+        # non-finite end state
+        sfx = '_energy' if H == 64 else ''
+        Wr = oracle_mod.load_weights(os.path.join(GOLD, 'weights_robot_box_h%d%s.npz' % (H, sfx)))
+        Wq = oracle_mod.load_weights(os.path.join(GOLD, 'weights_qualitative_h%d%s.npz' % (H, sfx)))
+        model, gd = build_composed_reference(H, Wr, Wq, (1, 1), T=T, S=S, energy=True)
+        b = batch.to_torch()
+        t0 = time.time()
+        with PatchedNoise(seed) as pn, contextlib.redirect_stdout(io.StringIO()):
+            out, hist = gd.sample(b.clone(), return_history=True)
+        dt = time.time() - t0
+        out = out.detach().numpy()
+        hist = np.stack([h.detach().numpy() for h in hist])
+        r = dict(batch_arrays(b))
+        r.update(final=out, hist_idx=np.arange(T + 1, dtype=np.int32), hist=hist, seed=np.int64(seed), T=np.int32(T), S=np.int32(S),
+                 H=np.int32(H), n_randn=np.int64(pn.c), weight=np.asarray((1, 1), dtype=np.float32), ref_seconds=np.float64(dt))
+        np.savez_compressed(os.path.join(GOLD, name + '.npz'), **r)
+        print('%-24s %6.1fs  randn calls %d  |final|max %.3g  |hist|max %.3g' % (name, dt, pn.c, np.abs(out).max(), np.abs(hist).max()), flush=True)
 
 
 def gen_chains(which):
@@ -747,6 +776,8 @@ if __name__ == '__main__':
         gen_single_eval_h128()
     if not which or 'composed' in which:
         gen_composed()
+    if not which or 'composed_energy' in which:
+        gen_composed_energy_chains()
     if not which or 'pre_transform' in which:
         gen_pre_transform()
     if not which or 'struct_diffusion' in which:

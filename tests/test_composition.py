@@ -52,6 +52,43 @@ def test_oracle_chain_vs_reference(name, H):
         assert rel_err(hist[idx], z['hist'][k]) < 2e-3, (name, int(idx))
 
 
+def _energy_pair(H, T, S):
+    sfx = '_energy' if H == 64 else ''
+    return (oracle_model('robot_box', H, 'weights_robot_box_h%d%s.npz' % (H, sfx), T=T, S=S, energy=True),
+            oracle_model('qualitative', H, 'weights_qualitative_h%d%s.npz' % (H, sfx), T=T, S=S, energy=True))
+
+
+def _energy_chain_errors(step, z):
+    """ULA on the ENERGY gradient of a composed model (chain_c{64,256}_ula_energy: the reference's ComposedEBMDenoiseFn around the
+    energy_wrapper 'robot_qualitative' model).  The reference's own chain overflows fp32 within a dozen timesteps (the zero column's
+    energy term alone has ULA gain >> 1 at beta -> 0.999), so every timestep is run from the reference's RECORDED state: while the
+    recorded successor is finite it must be reproduced to 1e-4 relative, afterwards the same rows must be non-finite"""
+    T = int(z['T'])
+    bad, checked = [], 0
+    for k in range(T):
+        if not np.isfinite(z['hist'][k]).all():
+            break
+        got, want = step(z['hist'][k], T - 1 - k), z['hist'][k + 1]
+        fin = np.isfinite(want).all(axis=1)
+        if not np.array_equal(np.isfinite(got).all(axis=1), fin) or (fin.any() and rel_err(got[fin], want[fin]) > 1e-4):
+            bad.append((k, rel_err(got[fin], want[fin]) if fin.any() else None))
+        checked += 1
+    assert checked >= 8
+    return bad
+
+
+@pytest.mark.parametrize('name,H', [('chain_c64_ula_energy', 64), ('chain_c256_ula_energy', 256)])
+def test_oracle_energy_chain_vs_reference(name, H):
+    z = golden(name)
+    T, S = int(z['T']), int(z['S'])
+    m1, m2 = _energy_pair(H, T, S)
+    g = compose_oracle.ComposedOracleGraph(m1, m2, golden_batch(z), weight=(1, 1))
+    zs = noise.normal_stream(int(z['seed']), int(z['n_randn']), z['x'].shape[0], 5)
+    with np.errstate(all='ignore'):
+        bad = _energy_chain_errors(lambda x, t: g.chain(zs, S, energy=True, x=x, t_first=t, t_last=t), z)
+    assert not bad, bad
+
+
 @pytest.mark.parametrize('tag,H', CASES)
 def test_oracle_energy_mode_vs_reference(tag, H):
     """energy and autograd gradients of the reference's composed model (tag='EBM', energy_wrapper) at composing_weight (1, 1)"""
@@ -131,6 +168,44 @@ def test_hip_chain_vs_reference(name, H, device):
     mid = T // 2
     x1 = gd.p_sample_segment(b, hist[T - mid], mid - 1, 0, seed=int(z['seed']))
     assert np.array_equal(x1.cpu().numpy(), x)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,H', [('chain_c64_ula_energy', 64), ('chain_c256_ula_energy', 256)])
+def test_hip_energy_chain_vs_reference(name, H, device):
+    """ccsp_compose_chain_run on two energy_wrapper models: every evaluation is the composed energy gradient; per-timestep parity
+    from the reference's recorded states (see _energy_chain_errors); the direct output of the same models (forward with
+    tag != 'EBM', denoise_fn.py:535-537) is still available; MALA / HMC refuse"""
+    from diffusion_ccsp_amd import ComposedEBMDenoiseFn, ConstraintDiffuser, GaussianDiffusion
+    z = golden(name)
+    T, S = int(z['T']), int(z['S'])
+    sfx = '_energy' if H == 64 else ''
+    first = ConstraintDiffuser(dims=worlds.MODE_DIMS['robot_box'], hidden_dim=H, input_mode='robot_qualitative', EBM='ULA', energy_wrapper=True,
+                               device=device, verbose=False)
+    first.load_state_dict(weights('weights_robot_box_h%d%s.npz' % (H, sfx)))
+    second = ConstraintDiffuser(dims=worlds.MODE_DIMS['qualitative'], hidden_dim=H, input_mode='qualitative', EBM='ULA', energy_wrapper=True,
+                                device=device, verbose=False)
+    second.load_state_dict(weights('weights_qualitative_h%d%s.npz' % (H, sfx)))
+    first.compose(second, (1, 1))
+    gd = GaussianDiffusion(ComposedEBMDenoiseFn(first), timesteps=T, EBM='ULA', samples_per_step=S)
+    b = golden_batch(z)
+    seed = int(z['seed'])
+    bad = _energy_chain_errors(lambda x, t: gd.p_sample_segment(b, torch.from_numpy(x), t, t, seed=seed).cpu().numpy(), z)
+    assert not bad, bad
+    # the whole chain ends where the reference's ends: every row non-finite or equal
+    x = gd.sample(b, seed=seed).cpu().numpy()
+    assert np.array_equal(np.isfinite(x).all(axis=1), np.isfinite(z['final']).all(axis=1))
+    # direct output of the energy_wrapper pair = the direct composed evaluation of the same weights
+    poses = z['hist'][0]
+    d_energy = first(torch.from_numpy(poses), b, torch.tensor([7]), tag='none').cpu().numpy()
+    first.energy_wrapper = False
+    first._drop_handle()
+    d_direct = first(torch.from_numpy(poses), b, torch.tensor([7])).cpu().numpy()
+    first.energy_wrapper = True
+    first._drop_handle()
+    assert np.array_equal(d_energy, d_direct)
+    with pytest.raises(NotImplementedError):
+        GaussianDiffusion(ComposedEBMDenoiseFn(first), timesteps=T, EBM='MALA', samples_per_step=S).sample(b, seed=1)
 
 
 @pytest.mark.gpu
