@@ -164,8 +164,8 @@ def _git_blob_hash(path):
 
 def pmc_traffic_file(config, symbols):
     """fabric-side bytes per launch of each kernel whose name starts with one of `symbols`, from the COMMITTED rocprofv3 --pmc
-    summary of this round (profiles/r03_pmc_<config>.txt, made by tools/pmc_run.sh).  -> ({symbol: {kernel name, bytes}}, stamp)"""
-    path = os.path.join(ROOT, 'profiles', 'r03_pmc_%s.txt' % config)
+    summary of this round (profiles/r04_pmc_<config>.txt, made by tools/pmc_run.sh).  -> ({symbol: {kernel name, bytes}}, stamp)"""
+    path = os.path.join(ROOT, 'profiles', 'r04_pmc_%s.txt' % config)
     if not os.path.isfile(path):
         return {}, None
     cur, got = None, {}
@@ -181,7 +181,7 @@ def pmc_traffic_file(config, symbols):
         for name, d in got.items():
             if name.startswith(sym) and len(d) == 2:
                 out[sym] = {'kernel_name': name, 'bytes': d['FETCH_SIZE'] * 1024.0 * 2.0 + d['WRITE_SIZE'] * 1024.0}
-    return out, {'source': 'profiles/r03_pmc_%s.txt' % config, 'git_blob': _git_blob_hash(path)}
+    return out, {'source': 'profiles/r04_pmc_%s.txt' % config, 'git_blob': _git_blob_hash(path)}
 
 
 def pmc_traffic_live(config, graphs, symbols, timeout=240):

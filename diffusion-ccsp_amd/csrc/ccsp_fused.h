@@ -831,3 +831,175 @@ __global__ __launch_bounds__(256, 2) void k_eval_fused4(FusedArgs fa) {
     CCSP_TRK(0, 16);
     CCSP_TRK_RT(0, 31);
 }
+
+// ------------------------------------------------------------------------------------------
+// k_rowgemm_h2d -- CCSP_ROW_MODE=7 of the forward row GEMM (round 4): what the fused kernels' phase 1 taught, applied to the
+// two-launch path.  The other modes stage BOTH operands through LDS chunk by chunk with a barrier per chunk (a workgroup is a
+// chain of eight load -> ds_write -> barrier -> ds_read -> MFMA round trips); phase 1 of k_eval_fused ran its K loop at the
+// matrix pipe's pace because (a) the tile's pose-embedding planes are resident in LDS for the whole K (one LDS-DMA burst, one
+// barrier) and (b) the weight fragments come straight from global memory in MFMA operand order (k_pack_wp_frag), eight k-steps
+// ahead with counted waits -- no LDS traffic, no VALU and no barrier for B.  Here: 64-row x 128-column tiles, 4 waves, each wave
+// ALL 64 rows x 32 columns (both row tiles share every B fragment: a weight byte is loaded once per workgroup), 64 KB of LDS and
+// <= 256 VGPRs: two workgroups per CU.  Same operands, exponents and MFMA order as every other mode: U and umax are bitwise the same.
+// Epilogue: accumulators -> wave-private LDS tile (over the A planes, after one barrier) -> rows of 128-byte segments; the maxima
+// of a row's 64-column piece are combined across the two waves that hold its halves.
+// ------------------------------------------------------------------------------------------
+constexpr int RD_D = 8;                       // k-steps of weight fragments in flight per wave (2 KB each)
+constexpr int RD_CW_LD = 36;                  // wave-private epilogue tile [64][36] floats
+constexpr int RD_LDS_BYTES = 8 * 2 * FZ_APL * 2;                   // 65 536: A planes [8 chunks][2 planes][64][32]; the epilogue tiles after the K loop
+static_assert(4 * 64 * RD_CW_LD * 4 + 4 * 64 * 4 <= RD_LDS_BYTES, "epilogue tiles and row maxima fit the A planes' bytes");
+
+__global__ __launch_bounds__(256, 2) void k_rowgemm_h2d(const unsigned short* __restrict__ A, size_t a_plane, const int* __restrict__ a_exp,
+                                                        const int* __restrict__ urow_node, const int4* __restrict__ tile_desc,
+                                                        const unsigned short* __restrict__ WpF, int w_exp,
+                                                        const float* __restrict__ base, const float* __restrict__ tau_t,
+                                                        float* __restrict__ U, float* __restrict__ umax, StepRef ref, size_t tau_stride) {
+    constexpr int ND = 512, NCT = 4;
+    if (ref.skip && *ref.skip == 0) return;                       // (uniform) MALA reuse: the state has not moved since this was computed
+    __shared__ __attribute__((aligned(16))) unsigned char smem[RD_LDS_BYTES + 64 * 4];
+    using gptr = const __attribute__((address_space(1))) void*;
+    using lptr = __attribute__((address_space(3))) void*;
+    unsigned short* As = reinterpret_cast<unsigned short*>(smem);
+    int* sE = reinterpret_cast<int*>(smem + RD_LDS_BYTES);
+    if (ref.tab) tau_t += (size_t)ref.tab[*ref.counter].t * tau_stride;      // hipGraph mode: timestep from the device table
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = bid / NCT, ct = bid % NCT;
+    const int4 td = tile_desc[tile];
+    const int row0 = td.x, nrows = td.y, ts = td.z;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int colw = ct * 128 + wave * 32;                        // first of this wave's 32 columns
+    // --- the weight stream: 2 fragments (planes) per k-step of this wave's 32-column tile, from the 64-column groups of k_pack_wp_frag
+    const int c32 = colw >> 5;
+    const unsigned short* bptr = WpF + ((((size_t)(ts * 2 + (c32 >> 3)) * 4 + ((c32 >> 1) & 3)) * 16) * 4 + 2 * (c32 & 1)) * 512 + lane * 8;
+    half8 bq[RD_D][2];
+    auto ldB = [&](int ks, half8 (&b)[2]) {
+        const unsigned short* p = bptr + (size_t)ks * 4 * 512;
+        fz_ld_frag<0>(b[0], p); fz_ld_frag<1024>(b[1], p);
+    };
+#pragma unroll
+    for (int d = 0; d < RD_D; ++d) ldB(d, bq[d]);
+    __builtin_amdgcn_sched_barrier(0);
+    // --- A planes of the 64 rows: wave = (plane, two 16-row blocks), source-side swizzle (k_rowgemm_h2 MODE 2)
+    const int a_row0 = (2 * (wave & 1)) * 16 + (lane >> 2);
+    int node[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        int r = a_row0 + 16 * q;
+        r = r < nrows ? r : nrows - 1;
+        node[q] = urow_node ? urow_node[row0 + r] : row0 + r;
+    }
+    {
+        const int plane = wave >> 1;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int row = a_row0 + 16 * q;
+            const int piece = (lane & 3) ^ ((row >> 2) & 3);
+            const unsigned short* ga = A + (size_t)plane * a_plane + (size_t)node[q] * 256 + piece * 8;
+            const int lo = __builtin_amdgcn_readfirstlane(plane * FZ_APL + (2 * (wave & 1) + q) * 16 * H2_BK);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) __builtin_amdgcn_global_load_lds((gptr)(ga + c * H2_BK), (lptr)(As + c * 2 * FZ_APL + lo), 16, 0, 0);
+        }
+    }
+    int ea[2];
+    h2_ld4(ea[0], a_exp + node[0]);
+    h2_ld4(ea[1], a_exp + node[1]);
+    // the time term of the wave's columns in the epilogue's row layout (slot-0 tiles; other tiles read `base` bytes and discard them)
+    const int er = lane >> 3, eq = lane & 7;                       // epilogue: rows er + 8 st, columns 4 eq .. + 3
+    const bool has_tau = tau_t && (ts & 1) == 0;
+    h2_f4 tv;
+    h2_ld16(tv, (has_tau ? tau_t + (size_t)(ts >> 1) * ND : base) + colw + 4 * eq);
+    __builtin_amdgcn_sched_barrier(0);
+    // the A planes have landed (younger: 2 exponents, the time term)
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    floatx16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    h2_f4 bs[8];                                                  // base values of the wave's 64 x 32 tile in the epilogue's layout, requested under the last k-steps
+    {
+        half8 af[2][2][2];                                         // [k-step parity][row tile][plane]
+        auto ldA = [&](int ks, half8 (&a)[2][2]) {
+            const unsigned short* Ac = As + (ks >> 1) * 2 * FZ_APL;
+            const int piece = (lane >> 5) + 2 * (ks & 1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i][1] = *reinterpret_cast<const half8*>(Ac + FZ_APL + h2_off(i * 32 + (lane & 31), piece));
+                a[i][0] = *reinterpret_cast<const half8*>(Ac + h2_off(i * 32 + (lane & 31), piece));
+            }
+        };
+        ldA(0, af[0]);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            half8 (&b)[2] = bq[ks % RD_D];
+            __builtin_amdgcn_sched_barrier(0);
+            // younger than the fragments of k-step ks: those of ks + 1 .. min(ks + D - 1, 15), and (ks >= 12) the base requests below
+            {
+                const int n = 2 * ((ks + RD_D - 1 < 15 ? ks + RD_D - 1 : 15) - ks) + (ks > 12 ? 8 : 0);
+#define RD_W(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(b[0]), "+v"(b[1]) :: "memory")
+                if (n >= 14) RD_W(14); else if (n >= 12) RD_W(12); else if (n >= 10) RD_W(10); else if (n >= 8) RD_W(8); else if (n >= 6) RD_W(6);
+                else if (n >= 4) RD_W(4); else if (n >= 2) RD_W(2); else RD_W(0);
+#undef RD_W
+            }
+            if (ks + 1 < 16) ldA(ks + 1, af[(ks + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            // smallest terms first (h2_kstep): (a lo, b hi), (a hi, b lo), (a hi, b hi)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][i][1], b[0], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][i][0], b[1], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][i][0], b[0], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + RD_D < 16) ldB(ks + RD_D, b);
+            if (ks == 12) {                                        // base rows of the tile (clamped: rows past the tile's end are never stored)
+#pragma unroll
+                for (int st = 0; st < 8; ++st) {
+                    const int trow = er + 8 * st;
+                    const int tr = trow < nrows ? trow : nrows - 1;
+                    h2_ld16_base(bs[st], base + (size_t)(row0 + tr) * ND + colw + 4 * eq);
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ea[0]), "+v"(ea[1]), "+v"(tv) :: "memory");
+    asm volatile("" : "+v"(bs[0]), "+v"(bs[1]), "+v"(bs[2]), "+v"(bs[3]), "+v"(bs[4]), "+v"(bs[5]), "+v"(bs[6]), "+v"(bs[7]) :: "memory");
+    if ((wave >> 1) == 0 && (lane & 3) == 0) { sE[a_row0] = ea[0]; sE[a_row0 + 16] = ea[1]; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                  // every wave is done reading the A planes; the row exponents are visible
+    __builtin_amdgcn_sched_barrier(0);
+    if (!has_tau) tv = h2_f4{0.f, 0.f, 0.f, 0.f};
+    float* Cw = reinterpret_cast<float*>(smem) + wave * 64 * RD_CW_LD;
+    float* sMaxW = reinterpret_cast<float*>(smem) + 4 * 64 * RD_CW_LD;                      // [4 waves][64 rows]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            Cw[rr * RD_CW_LD + (lane & 31)] = acc[i][r];
+        }
+    asm volatile("" ::: "memory");                                // (compiler ordering only: one wave's LDS operations execute in order)
+    float* const Ub = U + (size_t)row0 * ND + colw + 4 * eq;
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+        const int trow = er + 8 * st;
+        const int e = -(sE[trow] + w_exp);
+        const float4 v = *reinterpret_cast<const float4*>(Cw + trow * RD_CW_LD + 4 * eq);
+        const h2_f4 bt = bs[st] + tv;
+        float4 o;
+        o.x = ldexpf(v.x, e) + bt[0]; o.y = ldexpf(v.y, e) + bt[1]; o.z = ldexpf(v.z, e) + bt[2]; o.w = ldexpf(v.w, e) + bt[3];
+        float m = fmaxf(fmaxf(0.0f, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+        m = h2_max8(m);
+        if (trow < nrows) h2_store_u(Ub + (size_t)trow * ND, o);
+        if (eq == 0) sMaxW[wave * 64 + trow] = m;
+    }
+    __syncthreads();
+    if (tid < 128) {                                              // the two 32-column halves of a 64-column piece
+        const int row = tid & 63, pc = tid >> 6;
+        if (row < nrows) umax[(size_t)(row0 + row) * 8 + 2 * ct + pc] = fmaxf(sMaxW[(2 * pc) * 64 + row], sMaxW[(2 * pc + 1) * 64 + row]);
+    }
+}

@@ -1613,6 +1613,11 @@ int rowgemm_h2_mode(const ccsp_model* m, const ccsp_graph* g, int nct) {
 void launch_rowgemm_h2(ccsp_model* m, ccsp_graph* g, const float* tau_t, StepRef ref, size_t tau_stride, hipStream_t s) {
     constexpr int H = 256;
     const int mode = rowgemm_h2_mode(m, g, 2 * H / 128);
+    if (mode == 7 && m->WpF) {                          // resident A planes, weight fragments straight from global memory (ccsp_fused.h)
+        hipLaunchKernelGGL(k_rowgemm_h2d, dim3(g->n_tiles * 4), dim3(256), 0, s, g->pembH, (size_t)g->N * H, g->pexp, g->urow_node, g->td64, m->WpF,
+                           m->wp_exp, g->base, tau_t, g->U, g->umax, ref, tau_stride);
+        return;
+    }
     const bool small = mode == 4 || mode == 6;          // 64-row plan tiles instead of their 128-row pairs
     const int work = (small ? g->n_tiles : g->n_tiles2) * (2 * H / 128);
 #define CCSP_ROWGEMM_F(MODE)                                                                                                                          \
@@ -2860,7 +2865,7 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     // CCSP_MMA: f16x2 (default at hidden_dim 256: two-term fp16 operands, three MFMA products per fp32 product),
     //           bf16x3 (three-term bf16 operands, six products), f32 (v_mfma_f32_32x32x2_f32)
     m->f16x2 = (H == 256 && d->model_kind == CCSP_MODEL_DIFFUSION_CCSP) ? 1 : 0;
-    if (const char* e = getenv("CCSP_ROW_MODE")) { const int v = atoi(e); if (v >= 0 && v <= 6) m->row_mode = v; }
+    if (const char* e = getenv("CCSP_ROW_MODE")) { const int v = atoi(e); if (v >= 0 && v <= 7) m->row_mode = v; }
     if (const char* e = getenv("CCSP_EDGE_MT")) m->edge_mt = atoi(e) == 2 ? 2 : 1;
     if (const char* e = getenv("CCSP_EDGE_SMALL")) m->edge_small = atoi(e) != 0;
     m->valu_node_energy = getenv("CCSP_NODE_ENERGY_VALU") != nullptr;

@@ -76,9 +76,17 @@ __device__ __forceinline__ bool barrier(Bar* b, unsigned G, unsigned& my_gen) {
     return ok;
 }
 
+// filter > 1: the grid has filter x G workgroups and only those with blockIdx % filter == 0 take part (block b runs on XCD b % 8 with
+// the dispatcher's round-robin placement -- observed, not guaranteed: every participant checks its XCC id against the first one's)
 template <int MODE>
-__global__ void k_persistent(int G, int iters, float* buf0, float* buf1, int payload_f4, unsigned* bad, Bar* bar) {
-    const int w = blockIdx.x;
+__global__ void k_persistent(int G, int iters, float* buf0, float* buf1, int payload_f4, unsigned* bad, Bar* bar, int filter, unsigned* xcc_seen) {
+    if (blockIdx.x % filter != 0) return;
+    const int w = blockIdx.x / filter;
+    if (threadIdx.x == 0) {
+        unsigned id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        atomicOr(xcc_seen, 1u << (id & 0xf));
+    }
     unsigned my_gen = 0;
     const int partner = (w + G / 2 + 1) % G;
     for (int iter = 0; iter < iters; ++iter)
@@ -125,11 +133,13 @@ int main() {
     CHECK(hipMalloc(&d_xcc, 64 * sizeof(unsigned)));
     // which CU mask keeps a launch on one XCD?  candidates: every 8th bit; one contiguous run of ncu / 8 bits
     hipStream_t best = nullptr;
-    const char* kinds[2] = {"bits i with i % 8 == 0", "bits 0 .. ncu/8 - 1"};
-    for (int kind = 0; kind < 2 && !best; ++kind) {
+    // candidates: bits i with (i / s) % 8 == 0 for s = 1 .. 32 (s = 32: one contiguous run of ncu / 8 bits)
+    for (int sft = 0; sft <= 5 && !best; ++sft) {
+        const int st = 1 << sft;
         std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+        int nbits = 0;
         for (int i = 0; i < ncu; ++i)
-            if (kind == 0 ? (i % 8 == 0) : (i < ncu / 8)) mask[i >> 5] |= 1u << (i & 31);
+            if ((i / st) % 8 == 0) { mask[i >> 5] |= 1u << (i & 31); ++nbits; }
         hipStream_t s;
         CHECK(hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()));
         CHECK(hipMemsetAsync(d_xcc, 0xff, 64 * sizeof(unsigned), s));
@@ -139,13 +149,21 @@ int main() {
         CHECK(hipMemcpy(h, d_xcc, sizeof(h), hipMemcpyDeviceToHost));
         unsigned seen = 0;
         for (int i = 0; i < 32; ++i) seen |= 1u << h[i];
-        printf("CU mask %-24s: 32 workgroups ran on XCC ids {", kinds[kind]);
+        printf("CU mask {i : (i / %2d) %% 8 == 0} (%d bits): 32 workgroups ran on XCC ids {", st, nbits);
         for (int x = 0; x < 16; ++x) if (seen & (1u << x)) printf(" %d", x);
         printf(" }\n");
         if (__builtin_popcount(seen) == 1) best = s; else CHECK(hipStreamDestroy(s));
     }
-    if (!best) { printf("no candidate mask keeps a launch on one XCD: the XCD-local barrier cannot be set up through CU masks\n"); return 0; }
+    int filter = 1;
+    if (!best) {
+        printf("no CU mask keeps a launch on one XCD (the mask is applied inside every XCD); falling back to the dispatcher's round-robin placement:\n"
+               "a grid of 8 x 32 workgroups on an ordinary stream in which only blocks with blockIdx %% 8 == 0 take part\n");
+        CHECK(hipStreamCreateWithFlags(&best, hipStreamNonBlocking));
+        filter = 8;
+    }
     const int G = 32, iters = 2000;
+    unsigned* d_seen;
+    CHECK(hipMalloc(&d_seen, 4));
     for (int payload_f4 : {16, 256}) {                             // 256 B and 4 KB per workgroup and phase
         float *b0, *b1;
         unsigned* bad;
@@ -154,9 +172,9 @@ int main() {
         CHECK(hipMalloc(&bad, 4)); CHECK(hipMalloc(&bar, sizeof(Bar)));
         hipEvent_t e0, e1;
         CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-        auto reset = [&]() { CHECK(hipMemset(bad, 0, 4)); CHECK(hipMemset(bar, 0, sizeof(Bar))); CHECK(hipMemset(b0, 0, (size_t)G * payload_f4 * 16)); CHECK(hipMemset(b1, 0, (size_t)G * payload_f4 * 16)); };
+        auto reset = [&]() { CHECK(hipMemset(bad, 0, 4)); CHECK(hipMemset(d_seen, 0, 4)); CHECK(hipMemset(bar, 0, sizeof(Bar))); CHECK(hipMemset(b0, 0, (size_t)G * payload_f4 * 16)); CHECK(hipMemset(b1, 0, (size_t)G * payload_f4 * 16)); };
         float ms;
-        unsigned h_bad;
+        unsigned h_bad, h_seen;
         Bar h_bar;
         // (a) three dependent launches per evaluation
         reset();
@@ -166,20 +184,18 @@ int main() {
         CHECK(hipEventRecord(e1, best)); CHECK(hipEventSynchronize(e1)); CHECK(hipEventElapsedTime(&ms, e0, e1));
         CHECK(hipMemcpy(&h_bad, bad, 4, hipMemcpyDeviceToHost));
         printf("payload %5d B: dependent launches      %7.2f us per phase   (stale words: %u)\n", payload_f4 * 16, 1e3 * ms / (3.0 * iters), h_bad);
-        // (b) persistent, XCD-local barrier
-        reset();
-        CHECK(hipEventRecord(e0, best));
-        hipLaunchKernelGGL(k_persistent<0>, dim3(G), dim3(THREADS), 0, best, G, iters, b0, b1, payload_f4, bad, bar);
-        CHECK(hipEventRecord(e1, best)); CHECK(hipEventSynchronize(e1)); CHECK(hipEventElapsedTime(&ms, e0, e1));
-        CHECK(hipMemcpy(&h_bad, bad, 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(&h_bar, bar, sizeof(Bar), hipMemcpyDeviceToHost));
-        printf("payload %5d B: XCD-local barrier       %7.2f us per phase   (stale words: %u, barrier time-outs: %u)\n", payload_f4 * 16, 1e3 * ms / (3.0 * iters), h_bad, h_bar.error);
-        // (c) persistent, agent-scope fences
-        reset();
-        CHECK(hipEventRecord(e0, best));
-        hipLaunchKernelGGL(k_persistent<1>, dim3(G), dim3(THREADS), 0, best, G, iters, b0, b1, payload_f4, bad, bar);
-        CHECK(hipEventRecord(e1, best)); CHECK(hipEventSynchronize(e1)); CHECK(hipEventElapsedTime(&ms, e0, e1));
-        CHECK(hipMemcpy(&h_bad, bad, 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(&h_bar, bar, sizeof(Bar), hipMemcpyDeviceToHost));
-        printf("payload %5d B: agent-scope barrier     %7.2f us per phase   (stale words: %u, barrier time-outs: %u)\n", payload_f4 * 16, 1e3 * ms / (3.0 * iters), h_bad, h_bar.error);
+        for (int mode = 0; mode < 2; ++mode) {
+            reset();
+            CHECK(hipEventRecord(e0, best));
+            if (mode == 0) hipLaunchKernelGGL(k_persistent<0>, dim3(G * filter), dim3(THREADS), 0, best, G, iters, b0, b1, payload_f4, bad, bar, filter, d_seen);
+            else hipLaunchKernelGGL(k_persistent<1>, dim3(G * filter), dim3(THREADS), 0, best, G, iters, b0, b1, payload_f4, bad, bar, filter, d_seen);
+            CHECK(hipEventRecord(e1, best)); CHECK(hipEventSynchronize(e1)); CHECK(hipEventElapsedTime(&ms, e0, e1));
+            CHECK(hipMemcpy(&h_bad, bad, 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(&h_bar, bar, sizeof(Bar), hipMemcpyDeviceToHost));
+            CHECK(hipMemcpy(&h_seen, d_seen, 4, hipMemcpyDeviceToHost));
+            printf("payload %5d B: %-22s %7.2f us per phase   (stale words: %u, barrier time-outs: %u, XCC ids of the participants: 0x%x%s)\n", payload_f4 * 16,
+                   mode == 0 ? "XCD-local barrier" : "agent-scope barrier", 1e3 * ms / (3.0 * iters), h_bad, h_bar.error, h_seen,
+                   __builtin_popcount(h_seen) == 1 ? " = one XCD" : " = SEVERAL XCDs: the XCD-local form is not valid here");
+        }
         CHECK(hipFree(b0)); CHECK(hipFree(b1)); CHECK(hipFree(bad)); CHECK(hipFree(bar));
     }
     return 0;
