@@ -265,7 +265,7 @@ __global__ __launch_bounds__(512) void k_rowgemm_bf2(const unsigned short* __res
 // fp32 and split in registers; B = pose_decoder.0 planes [3][H/2][H].
 //   H=256: 64 rows x 128 cols per workgroup (waves 2x2, 32x64 each);  H=64: 128 rows x 32 cols (4x1)
 // ------------------------------------------------------------------------------------------
-template <int H> struct EdgeBfCfg;
+template <int H> struct EdgeBfCfg { static constexpr int WM = 4, WN = 1, TN = H / 64; };      // (any other multiple of 64)
 template <> struct EdgeBfCfg<256> { static constexpr int WM = 2, WN = 2, TN = 2; };
 template <> struct EdgeBfCfg<128> { static constexpr int WM = 2, WN = 2, TN = 1; };
 template <> struct EdgeBfCfg<64> { static constexpr int WM = 4, WN = 1, TN = 1; };

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void k_energy_sum(const float* __restrict__ pa
 // type-MLP output).  A[row, j] = (sum_p go[p] Wd2[p, j]) * SiLU'(q[row, j]) with go = 2 d = -O_csr.
 // B rows = Wd1^T [H, H/2].  Epilogue: GZ[k, s*H + n] = acc * SiLU'(U[u0(k)] + U[u1(k)])[s*H + n].
 // ------------------------------------------------------------------------------------------
-template <int H> struct BwdCfg;
+template <int H> struct BwdCfg { static constexpr int WM = 2, WN = 2, TN = 1; };      // (any other multiple of 64: 64 x 64 tiles, H / 64 column tiles)
 template <> struct BwdCfg<256> { static constexpr int WM = 2, WN = 2, TN = 2; };   // 64 x 128 tile, 2 column tiles
 template <> struct BwdCfg<128> { static constexpr int WM = 2, WN = 2, TN = 1; };   // 64 x 64 tile, 2 column tiles
 template <> struct BwdCfg<64> { static constexpr int WM = 2, WN = 2, TN = 1; };    // 64 x 64 tile, 1 column tile
@@ -276,6 +276,7 @@ __global__ __launch_bounds__(256) void k_node_energy(EnergyNodeArgs a) {
     }
     __syncthreads();
     {   // y2 and g_y2 = (sum_rows GP) * SiLU'(y2)
+        static_assert(256 % H == 0, "k_node_energy (the VALU form, CCSP_NODE_ENERGY_VALU) is written for widths that divide 256");
         constexpr int NG = 256 / H, NPT = NODE_TILE / NG;
         const int j = tid % H, g = tid / H;
         float acc[NPT];
@@ -339,7 +340,7 @@ template <int H>
 __global__ __launch_bounds__(256) void k_node_energy_mfma(EnergyNodeArgs a, const float* __restrict__ W2F /*pose_encoder.2 in fragment order*/) {
     constexpr int KC = H / 2, TPW = H / 64, KS = H / 8;          // forward: K = H/2 in steps of 4, TPW column tiles per wave
     constexpr int BT = KC / 16;                                   // backward: 16-wide tiles of the H/2 hidden units
-    constexpr int BTW = BT >= 4 ? BT / 4 : 1;                     // ... per wave
+    constexpr int BTW = (BT + 3) / 4;                             // ... per wave (the last wave's share may be short: `live` below)
     constexpr int PF = KS >= 16 ? 8 : KS / 2;                     // forward fragments requested at kernel entry
     __shared__ float xs[NODE_TILE][8];
     __shared__ float dir[NODE_TILE][8];
@@ -354,10 +355,11 @@ __global__ __launch_bounds__(256) void k_node_energy_mfma(EnergyNodeArgs a, cons
     // The kernel is a latency chain on 200-odd workgroups (CSR ranges -> rows -> two dependent small GEMMs), so every load
     // that does not depend on the chain is requested here, in the order it will be consumed: first-layer weights, the
     // node's U-row range, the first forward fragments.
-    float w0r[4];
+    constexpr int NW0 = (KC * 8 + 255) / 256;                      // first-layer weight elements per thread (4 at H = 256)
+    float w0r[NW0];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int idx = tid + 256 * i;                            // KC * 8 = 4 * 256 at H = 256
+    for (int i = 0; i < NW0; ++i) {
+        const int idx = tid + 256 * i;
         const int j = idx >> 3, d = idx & 7;
         w0r[i] = (idx < KC * 8 && d < a.P) ? a.W0[j * a.P + d] : 0.0f;
     }
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(256) void k_node_energy_mfma(EnergyNodeArgs a, cons
         dir[nl1][p] = dv;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NW0; ++i) {
         const int idx = tid + 256 * i;
         if (idx < KC * 8) w0s[idx >> 3][idx & 7] = w0r[i];
     }
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(256) void k_node_energy_mfma(EnergyNodeArgs a, cons
         }
     }
     __syncthreads();
-    {
+    if constexpr (256 % KC == 0) {
         const int j = tid % KC;
 #pragma unroll
         for (int i = 0; i < NODE_TILE * KC / 256; ++i) {
@@ -423,6 +425,16 @@ __global__ __launch_bounds__(256) void k_node_energy_mfma(EnergyNodeArgs a, cons
 #pragma unroll
             for (int d = 0; d < 8; ++d) acc = fmaf(xs[nn][d], w0s[j][d], acc);      // xs / w0s columns >= P are 0
             acc += b0j;
+            y1[nn][j] = acc;
+            s1[nn][j] = silu_fast(acc);
+        }
+    } else {                                     // hidden widths whose half does not divide 256
+        for (int idx = tid; idx < NODE_TILE * KC; idx += 256) {
+            const int nn = idx / KC, j = idx % KC;
+            float acc = 0.0f;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) acc = fmaf(xs[nn][d], w0s[j][d], acc);
+            acc += a.b0[j];
             y1[nn][j] = acc;
             s1[nn][j] = silu_fast(acc);
         }
@@ -457,15 +469,16 @@ __global__ __launch_bounds__(256) void k_node_energy_mfma(EnergyNodeArgs a, cons
     constexpr int KB = H / 4, KBH = KB / 2;
     const float* ap = a.W2 + (size_t)(lane >> 4) * KC + wave * 16 * BTW + (lane & 15);
     float wb0[KBH][BTW];
-    if (wave < BT) {
+    auto live = [&](int t) { return wave * BTW + t < BT; };       // (wave-uniform) tile t of this wave exists; others read tile 0's weights and store nothing
+    if (live(0)) {
 #pragma unroll
         for (int ks = 0; ks < KBH; ++ks)
 #pragma unroll
-            for (int t = 0; t < BTW; ++t) wb0[ks][t] = ap[(size_t)ks * 4 * KC + t * 16];
+            for (int t = 0; t < BTW; ++t) wb0[ks][t] = ap[(size_t)ks * 4 * KC + (live(t) ? t : 0) * 16];
     }
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
-    if (wave < BT) {   // g_s1^T tiles = W2^T . g_y2^T  (contraction over the H outputs);  g_y1 = g_s1 * SiLU'(y1)
+    if (live(0)) {   // g_s1^T tiles = W2^T . g_y2^T  (contraction over the H outputs);  g_y1 = g_s1 * SiLU'(y1)
         floatx4 acc[BTW];
 #pragma unroll
         for (int t = 0; t < BTW; ++t) acc[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -474,7 +487,7 @@ __global__ __launch_bounds__(256) void k_node_energy_mfma(EnergyNodeArgs a, cons
 #pragma unroll
         for (int ks = KBH; ks < KB; ++ks)
 #pragma unroll
-            for (int t = 0; t < BTW; ++t) wb1[ks - KBH][t] = ap[(size_t)ks * 4 * KC + t * 16];
+            for (int t = 0; t < BTW; ++t) wb1[ks - KBH][t] = ap[(size_t)ks * 4 * KC + (live(t) ? t : 0) * 16];
 #pragma unroll
         for (int ks = 0; ks < KB; ++ks) {
             const float b = bp[ks * 4];
@@ -484,6 +497,7 @@ __global__ __launch_bounds__(256) void k_node_energy_mfma(EnergyNodeArgs a, cons
         }
 #pragma unroll
         for (int t = 0; t < BTW; ++t) {
+            if (!live(t)) continue;
             const int k0 = wave * 16 * BTW + t * 16 + 4 * (lane >> 4);
             float4 g;
             g.x = acc[t][0] * silu_grad_fast(y1[nl][k0]);     g.y = acc[t][1] * silu_grad_fast(y1[nl][k0 + 1]);

@@ -327,7 +327,7 @@ __device__ __forceinline__ void encode_tile_mfma(const EncW w, const EncPrefetch
     using PFT = EncPrefetch<H>;
     constexpr int TPW = PFT::TPW, KS = PFT::KS, PF = PFT::PF;
     const int tid = threadIdx.x;
-    {
+    if constexpr (256 % (H / 2) == 0) {
         const int j = tid % (H / 2);
 #pragma unroll
         for (int i = 0; i < H / 32; ++i) {
@@ -336,6 +336,13 @@ __device__ __forceinline__ void encode_tile_mfma(const EncW w, const EncPrefetch
 #pragma unroll
             for (int d = 0; d < 8; ++d) acc = fmaf(xs[n][d], pf.w0[d], acc);     // xs columns >= in_dim are 0
             s1[n][j] = silu_fast(acc + pf.b0);
+        }
+    } else {                                     // hidden widths whose half does not divide 256: (node, unit) items in a plain loop
+        for (int idx = tid; idx < NODE_TILE * (H / 2); idx += 256) {
+            const int n = idx / (H / 2), j = idx % (H / 2);
+            float acc = 0.0f;
+            for (int d = 0; d < w.in_dim; ++d) acc = fmaf(xs[n][d], w.W0[j * w.in_dim + d], acc);
+            s1[n][j] = silu_fast(acc + w.b0[j]);
         }
     }
     __syncthreads();
@@ -472,22 +479,41 @@ __device__ __forceinline__ void encode_tile(const EncW w, float (*xs)[8], float 
         s1[n][j] = silu_fast(acc + w.b0[j]);
     }
     __syncthreads();
-    constexpr int NG = 256 / H;             // node groups per workgroup (H=256: 1, H=64: 4)
-    constexpr int NPT = NODE_TILE / NG;     // nodes per thread
-    const int j = tid % H, g = tid / H;
-    float acc[NPT];
+    if constexpr (256 % H == 0) {
+        constexpr int NG = 256 / H;             // node groups per workgroup (H=256: 1, H=64: 4)
+        constexpr int NPT = NODE_TILE / NG;     // nodes per thread
+        const int j = tid % H, g = tid / H;
+        float acc[NPT];
 #pragma unroll
-    for (int i = 0; i < NPT; ++i) acc[i] = 0.0f;
-    for (int k = 0; k < H / 2; ++k) {
-        const float wv = w.W2T[(size_t)k * H + j];
+        for (int i = 0; i < NPT; ++i) acc[i] = 0.0f;
+        for (int k = 0; k < H / 2; ++k) {
+            const float wv = w.W2T[(size_t)k * H + j];
 #pragma unroll
-        for (int i = 0; i < NPT; ++i) acc[i] = fmaf(s1[g * NPT + i][k], wv, acc[i]);
-    }
-    const float bj = w.b2[j];
+            for (int i = 0; i < NPT; ++i) acc[i] = fmaf(s1[g * NPT + i][k], wv, acc[i]);
+        }
+        const float bj = w.b2[j];
 #pragma unroll
-    for (int i = 0; i < NPT; ++i) {
-        const int n = node0 + g * NPT + i;
-        if (n < N) out[(size_t)n * H + j] = silu_fast(acc[i] + bj);
+        for (int i = 0; i < NPT; ++i) {
+            const int n = node0 + g * NPT + i;
+            if (n < N) out[(size_t)n * H + j] = silu_fast(acc[i] + bj);
+        }
+    } else {                                    // widths that do not divide 256: every thread walks columns tid, tid + 256, ... for all nodes
+        for (int j = tid; j < H; j += 256) {
+            float acc[NODE_TILE];
+#pragma unroll
+            for (int i = 0; i < NODE_TILE; ++i) acc[i] = 0.0f;
+            for (int k = 0; k < H / 2; ++k) {
+                const float wv = w.W2T[(size_t)k * H + j];
+#pragma unroll
+                for (int i = 0; i < NODE_TILE; ++i) acc[i] = fmaf(s1[i][k], wv, acc[i]);
+            }
+            const float bj = w.b2[j];
+#pragma unroll
+            for (int i = 0; i < NODE_TILE; ++i) {
+                const int n = node0 + i;
+                if (n < N) out[(size_t)n * H + j] = silu_fast(acc[i] + bj);
+            }
+        }
     }
 }
 
@@ -557,7 +583,7 @@ __device__ __forceinline__ void lds_store4(float* dst, const float4 v) {
 //   slot-0 rows only) seed the accumulators, so an edge's pre-activation downstream is U[u0] + U[u1].
 // ------------------------------------------------------------------------------------------
 template <int ND> struct RowGemmCfg {
-    static constexpr int TN_ = ND >= 128 ? TILE_N : 64;   // column tile
+    static constexpr int TN_ = ND % 128 == 0 ? TILE_N : 64;   // column tile (64 wide when the width is not a multiple of 128: hidden_dim 64, 192, 320, 448)
     static constexpr int TNW = TN_ / 64;                  // 32-column MFMA tiles per wave
     static constexpr int BROWS = TN_ / 32;                // B staging rows per thread
     static constexpr int NCT = ND / TN_;                  // column tiles per row tile
@@ -667,7 +693,7 @@ __global__ __launch_bounds__(256) void k_rowgemm(int n_work, const float* __rest
 }
 
 template <int KD, int ND>
-constexpr int rowgemm_col_tiles() { return ND / (ND >= 128 ? TILE_N : 64); }
+constexpr int rowgemm_col_tiles() { return ND / (ND % 128 == 0 ? TILE_N : 64); }
 
 // base[r, :] = UG[r, :] (+ UR[r, :] on slot-0 rows: grasp_emb[args_1], denoise_fn.py:337) -- the
 // chain-constant geometry/grasp part of row r's contribution to an edge pre-activation
@@ -703,7 +729,8 @@ __device__ __forceinline__ float dot4(const float* __restrict__ a, const float* 
     return (o0 + o1) + (o2 + o3);
 }
 
-template <int H> struct EdgeCfg;
+// (any other multiple of 64: four row tiles, one wave column, H / 64 column tiles per wave)
+template <int H> struct EdgeCfg { static constexpr int WM = 4, WN = 1, TN = H / 64; };
 template <> struct EdgeCfg<256> { static constexpr int WM = 1, WN = 4, TN = 1; };
 template <> struct EdgeCfg<128> { static constexpr int WM = 2, WN = 2, TN = 1; };
 template <> struct EdgeCfg<64> { static constexpr int WM = 4, WN = 1, TN = 1; };
@@ -1319,7 +1346,14 @@ template <typename F>
 auto dispatch_h(int H, F&& f) {
     if (H == 256) return f(std::integral_constant<int, 256>{});
     if (H == 128) return f(std::integral_constant<int, 128>{});
-    return f(std::integral_constant<int, 64>{});
+    if (H == 64) return f(std::integral_constant<int, 64>{});
+    // every other multiple of 64 up to 512 (train_utils.py:107 takes any -hidden_dim): the same templates through their generic tile
+    // configurations (EdgeCfg / EdgeBfCfg / BwdCfg primaries); the f16x2 kernels and their residency tuning are hidden_dim 256's
+    if (H == 192) return f(std::integral_constant<int, 192>{});
+    if (H == 320) return f(std::integral_constant<int, 320>{});
+    if (H == 384) return f(std::integral_constant<int, 384>{});
+    if (H == 448) return f(std::integral_constant<int, 448>{});
+    return f(std::integral_constant<int, 512>{});
 }
 
 struct StreamBuf {
@@ -2071,9 +2105,9 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     }
     EnergyNodeArgs a{g->N, P, g->node_ptr, g->O, g->nrow_ptr, g->nrow_idx, g->GP, xeval, g->eps, g->partial, n_part, E_out,
                      m->pe0_w, m->pe0_b, m->pe2_w, m->pe2_wT, m->pe2_b, skip, x_enc, enc_cols};
-    const bool valu_node_energy = m->valu_node_energy != 0;                              // the pre-MFMA kernel, kept for A/B runs
+    const bool valu_node_energy = m->valu_node_energy != 0 && 256 % H == 0;               // the pre-MFMA kernel, kept for A/B runs (widths that divide 256)
     prof_mark(g, s, CCSP_K_NODE_ENERGY);
-    if (valu_node_energy) hipLaunchKernelGGL(k_node_energy<H>, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a);
+    if (valu_node_energy) { if constexpr (256 % H == 0) hipLaunchKernelGGL(k_node_energy<H>, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a); }
     else {
         bool h2n = false;
         if constexpr (H == 256) {
@@ -2842,7 +2876,9 @@ int ccsp_schedule_get(const ccsp_model* m, int32_t which, float* out) {
 int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void* stream, ccsp_model** out) {
     if (!d || !params || !out) return fail("model_create: null argument");
     const int H = d->hidden_dim, P = d->pose_dim, C = d->n_types, T = d->timesteps;
-    if (H != 64 && H != 128 && H != 256) return fail("model_create: hidden_dim %d not supported (64, 128, 256)", H);
+    if (H < 64 || H > 512 || H % 64 != 0) return fail("model_create: hidden_dim %d not supported (multiples of 64 up to 512)", H);
+    if (d->model_kind == CCSP_MODEL_STRUCT_DIFFUSION && H * (d->grasp_dim > 0 ? 3 : 2) > 64 * SD_MAXV)
+        return fail("model_create: StructDiffusion width %d exceeds %d", H * (d->grasp_dim > 0 ? 3 : 2), 64 * SD_MAXV);
     if (P < 1 || P > 8) return fail("model_create: pose_dim %d not supported (1..8)", P);
     if (d->geom_dim < 1 || d->geom_dim > 8 || d->grasp_dim < 0 || d->grasp_dim > 8) return fail("model_create: geometry/grasp width not supported (1..8)");
     if (C < 1 || T < 1) return fail("model_create: bad n_types/timesteps");

@@ -48,7 +48,7 @@ typedef struct ccsp_graph ccsp_graph;   /* one collated batch of constraint grap
  * GaussianDiffusion (networks/ddpm.py:168-228).  `dims` is the reference's tuple of
  * (length, begin, end) per variable group (train_utils.py:266-278). */
 typedef struct {
-    int32_t hidden_dim;     /* H: -hidden_dim (train_utils.py:107); supported: 64, 128, 256     */
+    int32_t hidden_dim;     /* H: -hidden_dim (train_utils.py:107); supported: multiples of 64 up to 512 */
     int32_t pose_dim;       /* P = dims[-1][0] (4 or 5)                                          */
     int32_t pose_begin;     /* dims[-1][1]: ground-truth pose columns x[:, pose_begin:+P]        */
     int32_t geom_dim;       /* dims[0][0]: geometry columns x[:, 0:geom_dim]                     */
