@@ -230,9 +230,10 @@ def mala_segment_errors(run_segment, z, segments=None):
         x = run_segment(z['hist'][k0], 999 - i0, 1000 - i1)
         want = z['hist'][k1]
         scale = 1.0 + (np.abs(want).max() if i1 < 50 else 0.0)
-        rows_off = int((np.abs(x - want).max(axis=1) > 1e-4 * scale).sum())
+        err = np.abs(x - want).max(axis=1)
+        rows_off = int((err > 1e-4 * scale).sum())
         if rows_off:
-            bad.append((i0, i1, rows_off))
+            bad.append((i0, i1, rows_off, float(err.max() / scale)))
     return bad
 
 
