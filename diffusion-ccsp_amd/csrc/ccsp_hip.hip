@@ -1425,6 +1425,7 @@ struct ccsp_model {
     float* WpT;    // [C][2][H][2H]   their transposes (energy-mode backward)
     int lanes;     // concurrent sub-batch chains per ccsp_chain_run (direct mode), default 2
     int lane_min_edges;   // batches with fewer active edges run as one lane
+    int lane_min_tokens;  // StructDiffusion: batches with fewer token rows run as one lane
     std::vector<hipStream_t> lane_streams;   // created once per model: new HIP streams are expensive to
     std::vector<hipEvent_t> lane_events;     // create (hundreds of ms for the first few), graphs come and go
     hipEvent_t fork_event = nullptr;
@@ -1552,6 +1553,7 @@ struct ccsp_graph {
     // StructDiffusion: token layout (ccsp_graph_set_sequences) and activations
     bool seq_ready = false;
     int sd_B = 0, sd_M = 0;
+    std::vector<int> h_seq_graph, h_seq_pos, h_seq_cnt;   // host copies for the lanes: graph of node n, its position, nodes per graph (whole batch)
     int *tok_node = nullptr, *tok_pos = nullptr, *node_tok = nullptr, *mask_from = nullptr;
     float *gemb = nullptr, *remb = nullptr;
     float *sdX = nullptr, *sdY = nullptr, *sdQKV = nullptr, *sdA = nullptr, *sdF = nullptr;
@@ -1914,12 +1916,17 @@ int sd_gemm_h2(const ccsp_model* m, int M, int K, int N, const float* A, const u
     static const int force_ks = getenv("CCSP_SD_KSPLIT") ? atoi(getenv("CCSP_SD_KSPLIT")) : -1;
     const bool tn64 = force_tn ? force_tn == 64 : (long)nblk(M, 64) * (N / 128) < 2L * m->ncu;
     int ks = 1;
-    if (may_split && EPI == SD_EPI_BIAS && cmax == nullptr && K % (64 * SD_KSPLIT) == 0 && (long)nblk(M, 64) * (N / 64) < 2L * m->ncu) ks = 2;
+    // (chosen from K and N alone: the same batch run as one lane or as two adds the same partial products in the same order)
+    if (may_split && EPI == SD_EPI_BIAS && cmax == nullptr && K % (64 * SD_KSPLIT) == 0 && K >= 4 * N) ks = 2;
     if (may_split && force_ks >= 1 && K % (64 * force_ks) == 0 && force_ks <= SD_KSPLIT) ks = force_ks;
-    if (tn64)
-        hipLaunchKernelGGL((k_sd_gemm_h2<EPI, 64>), dim3(nblk(M, 64) * (N / 64), ks), dim3(256), 0, s, M, K, N, A, amax, WH, (size_t)N * K, w_exp, b, Cm, cmax);
-    else
-        hipLaunchKernelGGL((k_sd_gemm_h2<EPI, 128>), dim3(nblk(M, 64) * (N / 128), ks), dim3(256), 0, s, M, K, N, A, amax, WH, (size_t)N * K, w_exp, b, Cm, cmax);
+    // operands requested 2 chunks ahead; 4 (CCSP_SD_PD=4) when the slice is a multiple of 4 chunks
+    static const int force_pd = getenv("CCSP_SD_PD") ? atoi(getenv("CCSP_SD_PD")) : 0;
+    const bool pd4 = (K / ks) % 128 == 0 && force_pd == 4;      // (r04 A/B at 2048 token rows: 4 ahead 437 us per evaluation, 2 ahead 428 -- the chunk is not waiting for loads)
+    const dim3 gr64(nblk(M, 64) * (N / 64), ks), gr128(nblk(M, 64) * (N / 128), ks);
+    if (tn64 && pd4) hipLaunchKernelGGL((k_sd_gemm_h2<EPI, 64, 4>), gr64, dim3(256), 0, s, M, K, N, A, amax, WH, (size_t)N * K, w_exp, b, Cm, cmax);
+    else if (tn64) hipLaunchKernelGGL((k_sd_gemm_h2<EPI, 64, 2>), gr64, dim3(256), 0, s, M, K, N, A, amax, WH, (size_t)N * K, w_exp, b, Cm, cmax);
+    else if (pd4) hipLaunchKernelGGL((k_sd_gemm_h2<EPI, 128, 4>), gr128, dim3(256), 0, s, M, K, N, A, amax, WH, (size_t)N * K, w_exp, b, Cm, cmax);
+    else hipLaunchKernelGGL((k_sd_gemm_h2<EPI, 128, 2>), gr128, dim3(256), 0, s, M, K, N, A, amax, WH, (size_t)N * K, w_exp, b, Cm, cmax);
     return ks;
 }
 
@@ -1932,32 +1939,70 @@ int launch_eval_sd(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s) {
     hipLaunchKernelGGL(k_sd_embed, dim3(nblk(M, 4)), dim3(256), 0, s, M, H, Wd, m->d.grasp_dim > 0 ? 1 : 0, g->tok_node, g->tok_pos, g->gemb,
                        g->remb, g->pemb, m->temb + (size_t)t * H, m->sd_pe, m->lnpre_g, m->lnpre_b, g->sdX);
     unsigned int* const nomax = nullptr;
+    // LayerNorm kernels with the width at compile time (no bounds tests next to their loads) for the widths multiples of 128 give
+    static const bool ln_generic = getenv("CCSP_SD_LN") && !strcmp(getenv("CCSP_SD_LN"), "generic");
+    const int Wsel = ln_generic ? 0 : Wd;
+    auto ln0 = [&](const float* X, const float* ga, const float* be, float* Y, unsigned int* ym, unsigned int* z0, unsigned int* z1, unsigned int* z2, int parts) {
+        const dim3 gr(nblk(M, 4)), bl(256);
+        switch (Wsel) {
+            case 128: hipLaunchKernelGGL((k_sd_ln<0, 2>), gr, bl, 0, s, M, Wd, X, ga, be, Y, ym, z0, z1, z2, parts); break;
+            case 256: hipLaunchKernelGGL((k_sd_ln<0, 4>), gr, bl, 0, s, M, Wd, X, ga, be, Y, ym, z0, z1, z2, parts); break;
+            case 384: hipLaunchKernelGGL((k_sd_ln<0, 6>), gr, bl, 0, s, M, Wd, X, ga, be, Y, ym, z0, z1, z2, parts); break;
+            case 512: hipLaunchKernelGGL((k_sd_ln<0, 8>), gr, bl, 0, s, M, Wd, X, ga, be, Y, ym, z0, z1, z2, parts); break;
+            case 768: hipLaunchKernelGGL((k_sd_ln<0, 12>), gr, bl, 0, s, M, Wd, X, ga, be, Y, ym, z0, z1, z2, parts); break;
+            default: hipLaunchKernelGGL((k_sd_ln<0, 0>), gr, bl, 0, s, M, Wd, X, ga, be, Y, ym, z0, z1, z2, parts);
+        }
+    };
+    auto ln1 = [&](const float* X, const float* ga, const float* be, float* Y, int parts) {
+        const dim3 gr(nblk(M, 4)), bl(256);
+        switch (Wsel) {
+            case 128: hipLaunchKernelGGL((k_sd_ln<1, 2>), gr, bl, 0, s, M, Wd, X, ga, be, Y, nomax, nomax, nomax, nomax, parts); break;
+            case 256: hipLaunchKernelGGL((k_sd_ln<1, 4>), gr, bl, 0, s, M, Wd, X, ga, be, Y, nomax, nomax, nomax, nomax, parts); break;
+            case 384: hipLaunchKernelGGL((k_sd_ln<1, 6>), gr, bl, 0, s, M, Wd, X, ga, be, Y, nomax, nomax, nomax, nomax, parts); break;
+            case 512: hipLaunchKernelGGL((k_sd_ln<1, 8>), gr, bl, 0, s, M, Wd, X, ga, be, Y, nomax, nomax, nomax, nomax, parts); break;
+            case 768: hipLaunchKernelGGL((k_sd_ln<1, 12>), gr, bl, 0, s, M, Wd, X, ga, be, Y, nomax, nomax, nomax, nomax, parts); break;
+            default: hipLaunchKernelGGL((k_sd_ln<1, 0>), gr, bl, 0, s, M, Wd, X, ga, be, Y, nomax, nomax, nomax, nomax, parts);
+        }
+    };
+    auto ln21 = [&](float* X, const float* g2, const float* b2, const float* g1, const float* b1, float* Y, unsigned int* ym, unsigned int* z0, unsigned int* z1,
+                    unsigned int* z2, int parts) {
+        const dim3 gr(nblk(M, 4)), bl(256);
+        switch (Wsel) {
+            case 128: hipLaunchKernelGGL((k_sd_ln2ln1<2>), gr, bl, 0, s, M, Wd, X, g2, b2, g1, b1, Y, ym, z0, z1, z2, parts); break;
+            case 256: hipLaunchKernelGGL((k_sd_ln2ln1<4>), gr, bl, 0, s, M, Wd, X, g2, b2, g1, b1, Y, ym, z0, z1, z2, parts); break;
+            case 384: hipLaunchKernelGGL((k_sd_ln2ln1<6>), gr, bl, 0, s, M, Wd, X, g2, b2, g1, b1, Y, ym, z0, z1, z2, parts); break;
+            case 512: hipLaunchKernelGGL((k_sd_ln2ln1<8>), gr, bl, 0, s, M, Wd, X, g2, b2, g1, b1, Y, ym, z0, z1, z2, parts); break;
+            case 768: hipLaunchKernelGGL((k_sd_ln2ln1<12>), gr, bl, 0, s, M, Wd, X, g2, b2, g1, b1, Y, ym, z0, z1, z2, parts); break;
+            default: hipLaunchKernelGGL((k_sd_ln2ln1<0>), gr, bl, 0, s, M, Wd, X, g2, b2, g1, b1, Y, ym, z0, z1, z2, parts);
+        }
+    };
     unsigned int *mY = g->sdMax, *mA = g->sdMax + M, *mX = g->sdMax + 2 * (size_t)M, *mF = g->sdMax + 3 * (size_t)M;
     for (int l = 0; l < SD_LAYERS; ++l) {
         const ccsp_model::SdLayer& w = m->sd[l];
         if (m->sd_h2) {
             // row maxima travel with the activations: ln_1 stores those of its output and clears the three buffers this block accumulates
             // (from the second block on, ln_1 ran fused behind the previous block's ln_2: k_sd_ln2ln1)
-            if (l == 0) hipLaunchKernelGGL(k_sd_ln<0>, dim3(nblk(M, 4)), dim3(256), 0, s, M, Wd, g->sdX, w.ln1_g, w.ln1_b, g->sdY, mY, mA, mX, mF, 1);
+            if (l == 0) ln0(g->sdX, w.ln1_g, w.ln1_b, g->sdY, mY, mA, mX, mF, 1);
             sd_gemm_h2<SD_EPI_BIAS>(m, M, Wd, 3 * Wd, g->sdY, mY, w.in_wH, w.in_e, w.in_b, g->sdQKV, nomax, s);
             hipLaunchKernelGGL(k_sd_attn, dim3(g->sd_B * SD_HEADS), dim3(256), 0, s, Wd, g->sdQKV, g->mask_from, g->sdA, mA);
             sd_gemm_h2<SD_EPI_RESID>(m, M, Wd, Wd, g->sdA, mA, w.out_wH, w.out_e, w.out_b, g->sdX, mX, s);
             sd_gemm_h2<SD_EPI_QGELU>(m, M, Wd, 4 * Wd, g->sdX, mX, w.fc_wH, w.fc_e, w.fc_b, g->sdF, mF, s);
             const int parts = sd_gemm_h2<SD_EPI_BIAS>(m, M, 4 * Wd, Wd, g->sdF, mF, w.proj_wH, w.proj_e, w.proj_b, g->sdY, nomax, s, true);
-            if (l + 1 < SD_LAYERS)
-                hipLaunchKernelGGL(k_sd_ln2ln1, dim3(nblk(M, 4)), dim3(256), 0, s, M, Wd, g->sdX, w.ln2_g, w.ln2_b, m->sd[l + 1].ln1_g, m->sd[l + 1].ln1_b, g->sdY,
-                                   mY, mA, mX, mF, parts);
-            else
-                hipLaunchKernelGGL(k_sd_ln<1>, dim3(nblk(M, 4)), dim3(256), 0, s, M, Wd, g->sdY, w.ln2_g, w.ln2_b, g->sdX, nomax, nomax, nomax, nomax, parts);
+            static const bool no_ln21 = getenv("CCSP_SD_LN21") && atoi(getenv("CCSP_SD_LN21")) == 0;
+            if (l + 1 < SD_LAYERS && no_ln21) {
+                ln1(g->sdY, w.ln2_g, w.ln2_b, g->sdX, parts);
+                ln0(g->sdX, m->sd[l + 1].ln1_g, m->sd[l + 1].ln1_b, g->sdY, mY, mA, mX, mF, 1);
+            } else if (l + 1 < SD_LAYERS) ln21(g->sdX, w.ln2_g, w.ln2_b, m->sd[l + 1].ln1_g, m->sd[l + 1].ln1_b, g->sdY, mY, mA, mX, mF, parts);
+            else ln1(g->sdY, w.ln2_g, w.ln2_b, g->sdX, parts);
             continue;
         }
-        hipLaunchKernelGGL(k_sd_ln<0>, dim3(nblk(M, 4)), dim3(256), 0, s, M, Wd, g->sdX, w.ln1_g, w.ln1_b, g->sdY, nomax, nomax, nomax, nomax, 1);
+        ln0(g->sdX, w.ln1_g, w.ln1_b, g->sdY, nomax, nomax, nomax, nomax, 1);
         sd_gemm<SD_EPI_BIAS>(M, Wd, 3 * Wd, g->sdY, w.in_w, w.in_b, g->sdQKV, s);
         hipLaunchKernelGGL(k_sd_attn, dim3(g->sd_B * SD_HEADS), dim3(256), 0, s, Wd, g->sdQKV, g->mask_from, g->sdA, nomax);
         sd_gemm<SD_EPI_RESID>(M, Wd, Wd, g->sdA, w.out_w, w.out_b, g->sdX, s);
         sd_gemm<SD_EPI_QGELU>(M, Wd, 4 * Wd, g->sdX, w.fc_w, w.fc_b, g->sdF, s);
         sd_gemm<SD_EPI_BIAS>(M, 4 * Wd, Wd, g->sdF, w.proj_w, w.proj_b, g->sdY, s);
-        hipLaunchKernelGGL(k_sd_ln<1>, dim3(nblk(M, 4)), dim3(256), 0, s, M, Wd, g->sdY, w.ln2_g, w.ln2_b, g->sdX, nomax, nomax, nomax, nomax, 1);
+        ln1(g->sdY, w.ln2_g, w.ln2_b, g->sdX, 1);
     }
     hipLaunchKernelGGL(k_sd_decode<H>, dim3(nblk(g->N, 4)), dim3(256), 0, s, g->N, Wd, P, g->F, g->node_tok, g->sdX, m->lnpost_g, m->lnpost_b,
                        m->pd0_wT, m->pd0_b, m->pd2_w, m->pd2_b, g->xfeat, g->mask, g->eps);
@@ -2466,11 +2511,18 @@ int graph_build(ccsp_model* m, int N, int E, int F, const float* x, const signed
 
 // cut the batch into `want` contiguous node ranges that no edge crosses (graphs are independent
 // units: collation is block-diagonal) and build one child graph per range
+int sequences_build(ccsp_graph* g, int B, int b0, const std::vector<int>& cnt_all, const std::vector<int>& graph_of, const std::vector<int>& pos_of, hipStream_t s);
+
 int ensure_children(ccsp_model* m, ccsp_graph* g, int want, hipStream_t s) {
     if (g->lanes_tried) return 0;
     g->lanes_tried = 1;
     const int N = g->N, E = g->E;
     if (want < 2 || N < 2 * want) return 0;
+    const bool sd = m->d.model_kind == CCSP_MODEL_STRUCT_DIFFUSION;
+    if (sd) {                                            // lanes are cut between graphs: the nodes of a graph must be contiguous, graphs ascending
+        if (!g->seq_ready) return 0;
+        for (int n = 1; n < N; ++n) if (g->h_seq_graph[n] < g->h_seq_graph[n - 1]) return 0;
+    }
     std::vector<int> cross(N + 1, 0);                    // cross[i] > 0: some edge spans the boundary before node i
     for (int e = 0; e < E; ++e) {
         const int a = (int)g->h_ei[e], b = (int)g->h_ei[(size_t)E + e];
@@ -2481,7 +2533,7 @@ int ensure_children(ccsp_model* m, ccsp_graph* g, int want, hipStream_t s) {
     cuts.push_back(0);
     int run = 0;
     std::vector<char> ok(N + 1, 0);
-    for (int i = 1; i < N; ++i) { run += cross[i]; ok[i] = run == 0; }
+    for (int i = 1; i < N; ++i) { run += cross[i]; ok[i] = run == 0 && (!sd || g->h_seq_graph[i] != g->h_seq_graph[i - 1]); }
     for (int k = 1; k < want; ++k) {
         const int target = (int)((long)N * k / want);
         int best = -1;
@@ -2528,6 +2580,13 @@ int ensure_children(ccsp_model* m, ccsp_graph* g, int want, hipStream_t s) {
         if (graph_build(m, n1 - n0, (int)ea.size(), g->F, g->xfeat + (size_t)n0 * g->F, g->mask + n0, std::move(ei), std::move(ea), s, &c)) return 1;
         g->children.push_back(c);
         g->child_node0.push_back(n0);
+        if (sd) {
+            const int b0 = g->h_seq_graph[n0], b1 = g->h_seq_graph[n1 - 1] + 1;
+            std::vector<int> graph_of(n1 - n0), pos_of;
+            for (int n = n0; n < n1; ++n) graph_of[n - n0] = g->h_seq_graph[n] - b0;
+            if (!g->h_seq_pos.empty()) pos_of.assign(g->h_seq_pos.begin() + n0, g->h_seq_pos.begin() + n1);
+            if (sequences_build(c, b1 - b0, b0, g->h_seq_cnt, graph_of, pos_of, s)) return 1;
+        }
     }
     if (!m->fork_event) HIP_TRY(hipEventCreateWithFlags(&m->fork_event, hipEventDisableTiming));
     return 0;
@@ -2897,6 +2956,8 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     m->lanes = 2;
     m->lane_min_edges = 6144;
     if (const char* e = getenv("CCSP_LANE_MIN_EDGES")) m->lane_min_edges = atoi(e);
+    m->lane_min_tokens = 1024;
+    if (const char* e = getenv("CCSP_LANE_MIN_TOKENS")) m->lane_min_tokens = atoi(e);
     if (const char* e = getenv("CCSP_LANES")) { const int v = atoi(e); if (v >= 1 && v <= 8) m->lanes = v; }
     // CCSP_MMA: f16x2 (default at hidden_dim 256: two-term fp16 operands, three MFMA products per fp32 product),
     //           bf16x3 (three-term bf16 operands, six products), f32 (v_mfma_f32_32x32x2_f32)
@@ -2973,7 +3034,7 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     if (d->model_kind == CCSP_MODEL_STRUCT_DIFFUSION) {
         const int Wd = H * (grasp ? 3 : 2);
         m->Wd = Wd;
-        m->lanes = 1;       // the head/graph mask mix-up (denoise_fn.py:434) couples the graphs of a batch: never split it
+        // (the head/graph mask mix-up of denoise_fn.py:434 couples graphs only through their node COUNTS: lanes keep the whole batch's, sequences_build)
         TRY(dup(&m->lnpre_g, Wd)); TRY(dup(&m->lnpre_b, Wd));
         for (int l = 0; l < SD_LAYERS; ++l) {
             ccsp_model::SdLayer& w = m->sd[l];
@@ -3332,6 +3393,42 @@ int ccsp_denoise(ccsp_model* m, ccsp_graph* g, const float* poses_in, int32_t t,
     return 0;
 }
 
+namespace {
+// token layout of graphs [b0, b0 + B) of a batch of B_total graphs whose node counts are cnt_all; graph_of / pos_of: the sub-batch's
+// nodes (graph ids relative to b0).  The attention mask of (graph b, head h) is the one of graph (b heads + h) mod B_total OF THE
+// WHOLE BATCH (`(repeat b)` vs MHA's (b heads) ordering, denoise_fn.py:434): a static property of the batch, so a lane keeps it.
+int sequences_build(ccsp_graph* g, int B, int b0, const std::vector<int>& cnt_all, const std::vector<int>& graph_of, const std::vector<int>& pos_of, hipStream_t s) {
+    ccsp_model* m = g->m;
+    const int N = g->N, B_total = (int)cnt_all.size();
+    std::vector<int> cnt(B, 0), tok_node((size_t)B * SD_L, -1), tok_pos((size_t)B * SD_L, 0), node_tok(N), mask_from((size_t)B * SD_HEADS);
+    for (int n = 0; n < N; ++n) {
+        const int b = graph_of[n];
+        if (cnt[b] >= SD_L) return fail("graph_set_sequences: graph %d has more than %d nodes (max_seq_len, denoise_fn.py:272)", b0 + b, SD_L);
+        node_tok[n] = b * SD_L + cnt[b];
+        tok_node[(size_t)b * SD_L + cnt[b]] = n;
+        tok_pos[(size_t)b * SD_L + cnt[b]] = pos_of.empty() ? cnt[b] : pos_of[n];
+        cnt[b]++;
+    }
+    for (int b = 0; b < B; ++b)
+        for (int h = 0; h < SD_HEADS; ++h) {
+            const int c = cnt_all[(size_t)(((long)(b0 + b) * SD_HEADS + h) % B_total)];
+            mask_from[(size_t)b * SD_HEADS + h] = c == SD_L ? 0 : c;   // no padding: `[-0:]` marks everything
+        }
+    const int M = B * SD_L, Wd = m->Wd;
+    auto& reg = g->allocs;
+    if (dev_upload(reg, &g->tok_node, tok_node, s) || dev_upload(reg, &g->tok_pos, tok_pos, s) || dev_upload(reg, &g->node_tok, node_tok, s) ||
+        dev_upload(reg, &g->mask_from, mask_from, s) || dev_alloc(reg, &g->sdX, (size_t)M * Wd) || dev_alloc(reg, &g->sdY, (size_t)SD_KSPLIT * M * Wd) ||
+        dev_alloc(reg, &g->sdQKV, (size_t)M * 3 * Wd) || dev_alloc(reg, &g->sdA, (size_t)M * Wd) || dev_alloc(reg, &g->sdF, (size_t)M * 4 * Wd) ||
+        dev_alloc(reg, &g->sdMax, (size_t)4 * M))
+        return 1;
+    HIP_TRY(hipMemsetAsync(g->sdMax, 0, (size_t)4 * M * sizeof(unsigned int), s));
+    HIP_TRY(hipStreamSynchronize(s));       // the host vectors go out of scope
+    g->sd_B = B; g->sd_M = M;
+    g->seq_ready = true;
+    return 0;
+}
+}  // namespace
+
 int ccsp_graph_set_sequences(ccsp_graph* g, const int64_t* batch, const int64_t* shuffled, void* stream) {
     if (!g || !batch) return fail("graph_set_sequences: null argument");
     ccsp_model* m = g->m;
@@ -3349,36 +3446,17 @@ int ccsp_graph_set_sequences(ccsp_graph* g, const int64_t* batch, const int64_t*
         if (hb[n] < 0 || hb[n] >= N) return fail("graph_set_sequences: batch[%d]=%lld out of range", n, (long long)hb[n]);
         if ((int)hb[n] + 1 > B) B = (int)hb[n] + 1;
     }
-    std::vector<int> cnt(B, 0), tok_node((size_t)B * SD_L, -1), tok_pos((size_t)B * SD_L, 0), node_tok(N), mask_from((size_t)B * SD_HEADS);
-    for (int n = 0; n < N; ++n) {
-        const int b = (int)hb[n];
-        if (cnt[b] >= SD_L) return fail("graph_set_sequences: graph %d has more than %d nodes (max_seq_len, denoise_fn.py:272)", b, SD_L);
-        node_tok[n] = b * SD_L + cnt[b];
-        tok_node[(size_t)b * SD_L + cnt[b]] = n;
-        tok_pos[(size_t)b * SD_L + cnt[b]] = cnt[b];
-        cnt[b]++;
-    }
-    if (shuffled)
+    std::vector<int> graph_of(N), pos_of, cnt(B, 0);
+    for (int n = 0; n < N; ++n) { graph_of[n] = (int)hb[n]; cnt[graph_of[n]]++; }
+    if (shuffled) {
+        pos_of.resize(N);
         for (int n = 0; n < N; ++n) {
-            if (hs[n] < 0 || hs[n] >= cnt[hb[n]]) return fail("graph_set_sequences: shuffled[%d]=%lld outside its graph's %d positions", n, (long long)hs[n], cnt[hb[n]]);
-            tok_pos[node_tok[n]] = (int)hs[n];
+            if (hs[n] < 0 || hs[n] >= cnt[graph_of[n]]) return fail("graph_set_sequences: shuffled[%d]=%lld outside its graph's %d positions", n, (long long)hs[n], cnt[graph_of[n]]);
+            pos_of[n] = (int)hs[n];
         }
-    for (int b = 0; b < B; ++b)
-        for (int h = 0; h < SD_HEADS; ++h) {
-            const int c = cnt[(b * SD_HEADS + h) % B];      // `(repeat b)` vs MHA's (b heads) ordering, denoise_fn.py:434
-            mask_from[(size_t)b * SD_HEADS + h] = c == SD_L ? 0 : c;   // no padding: `[-0:]` marks everything
-        }
-    const int M = B * SD_L, Wd = m->Wd;
-    auto& reg = g->allocs;
-    if (dev_upload(reg, &g->tok_node, tok_node, s) || dev_upload(reg, &g->tok_pos, tok_pos, s) || dev_upload(reg, &g->node_tok, node_tok, s) ||
-        dev_upload(reg, &g->mask_from, mask_from, s) || dev_alloc(reg, &g->sdX, (size_t)M * Wd) || dev_alloc(reg, &g->sdY, (size_t)SD_KSPLIT * M * Wd) ||
-        dev_alloc(reg, &g->sdQKV, (size_t)M * 3 * Wd) || dev_alloc(reg, &g->sdA, (size_t)M * Wd) || dev_alloc(reg, &g->sdF, (size_t)M * 4 * Wd) ||
-        dev_alloc(reg, &g->sdMax, (size_t)4 * M))
-        return 1;
-    HIP_TRY(hipMemsetAsync(g->sdMax, 0, (size_t)4 * M * sizeof(unsigned int), s));
-    HIP_TRY(hipStreamSynchronize(s));       // the host vectors go out of scope
-    g->sd_B = B; g->sd_M = M;
-    g->seq_ready = true;
+    }
+    if (sequences_build(g, B, 0, cnt, graph_of, pos_of, s)) return 1;
+    g->h_seq_graph = std::move(graph_of); g->h_seq_pos = std::move(pos_of); g->h_seq_cnt = std::move(cnt);
     return 0;
 }
 
@@ -3440,7 +3518,8 @@ int ccsp_chain_run(ccsp_model* m, ccsp_graph* g, int32_t sampler, const ccsp_noi
     int want = m->lanes;
     // below ~6000 edges the half-batch kernels are too small to overlap usefully (C2-shaped batches: 64 graphs / 5.1 k
     // edges 143 vs 132 samples/s with 1 vs 2 lanes, 96 graphs / 7.6 k edges 167 vs 188); CCSP_LANE_MIN_EDGES overrides
-    if (m->d.energy_wrapper || g->profile || g->plan.E_act < m->lane_min_edges || g->N < 2 * want) want = 1;
+    const bool small = m->d.model_kind == CCSP_MODEL_STRUCT_DIFFUSION ? g->sd_M < m->lane_min_tokens : g->plan.E_act < m->lane_min_edges;
+    if (m->d.energy_wrapper || g->profile || small || g->N < 2 * want) want = 1;
     std::vector<Lane> lanes;
     if (want > 1) {
         if (ensure_children(m, g, want, s)) return 1;

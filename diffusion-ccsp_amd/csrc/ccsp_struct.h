@@ -108,51 +108,66 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 constexpr int SD_MAXV = 12;    // width <= 768: 12 values per lane
 
-// nn.LayerNorm(eps 1e-5) of the row held as v[i] = x[lane + 64 i]; two-pass mean / biased variance
-__device__ __forceinline__ void ln_row(float (&v)[SD_MAXV], int Wd, int lane, const float* __restrict__ gam, const float* __restrict__ bet) {
+// nn.LayerNorm(eps 1e-5) of the row held as v[i] = x[lane + 64 i]; two-pass mean / biased variance.
+// NV > 0: the width is 64 NV at compile time -- no bounds tests, so no branch sits next to a load (gfx950 counts loads and stores on
+// one counter and hipcc's wait insertion takes the minimum over paths: with the tests every load of these kernels was waited for on
+// its own; the LayerNorm kernels of the transformer took 16-19 us for 4 MB rows).  NV = 0: any width <= 64 SD_MAXV, run-time tests.
+template <int NV = 0>
+__device__ __forceinline__ void ln_row(float (&v)[NV ? NV : SD_MAXV], int Wd, int lane, const float* __restrict__ gam, const float* __restrict__ bet) {
+    constexpr int N = NV ? NV : SD_MAXV;
+    float gv[N], bv[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const bool in = NV || lane + 64 * i < Wd;
+        gv[i] = in ? gam[NV || in ? lane + 64 * i : 0] : 0.0f;
+        bv[i] = in ? bet[NV || in ? lane + 64 * i : 0] : 0.0f;
+    }
     float s = 0.0f;
 #pragma unroll
-    for (int i = 0; i < SD_MAXV; ++i) if (lane + 64 * i < Wd) s += v[i];
+    for (int i = 0; i < N; ++i) if (NV || lane + 64 * i < Wd) s += v[i];
     const float mean = wave_sum(s) / (float)Wd;
     float q = 0.0f;
 #pragma unroll
-    for (int i = 0; i < SD_MAXV; ++i) if (lane + 64 * i < Wd) { const float d = v[i] - mean; q += d * d; }
+    for (int i = 0; i < N; ++i) if (NV || lane + 64 * i < Wd) { const float d = v[i] - mean; q += d * d; }
     const float inv = 1.0f / sqrtf(wave_sum(q) / (float)Wd + 1e-5f);
 #pragma unroll
-    for (int i = 0; i < SD_MAXV; ++i) if (lane + 64 * i < Wd) v[i] = (v[i] - mean) * inv * gam[lane + 64 * i] + bet[lane + 64 * i];
+    for (int i = 0; i < N; ++i) if (NV || lane + 64 * i < Wd) v[i] = (v[i] - mean) * inv * gv[i] + bv[i];
 }
 
 // Y[r] = LN(X[r])  (ACC = 0)   or   Y[r] += LN(X[r])  (ACC = 1: x = x + ln_2(mlp(x)), transformer.py:66)
 // ymax (f16x2 path, or null): bits of max |Y[r]| for the GEMM that reads Y; z0..z2: per-row maxima the GEMM epilogues / the attention
 // kernel of THIS block accumulate by atomicMax, cleared here (their readers of the previous block are done: same stream)
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
-
 // xparts > 1: X is the sum of that many split-K partial products [xparts][M][Wd], added in order
-template <int ACC>
+template <int ACC, int NV = 0>
 __global__ __launch_bounds__(256) void k_sd_ln(int M, int Wd, const float* __restrict__ X, const float* __restrict__ gam,
                                                const float* __restrict__ bet, float* __restrict__ Y, unsigned int* __restrict__ ymax,
                                                unsigned int* __restrict__ z0, unsigned int* __restrict__ z1, unsigned int* __restrict__ z2, int xparts) {
+    constexpr int N = NV ? NV : SD_MAXV;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
     if (lane == 0) { if (z0) z0[row] = 0u; if (z1) z1[row] = 0u; if (z2) z2[row] = 0u; }
-    float v[SD_MAXV];
+    float v[N], y0[N];
 #pragma unroll
-    for (int i = 0; i < SD_MAXV; ++i) {
-        v[i] = lane + 64 * i < Wd ? X[(size_t)row * Wd + lane + 64 * i] : 0.0f;
-        for (int k = 1; k < xparts; ++k) v[i] += lane + 64 * i < Wd ? X[((size_t)k * M + row) * Wd + lane + 64 * i] : 0.0f;
+    for (int i = 0; i < N; ++i) {
+        const bool in = NV || lane + 64 * i < Wd;
+        const size_t o = (size_t)row * Wd + (in ? lane + 64 * i : 0);
+        v[i] = in ? X[o] : 0.0f;
+        y0[i] = (ACC && in) ? Y[o] : 0.0f;
     }
-    ln_row(v, Wd, lane, gam, bet);
+    for (int k = 1; k < xparts; ++k) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const bool in = NV || lane + 64 * i < Wd;
+            v[i] += in ? X[((size_t)k * M + row) * Wd + (in ? lane + 64 * i : 0)] : 0.0f;
+        }
+    }
+    ln_row<NV>(v, Wd, lane, gam, bet);
     unsigned int b = 0u;                                          // largest |Y| as float bits (NaN ranks above Inf and reaches the exponent as NaN)
 #pragma unroll
-    for (int i = 0; i < SD_MAXV; ++i)
-        if (lane + 64 * i < Wd) {
-            float* dst = Y + (size_t)row * Wd + lane + 64 * i;
-            const float o = ACC ? *dst + v[i] : v[i];
-            *dst = o;
+    for (int i = 0; i < N; ++i)
+        if (NV || lane + 64 * i < Wd) {
+            const float o = ACC ? y0[i] + v[i] : v[i];
+            Y[(size_t)row * Wd + lane + 64 * i] = o;
             const unsigned int ob = __float_as_uint(o) & 0x7fffffffu;
             b = b > ob ? b : ob;
         }
@@ -165,32 +180,42 @@ __global__ __launch_bounds__(256) void k_sd_ln(int M, int Wd, const float* __res
 
 // x = X[r] + LN_2(Y[r]) (the end of block l, transformer.py:66) and at once Y[r] = LN_1'(x) of block l + 1: one launch and one pass
 // over the row instead of two (k_sd_ln<1> then k_sd_ln<0>); same arithmetic in the same order as the two kernels.
+template <int NV = 0>
 __global__ __launch_bounds__(256) void k_sd_ln2ln1(int M, int Wd, float* __restrict__ X, const float* __restrict__ g2, const float* __restrict__ b2,
                                                    const float* __restrict__ g1, const float* __restrict__ b1, float* __restrict__ Y,
                                                    unsigned int* __restrict__ ymax, unsigned int* __restrict__ z0, unsigned int* __restrict__ z1,
                                                    unsigned int* __restrict__ z2, int yparts) {
+    constexpr int N = NV ? NV : SD_MAXV;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
     if (lane == 0) { if (z0) z0[row] = 0u; if (z1) z1[row] = 0u; if (z2) z2[row] = 0u; }
-    float v[SD_MAXV];
+    float v[N], x0[N];
 #pragma unroll
-    for (int i = 0; i < SD_MAXV; ++i) {
-        v[i] = lane + 64 * i < Wd ? Y[(size_t)row * Wd + lane + 64 * i] : 0.0f;
-        for (int k = 1; k < yparts; ++k) v[i] += lane + 64 * i < Wd ? Y[((size_t)k * M + row) * Wd + lane + 64 * i] : 0.0f;      // split-K partials, in order
+    for (int i = 0; i < N; ++i) {
+        const bool in = NV || lane + 64 * i < Wd;
+        const size_t o = (size_t)row * Wd + (in ? lane + 64 * i : 0);
+        v[i] = in ? Y[o] : 0.0f;
+        x0[i] = in ? X[o] : 0.0f;
     }
-    ln_row(v, Wd, lane, g2, b2);
+    for (int k = 1; k < yparts; ++k) {                             // split-K partials, in order
 #pragma unroll
-    for (int i = 0; i < SD_MAXV; ++i)
-        if (lane + 64 * i < Wd) {
-            float* dst = X + (size_t)row * Wd + lane + 64 * i;
-            v[i] = *dst + v[i];
-            *dst = v[i];
+        for (int i = 0; i < N; ++i) {
+            const bool in = NV || lane + 64 * i < Wd;
+            v[i] += in ? Y[((size_t)k * M + row) * Wd + (in ? lane + 64 * i : 0)] : 0.0f;
         }
-    ln_row(v, Wd, lane, g1, b1);
+    }
+    ln_row<NV>(v, Wd, lane, g2, b2);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        if (NV || lane + 64 * i < Wd) {
+            v[i] = x0[i] + v[i];
+            X[(size_t)row * Wd + lane + 64 * i] = v[i];
+        }
+    ln_row<NV>(v, Wd, lane, g1, b1);
     unsigned int b = 0u;
 #pragma unroll
-    for (int i = 0; i < SD_MAXV; ++i)
-        if (lane + 64 * i < Wd) {
+    for (int i = 0; i < N; ++i)
+        if (NV || lane + 64 * i < Wd) {
             Y[(size_t)row * Wd + lane + 64 * i] = v[i];
             const unsigned int ob = __float_as_uint(v[i]) & 0x7fffffffu;
             b = b > ob ? b : ob;
@@ -205,7 +230,7 @@ __global__ __launch_bounds__(256) void k_sd_ln2ln1(int M, int Wd, float* __restr
 // ------------------------------------------------------------------------------------------
 // k_sd_gemm_h2<EPI, TN>: C[M,N] (op)= A[M,K] . W[N,K]^T + bias on the f16 pipe (f16x2).  64 x TN tiles (TN = 128: 32 x 64 per wave;
 // TN = 64: 32 x 32 per wave -- for the N = Wd GEMMs, whose 128-wide tile list would leave half the chip empty), 4 waves as 2 x 2,
-// K chunks of 32 double-buffered through LDS, operands requested TWO chunks ahead into two register sets (with one chunk of
+// K chunks of 32 double-buffered through LDS, operands requested PD (2 or 4) chunks ahead into PD register sets (with one chunk of
 // lead every iteration waited an L2 round trip: 1.5 k cycles per chunk against 0.4 k of MFMA work, first build of this round).
 // A is fp32 in memory: a row's exponent comes from amax (bits of its largest magnitude, left by the producer), the split into two
 // fp16 planes happens while the chunk is staged.  W: planes [2][N][K] scaled by 2^w_exp.  Epilogue per wave through a wave-private
@@ -213,7 +238,7 @@ __global__ __launch_bounds__(256) void k_sd_ln2ln1(int M, int Wd, float* __restr
 // of the result for the next GEMM (DPP maximum over the lanes of a row, one atomicMax on the float bits per row and wave).
 // K % 64 == 0, N % TN == 0; M arbitrary (rows clamped).
 // ------------------------------------------------------------------------------------------
-template <int EPI, int TN>
+template <int EPI, int TN, int PD>
 __global__ __launch_bounds__(256, 2) void k_sd_gemm_h2(int M, int K, int N, const float* __restrict__ A, const unsigned int* __restrict__ amax,
                                                        const unsigned short* __restrict__ WH, size_t w_plane, int w_exp,
                                                        const float* __restrict__ bias, float* __restrict__ Cm, unsigned int* __restrict__ cmax) {
@@ -237,45 +262,48 @@ __global__ __launch_bounds__(256, 2) void k_sd_gemm_h2(int M, int K, int N, cons
     Cm += (size_t)blockIdx.y * M * N;
     const int lr = tid >> 3, lq = tid & 7;                        // A producer: rows lr, lr + 32, fp32 columns 4 lq .. + 3 of the chunk
     const float* a_ptr[2];
+    const unsigned int* a_mx[2];
     int a_exp[2], a_st[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         int r = lr + 32 * i;
         r = r < nrows ? r : nrows - 1;
         a_ptr[i] = A + (size_t)(row0 + r) * K + k_first + lq * 4;
-        a_exp[i] = h2_scale_exp(__uint_as_float(amax[row0 + r]));
+        a_mx[i] = amax + row0 + r;
         a_st[i] = h2_off(lr + 32 * i, lq >> 1) + (lq & 1) * 4;
     }
-    if (lq == 0) { sE[lr] = a_exp[0]; sE[lr + 32] = a_exp[1]; }
     const int brow = tid >> 2, bq = tid & 3;                      // B copy: rows brow (+ 64), piece bq, both planes
     const unsigned short* b_ptr = WH + (size_t)(col0 + brow) * K + k_first + bq * 8;
     const int b_st = h2_off(brow, bq);
     // operand loads by inline asm, waited for by counted s_waitcnt (h2_ld16): hipcc sinks an ordinary load to its first use -- the
     // ds_write of the NEXT trip -- which puts a memory round trip into every chunk (measured: 1.8 k cycles per chunk against 0.2 k of
     // MFMA work, whatever the prefetch distance written in the source)
-    h2_f4 ra[2][2];                                               // [register set][row]
-    h2_f4 rb[2][2 * NB];
+    h2_f4 ra[PD][2];                                              // [register set][row]
+    h2_f4 rb[PD][2 * NB];
     constexpr int NLD = 2 + 2 * NB;                               // loads per chunk and thread
+    // Every step of the chain issues the same loads and the same wait, with NO branch around either: chunks past the end of the slice are
+    // requested as dummies (every lane the slice's first 16 bytes: one request per instruction).  A wait inside `if (more chunks)` made
+    // hipcc merge the two paths' register sets with v_mov copies placed BEFORE the s_waitcnt of one path -- copies of registers whose
+    // loads were in flight (second build of this round: NaN in every transformer parity test).
+    const float* const a_dummy = A + (size_t)row0 * K + k_first;
+    const unsigned short* const b_dummy = WH + (size_t)col0 * K + k_first;
     auto gload = [&](int c, int set) {
+        const bool real = c < Ks / H2_BK;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) h2_ld16(ra[set][i], a_ptr[i] + c * H2_BK);
+        for (int i = 0; i < 2; ++i) h2_ld16(ra[set][i], real ? a_ptr[i] + c * H2_BK : a_dummy);
 #pragma unroll
         for (int i = 0; i < NB; ++i)
 #pragma unroll
             for (int p = 0; p < 2; ++p)
-                h2_ld16(rb[set][i * 2 + p], reinterpret_cast<const float*>(b_ptr + (size_t)p * w_plane + (size_t)i * 64 * K + c * H2_BK));
+                h2_ld16(rb[set][i * 2 + p], reinterpret_cast<const float*>(real ? b_ptr + (size_t)p * w_plane + (size_t)i * 64 * K + c * H2_BK : b_dummy));
     };
-    // the set's loads have landed; `younger`: the OTHER set was requested after it and may stay in flight
-    auto gwait = [&](int set, bool younger) {
-        if (NB == 1) {
-            if (younger) asm volatile("s_waitcnt vmcnt(4)" : "+v"(ra[set][0]), "+v"(ra[set][1]), "+v"(rb[set][0]), "+v"(rb[set][1]) :: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[set][0]), "+v"(ra[set][1]), "+v"(rb[set][0]), "+v"(rb[set][1]) :: "memory");
-        } else {
-            if (younger) asm volatile("s_waitcnt vmcnt(6)" : "+v"(ra[set][0]), "+v"(ra[set][1]), "+v"(rb[set][0]), "+v"(rb[set][1]), "+v"(rb[set][2 * NB - 2]), "+v"(rb[set][2 * NB - 1]) :: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[set][0]), "+v"(ra[set][1]), "+v"(rb[set][0]), "+v"(rb[set][1]), "+v"(rb[set][2 * NB - 2]), "+v"(rb[set][2 * NB - 1]) :: "memory");
-        }
+    // the set's loads have landed; the PD - 1 sets requested after it stay in flight
+    auto gwait = [&](int set) {
+        if (NB == 1) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ra[set][0]), "+v"(ra[set][1]), "+v"(rb[set][0]), "+v"(rb[set][1]) : "n"((PD - 1) * NLD) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%6)" : "+v"(ra[set][0]), "+v"(ra[set][1]), "+v"(rb[set][0]), "+v"(rb[set][1]), "+v"(rb[set][2 * NB - 2]), "+v"(rb[set][2 * NB - 1]) : "n"((PD - 1) * NLD) : "memory");
     };
-    static_assert(NLD == 4 || NLD == 6, "the literal wait counts above");
+    static_assert(PD == 2 || PD == 4, "prefetch depth");
+    static_assert(NB <= 2, "gwait names four B registers");
     auto lstore = [&](int stage, int set) {
         unsigned short* As = smem + stage * STAGE;
         unsigned short* Bs = As + 2 * APL;
@@ -315,36 +343,45 @@ __global__ __launch_bounds__(256, 2) void k_sd_gemm_h2(int M, int K, int N, cons
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[PA[q]], b[j][PB[q]], acc[j], 0, 0, 0);
     };
-    const int nch = Ks / H2_BK;                                   // (even: the slice is a multiple of 64)
-    gload(0, 0);
-    gwait(0, false);
+    const int nch = Ks / H2_BK;                                   // (a multiple of PD: the host picks PD)
+#pragma unroll
+    for (int u = 0; u < PD; ++u) gload(u, u);
+    {   // the rows' maxima ride behind the first operand requests (as an ordinary load in front of them they cost every workgroup a
+        // second memory round trip before its first chunk -- and hipcc's wait for them, blind to the asm loads, drained those too)
+        unsigned int mx[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) asm volatile("global_load_dword %0, %1, off" : "=v"(mx[i]) : "v"(a_mx[i]) : "memory");
+        if (NB == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(mx[0]), "+v"(mx[1]), "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(rb[0][0]), "+v"(rb[0][1]) :: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(mx[0]), "+v"(mx[1]), "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[0][2 * NB - 2]), "+v"(rb[0][2 * NB - 1]) :: "memory");
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a_exp[i] = h2_scale_exp(__uint_as_float(mx[i]));
+    }
     lstore(0, 0);
-    gload(1, 1);
-    if (nch > 2) gload(2, 0);
+    gload(PD, 0);
+    if (lq == 0) { sE[lr] = a_exp[0]; sE[lr + 32] = a_exp[1]; }  // (here and not where a_exp is loaded: its wait would sit in front of the first operand requests)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    for (int c = 0; c < nch; c += 2) {                            // two chunks per trip: the register-set indices are constants
-        kstep(smem, 0);
-        kstep(smem, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        gwait(1, c + 2 < nch);                                    // chunk c + 1, requested two chunks ago; younger: chunk c + 2 in set 0
-        lstore(1, 1);
-        if (c + 3 < nch) gload(c + 3, 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (not __syncthreads(): its fence is a vmcnt(0) that drains the prefetch)
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        kstep(smem + STAGE, 0);
-        kstep(smem + STAGE, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (c + 2 < nch) {
-            gwait(0, c + 3 < nch);                                // chunk c + 2; younger: chunk c + 3 in set 1
-            lstore(0, 0);
-            if (c + 4 < nch) gload(c + 4, 0);
+    for (int c0 = 0; c0 < nch; c0 += PD) {                        // PD chunks per trip: register-set and stage indices are constants
+#pragma unroll
+        for (int u = 0; u < PD; ++u) {
+            const int c = c0 + u;                                 // chunk multiplied now, from stage u & 1; chunk c + 1 is staged behind it
+            kstep(smem + (u & 1) * STAGE, 0);                     // (behind the last chunk: a dummy, into the stage nobody reads again)
+            kstep(smem + (u & 1) * STAGE, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            gwait((u + 1) % PD);
+            lstore((u + 1) & 1, (u + 1) % PD);
+            gload(c + 1 + PD, (u + 1) % PD);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (not __syncthreads(): its fence is a vmcnt(0) that drains the prefetch)
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (not __syncthreads(): its fence is a vmcnt(0) that drains the prefetch)
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
+    }
+    // the dummies still in flight land before their registers are handed to the epilogue
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+        if (NB == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[u][0]), "+v"(ra[u][1]), "+v"(rb[u][0]), "+v"(rb[u][1]) :: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[u][0]), "+v"(ra[u][1]), "+v"(rb[u][0]), "+v"(rb[u][1]), "+v"(rb[u][2 * NB - 2]), "+v"(rb[u][2 * NB - 1]) :: "memory");
     }
     // epilogue, one wave at a time through its private LDS tile (the stages are free: every wave is past the last barrier)
     float* Cw = reinterpret_cast<float*>(smem) + wave * CW_SZ;
@@ -434,22 +471,36 @@ __global__ __launch_bounds__(256) void k_sd_embed(int M, int H, int Wd, int gras
 // sees, (b heads + h) mod B -- the reference repeats the masks graph-major while MHA reads them
 // head-major.
 constexpr int SD_DH_MAX = 384;
+// 16-byte accesses throughout (DH is a multiple of 32): 6 DH / 4 requests of a (graph, head)'s q, k, v issued at once, scores and P.V read
+// as ds_read_b128; every sum keeps the element order of the scalar form it replaces (13.6 -> see profiles/r04_findings.md section 4).
 __global__ __launch_bounds__(256) void k_sd_attn(int Wd, const float* __restrict__ QKV, const int* __restrict__ mask_from,
                                                  float* __restrict__ Aout, unsigned int* __restrict__ amax /*[8 B] or null: atomicMax of |Aout| per token row*/) {
-    __shared__ float qkv[3][SD_L][SD_DH_MAX + 1];
+    constexpr int LD = SD_DH_MAX + 4;                             // row stride: 16-byte aligned, consecutive rows 4 banks apart
+    __shared__ __attribute__((aligned(16))) float qkv[3][SD_L][LD];
     __shared__ float part[4][SD_L * SD_L];
     __shared__ float ps[SD_L][SD_L];
     __shared__ unsigned int srow[SD_L];
     if (threadIdx.x < SD_L) srow[threadIdx.x] = 0u;
     const int b = blockIdx.x / SD_HEADS, h = blockIdx.x % SD_HEADS;
     const int DH = Wd / SD_HEADS, tid = threadIdx.x;
+    const int D4 = DH >> 2;                                       // 16-byte pieces per row segment
     const float* base = QKV + (size_t)b * SD_L * 3 * Wd + h * DH;
-    for (int idx = tid; idx < SD_L * DH; idx += 256) {
-        const int r = idx / DH, c = idx % DH;
-        const float* src = base + (size_t)r * 3 * Wd + c;
-        qkv[0][r][c] = src[0];
-        qkv[1][r][c] = src[Wd];
-        qkv[2][r][c] = src[2 * Wd];
+    constexpr int NLD = (3 * SD_L * (SD_DH_MAX / 4) + 255) / 256; // 9 pieces per thread at most
+    float4 ld[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int idx = tid + 256 * k;                            // (which, row, piece): which slowest
+        const int w = idx / (SD_L * D4), rem = idx - w * (SD_L * D4);
+        const int r = rem / D4, c4 = rem - r * D4;
+        const bool in = idx < 3 * SD_L * D4;
+        ld[k] = *reinterpret_cast<const float4*>(base + (in ? (size_t)r * 3 * Wd + (size_t)w * Wd + 4 * c4 : 0));
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int idx = tid + 256 * k;
+        const int w = idx / (SD_L * D4), rem = idx - w * (SD_L * D4);
+        const int r = rem / D4, c4 = rem - r * D4;
+        if (idx < 3 * SD_L * D4) *reinterpret_cast<float4*>(&qkv[w][r][4 * c4]) = ld[k];
     }
     __syncthreads();
     // 64 (query, key) pairs x 4 quarters of the head dimension; the quarters are added in order 0..3
@@ -457,33 +508,48 @@ __global__ __launch_bounds__(256) void k_sd_attn(int Wd, const float* __restrict
     const int i = pair >> 3, j = pair & 7;
     const float scale = 1.0f / sqrtf((float)DH);          // q is scaled before the product, like F.multi_head_attention_forward
     {
-        const int c0 = qt * (DH / 4), c1 = c0 + DH / 4;
-        float s = 0.0f;
-        for (int c = c0; c < c1; ++c) s += (qkv[0][i][c] * scale) * qkv[1][j][c];
-        part[qt][pair] = s;
+        const int c0 = qt * (DH / 4), c1 = c0 + DH / 4;   // (DH / 4 is a multiple of 4 when DH % 16 == 0; else the scalar tail below)
+        float sacc = 0.0f;
+        int c = c0;
+        for (; c + 4 <= c1 && (c0 & 3) == 0; c += 4) {
+            const float4 q = *reinterpret_cast<const float4*>(&qkv[0][i][c]);
+            const float4 kk = *reinterpret_cast<const float4*>(&qkv[1][j][c]);
+            sacc += (q.x * scale) * kk.x; sacc += (q.y * scale) * kk.y; sacc += (q.z * scale) * kk.z; sacc += (q.w * scale) * kk.w;
+        }
+        for (; c < c1; ++c) sacc += (qkv[0][i][c] * scale) * qkv[1][j][c];
+        part[qt][pair] = sacc;
     }
     __syncthreads();
     if (tid < 64) {
-        float s = ((part[0][pair] + part[1][pair]) + part[2][pair]) + part[3][pair];
+        float sc = ((part[0][pair] + part[1][pair]) + part[2][pair]) + part[3][pair];
         const int from = mask_from[blockIdx.x];
-        s += (i >= from || j >= from) ? 1.0f : 0.0f;
-        float mx = s;
+        sc += (i >= from || j >= from) ? 1.0f : 0.0f;
+        float mx = sc;
 #pragma unroll
         for (int o = 1; o < 8; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        const float e = expf(s - mx);
+        const float e = expf(sc - mx);
         float den = e;
 #pragma unroll
         for (int o = 1; o < 8; o <<= 1) den += __shfl_xor(den, o);
         ps[i][j] = e / den;
     }
     __syncthreads();
-    for (int idx = tid; idx < SD_L * DH; idx += 256) {
-        const int r = idx / DH, c = idx % DH;
-        float o = 0.0f;
+    for (int idx = tid; idx < SD_L * D4; idx += 256) {
+        const int r = idx / D4, c4 = idx - r * D4;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int jj = 0; jj < SD_L; ++jj) o += ps[r][jj] * qkv[2][jj][c];
-        Aout[((size_t)b * SD_L + r) * Wd + h * DH + c] = o;
-        if (amax) atomicMax(&srow[r], __float_as_uint(o) & 0x7fffffffu);      // (LDS; integer maximum of the bits: order-independent, NaN on top)
+        for (int jj = 0; jj < SD_L; ++jj) {
+            const float pw = ps[r][jj];
+            const float4 v = *reinterpret_cast<const float4*>(&qkv[2][jj][4 * c4]);
+            o.x += pw * v.x; o.y += pw * v.y; o.z += pw * v.z; o.w += pw * v.w;
+        }
+        *reinterpret_cast<float4*>(Aout + ((size_t)b * SD_L + r) * Wd + h * DH + 4 * c4) = o;
+        if (amax) {                                               // (LDS; integer maximum of the bits: order-independent, NaN on top)
+            unsigned int m0 = __float_as_uint(o.x) & 0x7fffffffu, m1 = __float_as_uint(o.y) & 0x7fffffffu;
+            const unsigned int m2 = __float_as_uint(o.z) & 0x7fffffffu, m3 = __float_as_uint(o.w) & 0x7fffffffu;
+            m0 = m0 > m2 ? m0 : m2; m1 = m1 > m3 ? m1 : m3;
+            atomicMax(&srow[r], m0 > m1 ? m0 : m1);
+        }
     }
     if (amax) {
         __syncthreads();
