@@ -64,18 +64,32 @@ def build(force=False, verbose=False):
         return SO
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     tmp = SO + '.tmp'
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-pthread',
-           '-Rpass-analysis=kernel-resource-usage', '-o', tmp, os.path.join(CSRC, 'ccsp_hip.hip'), '-ldl']
-    if verbose:
-        print(' '.join(cmd))
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
-    if r.returncode != 0:
-        raise CcspError('hipcc failed:\n' + r.stderr[-4000:])
-    bad = check_no_scratch(r.stderr)
-    if bad:
-        os.remove(tmp)
-        raise CcspError('register spills in kernels whose prefetch loads are inline asm with hand-counted s_waitcnt (a spill or reload '
-                        'next to them reads registers that are still in flight): %s -- this compiler needs the vmcnt(0) fallbacks' % bad)
+    import tempfile
+    from . import _asmlint
+    with tempfile.TemporaryDirectory(prefix='ccsp_build_') as work:      # -save-temps leaves the device assembly there: the lint reads it
+        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-pthread', '-save-temps',
+               '-Rpass-analysis=kernel-resource-usage', '-o', tmp, os.path.join(CSRC, 'ccsp_hip.hip'), '-ldl']
+        if verbose:
+            print(' '.join(cmd))
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, cwd=work)
+        if r.returncode != 0:
+            raise CcspError('hipcc failed:\n' + r.stderr[-4000:])
+        bad = check_no_scratch(r.stderr)
+        if bad:
+            os.remove(tmp)
+            raise CcspError('register spills in kernels whose prefetch loads are inline asm with hand-counted s_waitcnt (a spill or reload '
+                            'next to them reads registers that are still in flight): %s -- this compiler needs the vmcnt(0) fallbacks' % bad)
+        asm = [f for f in os.listdir(work) if f.endswith('gfx950.s')]
+        if not asm:
+            os.remove(tmp)
+            raise CcspError('hipcc -save-temps left no device assembly in %s: the in-flight register lint cannot run' % work)
+        checked, found = _asmlint.lint_text(open(os.path.join(work, asm[0])).read())
+        if found or checked == 0:
+            os.remove(tmp)
+            lines = ['%s line %d: %s (registers %s)' % (k[:80], ln, v[0][:60], v[1][:6]) for k, f in found.items() for ln, v in sorted(f.items())[:3]]
+            raise CcspError('the compiler placed instructions on registers whose inline-asm loads are still in flight (in front of the hand-counted '
+                            's_waitcnt; %d kernels checked): \n  %s\n(diffusion-ccsp_amd/_asmlint.py; usual cause: a wait inside a branch, DESIGN 4.7)'
+                            % (checked, '\n  '.join(lines[:12]) or 'no guarded kernel found in the assembly'))
     os.replace(tmp, SO)
     return SO
 
