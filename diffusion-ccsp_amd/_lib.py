@@ -169,6 +169,7 @@ def lib():
     L.ccsp_compose_chain_run.argtypes = [vp, vp, vp, vp, C.POINTER(Compose), i32, C.POINTER(Noise), vp, i32, i32, i32, vp, vp]
     L.ccsp_plan_host.argtypes = [i32, i32, i32] + [vp] * 14
     L.ccsp_plan_fused_host.argtypes = [i32, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp]
+    L.ccsp_plan_bwdsum_host.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     _lib = L
     return L
 
@@ -225,3 +226,21 @@ def plan_fused_host(n_nodes, n_types, edge_index, edge_attr, rows_per_slot=28, m
     nt = n.value
     e_act = int(tiles[:nt, 2].sum())
     return dict(n_tiles=nt, tiles=tiles[:nt].copy(), rows=rows[:nt].copy(), e_lu=e_lu[:e_act].copy())
+
+
+def plan_bwdsum_host(n_nodes, n_types, edge_index, edge_attr):
+    """host-only partial rows of the energy backward (include/ccsp.h ccsp_plan_bwdsum_host); numpy in, dict out"""
+    import numpy as np
+    L = lib()
+    ei = np.ascontiguousarray(edge_index, dtype=np.int64).reshape(2, -1)
+    ea = np.ascontiguousarray(edge_attr, dtype=np.float32)
+    E = ei.shape[1]
+    nb, npart = C.c_int32(), C.c_int32()
+    blocks = np.zeros((E // 64 + 1, 513), dtype=np.int32)
+    prow = np.zeros(max(2 * E, 1), dtype=np.int32)
+    nptr = np.zeros(n_nodes + 1, dtype=np.int32)
+    nidx = np.zeros(max(2 * E, 1), dtype=np.int32)
+    check(L.ccsp_plan_bwdsum_host(n_nodes, E, n_types, ei.ctypes.data, ea.ctypes.data, C.byref(nb), C.byref(npart), blocks.ctypes.data,
+                                  prow.ctypes.data, nptr.ctypes.data, nidx.ctypes.data))
+    return dict(n_blocks=nb.value, NP=npart.value, blocks=blocks[:nb.value].copy(), prow_urow=prow[:npart.value].copy(), nrow_ptr=nptr,
+                nrow_idx=nidx[:npart.value].copy())

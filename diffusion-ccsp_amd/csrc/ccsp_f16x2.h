@@ -1268,12 +1268,28 @@ __global__ __launch_bounds__(256, 2) void k_edge_h2s(int E_act, int P, const int
 // of a row has its go values, so the exponent costs nothing.  B = fp16 planes of Wd1^T [H, H/2] (same exponent as Wd1).
 // Epilogue: GZ[k, s H + n] = 2^-(e_row + wd_exp) acc * SiLU'(U[u0] + U[u1])[s H + n], through LDS as row segments.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void k_edge_bwd_h2(int E_act, int P, const int* __restrict__ e_u0, const int* __restrict__ e_u1,
+// SUM (round 4): the ordered row sums of g_z (k_rowsum_h2) formed here, in the epilogue.  A workgroup's 64 edges touch a handful of
+// distinct U rows; ccsp::build_bwdsum_plan lists them per edge block (a PARTIAL ROW per (block, U row)) with the block-local edges of
+// each.  The scaled tile goes back into LDS, every partial row is added up in ascending edge order and written as the transpose row
+// GEMM's operand planes -- which then runs on partial rows (linearity; the node kernel adds a node's partial-row products).  Row
+// exponent from a bound every one of the block's four workgroups can form alone: |g_z[k, s H + n]| <= 1.1 |acc| <= 1.1 max_j |A[k, s, j]|
+// max_n sum_j |Wd1[j, n]| <= bound_c sum_p |go[k, s, p]|, summed over both halves of an edge and over a partial row's edges.  A loose
+// bound costs nothing: elements keep their 22 bits down to 2^-18 of the scaled bound, below that the absolute error is 2^-25 of a
+// scaled unit (fp16 subnormals) -- far under the fp32 rounding of the K = 512 accumulation the planes feed.
+struct BwdSumArgs {
+    const int* blocks;            // [n_blocks][ccsp::BS_BLK]
+    unsigned short* GZPH;         // [2][NP][512] fp16 planes of the partial rows
+    size_t plane;                 // NP * 512
+    int* gexp;                    // [NP]
+    float bound_c;                // 1.21 max|Wd2| max_n sum_j |Wd1[j, n]|, rounded up
+};
+template <bool SUM>
+__global__ __launch_bounds__(256, 3) void k_edge_bwd_h2(int E_act, int P, const int* __restrict__ e_u0, const int* __restrict__ e_u1,
                                                         const int* __restrict__ ent_pos, const float* __restrict__ U,
                                                         const float* __restrict__ Ocsr, const float* __restrict__ Q /*[2E,128]*/,
                                                         const unsigned short* __restrict__ Wd1TH /*[2][256][128]*/, int wd_exp, float wd2_absmax,
                                                         const float* __restrict__ Wd2 /*[P,128]*/, float* __restrict__ GZ,
-                                                        const int* __restrict__ skip /*MALA reuse, or null*/) {
+                                                        const int* __restrict__ skip /*MALA reuse, or null*/, BwdSumArgs bs) {
     if (skip && *skip == 0) return;
     constexpr int H = 256, KD = 128, BM = 64, BN = 128, NCH = KD / H2_BK;
     constexpr int APL = BM * H2_BK, STAGE = 2 * APL + 2 * H2_BPL;             // 8 KB of A planes + 16 KB of B planes per stage
@@ -1281,6 +1297,14 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_h2(int E_act, int P, const 
     static_assert(2 * STAGE * 2 >= BM * C_LD * 4, "epilogue tile must fit the stages");
     __shared__ __attribute__((aligned(16))) unsigned short smem[2 * STAGE + 2 * 8 * KD];          // stages + pose_decoder.2.weight [8][128] fp32
     float* W2s = reinterpret_cast<float*>(smem + 2 * STAGE);
+    // SUM: the block's partial rows (build_bwdsum_plan) and the per-edge bounds on |g_z[k, :]| take the staged weight's bytes once the K
+    // loop is over (52 KB in all: three workgroups per CU, as without SUM -- with 1.8 KB more there were two, and the kernel 50 us for 29)
+    static_assert((ccsp::BS_BLK + 128) * 4 <= 8 * KD * 4 && ccsp::BS_BLK <= 3 * 256, "partial-row block and exponents must fit the staged weight");
+    static_assert(ccsp::BS_CLD == C_LD && ccsp::BS_EDGES == BM && 2 * STAGE * 2 >= (BM + 1) * C_LD * 4, "tile shape of build_bwdsum_plan");
+    int* bsb = reinterpret_cast<int*>(W2s);
+    int* pexp = bsb + ccsp::BS_BLK;                               // [128] exponent of every partial row
+    int bsr[3] = {0, 0, 0};
+    float bnd_r[2] = {0.0f, 0.0f};
     // Round 3: this kernel spent most of its 30 us in serialized round trips -- the P loads of -O under `p < P` branches, and the P
     // rows of pose_decoder.2.weight re-read from global memory for EVERY row pass of EVERY chunk, each load under its own branch
     // and waited for with vmcnt(0) (hipcc's wait insertion takes the minimum over paths, and gfx950 counts loads and stores on
@@ -1295,6 +1319,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_h2(int E_act, int P, const 
     float go[2][8];
     const float* q_ptr[2];
     int a_st[2], a_exp[2], o_pos[2], ku0[2], ku1[2];
+    int o_pos2[2] = {0, 0};                                       // SUM: CSR slot of the edge's OTHER half (its go values enter the bound)
     // index loads first: everything below hangs off them (CSR slot -> go -> row exponent; U rows of the epilogue)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -1302,6 +1327,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_h2(int E_act, int P, const 
         k = k < E_act ? k : E_act - 1;
         const size_t row = (size_t)2 * k + s;
         o_pos[i] = ent_pos[row];
+        if constexpr (SUM) o_pos2[i] = ent_pos[row ^ 1];
         ku0[i] = e_u0[k];
         ku1[i] = e_u1[k];
         q_ptr[i] = Q + row * KD + lq * 4;
@@ -1365,7 +1391,18 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_h2(int E_act, int P, const 
             sum += fabsf(go[i][p]);
         }
         a_exp[i] = h2_scale_exp(1.1f * wd2_absmax * sum);
+        if constexpr (SUM) {
+            const float* o2 = Ocsr + (size_t)o_pos2[i] * P;
+            float sum2 = 0.0f;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const float ov = o2[p < P ? p : P - 1];
+                sum2 += p < P ? fabsf(ov) : 0.0f;
+            }
+            bnd_r[i] = bs.bound_c * (sum + sum2);
+        }
     }
+
     floatx16 acc[1][2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -1405,8 +1442,18 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_h2(int E_act, int P, const 
             ub[i][mcol] = *reinterpret_cast<const float4*>(u1 + 32 * mcol);
         }
     };
+    if constexpr (SUM) {                                          // (requested here, not at entry: two registers less across the K loop keep three workgroups per CU)
+        const int* blk = bs.blocks + (size_t)(bid >> 2) * ccsp::BS_BLK;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) bsr[j] = blk[tid + 256 * j < ccsp::BS_BLK ? tid + 256 * j : ccsp::BS_BLK - 1];
+    }
     uload(0);
     uload(1);
+    if constexpr (SUM) {                                          // (the K loop ended with a barrier: the staged weight is dead)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (tid + 256 * j < ccsp::BS_BLK) bsb[tid + 256 * j] = bsr[j];
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1428,10 +1475,61 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_h2(int E_act, int P, const 
             g[mcol] = make_float4(ldexpf(v.x, e) * silu_grad_fast(a.x + b.x), ldexpf(v.y, e) * silu_grad_fast(a.y + b.y),
                                   ldexpf(v.z, e) * silu_grad_fast(a.z + b.z), ldexpf(v.w, e) * silu_grad_fast(a.w + b.w));
         }
-        if (k < E_act) {
+        if constexpr (SUM) {                                      // back into the tile (each element is read and written by this thread only)
+#pragma unroll
+            for (int mcol = 0; mcol < 4; ++mcol) *reinterpret_cast<float4*>(Cs + row * C_LD + lq * 4 + 32 * mcol) = g[mcol];
+            if (lq == 0) Cs[row * C_LD + BN] = bnd_r[i];          // the edge's bound rides in the row's first padding column
+        } else if (k < E_act) {
             float* gz = GZ + (size_t)k * (2 * H) + s * H + n0 + lq * 4;
 #pragma unroll
             for (int mcol = 0; mcol < 4; ++mcol) *reinterpret_cast<float4*>(gz + 32 * mcol) = g[mcol];
+        }
+    }
+    if constexpr (SUM) {
+        if (tid < C_LD) Cs[BM * C_LD + tid] = 0.0f;                // the all-zero row that pads odd entry counts (bound 0 with it)
+        __syncthreads();
+        const int np = bsb[0];
+        // exponents: one thread per partial row adds the bounds of its edges (the same sum in each of the block's four workgroups)
+        if (tid < np) {
+            const int span = bsb[129 + tid];
+            float bsum = 0.0f;
+            for (int q = span >> 16; q < (span & 0xffff); ++q) {
+                const int2 r = *reinterpret_cast<const int2*>(bsb + 257 + 2 * q);
+                bsum += Cs[(r.x >> 2) + BN];
+                bsum += Cs[(r.y >> 2) + BN];
+            }
+            const int e = h2_scale_exp(bsum);
+            pexp[tid] = e;
+            if (s == 0 && ct == 0) bs.gexp[bsb[1 + tid]] = e;
+        }
+        __syncthreads();
+        // sums: thread = (columns 4 cg .. + 3 and 64 + 4 cg .. + 3, one of 16 row lanes); a partial row's entries two at a time in
+        // ascending edge order (byte offsets straight from the plan, the zero row instead of a mask)
+        const int cg = tid & 15, rl = tid >> 4;
+        const char* Cb = reinterpret_cast<const char*>(Cs) + cg * 16;
+        for (int p = rl; p < np; p += 16) {
+            const int span = bsb[129 + p];
+            const int e = pexp[p];
+            const int gid = bsb[1 + p];
+            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+            for (int q = span >> 16; q < (span & 0xffff); ++q) {
+                const int2 r = *reinterpret_cast<const int2*>(bsb + 257 + 2 * q);
+                const float4 v0 = *reinterpret_cast<const float4*>(Cb + r.x), v1 = *reinterpret_cast<const float4*>(Cb + r.x + 256);
+                const float4 w0 = *reinterpret_cast<const float4*>(Cb + r.y), w1 = *reinterpret_cast<const float4*>(Cb + r.y + 256);
+                a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+                a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+                a0.x += w0.x; a0.y += w0.y; a0.z += w0.z; a0.w += w0.w;
+                a1.x += w1.x; a1.y += w1.y; a1.z += w1.z; a1.w += w1.w;
+            }
+            const float h[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            unsigned short p1[8], p2[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) split2h(ldexpf(h[k], e), p1[k], p2[k]);
+            const size_t o = (size_t)gid * (2 * H) + s * H + n0 + cg * 4;
+            *reinterpret_cast<uint2*>(bs.GZPH + o) = make_uint2(p1[0] | ((unsigned)p1[1] << 16), p1[2] | ((unsigned)p1[3] << 16));
+            *reinterpret_cast<uint2*>(bs.GZPH + o + 64) = make_uint2(p1[4] | ((unsigned)p1[5] << 16), p1[6] | ((unsigned)p1[7] << 16));
+            *reinterpret_cast<uint2*>(bs.GZPH + bs.plane + o) = make_uint2(p2[0] | ((unsigned)p2[1] << 16), p2[2] | ((unsigned)p2[3] << 16));
+            *reinterpret_cast<uint2*>(bs.GZPH + bs.plane + o + 64) = make_uint2(p2[4] | ((unsigned)p2[5] << 16), p2[6] | ((unsigned)p2[7] << 16));
         }
     }
 }

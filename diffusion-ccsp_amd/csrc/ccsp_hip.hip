@@ -1449,6 +1449,8 @@ struct ccsp_model {
     unsigned short* WpTH = nullptr;   // [2][C][2][H][2H] fp16 planes of WpT * 2^wp_exp (energy backward; energy_wrapper models only)
     unsigned short* Wd1TH = nullptr;  // [2][H][H/2]      fp16 planes of pose_decoder.0.weight^T * 2^wd_exp
     float wd2_absmax = 0.0f;          // max |pose_decoder.2.weight| (row-exponent bound of k_edge_bwd_h2)
+    float bwd_bound_c = 0.0f;         // 1.21 max|Wd2| max_n sum_j |Wd1[j, n]|: |g_z[k, s H + n]| <= bwd_bound_c sum_p |go[k, s, p]| (k_edge_bwd_h2<true>)
+    int bwd_rowsum_fused = 1;         // (CCSP_ENERGY_ROWSUM=kernel turns it off) row sums of g_z inside the decoder backward, transpose GEMM on partial rows
     unsigned short* pe2_wH = nullptr; // pose_encoder.2.weight * 2^pe2_exp, fp16 planes in fragment order (k_pack_enc_frag_h2); CCSP_ENC=f32 leaves it null
     unsigned short* pe2_wTH = nullptr;    // the same tensor transposed, for the energy backward (k_pack_enc_frag_h2t; energy_wrapper models)
     int pe2_exp = 0;
@@ -1534,6 +1536,15 @@ struct ccsp_graph {
     unsigned short* GZRS = nullptr;    // [3][R][2H] bf16 planes of GZR (energy backward on the bf16 pipe)
     unsigned short* GZRH = nullptr;    // [2][R][2H] fp16 planes of GZR rows scaled by 2^gexp[r] (energy backward on the f16 pipe)
     int* gexp = nullptr;               // [R]
+    // row sums inside the decoder backward (ccsp::BwdSumPlan): partial rows instead of U rows downstream of it
+    ccsp::BwdSumPlan bsplan;           // kept alive for the async upload
+    bool bs_ready = false;
+    int *bs_blocks = nullptr, *bs_nrow_ptr = nullptr, *bs_nrow_idx = nullptr, *bs_gexp = nullptr;
+    unsigned short* GZPH = nullptr;    // [2][NP][2H] fp16 planes of the partial rows scaled by 2^bs_gexp
+    float* GPP = nullptr;              // [NP][H]
+    int4 *bs_td64 = nullptr, *bs_td128 = nullptr;
+    std::vector<int4> h_bstd;
+    int bs_tiles = 0, bs_tiles2 = 0;
     float *Q = nullptr, *GZ = nullptr, *GZR = nullptr, *GP = nullptr, *xhat = nullptr, *partial = nullptr, *Escal = nullptr;
     int *acc_count = nullptr, *acc_denom = nullptr;
     int* mala_changed = nullptr;       // MALA reuse: nodes accepted by the last accept step
@@ -1634,15 +1645,16 @@ EncW enc_pose(const ccsp_model* m) { return EncW{m->pe0_w, m->pe0_b, m->pe2_wT, 
 // when even those are at most one workgroup per CU (short tile lists are latency chains: C5 +12 %; with more work than that
 // the 128-row forms win, C4 -1 % and C2 -4 % if forced), else 128-row tiles at 2 workgroups per CU with direct-to-LDS
 // staging if they fit, else 3 per CU
-int rowgemm_h2_mode(const ccsp_model* m, const ccsp_graph* g, int nct) {
+int rowgemm_h2_mode(const ccsp_model* m, const ccsp_graph* g, int nct, int n_tiles = -1 /*64-row tiles; default: the graph's U-row tiles*/) {
     if (m->row_mode >= 0) return m->row_mode;
-    if (g->n_tiles * nct <= m->ncu) return 4;
+    if (n_tiles < 0) n_tiles = g->n_tiles;
+    if (n_tiles * nct <= m->ncu) return 4;
     // round 3 (tools/ab_rowmode.sh, same-call A/B): with the straight-line epilogue the register-staged MODE 0 (three workgroups
     // per CU) is ahead of or equal to the direct-to-LDS MODE 2 at every size above the one-round limit -- C2's lanes 471-474
     // against 462, 128 graphs in one lane 287 against 275, 512 graphs 559 against 550, C4 +1 % -- so MODE 2 (and 1, 3) are only
     // reached through CCSP_ROW_MODE now.  Between the two, MODE 6 -- MODE 0's staging on 64-row tiles, four workgroups per CU -- while
     // its tile list still fits a bit more than two per CU (tools/ab_env.sh: 344 workgroups +3.4 %, 560 (C4) +1 %; 636 (a C2 lane) -3 %)
-    if (g->n_tiles * nct <= 9 * m->ncu / 4) return 6;
+    if (n_tiles * nct <= 9 * m->ncu / 4) return 6;
     return 0;
 }
 
@@ -2033,6 +2045,27 @@ int energy_prepare(ccsp_model* m, ccsp_graph* g, hipStream_t s) {
         return 1;
     HIP_TRY(hipMemsetAsync(g->Escal, 0, 4 * sizeof(float), s));
     HIP_TRY(hipMemsetAsync(g->partial, 0, n_partial * sizeof(float), s));
+    if (H == 256 && m->f16x2 && m->energy_bwd_h2 && m->WpTH && m->bwd_rowsum_fused && p.E_act > 0) {
+        ccsp::build_bwdsum_plan(p, TILE_M, g->bsplan);
+        const ccsp::BwdSumPlan& b = g->bsplan;
+        if (dev_upload(reg, &g->bs_blocks, b.blocks, s) || dev_upload(reg, &g->bs_nrow_ptr, b.nrow_ptr, s) || dev_upload(reg, &g->bs_nrow_idx, b.nrow_idx, s) ||
+            dev_alloc(reg, &g->GZPH, (size_t)2 * b.NP * 2 * H) || dev_alloc(reg, &g->bs_gexp, (size_t)b.NP) || dev_alloc(reg, &g->GPP, (size_t)b.NP * H))
+            return 1;
+        g->h_bstd.clear();
+        for (size_t i = 0; i < b.tile_row0.size(); ++i) g->h_bstd.push_back(make_int4(b.tile_row0[i], b.tile_nrows[i], b.tile_ts[i], 0));
+        g->bs_tiles = (int)b.tile_row0.size();
+        g->bs_tiles2 = 0;
+        for (size_t i = 0; i < b.tile_row0.size();) {       // 128-row tiles: consecutive 64-row tiles of one (type, slot) group, two at a time
+            const bool pair = i + 1 < b.tile_row0.size() && b.tile_ts[i + 1] == b.tile_ts[i] && b.tile_row0[i + 1] == b.tile_row0[i] + b.tile_nrows[i];
+            g->h_bstd.push_back(make_int4(b.tile_row0[i], b.tile_nrows[i] + (pair ? b.tile_nrows[i + 1] : 0), b.tile_ts[i], 0));
+            g->bs_tiles2++;
+            i += pair ? 2 : 1;
+        }
+        int4* td = nullptr;
+        if (dev_upload(reg, &td, g->h_bstd, s)) return 1;
+        g->bs_td64 = td; g->bs_td128 = td + g->bs_tiles;
+        g->bs_ready = true;
+    }
     g->energy_ready = true;
     return 0;
 }
@@ -2099,8 +2132,13 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     const bool h2_bwd = h2 && m->WpTH != nullptr && m->energy_bwd_h2;      // backward GEMMs on the f16x2 scheme as well
     if constexpr (H == 256) {
         if (h2_bwd) {
-            hipLaunchKernelGGL(k_edge_bwd_h2, dim3(nblk(p.E_act, 64) * 4), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->ent_pos, g->U, g->O, g->Q,
-                               m->Wd1TH, m->wd_exp, m->wd2_absmax, m->pd2_w, g->GZ, skip);
+            if (g->bs_ready)
+                hipLaunchKernelGGL(k_edge_bwd_h2<true>, dim3(nblk(p.E_act, 64) * 4), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->ent_pos, g->U, g->O, g->Q,
+                                   m->Wd1TH, m->wd_exp, m->wd2_absmax, m->pd2_w, g->GZ, skip,
+                                   BwdSumArgs{g->bs_blocks, g->GZPH, (size_t)g->bsplan.NP * 2 * H, g->bs_gexp, m->bwd_bound_c});
+            else
+            hipLaunchKernelGGL(k_edge_bwd_h2<false>, dim3(nblk(p.E_act, 64) * 4), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->ent_pos, g->U, g->O, g->Q,
+                               m->Wd1TH, m->wd_exp, m->wd2_absmax, m->pd2_w, g->GZ, skip, BwdSumArgs{nullptr, nullptr, 0, nullptr, 0.0f});
             bwd_done = true;
         } else if (m->bf16x3 && m->edge_kernel == 2) {
             hipLaunchKernelGGL(k_edge_bwd_bf, dim3(nblk(p.E_act, 64) * 4), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->ent_pos, g->U, g->O, g->Q,
@@ -2113,9 +2151,11 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
                        g->U, g->O, g->Q, m->pd0_wT, m->pd2_w, g->GZ);
     const bool bf_bwd = !h2_bwd && H == 256 && m->bf16x3 && m->WpTS != nullptr;      // (the 128-column tiles need H >= 128)
     if (bf_bwd && !g->GZRS && dev_alloc(g->allocs, &g->GZRS, (size_t)3 * p.R * 2 * H)) return 1;
-    if (h2_bwd && !g->GZRH && (dev_alloc(g->allocs, &g->GZRH, (size_t)2 * p.R * 2 * H) || dev_alloc(g->allocs, &g->gexp, (size_t)p.R))) return 1;
-    prof_mark(g, s, CCSP_K_ROWSUM);
-    if (h2_bwd)
+    const bool psum = h2_bwd && g->bs_ready;           // the row sums were formed by the decoder backward: partial rows from here on
+    if (h2_bwd && !psum && !g->GZRH && (dev_alloc(g->allocs, &g->GZRH, (size_t)2 * p.R * 2 * H) || dev_alloc(g->allocs, &g->gexp, (size_t)p.R))) return 1;
+    if (!psum) prof_mark(g, s, CCSP_K_ROWSUM);
+    if (psum) {}
+    else if (h2_bwd)
         hipLaunchKernelGGL(k_rowsum_h2, dim3(nblk(p.R, 4)), dim3(256), 0, s, p.R, g->row_ptr, g->row_edge, g->GZ, g->GZRH, g->gexp, skip);
     else
     hipLaunchKernelGGL(k_rowsum, dim3(nblk((long)p.R * (2 * H / 4), 256)), dim3(256), 0, s, p.R, 2 * H, g->row_ptr, g->row_edge, g->GZ, g->GZR,
@@ -2125,14 +2165,18 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     prof_mark(g, s, CCSP_K_ROWGEMM_T);
     if (h2_bwd) {
         if constexpr (H == 256) {       // g_p[row] = g_z[row] . Wp[type, slot]: the forward kernel with K = 2H, N = H, identity rows, no base
-            const int mode = rowgemm_h2_mode(m, g, H / 128);
+            const int mode = rowgemm_h2_mode(m, g, H / 128, psum ? g->bs_tiles : g->n_tiles);
             const bool small = mode == 4 || mode == 6;
-            const int work = (small ? g->n_tiles : g->n_tiles2) * (H / 128);
+            const int work = (small ? (psum ? g->bs_tiles : g->n_tiles) : (psum ? g->bs_tiles2 : g->n_tiles2)) * (H / 128);
             float* nou = nullptr;
+            const unsigned short* a_pl = psum ? g->GZPH : g->GZRH;
+            const size_t a_stride = (size_t)(psum ? g->bsplan.NP : p.R) * 2 * H;
+            const int* a_ex = psum ? g->bs_gexp : g->gexp;
+            const int4* tdesc = small ? (psum ? g->bs_td64 : g->td64) : (psum ? g->bs_td128 : g->td128);
+            float* gp_out = psum ? g->GPP : g->GP;
 #define CCSP_ROWGEMM_T(MODE)                                                                                                                        \
-            hipLaunchKernelGGL((k_rowgemm_h2<2 * H, H, MODE>), dim3(work), dim3(256), 0, s, g->GZRH, (size_t)p.R * 2 * H, g->gexp, no_map,              \
-                               small ? g->td64 : g->td128, m->WpTH,                                                                                     \
-                               (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, m->wp_exp, nof, nof, g->GP, nou, StepRef{nullptr, nullptr, skip}, \
+            hipLaunchKernelGGL((k_rowgemm_h2<2 * H, H, MODE>), dim3(work), dim3(256), 0, s, a_pl, a_stride, a_ex, no_map, tdesc, m->WpTH,               \
+                               (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, m->wp_exp, nof, nof, gp_out, nou, StepRef{nullptr, nullptr, skip}, \
                                (size_t)0)
             if (mode == 6) CCSP_ROWGEMM_T(6); else if (mode == 5) CCSP_ROWGEMM_T(5); else if (mode == 4) CCSP_ROWGEMM_T(4); else if (mode == 3) CCSP_ROWGEMM_T(3); else if (mode == 2) CCSP_ROWGEMM_T(2);
             else if (mode == 1) CCSP_ROWGEMM_T(1); else CCSP_ROWGEMM_T(0);
@@ -2148,7 +2192,8 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     hipLaunchKernelGGL((k_rowgemm<2 * H, H>), dim3(nw_b < m->max_wgs ? nw_b : m->max_wgs), dim3(256), 0, s, nw_b, g->GZR, no_map, g->tileb_row0,
                        g->tileb_nrows, g->tileb_ts, m->WpT, (size_t)2 * H * H, nof, nof, g->GP);
     }
-    EnergyNodeArgs a{g->N, P, g->node_ptr, g->O, g->nrow_ptr, g->nrow_idx, g->GP, xeval, g->eps, g->partial, n_part, E_out,
+    EnergyNodeArgs a{g->N, P, g->node_ptr, g->O, psum ? g->bs_nrow_ptr : g->nrow_ptr, psum ? g->bs_nrow_idx : g->nrow_idx, psum ? g->GPP : g->GP, xeval, g->eps,
+                     g->partial, n_part, E_out,
                      m->pe0_w, m->pe0_b, m->pe2_w, m->pe2_wT, m->pe2_b, skip, x_enc, enc_cols};
     const bool valu_node_energy = m->valu_node_energy != 0 && 256 % H == 0;               // the pre-MFMA kernel, kept for A/B runs (widths that divide 256)
     prof_mark(g, s, CCSP_K_NODE_ENERGY);
@@ -3189,6 +3234,19 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
             if (d->energy_wrapper) {    // the backward GEMMs' weights: the same tensors transposed, the same exponents
                 if (const char* e = getenv("CCSP_ENERGY_BWD")) m->energy_bwd_h2 = strcmp(e, "bf16x3") != 0;
                 if (const char* e = getenv("CCSP_MALA_REUSE")) m->mala_reuse = atoi(e) != 0;
+                if (const char* e = getenv("CCSP_ENERGY_ROWSUM")) m->bwd_rowsum_fused = strcmp(e, "kernel") != 0;
+                {   // bound of the decoder backward's output per unit of sum_p |go| (k_edge_bwd_h2<true>): 1.1^2 max|Wd2| max_n sum_j |Wd1[j, n]|
+                    std::vector<float> h_wd((size_t)nwd);
+                    HIP_TRY(hipMemcpyAsync(h_wd.data(), m->pd0_w, h_wd.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+                    HIP_TRY(hipStreamSynchronize(s));
+                    float l1 = 0.0f;
+                    for (int n = 0; n < H; ++n) {
+                        float c = 0.0f;
+                        for (int j = 0; j < H / 2; ++j) c += fabsf(h_wd[(size_t)j * H + n]);
+                        l1 = fmaxf(l1, c);
+                    }
+                    m->bwd_bound_c = 1.2101f * m->wd2_absmax * l1 * 1.0001f;
+                }
                 TRY(dev_alloc(reg, &m->WpTH, (size_t)2 * nwp));
                 TRY(dev_alloc(reg, &m->Wd1TH, (size_t)2 * nwd));
                 hipLaunchKernelGGL(k_split2h, dim3(nblk(nwp, 256)), dim3(256), 0, s, nwp, m->WpT, m->wp_exp, m->WpTH);
@@ -3829,6 +3887,22 @@ int ccsp_plan_fused_host(int32_t N, int32_t E, int32_t C, const int64_t* edge_in
     if (tiles && !f.tiles.empty()) memcpy(tiles, f.tiles.data(), f.tiles.size() * sizeof(int32_t));
     if (rows && !f.rows.empty()) memcpy(rows, f.rows.data(), f.rows.size() * sizeof(int32_t));
     if (e_lu && !f.e_lu.empty()) memcpy(e_lu, f.e_lu.data(), f.e_lu.size() * sizeof(uint16_t));
+    return 0;
+}
+
+int ccsp_plan_bwdsum_host(int32_t N, int32_t E, int32_t C, const int64_t* edge_index, const float* edge_attr, int32_t* n_blocks, int32_t* n_partial,
+                          int32_t* blocks, int32_t* prow_urow, int32_t* nrow_ptr, int32_t* nrow_idx) {
+    ccsp::Plan p;
+    const char* perr = "";
+    if (ccsp::build_plan(N, E, C, TILE_M, edge_index, edge_attr, p, &perr)) return fail("plan_bwdsum_host: %s", perr);
+    ccsp::BwdSumPlan b;
+    ccsp::build_bwdsum_plan(p, TILE_M, b);
+    *n_blocks = b.n_blocks;
+    *n_partial = b.NP;
+    if (blocks && !b.blocks.empty()) memcpy(blocks, b.blocks.data(), b.blocks.size() * sizeof(int32_t));
+    if (prow_urow && !b.prow_urow.empty()) memcpy(prow_urow, b.prow_urow.data(), b.prow_urow.size() * sizeof(int32_t));
+    if (nrow_ptr) memcpy(nrow_ptr, b.nrow_ptr.data(), b.nrow_ptr.size() * sizeof(int32_t));
+    if (nrow_idx && !b.nrow_idx.empty()) memcpy(nrow_idx, b.nrow_idx.data(), b.nrow_idx.size() * sizeof(int32_t));
     return 0;
 }
 

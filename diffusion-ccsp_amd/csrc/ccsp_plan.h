@@ -164,4 +164,93 @@ inline void build_fused_plan(const Plan& p, int rows_per_slot, int max_edges, Fu
     }
 }
 
+// Row sums of the energy backward inside the decoder-backward kernel (k_edge_bwd_h2<true>, ccsp_f16x2.h).  The gradient of an edge's
+// pre-activation goes to BOTH of its U rows (z = U[u0] + U[u1]), and a U row's gradient is the sum over the sorted edges that use it
+// (the backward of the reference's gather, denoise_fn.py:341-371 under autograd).  The backward kernel works on blocks of BS_EDGES
+// consecutive sorted edges; here every block gets the list of the DISTINCT U rows its edges touch -- a PARTIAL ROW per (block, U row) --
+// and, for each, the block-local edges to add up (ascending).  The kernel's epilogue forms these sums in LDS and writes them as the
+// operand planes of the transpose row GEMM, which then runs on partial rows instead of U rows (linearity: the node kernel adds the
+// products of a node's partial rows instead of those of its U rows), so no row-sum launch and no [E, 2H] gradient array remain.
+//   partial rows are numbered by (U row, block) ascending -- U rows are numbered (type, slot) group by group, so partial rows are too;
+//   blocks [n_blocks][BS_BLK]: [0] = partial rows of the block, [1 + p] = global partial row, [129 + p] = first << 16 | end of p's
+//   PAIRS in the block's reference list, [257 + 2 q], [258 + 2 q] = the two entries of pair q, each the BYTE offset of a block-local
+//   edge's row in the kernel's LDS tile (edge * BS_CLD * 4); an odd entry count is padded with the tile's all-zero row BS_EDGES.
+constexpr int BS_EDGES = 64, BS_CLD = 132, BS_BLK = 1 + 2 * 128 + 2 * 128;
+struct BwdSumPlan {
+    int n_blocks = 0, NP = 0;
+    std::vector<int32_t> blocks;                            // [n_blocks][BS_BLK]
+    std::vector<int32_t> prow_urow, prow_ts;                // [NP]
+    std::vector<int32_t> tile_row0, tile_nrows, tile_ts;    // tile_m-row tiles of partial rows, never straddling a (type, slot) group
+    std::vector<int32_t> nrow_ptr, nrow_idx;                // [N+1], [NP]  partial rows of each node (ascending)
+};
+
+inline void build_bwdsum_plan(const Plan& p, int tile_m, BwdSumPlan& b) {
+    b = BwdSumPlan();
+    b.n_blocks = (p.E_act + BS_EDGES - 1) / BS_EDGES;
+    struct Part { int32_t urow, block, local; };
+    std::vector<Part> parts;
+    std::vector<std::vector<int32_t>> refs;                 // per (block, local partial): block-local edges
+    std::vector<int32_t> stamp(p.R, -1), loc(p.R, 0), first(b.n_blocks + 1, 0);
+    for (int t = 0; t < b.n_blocks; ++t) {
+        first[t] = (int32_t)parts.size();
+        const int k0 = t * BS_EDGES, k1 = k0 + BS_EDGES < p.E_act ? k0 + BS_EDGES : p.E_act;
+        for (int k = k0; k < k1; ++k)
+            for (int s = 0; s < 2; ++s) {
+                const int r = s == 0 ? p.e_u0[k] : p.e_u1[k];
+                if (stamp[r] != t) {
+                    stamp[r] = t;
+                    loc[r] = (int32_t)parts.size();
+                    parts.push_back(Part{r, t, (int32_t)parts.size() - first[t]});
+                    refs.emplace_back();
+                }
+                refs[loc[r]].push_back(k - k0);
+            }
+    }
+    first[b.n_blocks] = (int32_t)parts.size();
+    b.NP = (int)parts.size();
+    // global numbering: (U row, block) ascending.  Counting sort by U row keeps the block order (parts are generated block by block)
+    std::vector<int32_t> start(p.R + 1, 0), gid(b.NP, 0);
+    for (const Part& q : parts) start[q.urow + 1]++;
+    for (int r = 0; r < p.R; ++r) start[r + 1] += start[r];
+    {
+        std::vector<int32_t> pos(start.begin(), start.end() - 1);
+        for (int i = 0; i < b.NP; ++i) gid[i] = pos[parts[i].urow]++;
+    }
+    b.prow_urow.assign(b.NP, 0);
+    b.prow_ts.assign(b.NP, 0);
+    for (int i = 0; i < b.NP; ++i) { b.prow_urow[gid[i]] = parts[i].urow; b.prow_ts[gid[i]] = p.urow_ts[parts[i].urow]; }
+    b.blocks.assign((size_t)b.n_blocks * BS_BLK, 0);
+    for (int t = 0; t < b.n_blocks; ++t) {
+        int32_t* blk = b.blocks.data() + (size_t)t * BS_BLK;
+        const int np = first[t + 1] - first[t];
+        blk[0] = np;
+        int q = 0;                                          // entries written (even at every partial row's start)
+        for (int j = 0; j < np; ++j) {
+            blk[1 + j] = gid[first[t] + j];
+            const int q0 = q;
+            for (int32_t le : refs[first[t] + j]) blk[257 + q++] = le * BS_CLD * 4;
+            if (q & 1) blk[257 + q++] = BS_EDGES * BS_CLD * 4;
+            blk[129 + j] = ((q0 / 2) << 16) | (q / 2);
+        }
+    }
+    for (int g0 = 0; g0 < b.NP;) {
+        int g1 = g0;
+        while (g1 < b.NP && b.prow_ts[g1] == b.prow_ts[g0]) ++g1;
+        for (int r = g0; r < g1; r += tile_m) {
+            b.tile_row0.push_back(r);
+            b.tile_nrows.push_back(g1 - r < tile_m ? g1 - r : tile_m);
+            b.tile_ts.push_back(b.prow_ts[g0]);
+        }
+        g0 = g1;
+    }
+    b.nrow_ptr.assign(p.N + 1, 0);
+    for (int i = 0; i < b.NP; ++i) b.nrow_ptr[p.urow_node[b.prow_urow[i]] + 1]++;
+    for (int n = 0; n < p.N; ++n) b.nrow_ptr[n + 1] += b.nrow_ptr[n];
+    b.nrow_idx.assign(b.NP, 0);
+    {
+        std::vector<int32_t> np(b.nrow_ptr.begin(), b.nrow_ptr.end() - 1);
+        for (int i = 0; i < b.NP; ++i) b.nrow_idx[np[p.urow_node[b.prow_urow[i]]]++] = i;
+    }
+}
+
 }  // namespace ccsp

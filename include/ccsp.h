@@ -277,6 +277,18 @@ int ccsp_plan_host(int32_t N, int32_t E, int32_t C, const int64_t* edge_index, c
 int ccsp_plan_fused_host(int32_t N, int32_t E, int32_t C, const int64_t* edge_index, const float* edge_attr, int32_t rows_per_slot,
                          int32_t max_edges, int32_t* n_tiles, int32_t* tiles, int32_t* rows, uint16_t* e_lu);
 
+/* Host-only: the PARTIAL ROWS of the energy backward (csrc/ccsp_plan.h build_bwdsum_plan).  The reference's autograd adds, for every
+ * constraint type, the gradient of an edge's MLP input back onto the two nodes' embeddings (the backward of the gathers at
+ * denoise_fn.py:341-371); here the decoder-backward kernel works on blocks of 64 consecutive sorted edges and adds up, per block, the
+ * gradients of the edges that share a U row -- one partial row per (block, U row), numbered by (U row, block) ascending.
+ * blocks [n_blocks][513]: [0] = partial rows of the block, [1 + p] = global partial row, [129 + p] = first << 16 | end (exclusive) of
+ * p's PAIRS of entries in the block's reference list, [257 + 2 q], [258 + 2 q] = pair q, each entry 528 x (block-local edge) -- the
+ * byte offset of that edge's row in the kernel's LDS tile -- an odd count padded with 528 x 64 (an all-zero row); prow_urow
+ * [n_partial] = U row of a partial row; nrow_ptr [N + 1] / nrow_idx [n_partial] = partial rows of every node, ascending.
+ * Caller-sized HOST arrays (blocks [513 (E / 64 + 1)], prow_urow and nrow_idx [2 E], nrow_ptr [N + 1]); any of them may be NULL. */
+int ccsp_plan_bwdsum_host(int32_t N, int32_t E, int32_t C, const int64_t* edge_index, const float* edge_attr, int32_t* n_blocks,
+                          int32_t* n_partial, int32_t* blocks, int32_t* prow_urow, int32_t* nrow_ptr, int32_t* nrow_idx);
+
 #ifdef __cplusplus
 }
 #endif

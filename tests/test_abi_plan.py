@@ -99,6 +99,77 @@ def test_plan_host_matches_numpy(case):
         assert (got['urow_ts'][r0:r0 + nr] == ts).all() and 1 <= nr <= 64
 
 
+@pytest.mark.parametrize('case', ['qualitative', 'triangular', 'robot', 'ragged', 'shuffled'])
+def test_bwdsum_plan_invariants(case):
+    """the partial rows of the energy backward (ccsp_plan_bwdsum_host): every (edge, slot) reference appears in exactly one partial row --
+    that of (its block of 64 sorted edges, its U row) --, a partial row's edges ascend, partial rows are numbered by (U row, block)
+    ascending, every node lists exactly the partial rows of its U rows (ascending), and summing the partial rows of a U row is the
+    ordered row sum of k_rowsum_h2"""
+    if case == 'qualitative':
+        b, C = worlds.qualitative_batch(40, 8, seed=3), 13
+    elif case == 'triangular':
+        b, C = worlds.triangular_batch(7, 12, seed=3), 2
+    elif case == 'robot':
+        b, C = worlds.robot_box_batch(9, 10, seed=3), 2
+    else:
+        b, C = worlds.qualitative_batch(12, 6, seed=9), 13
+        b.edge_attr = b.edge_attr.copy()
+        b.edge_attr[1] = 13.0
+        if case == 'shuffled':
+            perm = np.random.RandomState(0).permutation(b.edge_index.shape[1])
+            b.edge_index = b.edge_index[:, perm]
+            b.edge_attr = b.edge_attr[perm]
+    N = b.x.shape[0]
+    pl = _lib.plan_host(N, C, b.edge_index, b.edge_attr)
+    f = _lib.plan_bwdsum_host(N, C, b.edge_index, b.edge_attr)
+    E, R, NP = pl['E_act'], pl['R'], f['NP']
+    assert f['n_blocks'] == (E + 63) // 64 and R <= NP <= 2 * E
+    g = np.random.RandomState(1).randn(E, 3)                    # a stand-in for g_z
+    want = np.zeros((R, 3))
+    for k in range(E):
+        want[pl['e_u0'][k]] += g[k]
+        want[pl['e_u1'][k]] += g[k]
+    got = np.zeros((R, 3))
+    seen = np.zeros(NP, dtype=bool)
+    refs_total = 0
+    for t, blk in enumerate(f['blocks']):
+        n_p = blk[0]
+        ne = min(64, E - 64 * t)
+        assert 1 <= n_p <= 2 * ne
+        q0 = 0
+        urows = set()
+        for j in range(n_p):
+            gid, span = blk[1 + j], blk[129 + j]
+            assert span >> 16 == q0 // 2                         # pairs follow each other
+            q1 = 2 * (span & 0xffff)
+            assert q1 > q0 and not seen[gid]
+            seen[gid] = True
+            le = blk[257 + q0:257 + q1]
+            assert (le % 528 == 0).all()                         # byte offsets of rows of the kernel's [65][132] fp32 tile
+            le = le // 528
+            if le[-1] == 64:                                     # odd count: padded with the all-zero row
+                le = le[:-1]
+                assert len(le) % 2 == 1
+            assert (np.diff(le) > 0).all() and le.min() >= 0 and le.max() < ne
+            r = f['prow_urow'][gid]
+            assert r not in urows
+            urows.add(r)
+            for e in le:
+                k = 64 * t + e
+                assert r in (pl['e_u0'][k], pl['e_u1'][k])
+            got[r] += g[64 * t + le].sum(0)
+            refs_total += len(le)
+            q0 = q1
+    assert seen.all() and refs_total == 2 * E
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+    assert (np.diff(f['prow_urow']) >= 0).all()
+    ptr, idx = f['nrow_ptr'], f['nrow_idx']
+    assert ptr[0] == 0 and ptr[N] == NP
+    for n in range(N):
+        seg = idx[ptr[n]:ptr[n + 1]]
+        assert (np.diff(seg) > 0).all() and (pl['urow_node'][f['prow_urow'][seg]] == n).all()
+
+
 @pytest.mark.parametrize('shape', [(28, 112), (32, 128)])
 @pytest.mark.parametrize('case', ['qualitative', 'triangular', 'robot', 'ragged', 'shuffled'])
 def test_fused_plan_invariants(case, shape):
