@@ -233,6 +233,7 @@ struct EnergyNodeArgs {
     // enc_cols inputs are variables (the rest are constants of the batch); defaults: x_enc = x, every column
     const float* x_enc;      // or null
     int enc_cols;            // 0 = all P columns
+    int* skip_count;         // MALA reuse: += 1 per skipped gradient evaluation (or null)
 };
 
 template <int H>
@@ -539,7 +540,7 @@ __global__ void k_pack_enc_frag_h2t(const float* __restrict__ W2 /*[256,128]*/, 
     W2TH[256 * 128 + idx] = b;
 }
 
-__global__ __launch_bounds__(256) void k_node_energy_h2(EnergyNodeArgs a, EncW w, const unsigned short* __restrict__ W2TH) {
+__device__ __forceinline__ void node_energy_h2_body(const EnergyNodeArgs& a, const EncW& w, const unsigned short* __restrict__ W2TH) {
     constexpr int H = 256, KC = 128, LD1 = ENC_H2_LD, LD2 = H + 8;       // fp16 row strides: 16-byte fragment reads hit all banks once
     __shared__ float xs[NODE_TILE][8];
     __shared__ float dir[NODE_TILE][8];
@@ -550,10 +551,6 @@ __global__ __launch_bounds__(256) void k_node_energy_h2(EnergyNodeArgs a, EncW w
     __shared__ float red[256];
     __shared__ float smax[4][NODE_TILE];
     __shared__ int sexp[NODE_TILE];
-    if (a.skip && *a.skip == 0) {                                 // (uniform) MALA reuse: gradient and E(x) of the unmoved state stand
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(const_cast<int*>(a.skip) + 1, 1);      // [1]: evaluations skipped
-        return;
-    }
     const int node0 = blockIdx.x * NODE_TILE;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nl = lane & 15, n = node0 + nl;
@@ -785,6 +782,29 @@ __global__ __launch_bounds__(256) void k_node_energy_h2(EnergyNodeArgs a, EncW w
         const int n2 = node0 + nl2;
         if (half == 0 && n2 < a.N && p < a.P) a.grad[(size_t)n2 * a.P + p] = (a.enc_cols && p >= a.enc_cols) ? dir[nl2][p] : dir[nl2][p] + (gx + red[t7]);
     }
+}
+
+__global__ __launch_bounds__(256) void k_node_energy_h2(EnergyNodeArgs a, EncW w, const unsigned short* __restrict__ W2TH) {
+    if (a.skip && *a.skip == 0) {                                 // (uniform) MALA reuse: gradient and E(x) of the unmoved state stand
+        if (blockIdx.x == 0 && threadIdx.x == 0 && a.skip_count) atomicAdd(a.skip_count, 1);
+        return;
+    }
+    node_energy_h2_body(a, w, W2TH);
+}
+
+// The gradient evaluation's last kernel and the update that consumes it in ONE launch (MALA's propose step, the Langevin step of an
+// energy-mode ULA chain): both work on the same 16-node blocks and a thread of the update reads exactly the gradient element the
+// same thread stored a moment ago, so nothing but the launch boundary separated them (5 launches per gradient evaluation and
+// update instead of 6).  The MALA-reuse flag the evaluation reads and the one the update resets are different words (the inner
+// step's parity picks them: chain_run_impl), so a block that runs ahead cannot change what a later block reads.
+__global__ __launch_bounds__(256) void k_node_energy_h2_update(EnergyNodeArgs a, EncW w, const unsigned short* __restrict__ W2TH, NodeArgs b, EncW wb, EncOut eo) {
+    if (a.skip && *a.skip == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0 && a.skip_count) atomicAdd(a.skip_count, 1);
+    } else {
+        node_energy_h2_body(a, w, W2TH);
+    }
+    __syncthreads();
+    node_body<256, true>(b, wb, eo);
 }
 
 // acceptance counts -> mean acceptance rate per timestep

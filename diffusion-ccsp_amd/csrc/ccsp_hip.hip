@@ -955,7 +955,7 @@ __device__ __forceinline__ float step_ula(float xv, float eps, float z, float ka
 }
 
 template <int H, bool ENCH /*second encoder layer on the f16 pipe (encode_tile_h2)*/>
-__global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, EncOut eo) {
+__device__ __forceinline__ void node_body(NodeArgs a, const EncW w, const EncOut eo) {
     static_assert(!ENCH || H == 256, "the f16 encoder is written for hidden_dim 256");
     constexpr int S1_FLOATS = ENCH ? (2 * NODE_TILE * ENC_H2_LD) / 2 : NODE_TILE * (H / 2 + 1);
     __shared__ float xs[NODE_TILE][8];
@@ -1109,6 +1109,8 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, EncOut eo) {
     CCSP_TRK(2, 5);
     CCSP_TRK_RT(2, 31);
 }
+template <int H, bool ENCH>
+__global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, EncOut eo) { node_body<H, ENCH>(a, w, eo); }
 
 // ------------------------------------------------------------------------------------------
 // k_node_direct: k_node for what a direct-mode chain runs 11 000 times -- CSR reduce (src 0), ancestral or ULA step, f16
@@ -1451,6 +1453,7 @@ struct ccsp_model {
     float wd2_absmax = 0.0f;          // max |pose_decoder.2.weight| (row-exponent bound of k_edge_bwd_h2)
     float bwd_bound_c = 0.0f;         // 1.21 max|Wd2| max_n sum_j |Wd1[j, n]|: |g_z[k, s H + n]| <= bwd_bound_c sum_p |go[k, s, p]| (k_edge_bwd_h2<true>)
     int bwd_rowsum_fused = 1;         // (CCSP_ENERGY_ROWSUM=kernel turns it off) row sums of g_z inside the decoder backward, transpose GEMM on partial rows
+    int node_energy_fused = 1;        // (CCSP_ENERGY_NODE=split turns it off) k_node_energy_h2_update: the update that consumes the gradient in the same launch
     unsigned short* pe2_wH = nullptr; // pose_encoder.2.weight * 2^pe2_exp, fp16 planes in fragment order (k_pack_enc_frag_h2); CCSP_ENC=f32 leaves it null
     unsigned short* pe2_wTH = nullptr;    // the same tensor transposed, for the energy backward (k_pack_enc_frag_h2t; energy_wrapper models)
     int pe2_exp = 0;
@@ -2041,7 +2044,7 @@ int energy_prepare(ccsp_model* m, ccsp_graph* g, hipStream_t s) {
         dev_alloc(reg, &g->GZR, (size_t)p.R * 2 * H) || dev_alloc(reg, &g->GP, (size_t)p.R * H) ||
         dev_alloc(reg, &g->xhat, (size_t)g->N * P) || dev_alloc(reg, &g->partial, n_partial) ||
         dev_alloc(reg, &g->Escal, 4) || dev_alloc(reg, &g->acc_count, (size_t)T) || dev_alloc(reg, &g->acc_denom, (size_t)T) ||
-        dev_alloc(reg, &g->mala_changed, 2))                 // [0] nodes accepted by the last accept step, [1] evaluations skipped
+        dev_alloc(reg, &g->mala_changed, 3))                 // [0], [1] pose elements the accept step of an odd / even inner step moved, [2] evaluations skipped
         return 1;
     HIP_TRY(hipMemsetAsync(g->Escal, 0, 4 * sizeof(float), s));
     HIP_TRY(hipMemsetAsync(g->partial, 0, n_partial * sizeof(float), s));
@@ -2076,7 +2079,8 @@ int energy_prepare(ccsp_model* m, ccsp_graph* g, hipStream_t s) {
 template <int H>
 int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, bool with_grad, float* E_out, hipStream_t s,
                        const int* skip = nullptr /*MALA reuse: every kernel of the evaluation returns at once if *skip == 0*/,
-                       const float* x_enc = nullptr, int enc_cols = 0 /*composed domains: see EnergyNodeArgs*/) {
+                       const float* x_enc = nullptr, int enc_cols = 0 /*composed domains: see EnergyNodeArgs*/,
+                       const NodeArgs* tail = nullptr, bool* tail_done = nullptr /*the update that consumes the gradient: run in the last kernel if it can be*/) {
     const ccsp::Plan& p = g->plan;
     const int P = m->d.pose_dim;
     g->evals++;
@@ -2194,7 +2198,8 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     }
     EnergyNodeArgs a{g->N, P, g->node_ptr, g->O, psum ? g->bs_nrow_ptr : g->nrow_ptr, psum ? g->bs_nrow_idx : g->nrow_idx, psum ? g->GPP : g->GP, xeval, g->eps,
                      g->partial, n_part, E_out,
-                     m->pe0_w, m->pe0_b, m->pe2_w, m->pe2_wT, m->pe2_b, skip, x_enc, enc_cols};
+                     m->pe0_w, m->pe0_b, m->pe2_w, m->pe2_wT, m->pe2_b, skip, x_enc, enc_cols, skip ? g->mala_changed + 2 : nullptr};
+    if (tail_done) *tail_done = false;
     const bool valu_node_energy = m->valu_node_energy != 0 && 256 % H == 0;               // the pre-MFMA kernel, kept for A/B runs (widths that divide 256)
     prof_mark(g, s, CCSP_K_NODE_ENERGY);
     if (valu_node_energy) { if constexpr (256 % H == 0) hipLaunchKernelGGL(k_node_energy<H>, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a); }
@@ -2202,7 +2207,14 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
         bool h2n = false;
         if constexpr (H == 256) {
             h2n = m->pe2_wTH != nullptr;
-            if (h2n) hipLaunchKernelGGL(k_node_energy_h2, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a, enc_pose(m), (const unsigned short*)m->pe2_wTH);
+            if (h2n && tail && m->node_energy_fused && m->pe2_wH && m->bf16x3 && m->f16x2 && m->d.model_kind == CCSP_MODEL_DIFFUSION_CCSP) {
+                // (launch_node's EncOut for an energy_wrapper model on the f16x2 path: fp32 embeddings and the fp16 planes)
+                EncOut eo;
+                eo.f32 = g->pemb; eo.bf3 = nullptr; eo.h2 = g->pembH; eo.h2_exp = g->pexp;
+                hipLaunchKernelGGL(k_node_energy_h2_update, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a, enc_pose(m), (const unsigned short*)m->pe2_wTH, *tail,
+                                   enc_pose(m), eo);
+                *tail_done = true;
+            } else if (h2n) hipLaunchKernelGGL(k_node_energy_h2, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a, enc_pose(m), (const unsigned short*)m->pe2_wTH);
         }
         if (!h2n) hipLaunchKernelGGL(k_node_energy_mfma<H>, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a, (const float*)m->pe2_wF);
     }
@@ -2285,7 +2297,7 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
         std::vector<uint64_t> ucall0(T, 0);
         if (energy_prepare(m, g, s)) return 1;
         HIP_TRY(hipMemsetAsync(g->acc_count, 0, (size_t)T * sizeof(int), s));
-        HIP_TRY(hipMemsetAsync(g->mala_changed, 0, 2 * sizeof(int), s));
+        HIP_TRY(hipMemsetAsync(g->mala_changed, 0, 3 * sizeof(int), s));
         HIP_TRY(hipStreamSynchronize(s));      // a previous chain may still be reading h_denom
         g->h_denom.assign(T, 0);
         uint64_t uc0 = 0;
@@ -2299,7 +2311,6 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
             // (energy_function, ddpm.py:285-289) -- the gradient pass already gave E(x)
             const int S = steps_at(m, sampler, t);
             float* E_x = g->Escal, *E_hat = g->Escal + 1;
-            if (launch_eval_energy<H>(m, g, t, g->x, true, E_x, s)) return 1;
             {
                 NodeArgs a = node_args(m, g);
                 a.src = 1; a.eps_buf = g->eps; a.do_encode = 1; a.step = STEP_ANCESTRAL;
@@ -2307,7 +2318,9 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
                 a.hist = S == 0 ? hist_at(L, T - t) : nullptr;
                 sched(a, t);
                 if (noise_for(L, call0[t], a.noise)) return 1;
-                launch_node<H>(m, g, a, s);
+                bool tail_done = false;
+                if (launch_eval_energy<H>(m, g, t, g->x, true, E_x, s, nullptr, nullptr, 0, &a, &tail_done)) return 1;
+                if (!tail_done) launch_node<H>(m, g, a, s);
             }
             if (sampler == CCSP_SAMPLER_HMC && S > 0) {
                 // AnnealedMUHASampler.sample_step (ddpm.py:1087-1128); see ccsp_hmc.h.  The leapfrog runs at
@@ -2386,7 +2399,10 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
             float* E_xl = hook ? g->Escal + 2 : E_x;
             float* E_hatl = hook ? g->Escal + 3 : E_hat;
             for (int e = 1; e <= S; ++e) {
-                if (launch_eval_energy<H>(m, g, t, g->x, true, E_xl, s, (reuse && e >= 2) ? g->mala_changed : (const int*)nullptr)) return 1;
+                // the MALA-reuse flags: the accept step of inner step e counts the pose elements it moved in word e & 1 (reset by the same
+                // step's update kernel), the gradient evaluation of step e + 1 reads it -- two words, so the update that runs in the
+                // evaluation's last kernel resets a word no block of that kernel reads
+                const int* skip_flag = (reuse && e >= 2) ? g->mala_changed + ((e - 1) & 1) : (const int*)nullptr;
                 NodeArgs a = node_args(m, g);
                 a.src = 1; a.eps_buf = g->eps; a.do_encode = 1; a.xhat = g->xhat;
                 sched(a, t);
@@ -2395,12 +2411,14 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
                     a.step = STEP_ULA;
                     a.reset_mask = (e == S);
                     a.hist = e == S ? hist_at(L, T - t) : nullptr;
-                    launch_node<H>(m, g, a, s);
-                    continue;
+                } else {
+                    a.step = STEP_MALA_PROPOSE;
+                    a.changed = reuse ? g->mala_changed + (e & 1) : nullptr;
                 }
-                a.step = STEP_MALA_PROPOSE;
-                a.changed = reuse ? g->mala_changed : nullptr;
-                launch_node<H>(m, g, a, s);                                   // x_hat, and its pose embedding
+                bool tail_done = false;
+                if (launch_eval_energy<H>(m, g, t, g->x, true, E_xl, s, skip_flag, nullptr, 0, &a, &tail_done)) return 1;
+                if (!tail_done) launch_node<H>(m, g, a, s);                   // (MALA: x_hat, and its pose embedding)
+                if (sampler != CCSP_SAMPLER_MALA) continue;
                 // without a shard hook the accept kernel sums the proposal's energy partials itself (no k_energy_sum launch)
                 const bool fold_sum = !hook && g->plan.E_act > 0;
                 if (launch_eval_energy<H>(m, g, t, g->xhat, false, fold_sum ? (float*)nullptr : E_hatl, s)) return 1;
@@ -2417,7 +2435,7 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
                 NodeArgs b = node_args(m, g);
                 b.src = 1; b.eps_buf = g->eps; b.do_encode = 1; b.xhat = g->xhat; b.step = STEP_MALA_ACCEPT;
                 b.E_x = E_x; b.E_hat = E_hat; b.acc_count = g->acc_count + t;
-                b.changed = reuse ? g->mala_changed : nullptr;
+                b.changed = reuse ? g->mala_changed + (e & 1) : nullptr;
                 if (fold_sum) { b.E_hat_partial = g->partial; b.n_hat_partial = g->n_part_last; }
                 b.reset_mask = (e == S);
                 b.hist = e == S ? hist_at(L, T - t) : nullptr;
@@ -3235,6 +3253,7 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
                 if (const char* e = getenv("CCSP_ENERGY_BWD")) m->energy_bwd_h2 = strcmp(e, "bf16x3") != 0;
                 if (const char* e = getenv("CCSP_MALA_REUSE")) m->mala_reuse = atoi(e) != 0;
                 if (const char* e = getenv("CCSP_ENERGY_ROWSUM")) m->bwd_rowsum_fused = strcmp(e, "kernel") != 0;
+                if (const char* e = getenv("CCSP_ENERGY_NODE")) m->node_energy_fused = strcmp(e, "split") != 0;
                 {   // bound of the decoder backward's output per unit of sum_p |go| (k_edge_bwd_h2<true>): 1.1^2 max|Wd2| max_n sum_j |Wd1[j, n]|
                     std::vector<float> h_wd((size_t)nwd);
                     HIP_TRY(hipMemcpyAsync(h_wd.data(), m->pd0_w, h_wd.size() * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -3686,7 +3705,7 @@ int ccsp_chain_skipped(ccsp_graph* g, int64_t* evaluations_skipped) {
     if (!g->have_events) return fail("chain_skipped: no chain has run on this graph");
     HIP_TRY(hipEventSynchronize(g->ev1));
     int n = 0;
-    if (g->mala_changed) HIP_TRY(hipMemcpy(&n, g->mala_changed + 1, sizeof(int), hipMemcpyDeviceToHost));
+    if (g->mala_changed) HIP_TRY(hipMemcpy(&n, g->mala_changed + 2, sizeof(int), hipMemcpyDeviceToHost));
     *evaluations_skipped = n;
     return 0;
 }
