@@ -1283,8 +1283,11 @@ struct BwdSumArgs {
     int* gexp;                    // [NP]
     float bound_c;                // 1.21 max|Wd2| max_n sum_j |Wd1[j, n]|, rounded up
 };
-template <bool SUM>
-__global__ __launch_bounds__(256, 3) void k_edge_bwd_h2(int E_act, int P, const int* __restrict__ e_u0, const int* __restrict__ e_u1,
+// PP: pose_dim as a compile-time constant (4: every world but the robot's), or 0 = the run-time P with the loops run to 8 under selects --
+// which is 8 LDS reads, 32 FMAs and 32 selects per four A elements where pose_dim 4 needs 4 reads and 16 FMAs, in the loop that bounds
+// this kernel (VALU: 7.1 M instructions per launch at C4 against 7.7 M MFMA-busy cycles)
+template <bool SUM, int PP>
+__global__ __launch_bounds__(256, 3) void k_edge_bwd_h2(int E_act, int P_rt, const int* __restrict__ e_u0, const int* __restrict__ e_u1,
                                                         const int* __restrict__ ent_pos, const float* __restrict__ U,
                                                         const float* __restrict__ Ocsr, const float* __restrict__ Q /*[2E,128]*/,
                                                         const unsigned short* __restrict__ Wd1TH /*[2][256][128]*/, int wd_exp, float wd2_absmax,
@@ -1292,6 +1295,8 @@ __global__ __launch_bounds__(256, 3) void k_edge_bwd_h2(int E_act, int P, const 
                                                         const int* __restrict__ skip /*MALA reuse, or null*/, BwdSumArgs bs) {
     if (skip && *skip == 0) return;
     constexpr int H = 256, KD = 128, BM = 64, BN = 128, NCH = KD / H2_BK;
+    constexpr int PMAX = PP ? PP : 8;
+    const int P = PP ? PP : P_rt;
     constexpr int APL = BM * H2_BK, STAGE = 2 * APL + 2 * H2_BPL;             // 8 KB of A planes + 16 KB of B planes per stage
     constexpr int C_LD = BN + 4;
     static_assert(2 * STAGE * 2 >= BM * C_LD * 4, "epilogue tile must fit the stages");
@@ -1353,12 +1358,12 @@ __global__ __launch_bounds__(256, 3) void k_edge_bwd_h2(int E_act, int P, const 
         unsigned short* As = smem + stage * STAGE;
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
+        for (int p = 0; p < PMAX; ++p) {
             const float4 w2 = *reinterpret_cast<const float4*>(W2s + p * KD + c * H2_BK + lq * 4);
             const float gp = go[i][p];
             // (terms p >= P: go = 0 and a zero weight row -- exactly 0, added to nothing: the select keeps a NaN / Inf out)
-            g.x = p < P ? fmaf(gp, w2.x, g.x) : g.x; g.y = p < P ? fmaf(gp, w2.y, g.y) : g.y;
-            g.z = p < P ? fmaf(gp, w2.z, g.z) : g.z; g.w = p < P ? fmaf(gp, w2.w, g.w) : g.w;
+            g.x = (PP || p < P) ? fmaf(gp, w2.x, g.x) : g.x; g.y = (PP || p < P) ? fmaf(gp, w2.y, g.y) : g.y;
+            g.z = (PP || p < P) ? fmaf(gp, w2.z, g.z) : g.z; g.w = (PP || p < P) ? fmaf(gp, w2.w, g.w) : g.w;
         }
         const float4 q = rq[set][i];
         const float h[4] = {g.x * silu_grad_fast(q.x), g.y * silu_grad_fast(q.y), g.z * silu_grad_fast(q.z), g.w * silu_grad_fast(q.w)};
@@ -1385,7 +1390,9 @@ __global__ __launch_bounds__(256, 3) void k_edge_bwd_h2(int E_act, int P, const 
         const float* o = Ocsr + (size_t)o_pos[i] * P;
         float sum = 0.0f;
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
+        for (int p = 0; p < 8; ++p) go[i][p] = 0.0f;
+#pragma unroll
+        for (int p = 0; p < PMAX; ++p) {
             const float ov = o[p < P ? p : P - 1];                 // (unconditional load, clamped: no branch)
             go[i][p] = p < P ? -ov : 0.0f;                         // 2 d = -(-2 d)
             sum += fabsf(go[i][p]);
@@ -1395,7 +1402,7 @@ __global__ __launch_bounds__(256, 3) void k_edge_bwd_h2(int E_act, int P, const 
             const float* o2 = Ocsr + (size_t)o_pos2[i] * P;
             float sum2 = 0.0f;
 #pragma unroll
-            for (int p = 0; p < 8; ++p) {
+            for (int p = 0; p < PMAX; ++p) {
                 const float ov = o2[p < P ? p : P - 1];
                 sum2 += p < P ? fabsf(ov) : 0.0f;
             }

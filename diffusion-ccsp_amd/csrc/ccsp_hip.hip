@@ -1453,6 +1453,7 @@ struct ccsp_model {
     float wd2_absmax = 0.0f;          // max |pose_decoder.2.weight| (row-exponent bound of k_edge_bwd_h2)
     float bwd_bound_c = 0.0f;         // 1.21 max|Wd2| max_n sum_j |Wd1[j, n]|: |g_z[k, s H + n]| <= bwd_bound_c sum_p |go[k, s, p]| (k_edge_bwd_h2<true>)
     int bwd_rowsum_fused = 1;         // (CCSP_ENERGY_ROWSUM=kernel turns it off) row sums of g_z inside the decoder backward, transpose GEMM on partial rows
+    int bwd_generic_p = 0;            // (CCSP_ENERGY_BWD_P=generic) k_edge_bwd_h2 with the run-time pose_dim even where it is 4 (A/B runs)
     int node_energy_fused = 1;        // (CCSP_ENERGY_NODE=split turns it off) k_node_energy_h2_update: the update that consumes the gradient in the same launch
     unsigned short* pe2_wH = nullptr; // pose_encoder.2.weight * 2^pe2_exp, fp16 planes in fragment order (k_pack_enc_frag_h2); CCSP_ENC=f32 leaves it null
     unsigned short* pe2_wTH = nullptr;    // the same tensor transposed, for the energy backward (k_pack_enc_frag_h2t; energy_wrapper models)
@@ -2136,13 +2137,15 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     const bool h2_bwd = h2 && m->WpTH != nullptr && m->energy_bwd_h2;      // backward GEMMs on the f16x2 scheme as well
     if constexpr (H == 256) {
         if (h2_bwd) {
-            if (g->bs_ready)
-                hipLaunchKernelGGL(k_edge_bwd_h2<true>, dim3(nblk(p.E_act, 64) * 4), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->ent_pos, g->U, g->O, g->Q,
-                                   m->Wd1TH, m->wd_exp, m->wd2_absmax, m->pd2_w, g->GZ, skip,
-                                   BwdSumArgs{g->bs_blocks, g->GZPH, (size_t)g->bsplan.NP * 2 * H, g->bs_gexp, m->bwd_bound_c});
-            else
-            hipLaunchKernelGGL(k_edge_bwd_h2<false>, dim3(nblk(p.E_act, 64) * 4), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->ent_pos, g->U, g->O, g->Q,
-                               m->Wd1TH, m->wd_exp, m->wd2_absmax, m->pd2_w, g->GZ, skip, BwdSumArgs{nullptr, nullptr, 0, nullptr, 0.0f});
+            const BwdSumArgs bsa = g->bs_ready ? BwdSumArgs{g->bs_blocks, g->GZPH, (size_t)g->bsplan.NP * 2 * H, g->bs_gexp, m->bwd_bound_c}
+                                               : BwdSumArgs{nullptr, nullptr, 0, nullptr, 0.0f};
+#define CCSP_EDGE_BWD(SUM, PP)                                                                                                                      \
+            hipLaunchKernelGGL((k_edge_bwd_h2<SUM, PP>), dim3(nblk(p.E_act, 64) * 4), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->ent_pos, g->U, g->O, \
+                               g->Q, m->Wd1TH, m->wd_exp, m->wd2_absmax, m->pd2_w, g->GZ, skip, bsa)
+            const bool p4 = P == 4 && !m->bwd_generic_p;
+            if (g->bs_ready) { if (p4) CCSP_EDGE_BWD(true, 4); else CCSP_EDGE_BWD(true, 0); }
+            else { if (p4) CCSP_EDGE_BWD(false, 4); else CCSP_EDGE_BWD(false, 0); }
+#undef CCSP_EDGE_BWD
             bwd_done = true;
         } else if (m->bf16x3 && m->edge_kernel == 2) {
             hipLaunchKernelGGL(k_edge_bwd_bf, dim3(nblk(p.E_act, 64) * 4), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->ent_pos, g->U, g->O, g->Q,
@@ -3254,6 +3257,7 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
                 if (const char* e = getenv("CCSP_MALA_REUSE")) m->mala_reuse = atoi(e) != 0;
                 if (const char* e = getenv("CCSP_ENERGY_ROWSUM")) m->bwd_rowsum_fused = strcmp(e, "kernel") != 0;
                 if (const char* e = getenv("CCSP_ENERGY_NODE")) m->node_energy_fused = strcmp(e, "split") != 0;
+                if (const char* e = getenv("CCSP_ENERGY_BWD_P")) m->bwd_generic_p = strcmp(e, "generic") == 0;
                 {   // bound of the decoder backward's output per unit of sum_p |go| (k_edge_bwd_h2<true>): 1.1^2 max|Wd2| max_n sum_j |Wd1[j, n]|
                     std::vector<float> h_wd((size_t)nwd);
                     HIP_TRY(hipMemcpyAsync(h_wd.data(), m->pd0_w, h_wd.size() * sizeof(float), hipMemcpyDeviceToHost, s));
