@@ -150,7 +150,7 @@ KERNEL_SYMBOLS = {      # label -> kernel symbol prefix by GEMM mode (for the PM
     'node update + pose encoder': {m: 'k_node<256' for m in ('f16x2', 'bf16x3', 'f32')},
     'edge decoder backward': {'f16x2': 'k_edge_bwd_h2', 'bf16x3': 'k_edge_bwd_bf', 'f32': 'k_edge_bwd<256>'},
     'row GEMM (transpose)': {'f16x2': 'k_rowgemm_h2<512, 256', 'bf16x3': 'k_rowgemm_bf2<512, 256>', 'f32': 'k_rowgemm<512, 256>'},
-    'node energy backward': {m: 'k_node_energy_mfma' for m in ('f16x2', 'bf16x3', 'f32')},
+    'node energy backward': {m: 'k_node_energy' for m in ('f16x2', 'bf16x3', 'f32')},     # (_h2 / _h2_update / _mfma: same prefix)
     'row sum of g_z': {m: 'k_rowsum' for m in ('f16x2', 'bf16x3', 'f32')},
     'energy sum': {m: 'k_energy_sum' for m in ('f16x2', 'bf16x3', 'f32')},
 }
