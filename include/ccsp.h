@@ -38,7 +38,7 @@ extern "C" {
 #endif
 
 #define CCSP_VERSION_MAJOR 0
-#define CCSP_VERSION_MINOR 6
+#define CCSP_VERSION_MINOR 7
 #define CCSP_MAX_SAMPLES_PER_STEP 100000
 
 typedef struct ccsp_model ccsp_model;   /* ConstraintDiffuser weights + GaussianDiffusion schedule */

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 17
     for n in names:
         assert hasattr(L, n), n
-    assert L.ccsp_version() == 6
+    assert L.ccsp_version() == 7
     assert isinstance(L.ccsp_last_error(), bytes)
 
 
