@@ -1058,24 +1058,33 @@ __device__ __forceinline__ void node_body(NodeArgs a, const EncW w, const EncOut
                 } else if (a.step == STEP_MALA_ACCEPT) {        // ddpm.py:1026-1041
                     // one decision per node row from the batch-scalar energies and the proposal densities
                     // (the reverse density uses the SAME mu as the forward one, like the reference)
-                    const size_t r0 = (size_t)n * a.P;
+                    // Round 4: every thread of a node row used to walk all P components itself -- a loop of three loads and a wait per
+                    // component, P dependent round trips in a kernel that is one latency chain (10.8 us at C4).  Now a thread forms the
+                    // two density terms of ITS component from the three values it loads once, and the row's threads (eight consecutive
+                    // lanes) add the terms up in the same ascending order through lane reads: the same sums, bit for bit.
                     const float var = a.std_ * a.std_, log_scale = logf(a.std_), lc = 0.918938533204672742f;
+                    const float xc = a.x[i], hc = a.xhat[i];
+                    const float mu = xc + ((-a.eps_buf[i]) * a.kappa) * a.ss;
+                    const float dr = xc - mu, df = hc - mu;
+                    const float t_rev = -(dr * dr) / (2.0f * var) - log_scale - lc;
+                    const float t_fwd = -(df * df) / (2.0f * var) - log_scale - lc;
+                    const float ex0 = a.E_x[0];
                     float lrev = 0.0f, lfwd = 0.0f;
-                    for (int c = 0; c < a.P; ++c) {
-                        const float xc = a.x[r0 + c], hc = a.xhat[r0 + c];
-                        const float mu = xc + ((-a.eps_buf[r0 + c]) * a.kappa) * a.ss;
-                        const float dr = xc - mu, df = hc - mu;
-                        lrev += -(dr * dr) / (2.0f * var) - log_scale - lc;
-                        lfwd += -(df * df) / (2.0f * var) - log_scale - lc;
+                    const int lane0 = (tid & 63) & ~7;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {                // (lanes c < P of the row are live: same node, p = c)
+                        const float r = __shfl(t_rev, lane0 + c), f = __shfl(t_fwd, lane0 + c);
+                        lrev = c < a.P ? lrev + r : lrev;
+                        lfwd = c < a.P ? lfwd + f : lfwd;
                     }
-                    const float logp_x = (-a.E_x[0]) * a.kappa, logp_h = (-e_hat) * a.kappa;
+                    const float logp_x = (-ex0) * a.kappa, logp_h = (-e_hat) * a.kappa;
                     const float la = logp_h - logp_x + lrev - lfwd;
                     float u;
                     if (a.noise.mode == CCSP_NOISE_INJECTED) u = a.noise.uniform[n];
                     else u = ccsp::philox_uniform(a.noise.seed, a.noise.row_offset + (unsigned long long)n, a.noise.ucall);
                     const float accf = (u < expf(la)) ? 1.0f : 0.0f;
                     if (p == 0 && accf != 0.0f && a.acc_count) atomicAdd(a.acc_count, 1);
-                    xv = accf * a.xhat[i] + (1.0f - accf) * xv;
+                    xv = accf * hc + (1.0f - accf) * xv;
                 } else {                                        // ddpm.py:273
                     xv = 0.5f * z;
                 }
