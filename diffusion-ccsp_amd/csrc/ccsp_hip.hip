@@ -1935,7 +1935,7 @@ constexpr int SD_KSPLIT = 4;       // most K slices of the c_proj GEMM (sdY hold
 // returns the number of K slices written (1: Cm is the result; > 1: partial products [slices][M][N], summed by the LayerNorm kernel that reads them)
 template <int EPI>
 int sd_gemm_h2(const ccsp_model* m, int M, int K, int N, const float* A, const unsigned int* amax, const unsigned short* WH, int w_exp, const float* b, float* Cm,
-               unsigned int* cmax, hipStream_t s, bool may_split = false) {
+               unsigned int* cmax, hipStream_t s, bool may_split = false, bool split2 = false /*the consumer adds two K slices whatever the shape (in_proj -> k_sd_attn)*/) {
     // 64-column tiles when the 128-column tile list would not give every CU two workgroups (the N = Wd GEMMs of a 256-graph batch)
     static const int force_tn = getenv("CCSP_SD_TN") ? atoi(getenv("CCSP_SD_TN")) : 0;
     static const int force_ks = getenv("CCSP_SD_KSPLIT") ? atoi(getenv("CCSP_SD_KSPLIT")) : -1;
@@ -1944,6 +1944,10 @@ int sd_gemm_h2(const ccsp_model* m, int M, int K, int N, const float* A, const u
     // (chosen from K and N alone: the same batch run as one lane or as two adds the same partial products in the same order)
     if (may_split && EPI == SD_EPI_BIAS && cmax == nullptr && K % (64 * SD_KSPLIT) == 0 && K >= 4 * N) ks = 2;
     if (may_split && force_ks >= 1 && K % (64 * force_ks) == 0 && force_ks <= SD_KSPLIT) ks = force_ks;
+    // (opt-in, CCSP_SD_INSPLIT=1: measured SLOWER, 54.6 against 57.0 samples/s in one call -- the two lanes' in_proj already give the chip
+    // three workgroups per CU, and the attention kernel reads twice the bytes)
+    static const bool insplit = getenv("CCSP_SD_INSPLIT") && atoi(getenv("CCSP_SD_INSPLIT")) == 1;
+    if (split2 && insplit && EPI == SD_EPI_BIAS && cmax == nullptr && K % 128 == 0) ks = 2;
     // operands requested 2 chunks ahead; 4 (CCSP_SD_PD=4) when the slice is a multiple of 4 chunks
     static const int force_pd = getenv("CCSP_SD_PD") ? atoi(getenv("CCSP_SD_PD")) : 0;
     const bool pd4 = (K / ks) % 128 == 0 && force_pd == 4;      // (r04 A/B at 2048 token rows: 4 ahead 437 us per evaluation, 2 ahead 428 -- the chunk is not waiting for loads)
@@ -2008,8 +2012,10 @@ int launch_eval_sd(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s) {
             // row maxima travel with the activations: ln_1 stores those of its output and clears the three buffers this block accumulates
             // (from the second block on, ln_1 ran fused behind the previous block's ln_2: k_sd_ln2ln1)
             if (l == 0) ln0(g->sdX, w.ln1_g, w.ln1_b, g->sdY, mY, mA, mX, mF, 1);
-            sd_gemm_h2<SD_EPI_BIAS>(m, M, Wd, 3 * Wd, g->sdY, mY, w.in_wH, w.in_e, w.in_b, g->sdQKV, nomax, s);
-            hipLaunchKernelGGL(k_sd_attn, dim3(g->sd_B * SD_HEADS), dim3(256), 0, s, Wd, g->sdQKV, g->mask_from, g->sdA, mA);
+            // (CCSP_SD_INSPLIT=1: in_proj as two K slices -- twice the workgroups, each half the chain of chunks -- added by the attention kernel
+            // while it loads them; measured slower, see sd_gemm_h2)
+            const int qparts = sd_gemm_h2<SD_EPI_BIAS>(m, M, Wd, 3 * Wd, g->sdY, mY, w.in_wH, w.in_e, w.in_b, g->sdQKV, nomax, s, false, true);
+            hipLaunchKernelGGL(k_sd_attn, dim3(g->sd_B * SD_HEADS), dim3(256), 0, s, Wd, g->sdQKV, g->mask_from, g->sdA, mA, qparts, (size_t)M * 3 * Wd);
             sd_gemm_h2<SD_EPI_RESID>(m, M, Wd, Wd, g->sdA, mA, w.out_wH, w.out_e, w.out_b, g->sdX, mX, s);
             sd_gemm_h2<SD_EPI_QGELU>(m, M, Wd, 4 * Wd, g->sdX, mX, w.fc_wH, w.fc_e, w.fc_b, g->sdF, mF, s);
             const int parts = sd_gemm_h2<SD_EPI_BIAS>(m, M, 4 * Wd, Wd, g->sdF, mF, w.proj_wH, w.proj_e, w.proj_b, g->sdY, nomax, s, true);
@@ -2023,7 +2029,7 @@ int launch_eval_sd(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s) {
         }
         ln0(g->sdX, w.ln1_g, w.ln1_b, g->sdY, nomax, nomax, nomax, nomax, 1);
         sd_gemm<SD_EPI_BIAS>(M, Wd, 3 * Wd, g->sdY, w.in_w, w.in_b, g->sdQKV, s);
-        hipLaunchKernelGGL(k_sd_attn, dim3(g->sd_B * SD_HEADS), dim3(256), 0, s, Wd, g->sdQKV, g->mask_from, g->sdA, nomax);
+        hipLaunchKernelGGL(k_sd_attn, dim3(g->sd_B * SD_HEADS), dim3(256), 0, s, Wd, g->sdQKV, g->mask_from, g->sdA, nomax, 1, (size_t)0);
         sd_gemm<SD_EPI_RESID>(M, Wd, Wd, g->sdA, w.out_w, w.out_b, g->sdX, s);
         sd_gemm<SD_EPI_QGELU>(M, Wd, 4 * Wd, g->sdX, w.fc_w, w.fc_b, g->sdF, s);
         sd_gemm<SD_EPI_BIAS>(M, 4 * Wd, Wd, g->sdF, w.proj_w, w.proj_b, g->sdY, s);
@@ -3508,7 +3514,7 @@ int sequences_build(ccsp_graph* g, int B, int b0, const std::vector<int>& cnt_al
     auto& reg = g->allocs;
     if (dev_upload(reg, &g->tok_node, tok_node, s) || dev_upload(reg, &g->tok_pos, tok_pos, s) || dev_upload(reg, &g->node_tok, node_tok, s) ||
         dev_upload(reg, &g->mask_from, mask_from, s) || dev_alloc(reg, &g->sdX, (size_t)M * Wd) || dev_alloc(reg, &g->sdY, (size_t)SD_KSPLIT * M * Wd) ||
-        dev_alloc(reg, &g->sdQKV, (size_t)M * 3 * Wd) || dev_alloc(reg, &g->sdA, (size_t)M * Wd) || dev_alloc(reg, &g->sdF, (size_t)M * 4 * Wd) ||
+        dev_alloc(reg, &g->sdQKV, (size_t)2 * M * 3 * Wd) || dev_alloc(reg, &g->sdA, (size_t)M * Wd) || dev_alloc(reg, &g->sdF, (size_t)M * 4 * Wd) ||
         dev_alloc(reg, &g->sdMax, (size_t)4 * M))
         return 1;
     HIP_TRY(hipMemsetAsync(g->sdMax, 0, (size_t)4 * M * sizeof(unsigned int), s));

@@ -473,8 +473,11 @@ __global__ __launch_bounds__(256) void k_sd_embed(int M, int H, int Wd, int gras
 constexpr int SD_DH_MAX = 384;
 // 16-byte accesses throughout (DH is a multiple of 32): 6 DH / 4 requests of a (graph, head)'s q, k, v issued at once, scores and P.V read
 // as ds_read_b128; every sum keeps the element order of the scalar form it replaces (13.6 -> see profiles/r04_findings.md section 4).
+// parts / part_stride: in_proj run as `parts` K slices (k_sd_gemm_h2, gridDim.y): QKV holds that many partial products, added here in
+// slice order while they are loaded (deterministic; the bias rides on slice 0)
 __global__ __launch_bounds__(256) void k_sd_attn(int Wd, const float* __restrict__ QKV, const int* __restrict__ mask_from,
-                                                 float* __restrict__ Aout, unsigned int* __restrict__ amax /*[8 B] or null: atomicMax of |Aout| per token row*/) {
+                                                 float* __restrict__ Aout, unsigned int* __restrict__ amax /*[8 B] or null: atomicMax of |Aout| per token row*/,
+                                                 int parts, size_t part_stride) {
     constexpr int LD = SD_DH_MAX + 4;                             // row stride: 16-byte aligned, consecutive rows 4 banks apart
     __shared__ __attribute__((aligned(16))) float qkv[3][SD_L][LD];
     __shared__ float part[4][SD_L * SD_L];
@@ -494,6 +497,21 @@ __global__ __launch_bounds__(256) void k_sd_attn(int Wd, const float* __restrict
         const int r = rem / D4, c4 = rem - r * D4;
         const bool in = idx < 3 * SD_L * D4;
         ld[k] = *reinterpret_cast<const float4*>(base + (in ? (size_t)r * 3 * Wd + (size_t)w * Wd + 4 * c4 : 0));
+    }
+    if (parts > 1) {                                              // (uniform)
+        float4 l2[NLD];
+        for (int q = 1; q < parts; ++q) {
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int idx = tid + 256 * k;
+                const int w = idx / (SD_L * D4), rem = idx - w * (SD_L * D4);
+                const int r = rem / D4, c4 = rem - r * D4;
+                const bool in = idx < 3 * SD_L * D4;
+                l2[k] = *reinterpret_cast<const float4*>(base + (size_t)q * part_stride + (in ? (size_t)r * 3 * Wd + (size_t)w * Wd + 4 * c4 : 0));
+            }
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) { ld[k].x += l2[k].x; ld[k].y += l2[k].y; ld[k].z += l2[k].z; ld[k].w += l2[k].w; }
+        }
     }
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
