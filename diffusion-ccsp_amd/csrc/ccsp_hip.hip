@@ -2253,6 +2253,13 @@ int steps_at(const ccsp_model* m, int sampler, int t) {
     return m->sps[t];
 }
 
+// (experiment, CCSP_LANE_STAGGER_US) holds a lane's stream back at the start of a chain so that the lanes' kernels of the same kind do
+// not run side by side; wall_clock64 ticks at 100 MHz
+__global__ void k_delay(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
 // one concurrently running sub-batch of a chain
 struct Lane {
     ccsp_graph* g;
@@ -3651,6 +3658,8 @@ int ccsp_chain_run(ccsp_model* m, ccsp_graph* g, int32_t sampler, const ccsp_noi
         for (size_t i = 0; i < lanes.size(); ++i)
             th.emplace_back([&, i]() {
                 if (hipSetDevice(dev) != hipSuccess) { rcs[i] = 1; errs[i] = "hipSetDevice failed in lane thread"; return; }
+                static const int stagger_us = getenv("CCSP_LANE_STAGGER_US") ? atoi(getenv("CCSP_LANE_STAGGER_US")) : 0;
+                if (stagger_us > 0 && i > 0) hipLaunchKernelGGL(k_delay, dim3(1), dim3(1), 0, lanes[i].s, (long long)stagger_us * 100 * (long long)i);
                 rcs[i] = run(std::vector<Lane>{lanes[i]});
                 if (rcs[i]) errs[i] = g_err;
             });
