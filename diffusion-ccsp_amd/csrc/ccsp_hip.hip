@@ -2056,15 +2056,19 @@ int energy_prepare(ccsp_model* m, ccsp_graph* g, hipStream_t s) {
     const int BMf = dispatch_h(H, [](auto hc) { return 32 * EdgeCfg<decltype(hc)::value>::WM; });
     g->n_edge_blocks = 2 * nblk(p.E_act, BMf);
     const size_t n_partial = (size_t)(nblk(p.E_act, 16) > g->n_edge_blocks ? nblk(p.E_act, 16) : g->n_edge_blocks) + 1;   // (k_edge_h2s: one per 16 edges)
-    if (dev_alloc(reg, &g->Q, (size_t)2 * p.E_act * (H / 2)) || dev_alloc(reg, &g->GZ, (size_t)p.E_act * 2 * H) ||
-        dev_alloc(reg, &g->GZR, (size_t)p.R * 2 * H) || dev_alloc(reg, &g->GP, (size_t)p.R * H) ||
+    // (with the row sums inside the decoder backward -- partial rows, below -- the per-edge gradient array, its fp32 row sums and the U-row
+    // products are never written: 41 + 18 + 9 MB at C4 that are not allocated)
+    const bool partial_rows = H == 256 && m->f16x2 && m->energy_bwd_h2 && m->WpTH && m->bwd_rowsum_fused && p.E_act > 0;
+    if (!partial_rows && (dev_alloc(reg, &g->GZ, (size_t)p.E_act * 2 * H) || dev_alloc(reg, &g->GZR, (size_t)p.R * 2 * H) || dev_alloc(reg, &g->GP, (size_t)p.R * H)))
+        return 1;
+    if (dev_alloc(reg, &g->Q, (size_t)2 * p.E_act * (H / 2)) ||
         dev_alloc(reg, &g->xhat, (size_t)g->N * P) || dev_alloc(reg, &g->partial, n_partial) ||
         dev_alloc(reg, &g->Escal, 4) || dev_alloc(reg, &g->acc_count, (size_t)T) || dev_alloc(reg, &g->acc_denom, (size_t)T) ||
         dev_alloc(reg, &g->mala_changed, 3))                 // [0], [1] pose elements the accept step of an odd / even inner step moved, [2] evaluations skipped
         return 1;
     HIP_TRY(hipMemsetAsync(g->Escal, 0, 4 * sizeof(float), s));
     HIP_TRY(hipMemsetAsync(g->partial, 0, n_partial * sizeof(float), s));
-    if (H == 256 && m->f16x2 && m->energy_bwd_h2 && m->WpTH && m->bwd_rowsum_fused && p.E_act > 0) {
+    if (partial_rows) {
         ccsp::build_bwdsum_plan(p, TILE_M, g->bsplan);
         const ccsp::BwdSumPlan& b = g->bsplan;
         if (dev_upload(reg, &g->bs_blocks, b.blocks, s) || dev_upload(reg, &g->bs_nrow_ptr, b.nrow_ptr, s) || dev_upload(reg, &g->bs_nrow_idx, b.nrow_idx, s) ||
