@@ -854,7 +854,13 @@ __device__ __forceinline__ void edge_node_tail(const FuseArgs& fu, int wg, void*
     }
 }
 
-template <bool ENERGY, int MT, int L2, bool FUSE = false>
+// NG (round 4, CCSP_FUSE_NODE=2): the NODE-GROUPED form.  The decoder is shared by all types and halves and every output goes to its own
+// CSR slot, so a workgroup may take ANY 64 (edge, half) rows: here it takes the CSR entries of its own run of consecutive nodes (<= 16
+// nodes, <= 64 entries; ng_desc / ng_off0 / ng_off1 of FuseArgs, built by fuse2_prepare), i.e. the edge work is cut by DESTINATION node.
+// Every (edge, half) row is still computed exactly once, and when the tile is done the workgroup holds every input of its nodes'
+// update: the node kernel runs as its tail (node_group_tail) with no hand-over between workgroups -- no counters, no write-through
+// stores, no waiting for the slowest tile (what round 3's producer-side fusion, FUSE, paid for).  Same arithmetic, same order.
+template <bool ENERGY, int MT, int L2, bool FUSE = false, bool NG = false>
 __global__ __launch_bounds__(256, (MT == 1 && !FUSE) ? 3 : 2) void k_edge_h2(int E_act, int P, const int* __restrict__ e_u0, const int* __restrict__ e_u1,
                                                     const float* __restrict__ U, const float* __restrict__ umax /*[R][8]*/,
                                                     const unsigned short* __restrict__ Wd1H /*[2][128][256]*/, int wd_exp,
@@ -862,6 +868,7 @@ __global__ __launch_bounds__(256, (MT == 1 && !FUSE) ? 3 : 2) void k_edge_h2(int
                                                     const float* __restrict__ bd2, const int* __restrict__ ent_pos, float* __restrict__ O,
                                                     EdgeEnergyArgs en, int* __restrict__ counter_inc, FuseArgs fu) {
     static_assert(!(FUSE && ENERGY), "the fused node update is the direct-mode one");
+    static_assert(!NG || (!ENERGY && !FUSE && MT == 1), "the node-grouped form: direct mode, 64-row tiles");
     if constexpr (ENERGY) { if (en.skip && *en.skip == 0) return; }                        // (uniform) MALA reuse
     if (counter_inc && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(counter_inc, 1);     // hipGraph mode: next table entry
     CCSP_TRK(1, 0);
@@ -874,21 +881,33 @@ __global__ __launch_bounds__(256, (MT == 1 && !FUSE) ? 3 : 2) void k_edge_h2(int
     static_assert((64 * S1_LD + 8 * BN + 4 * 8 * 64 + 64 * 8) * 4 <= 2 * STAGE * 2, "epilogue tile, the layer-2 weights, partials and output rows must fit the stages");
     __shared__ __attribute__((aligned(16))) unsigned short smem[2 * STAGE + 2 * ROWS];
     int* sE = reinterpret_cast<int*>(smem + 2 * STAGE);
-    const int e0 = xcd_remap(blockIdx.x, gridDim.x) * ME;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int e0 = wg * ME;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = tid >> 3, lq = tid & 7;                        // A producer: rows lr + 32 i, fp32 columns 4 lq .. + 3 of the chunk
+    int4 ngd = make_int4(0, 0, 0, 0);                             // NG: {first node, nodes, first CSR entry, entries}
+    NodeGroupPre ngp{};
+    if constexpr (NG) {
+        ngd = fu.ng_desc[wg];
+        ngp = node_group_pre(fu.node, ngd.x, ngd.y);              // the update's own loads, at entry: nothing of the tile is needed for them
+    }
     // The kernel is one latency chain per tile: edge -> row indices -> U rows -> ... .  Issue order (vector-memory loads return
     // in order): the row indices; then, the moment they are here, the U rows of the first two chunks and the weights of the
     // first; only then the row maxima (the exponents are needed when chunk 0 is written to LDS, not before) and what the
     // epilogue needs -- CSR slot, biases, second-layer weights -- so that no load sits in the epilogue's path.
-    int r0v[NPASS], r1v[NPASS];
+    int r0v[NPASS], r1v[NPASS];                                   // (NG: element offsets of the row's two operands into U -- U row * 2H + half * H)
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
-        int k = e0 + ((lr + 32 * i) % ME);
-        k = k < E_act ? k : E_act - 1;
-        r0v[i] = e_u0[k];
-        r1v[i] = e_u1[k];
+        if constexpr (NG) {
+            r0v[i] = fu.ng_off0[wg * ROWS + lr + 32 * i];
+            r1v[i] = fu.ng_off1[wg * ROWS + lr + 32 * i];
+        } else {
+            int k = e0 + ((lr + 32 * i) % ME);
+            k = k < E_act ? k : E_act - 1;
+            r0v[i] = e_u0[k];
+            r1v[i] = e_u1[k];
+        }
     }
     const float* u0_ptr[NPASS];
     const float* u1_ptr[NPASS];
@@ -896,8 +915,13 @@ __global__ __launch_bounds__(256, (MT == 1 && !FUSE) ? 3 : 2) void k_edge_h2(int
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
         const int row = lr + 32 * i, s = row / ME;
-        u0_ptr[i] = U + (size_t)r0v[i] * (2 * H) + s * H + lq * 4;
-        u1_ptr[i] = U + (size_t)r1v[i] * (2 * H) + s * H + lq * 4;
+        if constexpr (NG) {
+            u0_ptr[i] = U + r0v[i] + lq * 4;
+            u1_ptr[i] = U + r1v[i] + lq * 4;
+        } else {
+            u0_ptr[i] = U + (size_t)r0v[i] * (2 * H) + s * H + lq * 4;
+            u1_ptr[i] = U + (size_t)r1v[i] * (2 * H) + s * H + lq * 4;
+        }
         a_st[i] = h2_off(row, lq >> 1) + (lq & 1) * 4;
     }
     const int brow = tid >> 2, bq = tid & 3;                      // B copy: rows brow, brow + 64, piece bq, both planes
@@ -945,8 +969,9 @@ __global__ __launch_bounds__(256, (MT == 1 && !FUSE) ? 3 : 2) void k_edge_h2(int
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
         const int row = lr + 32 * i, s = row / ME;
-        const float4 m0 = *reinterpret_cast<const float4*>(umax + (size_t)r0v[i] * 8 + 4 * s);
-        const float4 m1 = *reinterpret_cast<const float4*>(umax + (size_t)r1v[i] * 8 + 4 * s);
+        // (NG: offset = U row * 512 + half * 256  ->  umax index U row * 8 + half * 4 = offset / 64)
+        const float4 m0 = *reinterpret_cast<const float4*>(umax + (NG ? (size_t)(r0v[i] >> 6) : (size_t)r0v[i] * 8 + 4 * s));
+        const float4 m1 = *reinterpret_cast<const float4*>(umax + (NG ? (size_t)(r1v[i] >> 6) : (size_t)r1v[i] * 8 + 4 * s));
         // |SiLU(z)| <= |z| <= max|U[u0]| + max|U[u1]| over the half's four 64-column pieces
         a_exp[i] = h2_scale_exp(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)) + fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w)));
     }
@@ -959,9 +984,13 @@ __global__ __launch_bounds__(256, (MT == 1 && !FUSE) ? 3 : 2) void k_edge_h2(int
     int o_slot[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        int k = e0 + i * 32 + (o_row & 31);
-        k = k < E_act ? k : E_act - 1;
-        o_slot[i] = ent_pos[2 * k + (o_row >> 5)];
+        if constexpr (NG) {
+            o_slot[i] = ngd.z + o_row;                            // the row IS the CSR entry
+        } else {
+            int k = e0 + i * 32 + (o_row & 31);
+            k = k < E_act ? k : E_act - 1;
+            o_slot[i] = ent_pos[2 * k + (o_row >> 5)];
+        }
     }
     const float o_b2 = bd2[o_p < P ? o_p : 0];
     const float4 w2v = *reinterpret_cast<const float4*>(Wd2 + ((tid * 4) < P * BN ? tid * 4 : 0));      // Wd2 is [P][128] row-major: 4 P x 32 float4
@@ -1058,8 +1087,8 @@ __global__ __launch_bounds__(256, (MT == 1 && !FUSE) ? 3 : 2) void k_edge_h2(int
                 o = ((o0 + o1) + (o2 + o3)) + (idx == tid ? o_b2 : bd2[p]);
             }
             const int k = e0 + i * 32 + (lrow & 31), s = lrow >> 5;
-            if (k < E_act) {
-                const int slot = idx == tid ? o_slot[i] : ent_pos[2 * k + s];  // (the first 256 items' slots were requested in the prologue)
+            if (NG ? lrow < ngd.w : k < E_act) {
+                const int slot = NG ? ngd.z + lrow : (idx == tid ? o_slot[i] : ent_pos[2 * k + s]);  // (the first 256 items' slots were requested in the prologue)
                 if constexpr (ENERGY) {
                     const int node = s == 0 ? en.e_a[k] : en.e_b[k];
                     const float d = o - en.xeval[(size_t)node * P + p];
@@ -1069,7 +1098,7 @@ __global__ __launch_bounds__(256, (MT == 1 && !FUSE) ? 3 : 2) void k_edge_h2(int
                     O[(size_t)slot * P + p] = o;                               // straight to the node's CSR slot
                 }
             }
-            if constexpr (FUSE) Os[lrow * 8 + p] = o;
+            if constexpr (FUSE || NG) Os[lrow * 8 + p] = o;
         }
         if constexpr (FUSE) {                                                  // rows out through LDS: one lane per row, 16-byte write-through stores
             __syncthreads();
@@ -1079,6 +1108,11 @@ __global__ __launch_bounds__(256, (MT == 1 && !FUSE) ? 3 : 2) void k_edge_h2(int
             }
         }
         if (i + 1 < MT || ENERGY) __syncthreads();                             // (the next pass / the energy reduction reuse S1)
+    }
+    if constexpr (NG) {
+        __syncthreads();                                                       // the outputs of every row are in Os; S1 is dead (the node block's LDS)
+        node_group_tail(fu.node, fu.w, fu.eo, ngd.x, ngd.y, ngd.z, Os, node_lds(smem), ngp);
+        return;
     }
     if constexpr (FUSE) {
         CCSP_TRK(1, 13);

@@ -273,10 +273,11 @@ struct EncOut {
 // (v[tile][reg]).  One 16-byte store per tile (and 8 bytes per 2-byte plane) instead of four scattered ones: the 2-byte
 // plane stores of the untransposed layout cost 5 % of the whole chain (tools/ab.sh).
 template <int H>
-__device__ __forceinline__ void enc_store_tile(const float (&v)[H / 64][4], float (*smax)[NODE_TILE], int node0, int N, const EncOut out) {
+__device__ __forceinline__ void enc_store_tile(const float (&v)[H / 64][4], float (*smax)[NODE_TILE], int node0, int N, const EncOut out, int n_lim = -1 /*nodes >= n_lim are not this block's (default: N)*/) {
     constexpr int TPW = H / 64;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n = node0 + (lane & 15);
+    if (n_lim < 0) n_lim = N;
     int e2 = 0;
     if (out.h2) {
         // largest |element| of every node row: in-lane over the lane's 4 TPW columns, the four lanes of the wave that
@@ -293,9 +294,9 @@ __device__ __forceinline__ void enc_store_tile(const float (&v)[H / 64][4], floa
         CCSP_TRK(2, 4);
         m = fmaxf(fmaxf(smax[0][lane & 15], smax[1][lane & 15]), fmaxf(smax[2][lane & 15], smax[3][lane & 15]));
         e2 = h2_scale_exp(m);
-        if (n < N && wave == 0 && lane < NODE_TILE) out.h2_exp[n] = e2;
+        if (n < n_lim && wave == 0 && lane < NODE_TILE) out.h2_exp[n] = e2;
     }
-    if (n < N) {
+    if (n < n_lim) {
 #pragma unroll
         for (int j = 0; j < TPW; ++j) {
             const int c0 = wave * 16 * TPW + j * 16 + 4 * (lane >> 4);
@@ -1135,7 +1136,7 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, EncOut eo) { n
 // encode_tile_h2 with the layer-2 weight fragments streamed per k-step (two register sets of 32 VGPRs) instead of held in 128:
 // the form that fits next to the edge kernel's registers (node update folded into its tail).  Same products in the same order.
 __device__ __forceinline__ void encode_tile_h2_stream(const EncW w, float (*xs)[8], unsigned short* s1h, int* sexp, float (*smax)[NODE_TILE],
-                                                      int node0, int N, const EncOut out) {
+                                                      int node0, int N, const EncOut out, int n_lim = -1) {
     constexpr int H = 256, LD = ENC_H2_LD;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const half8* wh = reinterpret_cast<const half8*>(w.W2H) + (size_t)wave * 16 * 64 + lane;
@@ -1195,7 +1196,7 @@ __device__ __forceinline__ void encode_tile_h2_stream(const EncW w, float (*xs)[
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[j][r] = silu_fast(ldexpf(acc[j][r], eu) + b2[j][r]);
-    enc_store_tile<H>(v, smax, node0, N, out);
+    enc_store_tile<H>(v, smax, node0, N, out, n_lim);
 }
 
 // LDS of one node block (k_node_direct's own; a region of the stages in the fused edge kernel)
@@ -1214,6 +1215,73 @@ __device__ __forceinline__ NodeLds node_lds(void* base) {
     l.smax = reinterpret_cast<float (*)[NODE_TILE]>(b + 2 * NODE_TILE * ENC_H2_LD * 2 + NODE_TILE * 8 * 4);
     l.sexp = reinterpret_cast<int*>(b + 2 * NODE_TILE * ENC_H2_LD * 2 + NODE_TILE * 8 * 4 + 4 * NODE_TILE * 4);
     return l;
+}
+
+// Tail of the node-grouped edge kernel: the workgroup's rows were the CSR entries [csr0, csr0 + rows) of nodes node0 .. node0 + nn - 1
+// and their outputs are in LDS (Os[row][8]), so the update needs no other workgroup: CSR sum in the reference's order from LDS, count-
+// normalise, mask fill, ancestral / ULA step, history, encoder of the new pose (streamed weights) -- the arithmetic of node_block_direct,
+// bit for bit.  What the update needs from memory does not depend on the tile: node_group_pre requests it at kernel entry (and draws the
+// noise under the loads), so the tail starts with everything but the outputs in registers.  All 256 threads.
+struct NodeGroupPre {
+    int csr_beg, csr_cnt;
+    float x_old, xf_fill, xf_reset, z;
+    bool masked;
+};
+__device__ __forceinline__ NodeGroupPre node_group_pre(const NodeArgs& a, int node0, int nn) {
+    const int tid = threadIdx.x;
+    const int nl = (tid >> 3) & (NODE_TILE - 1), p = tid & 7;
+    const int nc = node0 + (nl < nn ? nl : 0), pc = p < a.P ? p : a.P - 1;
+    const size_t i = (size_t)nc * a.P + pc;
+    NodeGroupPre r;
+    r.csr_beg = a.node_ptr[nc];
+    r.csr_cnt = a.node_ptr[nc + 1] - r.csr_beg;
+    r.masked = a.mask[nc] != 0;
+    r.x_old = a.x[i];
+    r.xf_fill = a.xfeat[(size_t)nc * a.F + a.F - a.P + pc];
+    r.xf_reset = a.xfeat[(size_t)nc * a.F + a.pose_begin + pc];
+    const bool injected = a.noise.mode == CCSP_NOISE_INJECTED;
+    const float z_inj = (injected ? a.noise.normal : a.x)[i];
+    const float z = ccsp::philox_normal(a.noise.seed, a.noise.row_offset + (unsigned long long)nc, a.noise.call, pc);
+    r.z = injected ? z_inj : z;
+    return r;
+}
+__device__ __forceinline__ void node_group_tail(const NodeArgs& a, const EncW& w, const EncOut& eo, int node0, int nn, int csr0, const float* __restrict__ Os,
+                                                const NodeLds lds, const NodeGroupPre& pre) {
+    const int tid = threadIdx.x;
+    const int nl = (tid >> 3) & (NODE_TILE - 1), p = tid & 7;
+    const bool live = tid < NODE_TILE * 8 && nl < nn && p < a.P;
+    const int nc = node0 + (nl < nn ? nl : 0), pc = p < a.P ? p : a.P - 1;
+    const size_t i = (size_t)nc * a.P + pc;
+    const int csr_cnt = pre.csr_cnt;
+    float acc = 0.0f;
+    const float* op = Os + (pre.csr_beg - csr0) * 8 + pc;
+    for (int q0 = 0; q0 < csr_cnt; q0 += 8) {                             // eight entries per LDS round trip, added in CSR order
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = op[(q0 + j < csr_cnt ? q0 + j : csr_cnt - 1) * 8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = q0 + j < csr_cnt ? acc + v[j] : acc;
+    }
+    if (a.normalize) acc = acc / sqrtf((float)csr_cnt);                   // 0/0 -> NaN like the reference
+    const float eps = pre.masked ? pre.xf_fill : acc;
+    float xv = a.step == STEP_ANCESTRAL ? step_ancestral(pre.x_old, eps, pre.z, a.a_t, a.b_t, a.c1, a.c2, a.sigma)
+                                        : step_ula(pre.x_old, eps, pre.z, a.kappa, a.ss, a.std_);
+    if (a.reset_mask && pre.masked) xv = pre.xf_reset;
+    if (live) {
+        a.x[i] = xv;
+        if (a.hist) a.hist[i] = xv;
+    }
+    if (tid < NODE_TILE * 8) {
+        const float xnew = live ? xv : 0.0f;
+        lds.xs[nl][p] = xnew;
+        float amax = fabsf(xnew);
+        amax = fmaxf(amax, __shfl_xor(amax, 1));
+        amax = fmaxf(amax, __shfl_xor(amax, 2));
+        amax = fmaxf(amax, __shfl_xor(amax, 4));
+        if (p == 0) lds.sexp[nl] = h2_scale_exp(fmaf(w.c1, amax, w.c2));
+    }
+    __syncthreads();
+    encode_tile_h2_stream(w, lds.xs, lds.s1h, lds.sexp, lds.smax, node0, a.N, eo, node0 + nn);
 }
 
 // One 16-node block of the direct-mode update: CSR reduce in the reference's order, count-normalise, mask fill, ancestral /
@@ -1317,6 +1385,10 @@ __global__ __launch_bounds__(256, 3) void k_node_direct_s(NodeArgs a, EncW w, En
 // this evaluation since then, from 1).  The workgroup whose arrival completes a block runs node_block_direct<true> for it --
 // nobody waits for anybody, so no grid barrier and no spinning.
 struct FuseArgs {
+    // node-grouped form (CCSP_FUSE_NODE=2, k_edge_h2<.., NG>): a workgroup's rows ARE the CSR entries of its own run of nodes
+    const int4* ng_desc;        // [workgroups] {first node, nodes (<= 16), first CSR entry, entries (<= 64)}
+    const int* ng_off0;         // [workgroups][64] element offset into U of the row's first operand: U row * 2H + half * H (padding rows repeat row 0)
+    const int* ng_off1;
     const int* wg_blk_ptr;      // [workgroups + 1]
     const int* wg_blk;          // node blocks, ascending, per workgroup
     const int* blk_expect;      // [node blocks]
@@ -1529,6 +1601,12 @@ struct ccsp_graph {
     int *fuse_u0 = nullptr, *fuse_u1 = nullptr, *fuse_pos = nullptr;      // e_u0 / e_u1 / ent_pos in the fused kernel's edge order
     unsigned int* fuse_count = nullptr;
     int fuse_me = 0, fuse_blocks = 0;
+    // node-grouped edge tiles (CCSP_FUSE_NODE=2, fuse2_prepare): -1 = not possible for this graph (a node with more than 64 entries)
+    int ng_wgs = 0;
+    bool ng_use = false;                      // this chain runs them
+    int4* ng_desc = nullptr;
+    int *ng_off0 = nullptr, *ng_off1 = nullptr;
+    std::vector<int> h_ng;                    // kept alive for the async upload
     unsigned int fuse_epoch = 0;
     std::vector<int> h_fuse;                  // kept alive for the async upload
     // fused tiles of k_eval_fused (ccsp::FusedPlan)
@@ -1791,6 +1869,43 @@ int fuse_prepare(ccsp_model* m, ccsp_graph* g, int me, hipStream_t s) {
     return 0;
 }
 
+// Tables of the node-grouped edge kernel (k_edge_h2<.., NG>): consecutive nodes are packed into workgroups while their CSR entries fit
+// 64 rows (and the nodes one 16-node encoder tile); row r of a workgroup is CSR entry csr0 + r, i.e. (edge k, half s) with 2k + s =
+// node_ent[csr0 + r], and carries the element offsets of its two U operands.  Nodes without entries ride along (their update still runs).
+int fuse2_prepare(ccsp_model* m, ccsp_graph* g, hipStream_t s) {
+    if (g->ng_wgs != 0) return 0;
+    const ccsp::Plan& p = g->plan;
+    const int H = m->d.hidden_dim;
+    std::vector<int> desc, off0, off1;
+    int n = 0;
+    while (n < g->N) {
+        const int n0 = n, c0 = p.node_ptr[n];
+        while (n < g->N && n - n0 < NODE_TILE && p.node_ptr[n + 1] - c0 <= 64) ++n;
+        if (n == n0) { g->ng_wgs = -1; return 0; }            // a node with more than 64 entries: this graph keeps the separate node kernel
+        const int rows = p.node_ptr[n] - c0;
+        desc.push_back(n0); desc.push_back(n - n0); desc.push_back(c0); desc.push_back(rows);
+        for (int r = 0; r < 64; ++r) {
+            int q = c0 + (r < rows ? r : 0);                               // (padding rows repeat row 0: valid addresses, outputs never stored;
+            q = q < 2 * p.E_act ? q : 2 * p.E_act - 1;                     //  a workgroup of entry-less nodes reads a later node's first entry, or the last entry)
+            const int ent = p.node_ent[q];
+            const int k = ent >> 1, half = ent & 1;
+            off0.push_back(p.e_u0[k] * 2 * H + half * H);
+            off1.push_back(p.e_u1[k] * 2 * H + half * H);
+        }
+    }
+    const int n_wg = (int)desc.size() / 4;
+    HIP_TRY(hipStreamSynchronize(s));
+    g->h_ng = desc;
+    g->h_ng.insert(g->h_ng.end(), off0.begin(), off0.end());
+    g->h_ng.insert(g->h_ng.end(), off1.begin(), off1.end());
+    int* d = nullptr;
+    if (dev_upload(g->allocs, &d, g->h_ng, s)) return 1;
+    g->ng_desc = reinterpret_cast<int4*>(d);
+    g->ng_off0 = d + desc.size(); g->ng_off1 = g->ng_off0 + off0.size();
+    g->ng_wgs = n_wg;
+    return 0;
+}
+
 // fused: if non-null (direct-mode chain, f16x2 kernels), the node update with these arguments is folded into the edge kernel's
 // tail and *did_fuse is set; the caller then launches no node kernel
 template <int H>
@@ -1826,6 +1941,23 @@ int launch_eval(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s, bool tabled 
             launch_rowgemm_h2(m, g, tau_t, ref, tau_stride, s);
             prof_mark(g, s, CCSP_K_EDGE);
             FuseArgs fu;
+            if (fused != nullptr && g->ng_use && g->ng_wgs > 0) {          // node-grouped edge tiles with the node update as their tail
+                memset(&fu, 0, sizeof(fu));
+                fu.ng_desc = g->ng_desc; fu.ng_off0 = g->ng_off0; fu.ng_off1 = g->ng_off1;
+                fu.node = *fused; fu.w = enc_pose(m);
+                fu.eo.f32 = nullptr; fu.eo.bf3 = nullptr; fu.eo.h2 = g->pembH; fu.eo.h2_exp = g->pexp;
+                const EdgeEnergyArgs en0{};
+                if (nblk(p.E_act, 32) <= m->ncu)      // (the second decoder layer in the form the three-launch path picks for this batch: same sums, bit for bit)
+                    hipLaunchKernelGGL((k_edge_h2<false, 1, 1, false, true>), dim3(g->ng_wgs), dim3(256), 0, s, p.E_act, m->d.pose_dim, g->e_u0, g->e_u1, g->U, g->umax,
+                                       m->Wd1H, m->wd_exp, m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, en0, cinc, fu);
+                else
+                    hipLaunchKernelGGL((k_edge_h2<false, 1, 0, false, true>), dim3(g->ng_wgs), dim3(256), 0, s, p.E_act, m->d.pose_dim, g->e_u0, g->e_u1, g->U, g->umax,
+                                       m->Wd1H, m->wd_exp, m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, en0, cinc, fu);
+                if (did_fuse) *did_fuse = true;
+                prof_mark(g, s, -1);
+                g->evals++;
+                return 0;
+            }
             const bool fuse = fused != nullptr && g->fuse_me > 0 && g->fuse_me == edge_tile_edges(m, p.E_act) && g->fuse_me <= 32 &&
                               nblk(p.E_act, g->fuse_me) <= 2 * m->ncu;
             if (fuse) {
@@ -2555,10 +2687,16 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
         for (const Lane& L : lanes) {
             ccsp_graph* g = L.g;
             bool can = false;
-            if constexpr (H == 256)
-                can = m->fuse_node && m->f16x2 && m->bf16x3 && m->pe2_wH && !m->node_generic && m->d.model_kind == CCSP_MODEL_DIFFUSION_CCSP &&
+            bool can2 = false;
+            if constexpr (H == 256) {
+                can2 = m->fuse_node == 2 && m->f16x2 && m->bf16x3 && m->pe2_wH && !m->node_generic && m->d.model_kind == CCSP_MODEL_DIFFUSION_CCSP &&
+                       !m->d.energy_wrapper && g->plan.E_act > 0 && !g->profile;
+                can = m->fuse_node == 1 && m->f16x2 && m->bf16x3 && m->pe2_wH && !m->node_generic && m->d.model_kind == CCSP_MODEL_DIFFUSION_CCSP &&
                       !m->d.energy_wrapper && g->plan.E_act > 0 && edge_tile_edges(m, g->plan.E_act) <= 32 &&
                       nblk(g->plan.E_act, edge_tile_edges(m, g->plan.E_act)) <= 2 * m->ncu;
+            }
+            if (can2 && fuse2_prepare(m, g, L.s)) return 1;
+            g->ng_use = can2 && g->ng_wgs > 0;
             if (can) {
                 if (fuse_prepare(m, g, edge_tile_edges(m, g->plan.E_act), L.s)) return 1;
                 HIP_TRY(hipMemsetAsync(g->fuse_count, 0, (size_t)g->fuse_blocks * sizeof(unsigned int), L.s));
@@ -2585,7 +2723,7 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
                         a.src = 1; a.eps_buf = g->eps;
                     } else {
                         a.src = 0;
-                        if (launch_eval<H>(m, g, t, L.s, false, g->fuse_me > 0 ? &a : nullptr, &fused)) return 1;
+                        if (launch_eval<H>(m, g, t, L.s, false, (g->fuse_me > 0 || g->ng_use) ? &a : nullptr, &fused)) return 1;
                     }
                     if (!fused) launch_node<H>(m, g, a, L.s);
                 }
@@ -3059,7 +3197,7 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     if (const char* e = getenv("CCSP_EDGE_SMALL")) m->edge_small = atoi(e) != 0;
     m->valu_node_energy = getenv("CCSP_NODE_ENERGY_VALU") != nullptr;
     if (const char* e = getenv("CCSP_NODE")) { m->node_generic = strcmp(e, "generic") == 0; m->node_stream = strcmp(e, "stream") == 0; }
-    if (const char* e = getenv("CCSP_FUSE_NODE")) m->fuse_node = atoi(e) != 0;
+    if (const char* e = getenv("CCSP_FUSE_NODE")) m->fuse_node = atoi(e);      // 1: producer-side tail with arrival counters (round 3); 2: node-grouped edge tiles (round 4)
     if (const char* e = getenv("CCSP_EVAL")) m->eval_fused = strcmp(e, "fused") == 0 ? 1 : (strcmp(e, "fused8") == 0 ? 2 : 0);
     {
         int dev = 0;
