@@ -166,7 +166,7 @@ def lib():
     L.ccsp_graph_variant.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.ccsp_compose_denoise.argtypes = [vp, vp, vp, vp, C.POINTER(Compose), vp, i32, vp, vp]
     L.ccsp_compose_energy_grad.argtypes = [vp, vp, vp, vp, C.POINTER(Compose), vp, i32, vp, vp, vp]
-    L.ccsp_compose_chain_run.argtypes = [vp, vp, vp, vp, C.POINTER(Compose), i32, C.POINTER(Noise), vp, i32, i32, i32, vp, vp]
+    L.ccsp_compose_chain_run.argtypes = [vp, vp, vp, vp, C.POINTER(Compose), i32, C.POINTER(Noise), vp, i32, i32, i32, vp, vp, vp]
     L.ccsp_plan_host.argtypes = [i32, i32, i32] + [vp] * 14
     L.ccsp_plan_fused_host.argtypes = [i32, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp]
     L.ccsp_plan_bwdsum_host.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]

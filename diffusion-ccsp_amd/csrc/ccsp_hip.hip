@@ -3968,15 +3968,16 @@ int compose_energy_eval(ccsp_model* m1, ccsp_graph* g1, ccsp_model* m2, ccsp_gra
 extern "C" {
 
 int ccsp_compose_chain_run(ccsp_model* m1, ccsp_graph* g1, ccsp_model* m2, ccsp_graph* g2, const ccsp_compose* c, int32_t sampler,
-                           const ccsp_noise* nz, float* x, int32_t init, int32_t t_first, int32_t t_last, float* history, void* stream) {
+                           const ccsp_noise* nz, float* x, int32_t init, int32_t t_first, int32_t t_last, float* history, float* accept, void* stream) {
     if (compose_check(m1, g1, m2, g2, c, "compose_chain_run", true)) return 1;
     if (!nz || !x) return fail("compose_chain_run: null argument");
     ccsp_model* m = m1;
     ccsp_graph* g = g1;
     const int T = m->d.timesteps, P = m->d.pose_dim;
-    if (sampler != CCSP_SAMPLER_NONE && sampler != CCSP_SAMPLER_ULA && sampler != CCSP_SAMPLER_ULA_PLUS)
+    const bool mala = sampler == CCSP_SAMPLER_MALA;
+    if (sampler != CCSP_SAMPLER_NONE && sampler != CCSP_SAMPLER_ULA && sampler != CCSP_SAMPLER_ULA_PLUS && !(mala && m1->d.energy_wrapper))
         return fail("compose_chain_run: sampler %d: composed models run the ancestral / ULA / ULA+ samplers (on the denoiser output, or on the energy gradient "
-                    "when both are energy_wrapper models); MALA and HMC are not built for them", sampler);
+                    "when both are energy_wrapper models) and, as energy_wrapper models, MALA; HMC is not built for them", sampler);
     // energy mode (both energy_wrapper models; ComposedEBMDenoiseFn.forward: epsilon = dE/dposes, ddpm.py:940-966 on it): every evaluation
     // is the composed energy gradient of ccsp_compose_energy_grad
     const bool energy = m1->d.energy_wrapper != 0;
@@ -3990,15 +3991,24 @@ int ccsp_compose_chain_run(ccsp_model* m1, ccsp_graph* g1, ccsp_model* m2, ccsp_
     if (nz->mode == CCSP_NOISE_INJECTED && !nz->normal) return fail("compose_chain_run: injected noise without a normal stream");
     hipStream_t s = (hipStream_t)stream;
     const size_t N = (size_t)g->N, NP = N * P;
-    StreamBuf b1(s), b2(s), b3(s), b4(s);
+    StreamBuf b1(s), b2(s), b3(s), b4(s), b5(s);
     if (b1.alloc(NP * sizeof(float)) || b2.alloc(N * m2->d.pose_dim * sizeof(float)) || b3.alloc(N * m2->d.pose_dim * sizeof(float)) ||
-        b4.alloc(4 * sizeof(float))) return 1;
+        b4.alloc(6 * sizeof(float)) || (mala && b5.alloc(NP * sizeof(float)))) return 1;
+    if (mala && nz->mode == CCSP_NOISE_INJECTED && !nz->uniform) return fail("compose_chain_run: MALA with injected noise needs a uniform stream");
     const ComposeScratch w{b1.f(), b2.f(), b3.f()};
     if (energy && (energy_prepare(m1, g1, s) || energy_prepare(m2, g2, s))) return 1;
-    std::vector<uint64_t> call0(T);
+    std::vector<uint64_t> call0(T), ucall0(T, 0);
     {
-        uint64_t k = 1;
-        for (int t = T - 1; t >= 0; --t) { call0[t] = k; k += 1 + (uint64_t)steps_at(m, sampler, t); }
+        uint64_t k = 1, u = 0;
+        for (int t = T - 1; t >= 0; --t) { call0[t] = k; ucall0[t] = u; k += 1 + (uint64_t)steps_at(m, sampler, t); u += (uint64_t)steps_at(m, sampler, t); }
+    }
+    if (mala) {         // acceptance counters of the first domain's graph (energy_prepare below allocates them)
+        if (energy_prepare(m1, g1, s)) return 1;
+        HIP_TRY(hipMemsetAsync(g1->acc_count, 0, (size_t)T * sizeof(int), s));
+        HIP_TRY(hipStreamSynchronize(s));      // (a previous chain may still be reading h_denom)
+        g1->h_denom.assign(T, 0);
+        for (int t = 0; t < T; ++t) g1->h_denom[t] = g1->N * steps_at(m, sampler, t);
+        HIP_TRY(hipMemcpyAsync(g1->acc_denom, g1->h_denom.data(), (size_t)T * sizeof(int), hipMemcpyHostToDevice, s));
     }
     auto noise_for = [&](uint64_t call, NoiseArg& na) -> int {
         na.mode = nz->mode; na.seed = nz->seed; na.row_offset = nz->row_offset;
@@ -4040,9 +4050,32 @@ int ccsp_compose_chain_run(ccsp_model* m1, ccsp_graph* g1, ccsp_model* m2, ccsp_
             a.sigma = t != 0 ? expf(0.5f * m->post_lv[t]) : 0.0f;
             a.kappa = m->kappa[t]; a.ss = m->step[t]; a.std_ = sqrtf(2.0f * m->step[t]);
             if (noise_for(call0[t] + (uint64_t)e, a.noise)) return 1;
+            if (mala && e >= 1) {
+                // AnnealedMALASampler.sample_step (ddpm.py:1013-1041) on the composed model: the gradient evaluation above also left E(x)
+                // in b4[2]; propose, evaluate the composed energy at the proposal (its gradient goes to scratch), accept per node row
+                // from the batch-scalar energies
+                a.step = STEP_MALA_PROPOSE; a.do_encode = 0; a.xhat = g->xhat; a.reset_mask = 0; a.hist = nullptr;
+                node(a);
+                if (compose_energy_eval(m1, g1, m2, g2, c, g->xhat, t, w.s2, w.p2, b4.f(), b5.f(), b4.f() + 3, s)) return 1;
+                NodeArgs b = a;
+                b.step = STEP_MALA_ACCEPT;
+                b.E_x = b4.f() + 2; b.E_hat = b4.f() + 3; b.acc_count = g->acc_count + t;
+                b.reset_mask = (e == S);
+                b.hist = (e == S && history) ? history + (size_t)(T - t) * NP : nullptr;
+                const uint64_t uc = ucall0[t] + (uint64_t)(e - 1);
+                b.noise.ucall = (unsigned int)uc;
+                if (nz->mode == CCSP_NOISE_INJECTED) {
+                    if (uc < nz->ucall_base || uc - nz->ucall_base >= nz->n_uniform)
+                        return fail("compose_chain_run: injected uniform stream exhausted at call %llu", (unsigned long long)uc);
+                    b.noise.uniform = nz->uniform + (size_t)(uc - nz->ucall_base) * N;
+                }
+                node(b);
+                continue;
+            }
             node(a);
         }
     }
+    if (mala && accept) hipLaunchKernelGGL(k_accept_rates, dim3(nblk(T, 256)), dim3(256), 0, s, T, g->acc_count, g->acc_denom, accept);
     HIP_TRY(hipMemcpyAsync(x, g->x, NP * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipEventRecord(g->ev1, s));
     HIP_TRY(hipGetLastError());

@@ -187,7 +187,9 @@ int ccsp_chain_run(ccsp_model* model, ccsp_graph* graph, int32_t sampler, const 
  *     out = (w1 * sum1 + w2 * widen(sum2)) / sqrt(count1 + count2);  out[mask] = x[:, -P:][mask]
  * Both models must be Diffusion-CCSP models with the same `timesteps`, direct-mode (energy_wrapper 0) for ccsp_compose_denoise
  * and ccsp_compose_chain_run; their own `normalize` flags are not used.  The chain form runs samplers NONE / ULA / ULA+ with the
- * schedule of `first`. */
+ * schedule of `first`; when both are energy_wrapper models (every evaluation = the composed energy gradient) also MALA
+ * (ddpm.py:999-1047 on gradient_function / energy_function of the composed model, :280-289; `accept` [timesteps] = mean acceptance per
+ * timestep, or NULL).  HMC is not built for composed models. */
 typedef struct ccsp_compose {
     int32_t zero_col;       /* column of the P-wide pose the second domain does not produce (2: z) */
     float weight_first;     /* composing_weight[0] */
@@ -205,7 +207,7 @@ int ccsp_compose_energy_grad(ccsp_model* first, ccsp_graph* graph_first, ccsp_mo
                              void* stream);
 int ccsp_compose_chain_run(ccsp_model* first, ccsp_graph* graph_first, ccsp_model* second, ccsp_graph* graph_second,
                            const ccsp_compose* compose, int32_t sampler, const ccsp_noise* noise, float* x, int32_t init,
-                           int32_t t_first, int32_t t_last, float* history, void* stream);
+                           int32_t t_first, int32_t t_last, float* history, float* accept, void* stream);
 
 /* MALA across shards.  The reference's accept test uses ONE energy for the whole batch
  * (logp_x, logp_x_hat of shape [1], ddpm.py:1026-1038), so a batch cut into per-GPU shards only reproduces the

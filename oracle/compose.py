@@ -103,8 +103,10 @@ class ComposedOracleGraph(object):
         grad[:, z] += np.float32(2) * poses[:, z] * cnt2
         return grad, float(e1) + float(e2) + float((cnt2 * poses[:, z] ** 2).sum())
 
-    def chain(self, normal, samples_per_step, sampler='ULA', history=False, energy=False, x=None, t_first=None, t_last=0):
-        """full reverse chain with injected normal draws [n_calls, N, P]; sampler 'ULA' or None.  energy: epsilon is the gradient of
+    def chain(self, normal, samples_per_step, sampler='ULA', history=False, energy=False, x=None, t_first=None, t_last=0, uniform=None):
+        """full reverse chain with injected normal draws [n_calls, N, P]; sampler 'ULA', 'MALA' (energy only; uniform: [n_ucalls, N] draws of
+        the accept tests, AnnealedMALASampler.sample_step ddpm.py:1013-1041 with gradient_function / energy_function of :280-289) or None.
+        energy: epsilon is the gradient of
         the composed energy (ComposedEBMDenoiseFn around the energy_wrapper model, denoise_fn.py:539-548): no count normalisation,
         no mask fill inside an evaluation.  x / t_first / t_last: run timesteps t_first..t_last from the state x (the draws keep their
         call numbers: timestep t starts at call 1 + (T - 1 - t) (1 + S))"""
@@ -115,7 +117,11 @@ class ComposedOracleGraph(object):
         f = np.float32
         gt = self.x[:, m.dims[-1][1]:m.dims[-1][1] + P]
         z = np.asarray(normal, dtype=np.float32)
-        S = int(samples_per_step) if sampler == 'ULA' else 0
+        S = int(samples_per_step) if sampler in ('ULA', 'MALA') else 0
+        if sampler == 'MALA':
+            assert energy and uniform is not None
+            uni = np.asarray(uniform, dtype=np.float32)
+        accepted = []
         if x is None:
             x = (f(0.5) * z[0]).astype(np.float32)
             x[self.mask] = gt[self.mask]
@@ -124,6 +130,7 @@ class ComposedOracleGraph(object):
             x = np.array(x, dtype=np.float32)
         hist = [x.copy()]
         call = 1 + (T - 1 - int(t_first)) * (1 + S)
+        ucall = (T - 1 - int(t_first)) * S
         for t in range(int(t_first), int(t_last) - 1, -1):
             a_t, b_t = f(sc['sqrt_recip_alphas_cumprod'][t]), f(sc['sqrt_recipm1_alphas_cumprod'][t])
             c1, c2 = f(sc['posterior_mean_coef1'][t]), f(sc['posterior_mean_coef2'][t])
@@ -137,10 +144,32 @@ class ComposedOracleGraph(object):
                 x = (mean + sigma * z[call]).astype(np.float32)
                 call += 1
                 for _ in range(S):
+                    if sampler == 'MALA':
+                        eps, e_x = self.energy_grad(x, t)
+                        grad = ((-eps) * kappa).astype(np.float32)
+                        mu = (x + (grad * ss).astype(np.float32)).astype(np.float32)
+                        x_hat = (mu + (z[call] * std).astype(np.float32)).astype(np.float32)
+                        call += 1
+                        _, e_hat = self.energy_grad(x_hat, t)
+                        var, log_scale, lc = f(std * std), f(np.log(std)), f(0.918938533204672742)
+                        lrev = np.zeros(N, dtype=np.float32)
+                        lfwd = np.zeros(N, dtype=np.float32)
+                        for c in range(P):                                   # Normal(mu, std).log_prob(.).sum(1), column by column
+                            dr, df = (x[:, c] - mu[:, c]).astype(np.float32), (x_hat[:, c] - mu[:, c]).astype(np.float32)
+                            lrev = (lrev + ((-(dr * dr) / (f(2) * var) - log_scale).astype(np.float32) - lc).astype(np.float32)).astype(np.float32)
+                            lfwd = (lfwd + ((-(df * df) / (f(2) * var) - log_scale).astype(np.float32) - lc).astype(np.float32)).astype(np.float32)
+                        logp_x, logp_h = f(-f(e_x)) * kappa, f(-f(e_hat)) * kappa
+                        la = (((logp_h - logp_x) + lrev).astype(np.float32) - lfwd).astype(np.float32)
+                        acc = (uni[ucall] < np.exp(la).astype(np.float32)).astype(np.float32)
+                        ucall += 1
+                        accepted.append(float(acc.mean()))
+                        x = (acc[:, None] * x_hat + (f(1) - acc)[:, None] * x).astype(np.float32)
+                        continue
                     eps = ev(x, t)
                     grad = ((-eps) * kappa).astype(np.float32)
                     x = ((x + grad * ss).astype(np.float32) + (z[call] * std).astype(np.float32)).astype(np.float32)
                     call += 1
             x[self.mask] = gt[self.mask]
             hist.append(x.copy())
+        self.last_accept = accepted
         return (x, np.stack(hist)) if history else x

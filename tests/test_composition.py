@@ -175,7 +175,7 @@ def test_hip_chain_vs_reference(name, H, device):
 def test_hip_energy_chain_vs_reference(name, H, device):
     """ccsp_compose_chain_run on two energy_wrapper models: every evaluation is the composed energy gradient; per-timestep parity
     from the reference's recorded states (see _energy_chain_errors); the direct output of the same models (forward with
-    tag != 'EBM', denoise_fn.py:535-537) is still available; MALA / HMC refuse"""
+    tag != 'EBM', denoise_fn.py:535-537) is still available; HMC refuses"""
     from diffusion_ccsp_amd import ComposedEBMDenoiseFn, ConstraintDiffuser, GaussianDiffusion
     z = golden(name)
     T, S = int(z['T']), int(z['S'])
@@ -205,7 +205,91 @@ def test_hip_energy_chain_vs_reference(name, H, device):
     first._drop_handle()
     assert np.array_equal(d_energy, d_direct)
     with pytest.raises(NotImplementedError):
-        GaussianDiffusion(ComposedEBMDenoiseFn(first), timesteps=T, EBM='MALA', samples_per_step=S).sample(b, seed=1)
+        GaussianDiffusion(ComposedEBMDenoiseFn(first), timesteps=T, EBM='HMC', samples_per_step=S).sample(b, seed=1)
+
+
+def _composed_mala_oracle(H, T, S, b, seed, N):
+    m1, m2 = _energy_pair(H, T, S)
+    g = compose_oracle.ComposedOracleGraph(m1, m2, b, weight=(1, 1))
+    zs = noise.normal_stream(seed, 1 + T * (1 + S), N, 5)
+    us = noise.uniform_stream(seed, T * S, N)
+    with np.errstate(all='ignore'):
+        x, hist = g.chain(zs, S, sampler='MALA', energy=True, history=True, uniform=us)
+    return g, zs, us, x, hist
+
+
+def test_oracle_composed_mala_chain_is_a_metropolis_chain():
+    """MALA on the composed energy (oracle/compose.py; no reference golden: the composed energy and gradient it is built on are pinned
+    by `composed.npz`, the accept step restates ddpm.py:1013-1041): every inner step leaves a node row either where it was or at the
+    proposal, conditioned rows stay fixed, acceptance rates are rates"""
+    z = golden('chain_c64_ula_energy')
+    b = golden_batch(z)
+    T, S, seed = 6, 3, 11
+    g, zs, us, x, hist = _composed_mala_oracle(64, T, S, b, seed, z['x'].shape[0])
+    assert hist.shape[0] == T + 1 and len(g.last_accept) == T * S and all(0.0 <= a <= 1.0 for a in g.last_accept)
+    m = z['mask'].astype(bool)
+    p0 = g.m1.dims[-1][1]
+    assert m.any() and np.array_equal(hist[-1][m], g.x[m][:, p0:p0 + 5])
+
+
+@pytest.mark.gpu
+def test_hip_composed_mala_vs_oracle(device):
+    """ccsp_compose_chain_run with CCSP_SAMPLER_MALA on two energy_wrapper models (the reference's MALA on its composed model: ddpm.py:999-1047
+    over gradient_function / energy_function :280-289 of the 'robot_qualitative' ConstraintDiffuser): every timestep from the ORACLE's
+    recorded state (the composed energy chain leaves fp32 range within a dozen timesteps, see _energy_chain_errors) -- finite successors
+    within 1e-4 relative, the same rows non-finite otherwise, at most one flipped near-tie accept; acceptance rates reported"""
+    from diffusion_ccsp_amd import ComposedEBMDenoiseFn, ConstraintDiffuser, GaussianDiffusion
+    z = golden('chain_c64_ula_energy')
+    b = golden_batch(z)
+    H, T, S, seed = 64, 10, 3, 11
+    g, zs, us, x_o, hist = _composed_mala_oracle(H, T, S, b, seed, z['x'].shape[0])
+    first = ConstraintDiffuser(dims=worlds.MODE_DIMS['robot_box'], hidden_dim=H, input_mode='robot_qualitative', EBM='MALA', energy_wrapper=True,
+                               device=device, verbose=False)
+    first.load_state_dict(weights('weights_robot_box_h64_energy.npz'))
+    second = ConstraintDiffuser(dims=worlds.MODE_DIMS['qualitative'], hidden_dim=H, input_mode='qualitative', EBM='MALA', energy_wrapper=True,
+                                device=device, verbose=False)
+    second.load_state_dict(weights('weights_qualitative_h64_energy.npz'))
+    first.compose(second, (1, 1))
+    gd = GaussianDiffusion(ComposedEBMDenoiseFn(first), timesteps=T, EBM='MALA', samples_per_step=S)
+    bad, checked = [], 0
+    for k in range(T):
+        if not np.isfinite(hist[k]).all():
+            break
+        got = gd.p_sample_segment(b, torch.from_numpy(hist[k]), T - 1 - k, T - 1 - k, seed=seed).cpu().numpy()
+        want = hist[k + 1]
+        fin = np.isfinite(want).all(axis=1)
+        if not np.array_equal(np.isfinite(got).all(axis=1), fin) or (fin.any() and rel_err(got[fin], want[fin]) > 1e-4):
+            bad.append((k, rel_err(got[fin], want[fin]) if fin.any() else None))
+        checked += 1
+    assert checked >= 3 and len(bad) <= 1, (checked, bad)
+    rates = gd.last_accept_rates.cpu().numpy()
+    assert rates.shape == (T,) and (rates >= 0).all() and (rates <= 1).all()
+    x = gd.sample(b, seed=seed).cpu().numpy()
+    m = z['mask'].astype(bool)
+    p0 = g.m1.dims[-1][1]
+    assert np.array_equal(x[m], g.x[m][:, p0:p0 + 5])
+    # where proposals ARE accepted: late timesteps of the T = 1000 schedule from a small state (mixed acceptance, 0.14 .. 1.0 per inner step)
+    T, tf, n_t = 1000, 200, 6
+    m1, m2 = _energy_pair(H, T, S)
+    g = compose_oracle.ComposedOracleGraph(m1, m2, b, weight=(1, 1))
+    N = z['x'].shape[0]
+    zs = noise.normal_stream(seed, 1 + T * (1 + S), N, 5)
+    us = noise.uniform_stream(seed, T * S, N)
+    x0 = (0.3 * np.random.RandomState(0).randn(N, 5)).astype(np.float32)
+    with np.errstate(all='ignore'):
+        _, hist = g.chain(zs, S, sampler='MALA', energy=True, history=True, uniform=us, x=x0, t_first=tf, t_last=tf - n_t + 1)
+    acc_o = np.asarray(g.last_accept).reshape(n_t, S).mean(axis=1)
+    assert 0.2 < acc_o.mean() < 1.0 and np.isfinite(hist).all()
+    gd = GaussianDiffusion(ComposedEBMDenoiseFn(first), timesteps=T, EBM='MALA', samples_per_step=S)
+    flips = 0
+    for k in range(n_t):
+        t = tf - k
+        got = gd.p_sample_segment(b, torch.from_numpy(hist[k]), t, t, seed=seed).cpu().numpy()
+        rate = float(gd.last_accept_rates[t].cpu())
+        if rel_err(got, hist[k + 1]) > 1e-4 or abs(rate - acc_o[k]) > 1e-6:
+            flips += 1                                           # a near-tie accept decided the other way moves one node row by one proposal
+            assert abs(rate - acc_o[k]) <= 1.0 / (N * S) + 1e-6 and rel_err(got, hist[k + 1]) < 0.2, (t, rate, acc_o[k])
+    assert flips <= 1
 
 
 @pytest.mark.gpu
