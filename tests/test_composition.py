@@ -233,22 +233,24 @@ def test_oracle_composed_mala_chain_is_a_metropolis_chain():
 
 
 @pytest.mark.gpu
-def test_hip_composed_mala_vs_oracle(device):
+@pytest.mark.parametrize('name,H', [('chain_c64_ula_energy', 64), ('chain_c256_ula_energy', 256)])
+def test_hip_composed_mala_vs_oracle(name, H, device):
     """ccsp_compose_chain_run with CCSP_SAMPLER_MALA on two energy_wrapper models (the reference's MALA on its composed model: ddpm.py:999-1047
     over gradient_function / energy_function :280-289 of the 'robot_qualitative' ConstraintDiffuser): every timestep from the ORACLE's
     recorded state (the composed energy chain leaves fp32 range within a dozen timesteps, see _energy_chain_errors) -- finite successors
     within 1e-4 relative, the same rows non-finite otherwise, at most one flipped near-tie accept; acceptance rates reported"""
     from diffusion_ccsp_amd import ComposedEBMDenoiseFn, ConstraintDiffuser, GaussianDiffusion
-    z = golden('chain_c64_ula_energy')
+    z = golden(name)
     b = golden_batch(z)
-    H, T, S, seed = 64, 10, 3, 11
+    T, S, seed = 10, 3, 11
+    sfx = '_energy' if H == 64 else ''
     g, zs, us, x_o, hist = _composed_mala_oracle(H, T, S, b, seed, z['x'].shape[0])
     first = ConstraintDiffuser(dims=worlds.MODE_DIMS['robot_box'], hidden_dim=H, input_mode='robot_qualitative', EBM='MALA', energy_wrapper=True,
                                device=device, verbose=False)
-    first.load_state_dict(weights('weights_robot_box_h64_energy.npz'))
+    first.load_state_dict(weights('weights_robot_box_h%d%s.npz' % (H, sfx)))
     second = ConstraintDiffuser(dims=worlds.MODE_DIMS['qualitative'], hidden_dim=H, input_mode='qualitative', EBM='MALA', energy_wrapper=True,
                                 device=device, verbose=False)
-    second.load_state_dict(weights('weights_qualitative_h64_energy.npz'))
+    second.load_state_dict(weights('weights_qualitative_h%d%s.npz' % (H, sfx)))
     first.compose(second, (1, 1))
     gd = GaussianDiffusion(ComposedEBMDenoiseFn(first), timesteps=T, EBM='MALA', samples_per_step=S)
     bad, checked = [], 0
