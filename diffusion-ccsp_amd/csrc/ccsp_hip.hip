@@ -3974,10 +3974,12 @@ int ccsp_compose_chain_run(ccsp_model* m1, ccsp_graph* g1, ccsp_model* m2, ccsp_
     ccsp_model* m = m1;
     ccsp_graph* g = g1;
     const int T = m->d.timesteps, P = m->d.pose_dim;
-    const bool mala = sampler == CCSP_SAMPLER_MALA;
+    const bool hmc = sampler == CCSP_SAMPLER_HMC;
+    const bool mala = sampler == CCSP_SAMPLER_MALA || hmc;          // (what the two Metropolis samplers share: acceptance counters, uniform draws)
     if (sampler != CCSP_SAMPLER_NONE && sampler != CCSP_SAMPLER_ULA && sampler != CCSP_SAMPLER_ULA_PLUS && !(mala && m1->d.energy_wrapper))
         return fail("compose_chain_run: sampler %d: composed models run the ancestral / ULA / ULA+ samplers (on the denoiser output, or on the energy gradient "
-                    "when both are energy_wrapper models) and, as energy_wrapper models, MALA; HMC is not built for them", sampler);
+                    "when both are energy_wrapper models) and, as energy_wrapper models, MALA and HMC", sampler);
+    if (hmc && m1->d.timesteps < 4) return fail("compose_chain_run: HMC indexes the schedule with its inner step 0..3 (ddpm.py:1076-1084)");
     // energy mode (both energy_wrapper models; ComposedEBMDenoiseFn.forward: epsilon = dE/dposes, ddpm.py:940-966 on it): every evaluation
     // is the composed energy gradient of ccsp_compose_energy_grad
     const bool energy = m1->d.energy_wrapper != 0;
@@ -4000,7 +4002,10 @@ int ccsp_compose_chain_run(ccsp_model* m1, ccsp_graph* g1, ccsp_model* m2, ccsp_
     std::vector<uint64_t> call0(T), ucall0(T, 0);
     {
         uint64_t k = 1, u = 0;
-        for (int t = T - 1; t >= 0; --t) { call0[t] = k; ucall0[t] = u; k += 1 + (uint64_t)steps_at(m, sampler, t); u += (uint64_t)steps_at(m, sampler, t); }
+        for (int t = T - 1; t >= 0; --t) {      // (HMC draws the momentum once per timestep on top of its S refreshments, ddpm.py:1090,1096)
+            const uint64_t S = (uint64_t)steps_at(m, sampler, t);
+            call0[t] = k; ucall0[t] = u; k += 1 + S + (hmc && S > 0 ? 1 : 0); u += S;
+        }
     }
     if (mala) {         // acceptance counters of the first domain's graph (energy_prepare below allocates them)
         if (energy_prepare(m1, g1, s)) return 1;
@@ -4037,7 +4042,7 @@ int ccsp_compose_chain_run(ccsp_model* m1, ccsp_graph* g1, ccsp_model* m2, ccsp_
     }
     for (int t = t_first; t >= t_last; --t) {
         const int S = steps_at(m, sampler, t);
-        for (int e = 0; e <= S; ++e) {
+        for (int e = 0; e <= (hmc ? 0 : S); ++e) {
             if (energy) {      // gradient at the state (w.s1: the gradient; g1->eps / g2->eps hold the two domains' own gradients)
                 if (compose_energy_eval(m1, g1, m2, g2, c, g->x, t, w.s2, w.p2, b4.f(), w.s1, b4.f() + 2, s)) return 1;
             } else if (compose_eval(m1, g1, m2, g2, c, nullptr, t, w, g->eps, s)) return 1;
@@ -4050,7 +4055,7 @@ int ccsp_compose_chain_run(ccsp_model* m1, ccsp_graph* g1, ccsp_model* m2, ccsp_
             a.sigma = t != 0 ? expf(0.5f * m->post_lv[t]) : 0.0f;
             a.kappa = m->kappa[t]; a.ss = m->step[t]; a.std_ = sqrtf(2.0f * m->step[t]);
             if (noise_for(call0[t] + (uint64_t)e, a.noise)) return 1;
-            if (mala && e >= 1) {
+            if (mala && !hmc && e >= 1) {
                 // AnnealedMALASampler.sample_step (ddpm.py:1013-1041) on the composed model: the gradient evaluation above also left E(x)
                 // in b4[2]; propose, evaluate the composed energy at the proposal (its gradient goes to scratch), accept per node row
                 // from the batch-scalar energies
@@ -4073,6 +4078,59 @@ int ccsp_compose_chain_run(ccsp_model* m1, ccsp_graph* g1, ccsp_model* m2, ccsp_
                 continue;
             }
             node(a);
+        }
+        if (hmc && S > 0) {
+            // AnnealedMUHASampler.sample_step (ddpm.py:1087-1128; chain_run_impl's HMC block with the composed energy): the leapfrog runs at
+            // the INNER index e (step size, mass, gradient timestep), the energies at the real t.  Every evaluation encodes its own poses.
+            if (!g->hmc_vk && (dev_alloc(g->allocs, &g->hmc_vk, NP) || dev_alloc(g->allocs, &g->hmc_vp, NP) || dev_alloc(g->allocs, &g->hmc_vl, NP))) return 1;
+            const dim3 hgrid(nblk((long)NP, 256));
+            auto hargs = [&](int mode) {
+                HmcArgs h;
+                memset(&h, 0, sizeof(h));
+                h.N = g->N; h.P = P; h.F = g->F; h.mode = mode;
+                h.x = g->x; h.xl = g->xhat; h.vk = g->hmc_vk; h.vp = g->hmc_vp; h.vl = g->hmc_vl; h.eps = w.s1;
+                h.m_t = 9.0f * m->betas[t]; h.kappa_t = m->kappa[t];
+                h.mask = g->mask; h.xfeat = g->xfeat; h.pose_begin = m->d.pose_begin;
+                return h;
+            };
+            auto grad_at = [&](const float* poses, int tt, float* grad_out, float* e_out) {
+                return compose_energy_eval(m1, g1, m2, g2, c, poses, tt, w.s2, w.p2, b4.f(), grad_out, e_out, s);
+            };
+            {
+                HmcArgs h = hargs(HMC_MOMENTUM);
+                if (noise_for(call0[t] + 1, h.noise)) return 1;
+                hipLaunchKernelGGL(k_hmc, hgrid, dim3(256), 0, s, h);
+            }
+            for (int e = 0; e < S; ++e) {
+                HmcArgs r = hargs(HMC_REFRESH);
+                if (noise_for(call0[t] + 2 + (uint64_t)e, r.noise)) return 1;
+                hipLaunchKernelGGL(k_hmc, hgrid, dim3(256), 0, s, r);
+                const float m_i = 9.0f * m->betas[e];
+                for (int lf = 0; lf < 2; ++lf) {
+                    if (lf == 0 && grad_at(g->xhat, e, w.s1, b4.f() + 4)) return 1;
+                    HmcArgs la = hargs(HMC_LEAP_A);
+                    la.ss_i = m->step[e]; la.md_i = m_i * m_i; la.kap_i = m->kappa[e];
+                    hipLaunchKernelGGL(k_hmc, hgrid, dim3(256), 0, s, la);
+                    if (grad_at(g->xhat, e, w.s1, b4.f() + 4)) return 1;
+                    HmcArgs lb = la;
+                    lb.mode = HMC_LEAP_B;
+                    hipLaunchKernelGGL(k_hmc, hgrid, dim3(256), 0, s, lb);
+                }
+                if (grad_at(g->x, t, b5.f(), b4.f() + 2) || grad_at(g->xhat, t, b5.f(), b4.f() + 3)) return 1;
+                HmcArgs ac = hargs(HMC_ACCEPT);
+                ac.E_x = b4.f() + 2; ac.E_hat = b4.f() + 3; ac.acc_count = g->acc_count + t;
+                ac.reset_mask = (e == S - 1);
+                ac.hist = (e == S - 1 && history) ? history + (size_t)(T - t) * NP : nullptr;
+                ac.noise.mode = nz->mode; ac.noise.seed = nz->seed; ac.noise.row_offset = nz->row_offset;
+                const uint64_t uc = ucall0[t] + (uint64_t)e;
+                ac.noise.ucall = (unsigned int)uc;
+                if (nz->mode == CCSP_NOISE_INJECTED) {
+                    if (uc < nz->ucall_base || uc - nz->ucall_base >= nz->n_uniform)
+                        return fail("compose_chain_run: injected uniform stream exhausted at call %llu", (unsigned long long)uc);
+                    ac.noise.uniform = nz->uniform + (size_t)(uc - nz->ucall_base) * N;
+                }
+                hipLaunchKernelGGL(k_hmc, hgrid, dim3(256), 0, s, ac);
+            }
         }
     }
     if (mala && accept) hipLaunchKernelGGL(k_accept_rates, dim3(nblk(T, 256)), dim3(256), 0, s, T, g->acc_count, g->acc_denom, accept);

@@ -188,9 +188,9 @@ class GaussianDiffusion(object):
         nz, keep = self._noise_struct(seed, noise, row_offset)
         if getattr(core, '_second', None) is not None:
             # two composed domains (ConstraintDiffuser.compose): one evaluation per domain and evaluation, ccsp_compose_chain_run
-            if self._sampler() == 'HMC' or (self._sampler() == 'MALA' and not core.energy_wrapper):
+            if self._sampler() in ('MALA', 'HMC') and not core.energy_wrapper:
                 raise NotImplementedError('composed domains run EBM=False, ULA and ULA+ (on the denoiser output, or on the energy gradient '
-                                          'when the composed model is an energy_wrapper model) and, as energy_wrapper models, MALA; HMC is not built for them')
+                                          'when the composed model is an energy_wrapper model) and, as energy_wrapper models, MALA and HMC')
             if core.energy_wrapper and tuple(core.composing_weight) != (1, 1):
                 raise NotImplementedError('the energy of composed domains is built for composing_weight (1, 1)')
             first, second = core._composed_parts()
@@ -198,7 +198,7 @@ class GaussianDiffusion(object):
             g1, g2 = core._composed_graphs(batch)
             hist = torch.empty((T + 1, g1.N, self.dims[-1][0]), device=dev, dtype=torch.float32) if return_history else None
             c = core._compose_struct()
-            acc = torch.zeros(T, device=dev, dtype=torch.float32) if self._sampler() == 'MALA' else None
+            acc = torch.zeros(T, device=dev, dtype=torch.float32) if self._sampler() in ('MALA', 'HMC') else None
             with torch.cuda.device(dev):
                 _lib.check(L.ccsp_compose_chain_run(h, g1.h, second._h, g2.h, C.byref(c), _lib.SAMPLERS[self._sampler()], C.byref(nz), _ptr(x),
                                                     int(init), int(t_first), int(t_last), None if hist is None else _ptr(hist),

@@ -187,9 +187,9 @@ int ccsp_chain_run(ccsp_model* model, ccsp_graph* graph, int32_t sampler, const 
  *     out = (w1 * sum1 + w2 * widen(sum2)) / sqrt(count1 + count2);  out[mask] = x[:, -P:][mask]
  * Both models must be Diffusion-CCSP models with the same `timesteps`, direct-mode (energy_wrapper 0) for ccsp_compose_denoise
  * and ccsp_compose_chain_run; their own `normalize` flags are not used.  The chain form runs samplers NONE / ULA / ULA+ with the
- * schedule of `first`; when both are energy_wrapper models (every evaluation = the composed energy gradient) also MALA
- * (ddpm.py:999-1047 on gradient_function / energy_function of the composed model, :280-289; `accept` [timesteps] = mean acceptance per
- * timestep, or NULL).  HMC is not built for composed models. */
+ * schedule of `first`; when both are energy_wrapper models (every evaluation = the composed energy gradient) also MALA and HMC
+ * (ddpm.py:999-1047 / :1050-1128 on gradient_function / energy_function of the composed model, :280-289; `accept` [timesteps] = mean
+ * acceptance per timestep, or NULL). */
 typedef struct ccsp_compose {
     int32_t zero_col;       /* column of the P-wide pose the second domain does not produce (2: z) */
     float weight_first;     /* composing_weight[0] */

@@ -117,10 +117,11 @@ class ComposedOracleGraph(object):
         f = np.float32
         gt = self.x[:, m.dims[-1][1]:m.dims[-1][1] + P]
         z = np.asarray(normal, dtype=np.float32)
-        S = int(samples_per_step) if sampler in ('ULA', 'MALA') else 0
-        if sampler == 'MALA':
+        S = int(samples_per_step) if sampler in ('ULA', 'MALA') else (4 if sampler == 'HMC' else 0)      # HMC: samples_per_step = 4, ddpm.py:311
+        if sampler in ('MALA', 'HMC'):
             assert energy and uniform is not None
             uni = np.asarray(uniform, dtype=np.float32)
+        per_t = 1 + S + (1 if sampler == 'HMC' else 0)           # HMC draws the momentum once per timestep on top of its refreshments
         accepted = []
         if x is None:
             x = (f(0.5) * z[0]).astype(np.float32)
@@ -129,7 +130,7 @@ class ComposedOracleGraph(object):
         else:
             x = np.array(x, dtype=np.float32)
         hist = [x.copy()]
-        call = 1 + (T - 1 - int(t_first)) * (1 + S)
+        call = 1 + (T - 1 - int(t_first)) * per_t
         ucall = (T - 1 - int(t_first)) * S
         for t in range(int(t_first), int(t_last) - 1, -1):
             a_t, b_t = f(sc['sqrt_recip_alphas_cumprod'][t]), f(sc['sqrt_recipm1_alphas_cumprod'][t])
@@ -143,6 +144,44 @@ class ComposedOracleGraph(object):
                 mean = (c1 * x0 + c2 * x).astype(np.float32)
                 x = (mean + sigma * z[call]).astype(np.float32)
                 call += 1
+                if sampler == 'HMC':
+                    # AnnealedMUHASampler.sample_step (ddpm.py:1087-1128) + leapfrog_step (:917-937), the arithmetic of csrc/ccsp_hmc.h: the
+                    # leapfrog runs at the INNER index i (step size, mass, gradient timestep), the energies at the real t
+                    m_t = f(9) * f(sc['betas'][t])
+                    vk = (z[call] * m_t).astype(np.float32)
+                    call += 1
+                    lc = f(0.918938533204672742)
+                    for i in range(S):
+                        v = ((vk * f(0)).astype(np.float32) + ((f(1) * z[call]) * m_t).astype(np.float32)).astype(np.float32)
+                        call += 1
+                        vp, vl, xl = v.copy(), v.copy(), x.copy()
+                        ss_i, kap_i = f(sc['step_sizes'][i]), f(sc['kappa'][i])
+                        m_i = f(9) * f(sc['betas'][i])
+                        md_i = f(m_i * m_i)
+                        half = f(0.5) * ss_i
+                        g_ = self.energy_grad(xl, i)[0]
+                        for _lf in range(2):
+                            vl = (vl + (half * ((-g_) * kap_i).astype(np.float32)).astype(np.float32)).astype(np.float32)
+                            xl = (xl + ((ss_i * vl).astype(np.float32) / md_i).astype(np.float32)).astype(np.float32)
+                            g_ = self.energy_grad(xl, i)[0]
+                            vl = (vl + (half * ((-g_) * kap_i).astype(np.float32)).astype(np.float32)).astype(np.float32)
+                        e_x, e_hat = self.energy_grad(x, t)[1], self.energy_grad(xl, t)[1]
+                        var, log_scale = f(m_t * m_t), f(np.log(m_t))
+                        lvp = np.zeros(N, dtype=np.float32)
+                        lv = np.zeros(N, dtype=np.float32)
+                        for c in range(P):
+                            lvp = (lvp + ((-(vp[:, c] * vp[:, c]) / (f(2) * var) - log_scale).astype(np.float32) - lc).astype(np.float32)).astype(np.float32)
+                            lv = (lv + ((-(vl[:, c] * vl[:, c]) / (f(2) * var) - log_scale).astype(np.float32) - lc).astype(np.float32)).astype(np.float32)
+                        logp_x, logp_h = f(-f(e_x)) * kappa, f(-f(e_hat)) * kappa
+                        la = ((logp_h + lv).astype(np.float32) - (logp_x + lvp).astype(np.float32)).astype(np.float32)
+                        acc = (uni[ucall] < np.exp(la).astype(np.float32)).astype(np.float32)
+                        ucall += 1
+                        accepted.append(float(acc.mean()))
+                        x = (acc[:, None] * xl + (f(1) - acc)[:, None] * x).astype(np.float32)
+                        vk = (acc[:, None] * vl + (f(1) - acc)[:, None] * vp).astype(np.float32)
+                    x[self.mask] = gt[self.mask]
+                    hist.append(x.copy())
+                    continue
                 for _ in range(S):
                     if sampler == 'MALA':
                         eps, e_x = self.energy_grad(x, t)

@@ -175,7 +175,7 @@ def test_hip_chain_vs_reference(name, H, device):
 def test_hip_energy_chain_vs_reference(name, H, device):
     """ccsp_compose_chain_run on two energy_wrapper models: every evaluation is the composed energy gradient; per-timestep parity
     from the reference's recorded states (see _energy_chain_errors); the direct output of the same models (forward with
-    tag != 'EBM', denoise_fn.py:535-537) is still available; HMC refuses"""
+    tag != 'EBM', denoise_fn.py:535-537) is still available"""
     from diffusion_ccsp_amd import ComposedEBMDenoiseFn, ConstraintDiffuser, GaussianDiffusion
     z = golden(name)
     T, S = int(z['T']), int(z['S'])
@@ -204,8 +204,7 @@ def test_hip_energy_chain_vs_reference(name, H, device):
     first.energy_wrapper = True
     first._drop_handle()
     assert np.array_equal(d_energy, d_direct)
-    with pytest.raises(NotImplementedError):
-        GaussianDiffusion(ComposedEBMDenoiseFn(first), timesteps=T, EBM='HMC', samples_per_step=S).sample(b, seed=1)
+    # (MALA and HMC on the pair: test_hip_composed_mala_vs_oracle / _hmc_)
 
 
 def _composed_mala_oracle(H, T, S, b, seed, N):
@@ -351,3 +350,76 @@ def test_hip_degenerate_domains_and_fresh_chain(device):
     assert np.abs(x.cpu().numpy() - want).max() < 1e-4 * (1 + np.abs(want).max())
     for k in (1, 5, 20, T):
         assert rel_err(hist[k].cpu().numpy(), whist[k]) < 2e-3, k
+
+
+def _composed_pair_hip(H, device, EBM):
+    from diffusion_ccsp_amd import ConstraintDiffuser
+    sfx = '_energy' if H == 64 else ''
+    first = ConstraintDiffuser(dims=worlds.MODE_DIMS['robot_box'], hidden_dim=H, input_mode='robot_qualitative', EBM=EBM, energy_wrapper=True,
+                               device=device, verbose=False)
+    first.load_state_dict(weights('weights_robot_box_h%d%s.npz' % (H, sfx)))
+    second = ConstraintDiffuser(dims=worlds.MODE_DIMS['qualitative'], hidden_dim=H, input_mode='qualitative', EBM=EBM, energy_wrapper=True,
+                                device=device, verbose=False)
+    second.load_state_dict(weights('weights_qualitative_h%d%s.npz' % (H, sfx)))
+    first.compose(second, (1, 1))
+    return first
+
+
+def _hmc_oracle_segment(H, b, N, seed, T, tf, n_t, x0):
+    m1, m2 = _energy_pair(H, T, 4)
+    g = compose_oracle.ComposedOracleGraph(m1, m2, b, weight=(1, 1))
+    zs = noise.normal_stream(seed, 1 + T * 6, N, 5)
+    us = noise.uniform_stream(seed, T * 4, N)
+    with np.errstate(all='ignore'):
+        _, hist = g.chain(zs, 4, sampler='HMC', energy=True, history=True, uniform=us, x=x0, t_first=tf, t_last=tf - n_t + 1)
+    return g, hist
+
+
+def test_oracle_composed_hmc_chain_is_a_metropolis_chain():
+    """HMC on the composed energy (oracle/compose.py restating ddpm.py:1087-1128, 917-937 on the composed gradient / energy): rates are
+    rates, conditioned rows stay fixed, and with these step sizes (inner indices 0..3 of the schedule) proposals are accepted"""
+    z = golden('chain_c64_ula_energy')
+    b = golden_batch(z)
+    N = z['x'].shape[0]
+    x0 = (0.3 * np.random.RandomState(0).randn(N, 5)).astype(np.float32)
+    # (at T = 1000 the reference's HMC accepts nothing -- its leapfrog pairs the momentum scale of timestep t with the mass of inner index
+    # 0..3, chain_t64_hmc.npz: acceptance 0 everywhere -- so the accept path is exercised on short schedules)
+    g, hist = _hmc_oracle_segment(64, b, N, 11, 4, 3, 4, x0)
+    acc = np.asarray(g.last_accept)
+    assert acc.shape == (16,) and (acc >= 0).all() and (acc <= 1).all() and 0.5 < acc.mean() < 1.0 and np.isfinite(hist).all()
+    m = z['mask'].astype(bool)
+    p0 = g.m1.dims[-1][1]
+    assert np.array_equal(hist[-1][m], g.x[m][:, p0:p0 + 5])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,H', [('chain_c64_ula_energy', 64), ('chain_c256_ula_energy', 256)])
+def test_hip_composed_hmc_vs_oracle(name, H, device):
+    """ccsp_compose_chain_run with CCSP_SAMPLER_HMC on two energy_wrapper models (ddpm.py:1050-1128 over the composed model's
+    gradient_function / energy_function): every timestep of a T = 8 and a T = 4 schedule (where the reference's HMC accepts: rejected first
+    refreshments, accepted later ones, mixed acceptance at T = 4), each from the oracle's recorded state -- acceptance rates equal, at most
+    one flipped near-tie accept per schedule, successors within 1e-4 relative at hidden_dim 64.  At hidden_dim 256 the bar is 5e-2: the
+    leapfrog map of THIS energy is explosive (the zero column's term has Hessian 2 cnt, and ss_i / mass_i^2 = 6e2 with kappa_i ss_i / 2 = 6e-3
+    per half step: two leapfrogs amplify a gradient difference ~ 6e3-fold; the states grow tenfold per timestep), and the two
+    implementations' single gradient evaluations differ by 1e-7 .. 9e-7 there (5e-8 .. 1e-7 at hidden_dim 64) -- measured: 1e-3 .. 2e-2 per
+    timestep whatever the GEMM scheme (f16x2, bf16x3, fp32 MFMA), with every acceptance rate exact"""
+    from diffusion_ccsp_amd import ComposedEBMDenoiseFn, GaussianDiffusion
+    z = golden(name)
+    b = golden_batch(z)
+    N, seed = z['x'].shape[0], 11
+    x0 = (0.3 * np.random.RandomState(0).randn(N, 5)).astype(np.float32)
+    first = _composed_pair_hip(H, device, 'HMC')
+    for T in (8, 4):
+        g, hist = _hmc_oracle_segment(H, b, N, seed, T, T - 1, T, x0)
+        acc_o = np.asarray(g.last_accept).reshape(T, 4).mean(axis=1)
+        assert 0.3 < acc_o.mean() < 1.0 and np.isfinite(hist).all()
+        gd = GaussianDiffusion(ComposedEBMDenoiseFn(first), timesteps=T, EBM='HMC', samples_per_step=4)
+        flips = 0
+        for k in range(T):
+            t = T - 1 - k
+            got = gd.p_sample_segment(b, torch.from_numpy(hist[k]), t, t, seed=seed).cpu().numpy()
+            rate = float(gd.last_accept_rates[t].cpu())
+            if rel_err(got, hist[k + 1]) > (1e-4 if H == 64 else 5e-2) or abs(rate - acc_o[k]) > 1e-6:
+                flips += 1
+                assert abs(rate - acc_o[k]) <= 1.0 / (N * 4) + 1e-6 and rel_err(got, hist[k + 1]) < 0.2, (T, t, rate, acc_o[k])
+        assert flips <= 1, T
