@@ -15,8 +15,13 @@ rank's graphs (+ the gather of final poses when N > 1).  Inputs (the collated ba
 in HBM before the timed region.
 
     python bench.py --gpus 1 --steps 3 --warmup 1 [--config c2|c4|c5]
+    python bench.py --gpus N --steps K --warmup W          N > 1 with WORLD_SIZE unset: re-executes ITSELF as N ranks under
+                                                           torch.distributed.run (127.0.0.1, a free port); one rank per GPU over RCCL
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W          (the same, launched from outside)
+    python bench.py --gpus 2 --backend gloo --dry-run      the N > 1 host path WITHOUT a GPU: launcher, init_process_group, flat weight
+                                                           broadcast, shard bookkeeping, gather, per-rank timing, the JSON line
+                                                           ("dry_run": true, value null -- no sampling happens: there is no CPU fallback)
 
     python bench.py --gpus N --scaling strong     C3 proper: 2048 graphs in total, split over the N ranks (default: weak, 256 per GPU)
 
@@ -37,11 +42,16 @@ Rank 0 prints ONE JSON line.  Extra blocks:
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# kernel arguments in device memory (a chain is 33 000 short dependent launches; ROCm >= 7 default): read by the HIP runtime at its first call,
+# so it is set HERE, before torch is imported, and inherited by the ranks of a self-launched N > 1 run (profiles/r03_findings.md: 13-27 %)
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # the host driver only supports dmabuf IPC (RCCL across processes)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -221,6 +231,36 @@ def pmc_traffic_live(config, graphs, symbols, timeout=240):
             if name.startswith(sym) and name in vals['WRITE_SIZE']:
                 out[sym] = {'kernel_name': name, 'bytes': vals['FETCH_SIZE'][name] * 1024.0 * 2.0 + vals['WRITE_SIZE'][name] * 1024.0}
     return out, {'source': 'live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two passes) over tools/profile_eval.py 6 %d %s in this run' % (graphs, config)}
+
+
+def rocprof_kernel_stats_live(config, graphs, symbols, timeout=240):
+    """rocprofv3 --kernel-trace --stats (no counters) over tools/profile_eval.py on the same batch, in THIS run: the profiler's own AverageNs of
+    each kernel, to stand next to the HIP-event us_mean of the timed pass (which spans launch to next mark).  One-lane launches of a few
+    timesteps of the chain.  -> ({symbol: {kernel name, calls, avg_ns, min_ns, max_ns}}, stamp) or ({}, reason)"""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.isfile('/opt/rocm/bin/rocprofv3') else None)
+    if exe is None:
+        return {}, {'source': 'none', 'reason': 'rocprofv3 not found'}
+    d = tempfile.mkdtemp(prefix='ccsp_stats_', dir='/tmp')
+    try:
+        cmd = [exe, '--kernel-trace', '--stats', '--output-format', 'csv', '-d', d, '--', sys.executable,
+               os.path.join(ROOT, 'tools', 'profile_eval.py'), '220', str(graphs), config]
+        r = subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+        files = glob.glob(d + '/**/*kernel_stats.csv', recursive=True)
+        if r.returncode != 0 or not files:
+            return {}, {'source': 'none', 'reason': 'rocprofv3 --kernel-trace --stats failed (rc %d)' % r.returncode}
+        out = {}
+        for row in csv.DictReader(open(files[0])):
+            name = row['Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
+            for sym in symbols:
+                if name.startswith(sym) and (sym not in out or int(row['Calls']) > out[sym]['calls']):
+                    out[sym] = {'kernel_name': name, 'calls': int(row['Calls']), 'avg_ns': float(row['AverageNs']),
+                                'min_ns': float(row['MinNs']), 'max_ns': float(row['MaxNs'])}
+        return out, {'source': 'live: rocprofv3 --kernel-trace --stats over tools/profile_eval.py 220 %d %s in this run (one lane)' % (graphs, config)}
+    except Exception as e:           # noqa: a profiler problem must not take the benchmark down
+        return {}, {'source': 'none', 'reason': 'rocprofv3 --kernel-trace --stats: %s' % e}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def algorithmic_bytes(n_nodes, n_types_present, H, P, grasp):
@@ -406,6 +446,144 @@ def sd_main(args):
         print(json.dumps(rec), flush=True)
 
 
+def world_label(cfg):
+    """'RandomSplitQualitativeWorld 8-obj' from the configuration's label"""
+    return re.sub(r' \d+ objects$', '', cfg['label'].split(':')[1].split(',')[0].strip()) + ' %d-obj' % cfg['n_objects']
+
+
+def _free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` with WORLD_SIZE unset: become N ranks -- this same command line under torch.distributed.run, one process per
+    GPU, rendezvous on 127.0.0.1 at a free port.  The ranks' stdout passes through (rank 0 prints the one JSON line); -> exit code"""
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // max(1, n))))      # torchrun would set 1: the lanes' host threads need a few
+    print('bench.py: launching %d ranks: %s' % (n, ' '.join(cmd)), file=sys.stderr, flush=True)
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        raise SystemExit(rc)
+    return 0
+
+
+def rank_times(elapsed, world, dist, dev):
+    """every rank's wall time of the timed region, on every rank (one all_gather of a double)"""
+    if dist is None or world == 1:
+        return [float(elapsed)]
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    return [float(p.item()) for p in parts]
+
+
+def communicator_proof(dist, dev, backend):
+    """what shows that the collective library joined N ranks: the process group's size, a sum over ranks whose value only N distinct
+    participants produce ([1, rank] -> [N, N(N-1)/2]), and -- on RCCL -- ncclCommCount of a communicator the LIBRARY creates over the same
+    ranks (ccsp_rccl_comm_create; the one the MALA global-batch reduction uses) with the same sum through ncclAllReduce from C"""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    t = torch.tensor([1.0, float(rank)], device=dev, dtype=torch.float32)
+    dist.all_reduce(t)
+    proof = {'backend': backend, 'world': world, 'allreduce_of_[1,rank]': [float(v) for v in t.cpu()],
+             'allreduce_expected': [float(world), float(world * (world - 1) // 2)]}
+    if backend == 'nccl':
+        import ctypes as C
+        from diffusion_ccsp_amd import _lib, sharding
+        L = _lib.lib()
+        comm = sharding._native_comm(dist, dev)
+        n, ver = C.c_int32(), C.c_int32()
+        _lib.check(L.ccsp_rccl_comm_count(C.c_void_p(comm), C.byref(n), C.byref(ver)))
+        u = torch.tensor([1.0, float(rank)], device=dev, dtype=torch.float32)
+        _lib.check(L.ccsp_rccl_allreduce_sum_f32(C.c_void_p(comm), C.c_void_p(u.data_ptr()), 2, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        torch.cuda.synchronize(dev)
+        proof.update({'rccl_ranks': int(n.value), 'rccl_version_code': int(ver.value), 'rccl_allreduce_of_[1,rank]': [float(v) for v in u.cpu()]})
+        L.ccsp_rccl_comm_destroy(C.c_void_p(comm))
+    return proof
+
+
+def dry_run_main(args):
+    """the N > 1 host path on CPU (gloo or, on a GPU box, nccl): everything bench.py does around the chains -- rank bookkeeping, the weight
+    file read on rank 0 and broadcast as ONE flat buffer, every rank's shard of the global batch and its row offset, the gather of the
+    final poses, barrier-bracketed timing with the maximum over ranks, the JSON line -- with NO sampling (zeros stand in for the poses;
+    there is no CPU fallback to run instead).  value is null.  tests/test_bench_launcher.py drives it with world size 2 every round."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    import torch.distributed as dist
+    dev = torch.device('cpu')
+    if args.backend == 'nccl':
+        local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        torch.cuda.set_device(local_rank)
+        dev = torch.device('cuda', local_rank)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    dist.init_process_group(args.backend, rank=rank, world_size=world)
+    from diffusion_ccsp_amd import sharding, worlds
+    cname = 'c2' if args.config in ('c3', 'sd') else args.config
+    cfg = CONFIGS[cname]
+    B = args.graphs_per_gpu or cfg['graphs']
+    if args.scaling == 'strong':
+        B = 8 * cfg['graphs'] // world
+    P = worlds.MODE_DIMS[cfg['mode']][-1][0]
+    batch_np = getattr(worlds, cfg['batch'])(B, cfg['n_objects'], seed=5 + rank)
+    n_nodes = batch_np.x.shape[0]
+    wrel = next(w for w in cfg['weights'] if os.path.isfile(os.path.join(ROOT, w)))
+    ref = load_weights(os.path.join(ROOT, wrel))
+    shapes = {k[:-7]: v.shape for k, v in ref.items() if k.endswith('.weight')}
+    sd = sharding.broadcast_state_dict(ref if rank == 0 else None, shapes, dev, dist)
+    weights_equal = all(np.array_equal(sd[k].cpu().numpy(), ref[k]) for k in sd)
+    proof = communicator_proof(dist, dev, args.backend)
+    sizes = [None] * world
+    dist.all_gather_object(sizes, n_nodes)
+
+    def one_step(k):
+        x = torch.zeros(n_nodes, P, dtype=torch.float32, device=dev)          # NOT a sample: the chain is what the dry run leaves out
+        x[:, 0] = float(rank)
+        return sharding.gather_poses(x, dist, sizes)
+    for k in range(args.warmup):
+        one_step(k)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        full = one_step(args.warmup + k)
+    local = time.perf_counter() - t0
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    times = rank_times(local, world, dist, dev)
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    owner = full[:, 0].cpu().numpy()
+    gathered_ok = bool(full.shape[0] == sum(sizes) and np.array_equal(owner, np.concatenate([np.full(n, r, np.float32) for r, n in enumerate(sizes)])))
+    rec = {'metric': 'samples/sec (all chains), T=1000 %s, %s' % (cfg['EBM'], world_label(cfg)),
+           'value': None, 'unit': 'samples/s', 'dry_run': True, 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+           'ms_per_step': 1e3 * elapsed / max(1, args.steps), 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
+           'dtype': 'none (dry run: no kernels)', 'data': 'synthetic',
+           'world': world, 'rccl_ranks': proof.get('rccl_ranks'), 'communicator': proof,
+           'per_rank_ms_per_step': [1e3 * v / max(1, args.steps) for v in times],
+           'config': {'workload': 'DRY RUN of the N > 1 host path of: %s, %d graphs per GPU' % (cfg['label'], B), 'name': args.config, 'graphs_per_gpu': B,
+                      'nodes_per_rank': sizes, 'weights': wrel, 'weights_broadcast_equal_to_file_on_every_rank': None,
+                      'gathered_rows_in_rank_order': gathered_ok,
+                      'parallelism': 'independent graph shards x%d, %s weight broadcast + final gather only' % (world, args.backend)}}
+    ok = torch.tensor([int(weights_equal)], dtype=torch.int64, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    rec['config']['weights_broadcast_equal_to_file_on_every_rank'] = bool(ok.item())
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(rec), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -428,7 +606,18 @@ def main():
     ap.add_argument('--force-dist', action='store_true', help='initialise RCCL even for one rank (exercises the N>1 code path)')
     ap.add_argument('--mala-global-batch', action='store_true',
                     help='c4 with N > 1: couple the shards through the reference\'s batch-scalar energies (2-float all_reduce per inner step)')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='torch.distributed backend of an N > 1 run (nccl = RCCL; gloo only with --dry-run)')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='host path only, no GPU: launcher -> init_process_group -> flat weight broadcast -> gather -> JSON line with "dry_run": true '
+                         'and value null (nothing is sampled: the HIP path has no CPU fallback)')
+    ap.add_argument('--no-strict-fp32', action='store_true', help='skip the CCSP_MMA=f32 sub-run behind value_strict_fp32 (c2)')
     args = ap.parse_args()
+    if args.backend == 'gloo' and not args.dry_run:
+        raise SystemExit('--backend gloo is the CPU dry run of the launcher (add --dry-run); sampling needs a GPU and RCCL')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return self_launch(args.gpus)
+    if args.dry_run:
+        return dry_run_main(args)
     if args.config == 'sd':
         return sd_main(args)
     cname = 'c2' if args.config == 'c3' else args.config
@@ -439,8 +628,8 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch one rank per GPU (python bench.py --gpus N launches them itself when WORLD_SIZE is unset)'
+                         % (args.gpus, world))
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP path has no CPU fallback)'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
@@ -496,14 +685,17 @@ def main():
     for k in range(args.steps):
         x = one_step(args.warmup + k)
     torch.cuda.synchronize()
+    local_elapsed = time.perf_counter() - t0          # this rank's own K steps (before it waits for the others)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    times = rank_times(local_elapsed, world, dist, dev)
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    proof = communicator_proof(dist, dev, 'nccl') if dist is not None else None
     finite = bool(torch.isfinite(x).all().item())
     nan_graphs = len(set(batch_np.batch[(~torch.isfinite(x).all(dim=1)).cpu().numpy()].tolist()))
     samples = world * B * args.steps
@@ -511,15 +703,19 @@ def main():
     evals_per_chain = T_STEPS * (1 + (2 if cfg['EBM'] == 'MALA' else 1) * S)
 
     rec = {
-        'metric': 'solved samples/sec, T=1000 %s, %s (%s)' %
-                  (cfg['EBM'], cfg['label'].split(':')[1].split(',')[0].strip() + ' %d-obj' % cfg['n_objects'],
-                   'value = all chains per second; solved_samples_per_s = value x solved_fraction, both top-level' if args.config in ('c2', 'c3') else
-                   'value = all chains per second with the gradient evaluations of unmoved states skipped, a property of the acceptance rate; '
-                   'value_recomputing_every_evaluation and mean_acceptance_rate beside it at top level; no solved check for this world' if cfg['EBM'] == 'MALA' else
-                   'value = all chains per second; no solved check for this world'),
+        # `value` is ALL chains per second, and the metric says so; BASELINE.json's "solved samples/sec" is the separate top-level pair
+        # solved_metric / solved_samples_per_s (= value x solved_fraction; c2 / c3 only: the other worlds have no solved check)
+        'metric': 'samples/sec (all chains), T=1000 %s, %s' % (cfg['EBM'], world_label(cfg)),
+        'value_note': ('value = all chains per second; BASELINE.json\'s metric proper is solved_samples_per_s (its name: solved_metric)' if args.config in ('c2', 'c3') else
+                       'value = all chains per second with the gradient evaluations of unmoved states skipped, a property of the acceptance rate; '
+                       'value_recomputing_every_evaluation and mean_acceptance_rate beside it at top level; no solved check for this world' if cfg['EBM'] == 'MALA' else
+                       'value = all chains per second; no solved check for this world'),
         'value': value, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': args.scaling,
         'vs_baseline': None,
+        'value_per_gpu': value / world, 'world': world, 'rccl_ranks': (proof or {}).get('rccl_ranks'),
+        'per_rank_ms_per_step': [1e3 * v / args.steps for v in times],
+        'per_rank_ms_per_step_min_max': [1e3 * min(times) / args.steps, 1e3 * max(times) / args.steps],
         'dtype': {'f16x2': 'f32 (f16x2 split operands: 3 fp16 MFMA products per fp32 product, fp32 accumulate)',
                   'bf16x3': 'f32 (bf16x3 split operands: 6 bf16 MFMA products per fp32 product, fp32 accumulate)'}.get(os.environ.get('CCSP_MMA', 'f16x2'), 'f32'),
         'data': 'synthetic',
@@ -596,6 +792,7 @@ def main():
             dist.all_reduce(n_solved)
         solved_fraction = float(n_solved[0].item()) / max(1, int(n_solved[1].item()))
         rec['solved_fraction'] = solved_fraction
+        rec['solved_metric'] = 'solved samples/sec, T=1000 ULA, RandomSplitQualitativeWorld 8-obj (BASELINE.json metric)'
         rec['solved_samples_per_s'] = value * solved_fraction
         rec['config']['solved_note'] = ('solved_fraction = share of the last timed batch (one try per graph, no rejection) passing the collision + '
                                         'qualitative-constraint check of diffusion-ccsp_amd/checker.py; the reference sampler itself overflows fp32 in its '
@@ -617,6 +814,33 @@ def main():
                                'sets': {k: {'success_rate': v['success_rate'], 'success_rate_top10': v.get('success_rate_top10', v.get('success_rate_top3')),
                                             'sampling_s_per_graph': float(np.mean([s[2] for s in v['sampling_time']]))} for k, v in log.items()}}
 
+    if proof is not None:
+        rec['communicator'] = proof
+
+    if cname == 'c2' and world == 1 and os.environ.get('CCSP_MMA', 'f16x2') == 'f16x2' and not args.no_strict_fp32:
+        # the same step with every GEMM on the fp32 matrix pipe (CCSP_MMA=f32: v_mfma_f32_32x32x2_f32, no operand split): a second model of
+        # the same weights, 1 warm-up + 3 timed steps bracketed like the headline.  Read at model creation, so the variable is set around it.
+        os.environ['CCSP_MMA'] = 'f32'
+        try:
+            den32 = ConstraintDiffuser(dims=dims, hidden_dim=HIDDEN, input_mode=mode, EBM=cfg['EBM'], energy_wrapper=energy, device=dev, verbose=False)
+            den32.load_state_dict(sd)
+            gd32 = GaussianDiffusion(den32, timesteps=T_STEPS, EBM=cfg['EBM'], samples_per_step=S)
+        finally:
+            del os.environ['CCSP_MMA']
+        gd32.sample(base.clone(), seed=999, row_offset=rank * n_nodes)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(3):
+            x32 = gd32.sample(base.clone(), seed=1000 + args.warmup + args.steps - 3 + k, row_offset=rank * n_nodes)
+        torch.cuda.synchronize()
+        rec['value_strict_fp32'] = 3 * B / (time.perf_counter() - t1)
+        ok32 = torch.isfinite(x32).all(dim=1) & torch.isfinite(x).all(dim=1)
+        rec['strict_fp32'] = {'gemm_mode': 'f32', 'steps': 3, 'warmup': 1,
+                              'max_abs_diff_final_poses_vs_headline_mode': float((x32 - x)[ok32].abs().max().item()) if bool(ok32.any().item()) else None,
+                              'note': 'value_strict_fp32 = the same step with CCSP_MMA=f32 (fp32 MFMA, no fp16 operand split); the last of its chains has the '
+                                      'seed of the last headline chain'}
+        del gd32, den32
+
     if rank == 0 and not args.no_roofline:
         # separate profiled pass: a HIP event before every launch of one more chain, on the stream the kernels run on
         b = base.clone()
@@ -635,9 +859,11 @@ def main():
         syms = sorted(set(filter(None, (kernel_symbol(label, mma, energy) for label in ks))))
         pmc_cfg = args.config if args.config != 'c3' else 'c2'
         traffic, stamp = ({}, None)
+        rstats, rstamp = ({}, None)
         if world == 1 and not args.no_live_pmc and mma == 'f16x2':
             del b
             traffic, stamp = pmc_traffic_live(pmc_cfg, B, syms)
+            rstats, rstamp = rocprof_kernel_stats_live(pmc_cfg, B, syms)
         if not traffic:
             live_reason = stamp
             traffic, stamp = pmc_traffic_file(pmc_cfg, syms)
@@ -653,6 +879,13 @@ def main():
                 ent.update({'executed_flops_fp32_equiv': flops, 'products_per_fp32_product': prods, 'pipe': pipe,
                             'pipe_tflops': prods * flops / (ms * 1e-3) / 1e12, 'pipe_peak_tflops': PEAKS[pipe],
                             'frac': prods * flops / (ms * 1e-3) / 1e12 / PEAKS[pipe]})
+            rs = rstats.get(sym)
+            if rs is not None and (variant.get(label) is None or rs['kernel_name'].startswith(variant[label])):
+                ent['rocprof_avg_ns'] = rs['avg_ns']          # the profiler's AverageNs of the same kernel (separate pass; us_mean spans launch to next mark)
+                ent['rocprof_calls'] = rs['calls']
+                ent['rocprof_min_max_ns'] = [rs['min_ns'], rs['max_ns']]
+                if w is not None:
+                    ent['frac_at_rocprof_avg'] = prods * flops / (rs['avg_ns'] * 1e-9) / 1e12 / PEAKS[pipe]
             tr = traffic.get(sym)
             if tr is not None:
                 want = variant.get(label)
@@ -694,6 +927,7 @@ def main():
                           'achieved / peak / frac are the MATRIX-PIPE figures (frac = frac_mfma).  bound = "hbm" only when the working set exceeds the '
                           'Infinity Cache (see throughput_regime); "mfma" when the pipe fraction is the larger one',
             'traffic': dom.get('fabric_bytes_per_launch'), 'traffic_source': stamp,
+            'rocprof_avg_ns': dom.get('rocprof_avg_ns'), 'frac_at_rocprof_avg': dom.get('frac_at_rocprof_avg'), 'rocprof_source': rstamp,
             'fabric_bytes_per_evaluation': fabric_eval, 'algorithmic_bytes_per_evaluation': alg_bytes,
             'wasted_traffic_ratio': (fabric_eval / alg_bytes) if fabric_eval else None,
             'kernel': '%s: %s' % (dom['kernel'], dom.get('counters_taken_on') or variant.get(dom['kernel']) or dom['symbol']),

@@ -10,7 +10,7 @@ import os as _os
 # Kernel arguments in device memory: the dispatch of every launch reads them, and a chain is 33 000 short dependent launches.  ROCm 7
 # does this by default; with HIP_FORCE_DEV_KERNARG=0 the same chain runs 13 % (C2) to 27 % (C5, C1) slower (profiles/r03_findings.md).
 # Read by the HIP runtime when it initialises, i.e. at the process's first HIP call: set here only if the user has not set it and the
-# runtime is not up yet (bench.py and the tools import this package before their first HIP call).
+# runtime is not up yet.  bench.py sets it itself before it imports torch (it initialises HIP and RCCL before it imports this package).
 if 'HIP_FORCE_DEV_KERNARG' not in _os.environ:
     import sys as _sys
     _t = _sys.modules.get('torch')

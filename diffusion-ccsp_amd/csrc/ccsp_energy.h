@@ -158,6 +158,7 @@ __global__ __launch_bounds__(256) void k_rowsum(int R, int W2, const int* __rest
     }
 }
 
+#ifdef CCSP_EXPERIMENTS      // (round 3's separate row-sum launch, CCSP_ENERGY_ROWSUM=kernel: the product path forms the sums in k_edge_bwd_h2's epilogue)
 // the f16x2 form of k_rowsum at hidden_dim 256 (W2 = 512): one wavefront per U row, two float4 column groups per lane, so the
 // row maximum is one shuffle butterfly (no LDS, no barrier) and a row's edge indices are fetched four at a time ahead of the
 // GZ rows they address (the sum keeps the ascending edge order)
@@ -204,6 +205,7 @@ __global__ __launch_bounds__(256) void k_rowsum_h2(int R, const int* __restrict_
     *reinterpret_cast<uint2*>(GZRH + pl + o) = make_uint2(p2[0] | ((unsigned)p2[1] << 16), p2[2] | ((unsigned)p2[3] << 16));
     *reinterpret_cast<uint2*>(GZRH + pl + o + 256) = make_uint2(p2[4] | ((unsigned)p2[5] << 16), p2[6] | ((unsigned)p2[7] << 16));
 }
+#endif  // CCSP_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------------
 // k_node_energy: dE/dpose for a tile of 16 nodes

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <algorithm>
 #include <thread>
@@ -929,6 +930,7 @@ struct NodeArgs {
     int n_hat_partial;            // kernel (same order as k_energy_sum) and E_hat is not read: one launch less per inner step
     int* acc_count;         // MALA: accepted-node counter of this timestep
     int* changed;           // MALA reuse: reset by the propose step, += pose elements the accept step changed bitwise (or null)
+    float* margin;          // MALA accept, debugging aid (ccsp_chain_margins): [N] log acceptance ratio - log u of this inner step, or null
     // schedule scalars of this timestep
     float a_t, b_t, c1, c2, sigma, kappa, ss, std_;
     NoiseArg noise;
@@ -1085,6 +1087,7 @@ __device__ __forceinline__ void node_body(NodeArgs a, const EncW w, const EncOut
                     else u = ccsp::philox_uniform(a.noise.seed, a.noise.row_offset + (unsigned long long)n, a.noise.ucall);
                     const float accf = (u < expf(la)) ? 1.0f : 0.0f;
                     if (p == 0 && accf != 0.0f && a.acc_count) atomicAdd(a.acc_count, 1);
+                    if (p == 0 && a.margin) a.margin[n] = la - logf(u);      // > 0 accepted, < 0 rejected; |margin| small = a near-tie
                     xv = accf * hc + (1.0f - accf) * xv;
                 } else {                                        // ddpm.py:273
                     xv = 0.5f * z;
@@ -1372,6 +1375,7 @@ __global__ __launch_bounds__(256) void k_node_direct(NodeArgs a, EncW w, EncOut 
     CCSP_TRK(2, 5);
     CCSP_TRK_RT(2, 31);
 }
+#ifdef CCSP_EXPERIMENTS
 // the same with the encoder's weights streamed (CCSP_NODE=stream, A/B): a third of the registers, so that its waves fit next to
 // the other lane's GEMM waves on more SIMDs
 __global__ __launch_bounds__(256, 3) void k_node_direct_s(NodeArgs a, EncW w, EncOut eo, int n_ent) {
@@ -1379,6 +1383,7 @@ __global__ __launch_bounds__(256, 3) void k_node_direct_s(NodeArgs a, EncW w, En
     __builtin_amdgcn_s_setprio(3);
     node_block_direct<false, true>(a, w, eo, n_ent, blockIdx.x * NODE_TILE, node_lds(lds_raw));
 }
+#endif
 
 // the node update folded into the edge kernel's tail (k_edge_h2 / k_edge_h2s, FUSE): which 16-node blocks a workgroup's
 // outputs touch, how many workgroups touch each block, and the arrival counters (zeroed when a chain starts; `epoch` = index of
@@ -1403,7 +1408,9 @@ struct FuseArgs {
 #include "ccsp_energy.h"
 #include "ccsp_bf16x3.h"
 #include "ccsp_f16x2.h"
-#include "ccsp_fused.h"
+#ifdef CCSP_EXPERIMENTS
+#include "ccsp_fused.h"      // the one-launch evaluation (k_eval_fused*, k_rowgemm_h2d): bitwise equal, slower at every batch size
+#endif
 #include "ccsp_struct.h"
 #include "ccsp_hmc.h"
 
@@ -1459,34 +1466,56 @@ struct StreamBuf {
 // RCCL, bound at run time (dlopen): the library has no link-time dependency on it, and a process that already carries an RCCL
 // (PyTorch-ROCm ships one) gets that same instance.  Only what the MALA global-batch reduction needs.
 namespace {
+// Variants that lost their same-call A/Bs (profiles/r0*_findings.md) are compiled only with -DCCSP_EXPERIMENTS
+// (diffusion-ccsp_amd/_lib.py build(experiments=True) -> libccsp_hip_exp.so; tests marked gpu_experiments); their switches are read through
+// exp_env, which is nullptr in the product build.
+#ifdef CCSP_EXPERIMENTS
+inline const char* exp_env(const char* name) { return getenv(name); }
+#else
+inline const char* exp_env(const char*) { return nullptr; }
+#endif
+}  // namespace
+
+namespace {
 struct RcclId { char internal[128]; };        // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128), passed by value
 struct RcclApi {
     void* lib = nullptr;
+    int version = 0;
     int (*get_unique_id)(RcclId*) = nullptr;
     int (*comm_init_rank)(void**, int, RcclId, int) = nullptr;
     int (*comm_destroy)(void*) = nullptr;
+    int (*comm_count)(void*, int*) = nullptr;
     int (*all_reduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     const char* (*error_string)(int) = nullptr;
 };
+// The instance the process already carries is found by its soname (PyTorch-ROCm loads librccl.so.1): RTLD_NOLOAD first, so that a second
+// RCCL from /opt/rocm is never mapped next to torch's; then the versioned name, then the unversioned one.  ncclFloat32 = 7 and ncclSum = 0
+// and the by-value 128-byte id are the NCCL 2.x ABI: ncclGetVersion must report major version 2.
 RcclApi* rccl_api() {
     static RcclApi api;
-    static bool tried = false;
-    if (tried) return api.lib ? &api : nullptr;
-    tried = true;
-    const char* names[] = {getenv("CCSP_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
-    for (const char* n : names) {
-        if (!n || !*n) continue;
-        api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-        if (api.lib) break;
-    }
-    if (!api.lib) return nullptr;
-    api.get_unique_id = (int (*)(RcclId*))dlsym(api.lib, "ncclGetUniqueId");
-    api.comm_init_rank = (int (*)(void**, int, RcclId, int))dlsym(api.lib, "ncclCommInitRank");
-    api.comm_destroy = (int (*)(void*))dlsym(api.lib, "ncclCommDestroy");
-    api.all_reduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(api.lib, "ncclAllReduce");
-    api.error_string = (const char* (*)(int))dlsym(api.lib, "ncclGetErrorString");
-    if (!api.get_unique_id || !api.comm_init_rank || !api.comm_destroy || !api.all_reduce) { dlclose(api.lib); api.lib = nullptr; return nullptr; }
-    return &api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* env = getenv("CCSP_RCCL_LIB");
+        if (env && *env) api.lib = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char* n : names) if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+        for (const char* n : names) if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!api.lib) return;
+        api.get_unique_id = (int (*)(RcclId*))dlsym(api.lib, "ncclGetUniqueId");
+        api.comm_init_rank = (int (*)(void**, int, RcclId, int))dlsym(api.lib, "ncclCommInitRank");
+        api.comm_destroy = (int (*)(void*))dlsym(api.lib, "ncclCommDestroy");
+        api.comm_count = (int (*)(void*, int*))dlsym(api.lib, "ncclCommCount");
+        api.all_reduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(api.lib, "ncclAllReduce");
+        api.error_string = (const char* (*)(int))dlsym(api.lib, "ncclGetErrorString");
+        int (*get_version)(int*) = (int (*)(int*))dlsym(api.lib, "ncclGetVersion");
+        if (get_version) get_version(&api.version);
+        const int major = api.version >= 10000 ? api.version / 10000 : api.version / 1000;     // NCCL_VERSION_CODE: X*10000 + Y*100 + Z since 2.9
+        if (!api.get_unique_id || !api.comm_init_rank || !api.comm_destroy || !api.all_reduce || !api.comm_count || major != 2) {
+            dlclose(api.lib);
+            api.lib = nullptr;
+        }
+    });
+    return api.lib ? &api : nullptr;
 }
 const char* rccl_err(RcclApi* a, int rc) { return a && a->error_string ? a->error_string(rc) : "?"; }
 }  // namespace
@@ -1509,8 +1538,9 @@ struct ccsp_model {
     int lanes;     // concurrent sub-batch chains per ccsp_chain_run (direct mode), default 2
     int lane_min_edges;   // batches with fewer active edges run as one lane
     int lane_min_tokens;  // StructDiffusion: batches with fewer token rows run as one lane
-    std::vector<hipStream_t> lane_streams;   // created once per model: new HIP streams are expensive to
-    std::vector<hipEvent_t> lane_events;     // create (hundreds of ms for the first few), graphs come and go
+    std::vector<hipStream_t> lane_streams;   // taken from the process-wide pool (lane_stream_get): new HIP streams are expensive to create
+    std::vector<char> lane_stream_owned;     // (1: created for this model alone -- the CU-mask experiment -- and destroyed with it)
+    std::vector<hipEvent_t> lane_events;     // (hundreds of ms for the first few), graphs come and go
     hipEvent_t fork_event = nullptr;
     hipStream_t capture_stream = nullptr;    // hipGraph captures (the caller's stream may be the legacy default stream)
     int graph_mode;    // CCSP_GRAPH=1: small batches replay captured hipGraphs; default 0 -- measured no faster
@@ -1639,6 +1669,8 @@ struct ccsp_graph {
     float *Q = nullptr, *GZ = nullptr, *GZR = nullptr, *GP = nullptr, *xhat = nullptr, *partial = nullptr, *Escal = nullptr;
     int *acc_count = nullptr, *acc_denom = nullptr;
     int* mala_changed = nullptr;       // MALA reuse: nodes accepted by the last accept step
+    float* margin_buf = nullptr;       // ccsp_chain_margins: caller-owned [accept steps of a call][N] buffer, or null
+    int64_t margin_cap = 0;            // its size in floats
     float *hmc_vk = nullptr, *hmc_vp = nullptr, *hmc_vl = nullptr;   // HMC momenta (allocated on first use)
     std::vector<int> h_denom;      // host copy kept alive for the async upload
     std::vector<int> h_t2;         // (row0 | nrows | ts) of the 128-row tiles, kept alive for the async upload
@@ -1752,19 +1784,24 @@ int rowgemm_h2_mode(const ccsp_model* m, const ccsp_graph* g, int nct, int n_til
 void launch_rowgemm_h2(ccsp_model* m, ccsp_graph* g, const float* tau_t, StepRef ref, size_t tau_stride, hipStream_t s) {
     constexpr int H = 256;
     const int mode = rowgemm_h2_mode(m, g, 2 * H / 128);
+#ifdef CCSP_EXPERIMENTS
     if (mode == 7 && m->WpF) {                          // resident A planes, weight fragments straight from global memory (ccsp_fused.h)
         hipLaunchKernelGGL(k_rowgemm_h2d, dim3(g->n_tiles * 4), dim3(256), 0, s, g->pembH, (size_t)g->N * H, g->pexp, g->urow_node, g->td64, m->WpF,
                            m->wp_exp, g->base, tau_t, g->U, g->umax, ref, tau_stride);
         return;
     }
+#endif
     const bool small = mode == 4 || mode == 6;          // 64-row plan tiles instead of their 128-row pairs
     const int work = (small ? g->n_tiles : g->n_tiles2) * (2 * H / 128);
 #define CCSP_ROWGEMM_F(MODE)                                                                                                                          \
     hipLaunchKernelGGL((k_rowgemm_h2<H, 2 * H, MODE>), dim3(work), dim3(256), 0, s, g->pembH, (size_t)g->N * H, g->pexp, g->urow_node,                  \
                        small ? g->td64 : g->td128, m->WpH,                                                                                              \
                        (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, m->wp_exp, g->base, tau_t, g->U, g->umax, ref, tau_stride)
-    if (mode == 6) CCSP_ROWGEMM_F(6); else if (mode == 5) CCSP_ROWGEMM_F(5); else if (mode == 4) CCSP_ROWGEMM_F(4); else if (mode == 3) CCSP_ROWGEMM_F(3); else if (mode == 2) CCSP_ROWGEMM_F(2);
-    else if (mode == 1) CCSP_ROWGEMM_F(1); else CCSP_ROWGEMM_F(0);
+    if (mode == 6) CCSP_ROWGEMM_F(6); else if (mode == 4) CCSP_ROWGEMM_F(4);
+#ifdef CCSP_EXPERIMENTS
+    else if (mode == 5) CCSP_ROWGEMM_F(5); else if (mode == 3) CCSP_ROWGEMM_F(3); else if (mode == 2) CCSP_ROWGEMM_F(2); else if (mode == 1) CCSP_ROWGEMM_F(1);
+#endif
+    else CCSP_ROWGEMM_F(0);
 #undef CCSP_ROWGEMM_F
 }
 
@@ -1784,7 +1821,12 @@ int launch_edge_h2(ccsp_model* m, ccsp_graph* g, EdgeEnergyArgs en, int* cinc, h
     FuseArgs f0;
     memset(&f0, 0, sizeof(f0));
     // (the fused forms hold the node update's registers: two workgroups per CU, so only for tile lists that fit that)
+#ifdef CCSP_EXPERIMENTS
     const bool fuse = !ENERGY && fu != nullptr && me == g->fuse_me && nblk(E_act, me) <= 2 * m->ncu;
+#else
+    constexpr bool fuse = false;        // (the node update in the edge kernel's tail: an experiment, slower -- DESIGN.md 9)
+    (void)fu;
+#endif
     const FuseArgs& fa = fuse ? *fu : f0;
     if (me == 16) {
         const int nws = nblk(E_act, 16);
@@ -1792,8 +1834,12 @@ int launch_edge_h2(ccsp_model* m, ccsp_graph* g, EdgeEnergyArgs en, int* cinc, h
         hipLaunchKernelGGL((k_edge_h2s<ENERGY, FUSE>), dim3(nws), dim3(256), 0, s, E_act, m->d.pose_dim, FUSE ? g->fuse_u0 : g->e_u0,                     \
                            FUSE ? g->fuse_u1 : g->e_u1, g->U, g->umax, m->Wd1H, m->wd_exp, m->pd0_b, m->pd2_w, m->pd2_b, FUSE ? g->fuse_pos : g->ent_pos, \
                            g->O, en, cinc, fa)
+#ifdef CCSP_EXPERIMENTS
         if constexpr (!ENERGY) { if (fuse) CCSP_EDGE_S(true); else CCSP_EDGE_S(false); }
         else CCSP_EDGE_S(false);
+#else
+        CCSP_EDGE_S(false);
+#endif
 #undef CCSP_EDGE_S
         return nws;
     }
@@ -1803,12 +1849,14 @@ int launch_edge_h2(ccsp_model* m, ccsp_graph* g, EdgeEnergyArgs en, int* cinc, h
     hipLaunchKernelGGL((k_edge_h2<ENERGY, MT, L2, FUSE>), dim3(nwg), dim3(256), 0, s, E_act, m->d.pose_dim, FUSE ? g->fuse_u0 : g->e_u0,                \
                        FUSE ? g->fuse_u1 : g->e_u1, g->U, g->umax, m->Wd1H, m->wd_exp, m->pd0_b, m->pd2_w, m->pd2_b, FUSE ? g->fuse_pos : g->ent_pos,     \
                        g->O, en, cinc, fa)
+#ifdef CCSP_EXPERIMENTS
     if constexpr (!ENERGY) {
         if (fuse && mt == 1) {
             if (nwg <= m->ncu) CCSP_EDGE_F(1, 1, true); else CCSP_EDGE_F(1, 0, true);
             return nwg;
         }
     }
+#endif
     if (mt == 1 && nwg <= m->ncu) CCSP_EDGE_F(1, 1, false);  // a single round of workgroups: the short-latency second layer
     else if (mt == 1) CCSP_EDGE_F(1, 0, false);
     else CCSP_EDGE_F(2, 0, false);
@@ -1816,6 +1864,7 @@ int launch_edge_h2(ccsp_model* m, ccsp_graph* g, EdgeEnergyArgs en, int* cinc, h
     return nwg;
 }
 
+#ifdef CCSP_EXPERIMENTS
 // Tables of the fused node update for edge tiles of `me` edges.  The edge kernel may take the edges in any order (the decoder is
 // shared by all types; every output goes to its own CSR slot), so the fused form walks them NODE-BLOCK-major instead of
 // type-major: a tile's outputs then land in one or two 16-node blocks and a block is completed by the few neighbouring tiles
@@ -1906,6 +1955,8 @@ int fuse2_prepare(ccsp_model* m, ccsp_graph* g, hipStream_t s) {
     return 0;
 }
 
+#endif  // CCSP_EXPERIMENTS
+
 // fused: if non-null (direct-mode chain, f16x2 kernels), the node update with these arguments is folded into the edge kernel's
 // tail and *did_fuse is set; the caller then launches no node kernel
 template <int H>
@@ -1921,6 +1972,7 @@ int launch_eval(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s, bool tabled 
     const StepRef ref{tabled ? g->d_tab : nullptr, tabled ? g->d_counter : nullptr};
     int* const cinc = tabled ? g->d_counter : nullptr;
     if constexpr (H == 256) {
+#ifdef CCSP_EXPERIMENTS
         if (m->f16x2 && m->eval_fused && !tabled && g->n_ftiles > 0 && fused == nullptr) {
             prof_mark(g, s, CCSP_K_EVAL_FUSED);
             FusedArgs fa;
@@ -1937,9 +1989,15 @@ int launch_eval(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s, bool tabled 
             g->evals++;
             return 0;
         }
+#endif
         if (m->f16x2) {
             launch_rowgemm_h2(m, g, tau_t, ref, tau_stride, s);
             prof_mark(g, s, CCSP_K_EDGE);
+#ifndef CCSP_EXPERIMENTS
+            (void)fused;
+            launch_edge_h2<false>(m, g, EdgeEnergyArgs{}, cinc, s, nullptr);
+            if (did_fuse) *did_fuse = false;
+#else
             FuseArgs fu;
             if (fused != nullptr && g->ng_use && g->ng_wgs > 0) {          // node-grouped edge tiles with the node update as their tail
                 memset(&fu, 0, sizeof(fu));
@@ -1969,6 +2027,7 @@ int launch_eval(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s, bool tabled 
             }
             launch_edge_h2<false>(m, g, EdgeEnergyArgs{}, cinc, s, fuse ? &fu : nullptr);
             if (did_fuse) *did_fuse = fuse;
+#endif
             prof_mark(g, s, -1);
             g->evals++;
             return 0;
@@ -2040,8 +2099,10 @@ void launch_node(ccsp_model* m, ccsp_graph* g, const NodeArgs& a, hipStream_t s)
         const bool direct = ench && h2 && !m->node_generic && a.src == 0 && (a.step == STEP_ANCESTRAL || a.step == STEP_ULA) && a.do_encode &&
                             !a.x_in && !a.eps_out && !a.tab && g->plan.E_act > 0 && !eo.f32;
         if (direct) {
+#ifdef CCSP_EXPERIMENTS
             if (m->node_stream) hipLaunchKernelGGL(k_node_direct_s, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a, enc_pose(m), eo, 2 * g->plan.E_act);
             else
+#endif
             hipLaunchKernelGGL(k_node_direct, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a, enc_pose(m), eo, 2 * g->plan.E_act);
             prof_mark(g, s, -1);
             return;
@@ -2069,8 +2130,8 @@ template <int EPI>
 int sd_gemm_h2(const ccsp_model* m, int M, int K, int N, const float* A, const unsigned int* amax, const unsigned short* WH, int w_exp, const float* b, float* Cm,
                unsigned int* cmax, hipStream_t s, bool may_split = false, bool split2 = false /*the consumer adds two K slices whatever the shape (in_proj -> k_sd_attn)*/) {
     // 64-column tiles when the 128-column tile list would not give every CU two workgroups (the N = Wd GEMMs of a 256-graph batch)
-    static const int force_tn = getenv("CCSP_SD_TN") ? atoi(getenv("CCSP_SD_TN")) : 0;
-    static const int force_ks = getenv("CCSP_SD_KSPLIT") ? atoi(getenv("CCSP_SD_KSPLIT")) : -1;
+    static const int force_tn = exp_env("CCSP_SD_TN") ? atoi(exp_env("CCSP_SD_TN")) : 0;
+    static const int force_ks = exp_env("CCSP_SD_KSPLIT") ? atoi(exp_env("CCSP_SD_KSPLIT")) : -1;
     const bool tn64 = force_tn ? force_tn == 64 : (long)nblk(M, 64) * (N / 128) < 2L * m->ncu;
     int ks = 1;
     // (chosen from K and N alone: the same batch run as one lane or as two adds the same partial products in the same order)
@@ -2078,15 +2139,18 @@ int sd_gemm_h2(const ccsp_model* m, int M, int K, int N, const float* A, const u
     if (may_split && force_ks >= 1 && K % (64 * force_ks) == 0 && force_ks <= SD_KSPLIT) ks = force_ks;
     // (opt-in, CCSP_SD_INSPLIT=1: measured SLOWER, 54.6 against 57.0 samples/s in one call -- the two lanes' in_proj already give the chip
     // three workgroups per CU, and the attention kernel reads twice the bytes)
-    static const bool insplit = getenv("CCSP_SD_INSPLIT") && atoi(getenv("CCSP_SD_INSPLIT")) == 1;
+    static const bool insplit = exp_env("CCSP_SD_INSPLIT") && atoi(exp_env("CCSP_SD_INSPLIT")) == 1;
     if (split2 && insplit && EPI == SD_EPI_BIAS && cmax == nullptr && K % 128 == 0) ks = 2;
     // operands requested 2 chunks ahead; 4 (CCSP_SD_PD=4) when the slice is a multiple of 4 chunks
+    const dim3 gr64(nblk(M, 64) * (N / 64), ks), gr128(nblk(M, 64) * (N / 128), ks);
+#ifdef CCSP_EXPERIMENTS
     static const int force_pd = getenv("CCSP_SD_PD") ? atoi(getenv("CCSP_SD_PD")) : 0;
     const bool pd4 = (K / ks) % 128 == 0 && force_pd == 4;      // (r04 A/B at 2048 token rows: 4 ahead 437 us per evaluation, 2 ahead 428 -- the chunk is not waiting for loads)
-    const dim3 gr64(nblk(M, 64) * (N / 64), ks), gr128(nblk(M, 64) * (N / 128), ks);
     if (tn64 && pd4) hipLaunchKernelGGL((k_sd_gemm_h2<EPI, 64, 4>), gr64, dim3(256), 0, s, M, K, N, A, amax, WH, (size_t)N * K, w_exp, b, Cm, cmax);
-    else if (tn64) hipLaunchKernelGGL((k_sd_gemm_h2<EPI, 64, 2>), gr64, dim3(256), 0, s, M, K, N, A, amax, WH, (size_t)N * K, w_exp, b, Cm, cmax);
     else if (pd4) hipLaunchKernelGGL((k_sd_gemm_h2<EPI, 128, 4>), gr128, dim3(256), 0, s, M, K, N, A, amax, WH, (size_t)N * K, w_exp, b, Cm, cmax);
+    else
+#endif
+    if (tn64) hipLaunchKernelGGL((k_sd_gemm_h2<EPI, 64, 2>), gr64, dim3(256), 0, s, M, K, N, A, amax, WH, (size_t)N * K, w_exp, b, Cm, cmax);
     else hipLaunchKernelGGL((k_sd_gemm_h2<EPI, 128, 2>), gr128, dim3(256), 0, s, M, K, N, A, amax, WH, (size_t)N * K, w_exp, b, Cm, cmax);
     return ks;
 }
@@ -2101,7 +2165,7 @@ int launch_eval_sd(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s) {
                        g->remb, g->pemb, m->temb + (size_t)t * H, m->sd_pe, m->lnpre_g, m->lnpre_b, g->sdX);
     unsigned int* const nomax = nullptr;
     // LayerNorm kernels with the width at compile time (no bounds tests next to their loads) for the widths multiples of 128 give
-    static const bool ln_generic = getenv("CCSP_SD_LN") && !strcmp(getenv("CCSP_SD_LN"), "generic");
+    static const bool ln_generic = exp_env("CCSP_SD_LN") && !strcmp(exp_env("CCSP_SD_LN"), "generic");
     const int Wsel = ln_generic ? 0 : Wd;
     auto ln0 = [&](const float* X, const float* ga, const float* be, float* Y, unsigned int* ym, unsigned int* z0, unsigned int* z1, unsigned int* z2, int parts) {
         const dim3 gr(nblk(M, 4)), bl(256);
@@ -2151,7 +2215,7 @@ int launch_eval_sd(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s) {
             sd_gemm_h2<SD_EPI_RESID>(m, M, Wd, Wd, g->sdA, mA, w.out_wH, w.out_e, w.out_b, g->sdX, mX, s);
             sd_gemm_h2<SD_EPI_QGELU>(m, M, Wd, 4 * Wd, g->sdX, mX, w.fc_wH, w.fc_e, w.fc_b, g->sdF, mF, s);
             const int parts = sd_gemm_h2<SD_EPI_BIAS>(m, M, 4 * Wd, Wd, g->sdF, mF, w.proj_wH, w.proj_e, w.proj_b, g->sdY, nomax, s, true);
-            static const bool no_ln21 = getenv("CCSP_SD_LN21") && atoi(getenv("CCSP_SD_LN21")) == 0;
+            static const bool no_ln21 = exp_env("CCSP_SD_LN21") && atoi(exp_env("CCSP_SD_LN21")) == 0;
             if (l + 1 < SD_LAYERS && no_ln21) {
                 ln1(g->sdY, w.ln2_g, w.ln2_b, g->sdX, parts);
                 ln0(g->sdX, m->sd[l + 1].ln1_g, m->sd[l + 1].ln1_b, g->sdY, mY, mA, mX, mF, 1);
@@ -2294,8 +2358,11 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
             hipLaunchKernelGGL((k_edge_bwd_h2<SUM, PP>), dim3(nblk(p.E_act, 64) * 4), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->ent_pos, g->U, g->O, \
                                g->Q, m->Wd1TH, m->wd_exp, m->wd2_absmax, m->pd2_w, g->GZ, skip, bsa)
             const bool p4 = P == 4 && !m->bwd_generic_p;
-            if (g->bs_ready) { if (p4) CCSP_EDGE_BWD(true, 4); else CCSP_EDGE_BWD(true, 0); }
-            else { if (p4) CCSP_EDGE_BWD(false, 4); else CCSP_EDGE_BWD(false, 0); }
+#ifdef CCSP_EXPERIMENTS
+            if (!g->bs_ready) { if (p4) CCSP_EDGE_BWD(false, 4); else CCSP_EDGE_BWD(false, 0); }      // (CCSP_ENERGY_ROWSUM=kernel: round 3's k_rowsum_h2 downstream)
+            else
+#endif
+            { if (p4) CCSP_EDGE_BWD(true, 4); else CCSP_EDGE_BWD(true, 0); }      // (bs_ready whenever these kernels run: energy_prepare)
 #undef CCSP_EDGE_BWD
             bwd_done = true;
         } else if (m->bf16x3 && m->edge_kernel == 2) {
@@ -2313,8 +2380,10 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     if (h2_bwd && !psum && !g->GZRH && (dev_alloc(g->allocs, &g->GZRH, (size_t)2 * p.R * 2 * H) || dev_alloc(g->allocs, &g->gexp, (size_t)p.R))) return 1;
     if (!psum) prof_mark(g, s, CCSP_K_ROWSUM);
     if (psum) {}
+#ifdef CCSP_EXPERIMENTS
     else if (h2_bwd)
         hipLaunchKernelGGL(k_rowsum_h2, dim3(nblk(p.R, 4)), dim3(256), 0, s, p.R, g->row_ptr, g->row_edge, g->GZ, g->GZRH, g->gexp, skip);
+#endif
     else
     hipLaunchKernelGGL(k_rowsum, dim3(nblk((long)p.R * (2 * H / 4), 256)), dim3(256), 0, s, p.R, 2 * H, g->row_ptr, g->row_edge, g->GZ, g->GZR,
                        bf_bwd ? g->GZRS : (unsigned short*)nullptr);
@@ -2336,8 +2405,11 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
             hipLaunchKernelGGL((k_rowgemm_h2<2 * H, H, MODE>), dim3(work), dim3(256), 0, s, a_pl, a_stride, a_ex, no_map, tdesc, m->WpTH,               \
                                (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, m->wp_exp, nof, nof, gp_out, nou, StepRef{nullptr, nullptr, skip}, \
                                (size_t)0)
-            if (mode == 6) CCSP_ROWGEMM_T(6); else if (mode == 5) CCSP_ROWGEMM_T(5); else if (mode == 4) CCSP_ROWGEMM_T(4); else if (mode == 3) CCSP_ROWGEMM_T(3); else if (mode == 2) CCSP_ROWGEMM_T(2);
-            else if (mode == 1) CCSP_ROWGEMM_T(1); else CCSP_ROWGEMM_T(0);
+            if (mode == 6) CCSP_ROWGEMM_T(6); else if (mode == 4) CCSP_ROWGEMM_T(4);
+#ifdef CCSP_EXPERIMENTS
+            else if (mode == 5) CCSP_ROWGEMM_T(5); else if (mode == 3) CCSP_ROWGEMM_T(3); else if (mode == 2) CCSP_ROWGEMM_T(2); else if (mode == 1) CCSP_ROWGEMM_T(1);
+#endif
+            else CCSP_ROWGEMM_T(0);
 #undef CCSP_ROWGEMM_T
         }
     } else if (bf_bwd) {
@@ -2356,8 +2428,11 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     if (tail_done) *tail_done = false;
     const bool valu_node_energy = m->valu_node_energy != 0 && 256 % H == 0;               // the pre-MFMA kernel, kept for A/B runs (widths that divide 256)
     prof_mark(g, s, CCSP_K_NODE_ENERGY);
+#ifdef CCSP_EXPERIMENTS
     if (valu_node_energy) { if constexpr (256 % H == 0) hipLaunchKernelGGL(k_node_energy<H>, dim3(nblk(g->N, NODE_TILE)), dim3(256), 0, s, a); }
-    else {
+    else
+#endif
+    {
         bool h2n = false;
         if constexpr (H == 256) {
             h2n = m->pe2_wTH != nullptr;
@@ -2376,6 +2451,12 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     return 0;
 }
 
+// slot k (= index of the accept step within this call, chain order) of the margin buffer installed by ccsp_chain_margins, or null
+float* margin_at(const ccsp_graph* g, uint64_t k) {
+    if (!g->margin_buf || (int64_t)((k + 1) * (uint64_t)g->N) > g->margin_cap) return nullptr;
+    return g->margin_buf + (size_t)k * g->N;
+}
+
 int steps_at(const ccsp_model* m, int sampler, int t) {
     if (sampler == CCSP_SAMPLER_NONE) return 0;
     if (t % m->d.ebm_per_steps != 0) return 0;                 // ddpm.py:330
@@ -2391,9 +2472,31 @@ int steps_at(const ccsp_model* m, int sampler, int t) {
 
 // (experiment, CCSP_LANE_STAGGER_US) holds a lane's stream back at the start of a chain so that the lanes' kernels of the same kind do
 // not run side by side; wall_clock64 ticks at 100 MHz
+#ifdef CCSP_EXPERIMENTS
 __global__ void k_delay(long long ticks) {
     const long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+#endif
+
+// Lane streams are shared by every model of the process, one pool per device.  HIP maps streams onto a handful of hardware queues in creation
+// order, so the streams a SECOND model created for itself could land on one queue next to each other: its two lanes then ran one after the other
+// (round 5, bench.py's strict-fp32 sub-run: 176 samples/s on a second model's own streams against 257 in a process of its own).  Pooled, every
+// model's lane k is the same stream; chains of different models enqueued on it simply queue up like work on the caller's stream.
+int lane_stream_get(size_t k, hipStream_t* out) {
+    static std::mutex mu;
+    static std::map<int, std::vector<hipStream_t>> pool;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    std::vector<hipStream_t>& v = pool[dev];
+    while (v.size() <= k) {
+        hipStream_t cs = nullptr;
+        HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        v.push_back(cs);
+    }
+    *out = v[k];
+    return 0;
 }
 
 // one concurrently running sub-batch of a chain
@@ -2532,6 +2635,7 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
                     if (launch_eval_energy<H>(m, g, t, g->xhat, false, E_hat, s)) return 1;
                     HmcArgs c = hargs(HMC_ACCEPT);
                     c.E_x = E_x; c.E_hat = E_hat; c.acc_count = g->acc_count + t;
+                    c.margin = margin_at(g, ucall0[t] + (uint64_t)e - ucall0[t_first]);
                     c.reset_mask = (e == S - 1);
                     c.hist = e == S - 1 ? hist_at(L, T - t) : nullptr;
                     c.noise.mode = nz->mode; c.noise.seed = nz->seed; c.noise.row_offset = nz->row_offset;
@@ -2597,6 +2701,7 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
                 b.src = 1; b.eps_buf = g->eps; b.do_encode = 1; b.xhat = g->xhat; b.step = STEP_MALA_ACCEPT;
                 b.E_x = E_x; b.E_hat = E_hat; b.acc_count = g->acc_count + t;
                 b.changed = reuse ? g->mala_changed + (e & 1) : nullptr;
+                b.margin = margin_at(g, ucall0[t] + (uint64_t)(e - 1) - ucall0[t_first]);
                 if (fold_sum) { b.E_hat_partial = g->partial; b.n_hat_partial = g->n_part_last; }
                 b.reset_mask = (e == S);
                 b.hist = e == S ? hist_at(L, T - t) : nullptr;
@@ -2613,6 +2718,7 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
             }
         }
         if (accept) hipLaunchKernelGGL(k_accept_rates, dim3(nblk(T, 256)), dim3(256), 0, s, T, g->acc_count, g->acc_denom, accept);
+#ifdef CCSP_EXPERIMENTS
     } else if (m->graph_mode && lanes.size() == 1 && lanes[0].g->N < 512 && m->bf16x3 && m->d.model_kind == CCSP_MODEL_DIFFUSION_CCSP &&
                !lanes[0].g->profile && lanes[0].g->plan.E_act > 0 && t_first >= t_last) {
         // hipGraph mode (opt-in): a small batch is three short dependent launches per evaluation.  One graph of
@@ -2682,7 +2788,9 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
             HIP_TRY(hipGraphLaunch(it->second, s));
             g->evals += 1 + S;
         }
+#endif
     } else {
+#ifdef CCSP_EXPERIMENTS
         // the node update rides in the edge kernel's tail when the f16x2 kernels run with 16- / 32-edge tiles (FuseArgs)
         for (const Lane& L : lanes) {
             ccsp_graph* g = L.g;
@@ -2705,6 +2813,7 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
                 g->fuse_me = 0;
             }
         }
+#endif
         for (int t = t_first; t >= t_last; --t) {
             const int S = steps_at(m, sampler, t);
             for (int e = 0; e <= S; ++e) {
@@ -2791,7 +2900,7 @@ int ensure_children(ccsp_model* m, ccsp_graph* g, int want, hipStream_t s) {
             hipEvent_t ce = nullptr;
             // CCSP_LANE_CUMASK (experiment, default off): give every lane its own share of the compute units instead of letting the
             // lanes' kernels interleave on all of them; 1 = contiguous ranges of the mask, 2 = every want-th bit
-            const char* cm = getenv("CCSP_LANE_CUMASK");
+            const char* cm = exp_env("CCSP_LANE_CUMASK");
             const int cmode = cm ? atoi(cm) : 0;
             if (cmode == 1 || cmode == 2) {
                 const int ncu = m->ncu > 0 ? m->ncu : 256;
@@ -2801,9 +2910,9 @@ int ensure_children(ccsp_model* m, ccsp_graph* g, int want, hipStream_t s) {
                     if (mine) mask[i >> 5] |= 1u << (i & 31);
                 }
                 HIP_TRY(hipExtStreamCreateWithCUMask(&cs, (uint32_t)mask.size(), mask.data()));
-            } else
-            HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+            } else if (lane_stream_get(k, &cs)) return 1;
             HIP_TRY(hipEventCreateWithFlags(&ce, hipEventDisableTiming));
+            m->lane_stream_owned.push_back((cmode == 1 || cmode == 2) ? 1 : 0);
             m->lane_streams.push_back(cs);
             m->lane_events.push_back(ce);
         }
@@ -2886,6 +2995,7 @@ int graph_build(ccsp_model* m, int N, int E, int F, const float* x, const signed
         TRY(dev_upload(reg, &td, g->h_td, s));
         g->td64 = td; g->td128 = td + p.tile_row0.size();
     }
+#ifdef CCSP_EXPERIMENTS
     if (m->f16x2 && m->WpF && m->eval_fused && p.E_act > 0) {   // fused tiles: <= 28 (32) U rows per slot, <= 112 (128) edges
         ccsp::build_fused_plan(p, m->eval_fused == 1 ? F4_RS : FZ_RS, m->eval_fused == 1 ? F4_ME : FZ_ME, g->fplan);
         g->n_ftiles = g->fplan.n_tiles;
@@ -2904,6 +3014,7 @@ int graph_build(ccsp_model* m, int N, int E, int F, const float* x, const signed
             TRY(dev_upload(reg, &g->ft_order, g->h_forder, s));
         }
     }
+#endif
     TRY(dev_alloc(reg, &g->base, (size_t)p.R * 2 * H));
     TRY(dev_alloc(reg, &g->U, (size_t)p.R * 2 * H));
     TRY(dev_alloc(reg, &g->O, (size_t)2 * p.E_act * P));
@@ -3080,6 +3191,14 @@ __global__ __launch_bounds__(256) void k_compose_energy(int N, int P, int zero_c
     float e = 0.0f;
     for (int i = threadIdx.x; i < N * P; i += 256) {
         const int n = i / P, c = i % P;
+        if (!grad) {                    // (uniform) energy only: the zero column's own term, summed in the same order
+            if (c == zero_col) {
+                const float cnt = nptr2 ? (float)(nptr2[n + 1] - nptr2[n]) : 0.0f;
+                const float pz = poses[i];
+                e += cnt * pz * pz;
+            }
+            continue;
+        }
         float v = g1[i];
         if (c == zero_col) {
             const float cnt = nptr2 ? (float)(nptr2[n + 1] - nptr2[n]) : 0.0f;
@@ -3192,13 +3311,17 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     // CCSP_MMA: f16x2 (default at hidden_dim 256: two-term fp16 operands, three MFMA products per fp32 product),
     //           bf16x3 (three-term bf16 operands, six products), f32 (v_mfma_f32_32x32x2_f32)
     m->f16x2 = (H == 256 && d->model_kind == CCSP_MODEL_DIFFUSION_CCSP) ? 1 : 0;
+#ifdef CCSP_EXPERIMENTS
     if (const char* e = getenv("CCSP_ROW_MODE")) { const int v = atoi(e); if (v >= 0 && v <= 7) m->row_mode = v; }
+#else
+    if (const char* e = getenv("CCSP_ROW_MODE")) { const int v = atoi(e); if (v == 0 || v == 4 || v == 6) m->row_mode = v; }      // (the three forms the selection uses)
+#endif
     if (const char* e = getenv("CCSP_EDGE_MT")) m->edge_mt = atoi(e) == 2 ? 2 : 1;
     if (const char* e = getenv("CCSP_EDGE_SMALL")) m->edge_small = atoi(e) != 0;
-    m->valu_node_energy = getenv("CCSP_NODE_ENERGY_VALU") != nullptr;
-    if (const char* e = getenv("CCSP_NODE")) { m->node_generic = strcmp(e, "generic") == 0; m->node_stream = strcmp(e, "stream") == 0; }
-    if (const char* e = getenv("CCSP_FUSE_NODE")) m->fuse_node = atoi(e);      // 1: producer-side tail with arrival counters (round 3); 2: node-grouped edge tiles (round 4)
-    if (const char* e = getenv("CCSP_EVAL")) m->eval_fused = strcmp(e, "fused") == 0 ? 1 : (strcmp(e, "fused8") == 0 ? 2 : 0);
+    m->valu_node_energy = exp_env("CCSP_NODE_ENERGY_VALU") != nullptr;
+    if (const char* e = getenv("CCSP_NODE")) { m->node_generic = strcmp(e, "generic") == 0; m->node_stream = exp_env("CCSP_NODE") && strcmp(e, "stream") == 0; }
+    if (const char* e = exp_env("CCSP_FUSE_NODE")) m->fuse_node = atoi(e);      // 1: producer-side tail with arrival counters (round 3); 2: node-grouped edge tiles (round 4)
+    if (const char* e = exp_env("CCSP_EVAL")) m->eval_fused = strcmp(e, "fused") == 0 ? 1 : (strcmp(e, "fused8") == 0 ? 2 : 0);
     {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -3211,12 +3334,12 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     m->row_tile = 128;
     m->edge_kernel = 2;
     m->graph_mode = 0;
-    if (const char* e = getenv("CCSP_GRAPH")) m->graph_mode = atoi(e) != 0;
-    if (const char* e = getenv("CCSP_EDGE_KERNEL")) m->edge_kernel = atoi(e) == 1 ? 1 : 2;
-    if (const char* e = getenv("CCSP_ROW_TILE")) m->row_tile = atoi(e) == 64 ? 64 : 128;
+    if (const char* e = exp_env("CCSP_GRAPH")) m->graph_mode = atoi(e) != 0;
+    if (const char* e = exp_env("CCSP_EDGE_KERNEL")) m->edge_kernel = atoi(e) == 1 ? 1 : 2;
+    if (const char* e = exp_env("CCSP_ROW_TILE")) m->row_tile = atoi(e) == 64 ? 64 : 128;
     m->WpS = nullptr; m->Wd1S = nullptr; m->Wd1TS = nullptr; m->WpTS = nullptr;
     m->max_wgs = 1 << 30;
-    if (const char* e = getenv("CCSP_MAX_WGS")) { const int v = atoi(e); if (v > 0) m->max_wgs = v; }
+    if (const char* e = exp_env("CCSP_MAX_WGS")) { const int v = atoi(e); if (v > 0) m->max_wgs = v; }
     auto& reg = m->allocs;
     int k = 0;
     auto dup = [&](float** dst, size_t n) -> int {
@@ -3409,19 +3532,21 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
             TRY(dev_alloc(reg, &m->Wd1H, (size_t)2 * nwd));
             hipLaunchKernelGGL(k_split2h, dim3(nblk(nwp, 256)), dim3(256), 0, s, nwp, m->Wp, m->wp_exp, m->WpH);
             hipLaunchKernelGGL(k_split2h, dim3(nblk(nwd, 256)), dim3(256), 0, s, nwd, m->pd0_w, m->wd_exp, m->Wd1H);
-            {   // the same planes in MFMA fragment order for the fused evaluation kernel (ccsp_fused.h)
+#ifdef CCSP_EXPERIMENTS
+            if (m->eval_fused || m->row_mode == 7) {   // the same planes in MFMA fragment order for the fused evaluation kernel (ccsp_fused.h)
                 const long n16 = (long)d->n_types * 2 * 32768;
                 TRY(dev_alloc(reg, &m->WpF, (size_t)2 * nwp));
                 TRY(dev_alloc(reg, &m->Wd1F, (size_t)2 * nwd));
                 hipLaunchKernelGGL(k_pack_wp_frag, dim3(nblk(n16, 256)), dim3(256), 0, s, n16, m->WpH, (size_t)nwp, m->WpF);
                 hipLaunchKernelGGL(k_pack_wd1_frag, dim3(nblk(4 * 16 * 2 * 64, 256)), dim3(256), 0, s, m->Wd1H, m->Wd1F);
             }
+#endif
             if (d->energy_wrapper) {    // the backward GEMMs' weights: the same tensors transposed, the same exponents
                 if (const char* e = getenv("CCSP_ENERGY_BWD")) m->energy_bwd_h2 = strcmp(e, "bf16x3") != 0;
                 if (const char* e = getenv("CCSP_MALA_REUSE")) m->mala_reuse = atoi(e) != 0;
-                if (const char* e = getenv("CCSP_ENERGY_ROWSUM")) m->bwd_rowsum_fused = strcmp(e, "kernel") != 0;
-                if (const char* e = getenv("CCSP_ENERGY_NODE")) m->node_energy_fused = strcmp(e, "split") != 0;
-                if (const char* e = getenv("CCSP_ENERGY_BWD_P")) m->bwd_generic_p = strcmp(e, "generic") == 0;
+                if (const char* e = exp_env("CCSP_ENERGY_ROWSUM")) m->bwd_rowsum_fused = strcmp(e, "kernel") != 0;
+                if (const char* e = exp_env("CCSP_ENERGY_NODE")) m->node_energy_fused = strcmp(e, "split") != 0;
+                if (const char* e = exp_env("CCSP_ENERGY_BWD_P")) m->bwd_generic_p = strcmp(e, "generic") == 0;
                 {   // bound of the decoder backward's output per unit of sum_p |go| (k_edge_bwd_h2<true>): 1.1^2 max|Wd2| max_n sum_j |Wd1[j, n]|
                     std::vector<float> h_wd((size_t)nwd);
                     HIP_TRY(hipMemcpyAsync(h_wd.data(), m->pd0_w, h_wd.size() * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -3454,7 +3579,10 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
 void ccsp_model_destroy(ccsp_model* m) {
     if (!m) return;
     for (ccsp_graph* g : m->graphs) g->m = nullptr;      // graphs may outlive the model (ccsp_graph_destroy checks)
-    for (hipStream_t st : m->lane_streams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (size_t i = 0; i < m->lane_streams.size(); ++i) {
+        (void)hipStreamSynchronize(m->lane_streams[i]);
+        if (m->lane_stream_owned[i]) (void)hipStreamDestroy(m->lane_streams[i]);
+    }
     for (hipEvent_t e : m->lane_events) (void)hipEventDestroy(e);
     if (m->fork_event) (void)hipEventDestroy(m->fork_event);
     if (m->capture_stream) (void)hipStreamDestroy(m->capture_stream);
@@ -3505,6 +3633,26 @@ int ccsp_rccl_comm_destroy(void* comm) {
     if (!ra || !comm) return 0;
     const int rc = ra->comm_destroy(comm);
     return rc == 0 ? 0 : fail("ncclCommDestroy failed: %s", rccl_err(ra, rc));
+}
+
+int ccsp_rccl_comm_count(void* comm, int32_t* n_ranks, int32_t* version) {
+    RcclApi* ra = rccl_api();
+    if (!ra) return fail("rccl_comm_count: librccl.so could not be loaded (set CCSP_RCCL_LIB)");
+    if (!comm || !n_ranks) return fail("rccl_comm_count: null argument");
+    int n = 0;
+    const int rc = ra->comm_count(comm, &n);
+    if (rc != 0) return fail("ncclCommCount failed: %s", rccl_err(ra, rc));
+    *n_ranks = n;
+    if (version) *version = ra->version;
+    return 0;
+}
+
+int ccsp_rccl_allreduce_sum_f32(void* comm, float* buf, int64_t n, void* stream) {
+    RcclApi* ra = rccl_api();
+    if (!ra) return fail("rccl_allreduce_sum_f32: librccl.so could not be loaded (set CCSP_RCCL_LIB)");
+    if (!comm || !buf || n < 0) return fail("rccl_allreduce_sum_f32: bad argument");
+    const int rc = ra->all_reduce(buf, buf, (size_t)n, 7 /*ncclFloat32*/, 0 /*ncclSum*/, comm, (hipStream_t)stream);
+    return rc == 0 ? 0 : fail("ncclAllReduce failed: %s", rccl_err(ra, rc));
 }
 
 int ccsp_time_embedding(ccsp_model* m, int32_t t, float* out, void* stream) {
@@ -3800,8 +3948,10 @@ int ccsp_chain_run(ccsp_model* m, ccsp_graph* g, int32_t sampler, const ccsp_noi
         for (size_t i = 0; i < lanes.size(); ++i)
             th.emplace_back([&, i]() {
                 if (hipSetDevice(dev) != hipSuccess) { rcs[i] = 1; errs[i] = "hipSetDevice failed in lane thread"; return; }
+#ifdef CCSP_EXPERIMENTS
                 static const int stagger_us = getenv("CCSP_LANE_STAGGER_US") ? atoi(getenv("CCSP_LANE_STAGGER_US")) : 0;
                 if (stagger_us > 0 && i > 0) hipLaunchKernelGGL(k_delay, dim3(1), dim3(1), 0, lanes[i].s, (long long)stagger_us * 100 * (long long)i);
+#endif
                 rcs[i] = run(std::vector<Lane>{lanes[i]});
                 if (rcs[i]) errs[i] = g_err;
             });
@@ -3867,6 +4017,14 @@ int ccsp_graph_variant(ccsp_graph* g, int32_t* row_mode, int32_t* edge_tile) {
     const bool h2 = m->f16x2 && m->d.hidden_dim == 256 && m->d.model_kind == CCSP_MODEL_DIFFUSION_CCSP && g->plan.E_act > 0;
     if (row_mode) *row_mode = h2 ? rowgemm_h2_mode(m, g, 4) : -1;
     if (edge_tile) *edge_tile = h2 ? edge_tile_edges(m, g->plan.E_act) : -1;
+    return 0;
+}
+
+int ccsp_chain_margins(ccsp_graph* g, float* margins, int64_t n_floats) {
+    if (!g) return fail("chain_margins: null graph");
+    if (margins && n_floats < 0) return fail("chain_margins: negative size");
+    g->margin_buf = margins;
+    g->margin_cap = margins ? n_floats : 0;
     return 0;
 }
 
@@ -3942,8 +4100,10 @@ int ccsp_compose_energy_grad(ccsp_model* m1, ccsp_graph* g1, ccsp_model* m2, ccs
 namespace {
 // the composed energy and its gradient at poses_in (the body of ccsp_compose_energy_grad; also one evaluation of an energy-mode
 // chain of a composed model, ccsp_compose_chain_run).  p_enc / p_tgt: [N, P2] scratch, E12: 2 floats of scratch
+// grad == nullptr: the energy only (forward passes of both domains, no backward: MALA's evaluation at the proposal, HMC's two energies per inner step)
 int compose_energy_eval(ccsp_model* m1, ccsp_graph* g1, ccsp_model* m2, ccsp_graph* g2, const ccsp_compose* c, const float* poses_in, int t,
                         float* p_enc, float* p_tgt, float* E12, float* grad, float* energy, hipStream_t s) {
+    const bool with_grad = grad != nullptr;
     const int N = g1->N, P = m1->d.pose_dim, P2 = m2->d.pose_dim;
     hipLaunchKernelGGL(k_compose_pack, dim3(nblk((long)N * P2, 256)), dim3(256), 0, s, N, P, P2, poses_in, g1->xfeat, g1->F, p_enc);
     hipLaunchKernelGGL(k_compose_targets, dim3(nblk((long)N * P2, 256)), dim3(256), 0, s, N, P, c->zero_col, poses_in, p_tgt);
@@ -3952,11 +4112,11 @@ int compose_energy_eval(ccsp_model* m1, ccsp_graph* g1, ccsp_model* m2, ccsp_gra
         NodeArgs a = node_args(m1, g1);
         a.src = 2; a.step = STEP_NONE; a.do_encode = 1; a.x_in = poses_in;
         launch_node<HH>(m1, g1, a, s);
-        if (launch_eval_energy<HH>(m1, g1, t, poses_in, true, E12, s)) return 1;
+        if (launch_eval_energy<HH>(m1, g1, t, poses_in, with_grad, E12, s)) return 1;
         NodeArgs b = node_args(m2, g2);
         b.src = 2; b.step = STEP_NONE; b.do_encode = 1; b.x_in = p_enc;
         launch_node<HH>(m2, g2, b, s);
-        return launch_eval_energy<HH>(m2, g2, t, p_tgt, true, E12 + 1, s, nullptr, p_enc, 2);
+        return launch_eval_energy<HH>(m2, g2, t, p_tgt, with_grad, E12 + 1, s, nullptr, p_enc, 2);
     });
     if (rc) return 1;
     hipLaunchKernelGGL(k_compose_energy, dim3(1), dim3(256), 0, s, N, P, c->zero_col, poses_in, g1->eps, g2->eps,
@@ -3980,6 +4140,11 @@ int ccsp_compose_chain_run(ccsp_model* m1, ccsp_graph* g1, ccsp_model* m2, ccsp_
         return fail("compose_chain_run: sampler %d: composed models run the ancestral / ULA / ULA+ samplers (on the denoiser output, or on the energy gradient "
                     "when both are energy_wrapper models) and, as energy_wrapper models, MALA and HMC", sampler);
     if (hmc && m1->d.timesteps < 4) return fail("compose_chain_run: HMC indexes the schedule with its inner step 0..3 (ddpm.py:1076-1084)");
+    if (hmc && (m1->energy_hook || m1->rccl_comm || m2->energy_hook || m2->rccl_comm))
+        return fail("compose_chain_run: a shard energy hook / communicator is installed, but the HMC chain does not reduce its energies across shards "
+                    "(only MALA does): the shards would silently decouple -- remove it (ccsp_model_set_energy_hook(model, NULL, NULL)) or run MALA");
+    if (sampler == CCSP_SAMPLER_MALA && (m2->energy_hook || m2->rccl_comm) && !(m1->energy_hook || m1->rccl_comm))
+        return fail("compose_chain_run: the shard energy hook / communicator must be installed on the FIRST domain's model (the one whose chain this is)");
     // energy mode (both energy_wrapper models; ComposedEBMDenoiseFn.forward: epsilon = dE/dposes, ddpm.py:940-966 on it): every evaluation
     // is the composed energy gradient of ccsp_compose_energy_grad
     const bool energy = m1->d.energy_wrapper != 0;
@@ -3993,9 +4158,9 @@ int ccsp_compose_chain_run(ccsp_model* m1, ccsp_graph* g1, ccsp_model* m2, ccsp_
     if (nz->mode == CCSP_NOISE_INJECTED && !nz->normal) return fail("compose_chain_run: injected noise without a normal stream");
     hipStream_t s = (hipStream_t)stream;
     const size_t N = (size_t)g->N, NP = N * P;
-    StreamBuf b1(s), b2(s), b3(s), b4(s), b5(s);
+    StreamBuf b1(s), b2(s), b3(s), b4(s);
     if (b1.alloc(NP * sizeof(float)) || b2.alloc(N * m2->d.pose_dim * sizeof(float)) || b3.alloc(N * m2->d.pose_dim * sizeof(float)) ||
-        b4.alloc(6 * sizeof(float)) || (mala && b5.alloc(NP * sizeof(float)))) return 1;
+        b4.alloc(6 * sizeof(float))) return 1;
     if (mala && nz->mode == CCSP_NOISE_INJECTED && !nz->uniform) return fail("compose_chain_run: MALA with injected noise needs a uniform stream");
     const ComposeScratch w{b1.f(), b2.f(), b3.f()};
     if (energy && (energy_prepare(m1, g1, s) || energy_prepare(m2, g2, s))) return 1;
@@ -4061,10 +4226,18 @@ int ccsp_compose_chain_run(ccsp_model* m1, ccsp_graph* g1, ccsp_model* m2, ccsp_
                 // from the batch-scalar energies
                 a.step = STEP_MALA_PROPOSE; a.do_encode = 0; a.xhat = g->xhat; a.reset_mask = 0; a.hist = nullptr;
                 node(a);
-                if (compose_energy_eval(m1, g1, m2, g2, c, g->xhat, t, w.s2, w.p2, b4.f(), b5.f(), b4.f() + 3, s)) return 1;
+                if (compose_energy_eval(m1, g1, m2, g2, c, g->xhat, t, w.s2, w.p2, b4.f(), nullptr, b4.f() + 3, s)) return 1;      // (energy only)
                 NodeArgs b = a;
                 b.step = STEP_MALA_ACCEPT;
                 b.E_x = b4.f() + 2; b.E_hat = b4.f() + 3; b.acc_count = g->acc_count + t;
+                b.margin = margin_at(g, ucall0[t] + (uint64_t)(e - 1) - ucall0[t_first]);
+                // MALA across shards (ccsp_model_set_energy_hook / _allreduce on the FIRST domain's model): {E(x), E(x_hat)} of this shard ->
+                // sums over all shards, in place (b4[2], b4[3] are adjacent and rewritten by the next inner step's evaluations), on this stream
+                if (m1->rccl_comm) {
+                    RcclApi* ra = rccl_api();
+                    const int rc = ra ? ra->all_reduce(b4.f() + 2, b4.f() + 2, 2, 7 /*ncclFloat32*/, 0 /*ncclSum*/, m1->rccl_comm, s) : -1;
+                    if (rc != 0) return fail("compose_chain_run: ncclAllReduce of the batch energies failed: %s", rccl_err(ra, rc));
+                } else if (m1->energy_hook && m1->energy_hook(m1->energy_hook_ctx, b4.f() + 2, (void*)s)) return fail("compose_chain_run: the energy hook failed");
                 b.reset_mask = (e == S);
                 b.hist = (e == S && history) ? history + (size_t)(T - t) * NP : nullptr;
                 const uint64_t uc = ucall0[t] + (uint64_t)(e - 1);
@@ -4116,9 +4289,10 @@ int ccsp_compose_chain_run(ccsp_model* m1, ccsp_graph* g1, ccsp_model* m2, ccsp_
                     lb.mode = HMC_LEAP_B;
                     hipLaunchKernelGGL(k_hmc, hgrid, dim3(256), 0, s, lb);
                 }
-                if (grad_at(g->x, t, b5.f(), b4.f() + 2) || grad_at(g->xhat, t, b5.f(), b4.f() + 3)) return 1;
+                if (grad_at(g->x, t, nullptr, b4.f() + 2) || grad_at(g->xhat, t, nullptr, b4.f() + 3)) return 1;                     // (energies only)
                 HmcArgs ac = hargs(HMC_ACCEPT);
                 ac.E_x = b4.f() + 2; ac.E_hat = b4.f() + 3; ac.acc_count = g->acc_count + t;
+                ac.margin = margin_at(g, ucall0[t] + (uint64_t)e - ucall0[t_first]);
                 ac.reset_mask = (e == S - 1);
                 ac.hist = (e == S - 1 && history) ? history + (size_t)(T - t) * NP : nullptr;
                 ac.noise.mode = nz->mode; ac.noise.seed = nz->seed; ac.noise.row_offset = nz->row_offset;
@@ -4155,6 +4329,7 @@ int ccsp_plan_host(int32_t N, int32_t E, int32_t C, const int64_t* edge_index, c
     return 0;
 }
 
+#ifdef CCSP_EXPERIMENTS
 int ccsp_plan_fused_host(int32_t N, int32_t E, int32_t C, const int64_t* edge_index, const float* edge_attr, int32_t rows_per_slot,
                          int32_t max_edges, int32_t* n_tiles, int32_t* tiles, int32_t* rows, uint16_t* e_lu) {
     if (rows_per_slot < 1 || rows_per_slot > 32 || max_edges < 1 || max_edges > 128) return fail("plan_fused_host: rows_per_slot in 1..32, max_edges in 1..128");
@@ -4169,6 +4344,7 @@ int ccsp_plan_fused_host(int32_t N, int32_t E, int32_t C, const int64_t* edge_in
     if (e_lu && !f.e_lu.empty()) memcpy(e_lu, f.e_lu.data(), f.e_lu.size() * sizeof(uint16_t));
     return 0;
 }
+#endif
 
 int ccsp_plan_bwdsum_host(int32_t N, int32_t E, int32_t C, const int64_t* edge_index, const float* edge_attr, int32_t* n_blocks, int32_t* n_partial,
                           int32_t* blocks, int32_t* prow_urow, int32_t* nrow_ptr, int32_t* nrow_idx) {

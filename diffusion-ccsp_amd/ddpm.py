@@ -41,6 +41,8 @@ class GaussianDiffusion(object):
         self._apply_schedule()
         self.sample_loop_time = []
         self.last_stats = None
+        self.record_margins = False       # debugging aid: see last_margins
+        self.last_margins = None
 
     # the native handle lives on the ConstraintDiffuser (possibly behind the EBM wrapper)
     def _core(self):
@@ -199,25 +201,56 @@ class GaussianDiffusion(object):
             hist = torch.empty((T + 1, g1.N, self.dims[-1][0]), device=dev, dtype=torch.float32) if return_history else None
             c = core._compose_struct()
             acc = torch.zeros(T, device=dev, dtype=torch.float32) if self._sampler() in ('MALA', 'HMC') else None
+            marg = self._margin_buffer(g1, t_first, t_last)
             with torch.cuda.device(dev):
                 _lib.check(L.ccsp_compose_chain_run(h, g1.h, second._h, g2.h, C.byref(c), _lib.SAMPLERS[self._sampler()], C.byref(nz), _ptr(x),
                                                     int(init), int(t_first), int(t_last), None if hist is None else _ptr(hist),
                                                     None if acc is None else _ptr(acc), _stream_ptr(dev)))
+            if marg is not None:
+                _lib.check(L.ccsp_chain_margins(g1.h, None, 0))
             self._last_graph = g1
             self._keepalive = keep + [g2]
             self.last_accept_rates = acc
+            self.last_margins = marg
             return hist
         g = core._graph(batch)
         hist = torch.empty((T + 1, g.N, self.dims[-1][0]), device=dev, dtype=torch.float32) if return_history else None
         acc = torch.zeros(T, device=dev, dtype=torch.float32) if self._sampler() in ('MALA', 'HMC') else None
+        marg = self._margin_buffer(g, t_first, t_last)
         with torch.cuda.device(dev):
             _lib.check(L.ccsp_chain_run(h, g.h, _lib.SAMPLERS[self._sampler()], C.byref(nz), _ptr(x), int(init), int(t_first),
                                         int(t_last), None if hist is None else _ptr(hist), None if acc is None else _ptr(acc),
                                         _stream_ptr(dev)))
+        if marg is not None:
+            _lib.check(L.ccsp_chain_margins(g.h, None, 0))
         self._last_graph = g
         self._keepalive = keep
         self.last_accept_rates = acc          # MetropolisSampler's per-timestep acceptance (ddpm.py:979-996)
+        self.last_margins = marg
         return hist
+
+    def _inner_steps(self, t):
+        """accept steps of timestep t under MALA / HMC (samples_per_step; HMC: the reference's fixed 4, ddpm.py:311)"""
+        if t % max(1, int(getattr(self.denoise_fn, 'ebm_per_steps', 1))) != 0:
+            return 0
+        if self._sampler() == 'HMC':
+            return 4
+        sps = self.samples_per_step
+        if torch.is_tensor(sps):
+            sps = sps.cpu().numpy()
+        return int(sps) if np.isscalar(sps) else int(np.asarray(sps)[t])
+
+    def _margin_buffer(self, g, t_first, t_last):
+        """record_margins (debugging aid; ccsp_chain_margins): a [accept steps of this call, N] buffer the accept kernels fill with
+        log(acceptance ratio) - log(u) per node row -- positive = accepted, negative = rejected, |value| small = a near-tie that fp32
+        rounding may decide either way (the parity tests assert that every decision differing from the reference's is one).
+        -> self.last_margins after the chain"""
+        if not self.record_margins or self._sampler() not in ('MALA', 'HMC'):
+            return None
+        k = sum(self._inner_steps(t) for t in range(int(t_last), int(t_first) + 1))
+        marg = torch.full((max(k, 1), g.N), float('nan'), device=self.device, dtype=torch.float32)
+        _lib.check(_lib.lib().ccsp_chain_margins(g.h, _ptr(marg), marg.numel()))
+        return marg
 
     def p_sample_loop(self, batch, return_history=False, seed=None, noise=None, row_offset=0, **kwargs):
         """GaussianDiffusion.p_sample_loop (ddpm.py:260-340)"""

@@ -127,12 +127,35 @@ def _native_comm(dist, device):
     if rank == 0:
         _lib.check(L.ccsp_rccl_unique_id(buf))
     box = [bytes(buf.raw)]
-    if world > 1:
-        dist.broadcast_object_list(box, src=0)
     comm = C.c_void_p()
-    with torch.cuda.device(device):
+    dev = torch.device(device)
+    if dev.type == 'cuda':
+        # the broadcast too: with the nccl backend broadcast_object_list stages through the CURRENT device, GPU 0 on every rank unless the
+        # caller has called set_device
+        with torch.cuda.device(dev):
+            if world > 1:
+                dist.broadcast_object_list(box, src=0, device=dev)
+            _lib.check(L.ccsp_rccl_comm_create(world, rank, box[0], C.byref(comm)))
+    else:
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
         _lib.check(L.ccsp_rccl_comm_create(world, rank, box[0], C.byref(comm)))
     return comm.value
+
+
+def _group_key(dist):
+    """identity of the process group a communicator was made over (the default group of a `torch.distributed`-like module, or the object)"""
+    g = getattr(getattr(dist, 'group', None), 'WORLD', None)
+    return (id(g if g is not None else dist), dist.get_rank(), dist.get_world_size())
+
+
+def _destroy_comm(comm):
+    try:
+        import ctypes as C
+        from . import _lib
+        _lib.lib().ccsp_rccl_comm_destroy(C.c_void_p(comm))
+    except Exception:       # noqa: interpreter shutdown
+        pass
 
 
 def enable_global_batch_energy(gd, dist, native=None):
@@ -153,6 +176,9 @@ def enable_global_batch_energy(gd, dist, native=None):
         _lib.check(L.ccsp_model_set_energy_allreduce(h, None))
         old = getattr(core, '_energy_comm', None)
         if old:
+            fin = getattr(core, '_energy_comm_finalizer', None)
+            if fin is not None:
+                fin.detach()
             L.ccsp_rccl_comm_destroy(C.c_void_p(old))
         core._energy_hook = None
         core._energy_comm = None
@@ -160,8 +186,20 @@ def enable_global_batch_energy(gd, dist, native=None):
     if native is None:
         native = getattr(dist, 'get_backend', lambda: '')() == 'nccl'
     if native:
-        comm = getattr(core, '_energy_comm', None) or _native_comm(dist, core.device)
+        key = _group_key(dist)
+        comm = getattr(core, '_energy_comm', None)
+        if comm and getattr(core, '_energy_comm_key', None) != key:      # another process group: the cached communicator is not over its ranks
+            fin = getattr(core, '_energy_comm_finalizer', None)
+            if fin is not None:
+                fin.detach()
+            L.ccsp_rccl_comm_destroy(C.c_void_p(comm))
+            comm = None
+        if not comm:
+            comm = _native_comm(dist, core.device)
+            import weakref
+            core._energy_comm_finalizer = weakref.finalize(core, _destroy_comm, comm)      # destroyed with the denoiser
         core._energy_comm = comm
+        core._energy_comm_key = key
         core._energy_hook = None
         _lib.check(L.ccsp_model_set_energy_allreduce(h, C.c_void_p(comm)))
         return

@@ -14,9 +14,9 @@
  *    ccsp_chain_stats and the ccsp_*_get calls synchronise.  ccsp_denoise / ccsp_energy_grad /
  *    ccsp_edge_outputs never do.  ccsp_chain_run does not wait for the chain it enqueues; it waits
  *    for EARLIER work on the stream only where a host table of a previous chain on the same graph is
- *    about to be rewritten (energy-mode samplers, the opt-in hipGraph mode);
+ *    about to be rewritten (energy-mode samplers);
  *  - streams and threads the library owns: a direct-mode ccsp_chain_run on a batch of >= 6144 active edges cuts it into two
- *    independent sub-batches ("lanes") that run on two streams created once per model, forked from and joined to the caller's
+ *    independent sub-batches ("lanes") that run on two streams created once per process and device (shared by every model), forked from and joined to the caller's
  *    stream by events; the two lanes are enqueued by two std::thread workers that live for the duration of the call (a
  *    chain is 33 000 launches per lane: one thread alternating between streams is launch-bound).  The call returns when both
  *    have enqueued everything, i.e. it blocks for the enqueue time but not for the chain.  Host cost measured on an MI355X
@@ -37,8 +37,12 @@
 extern "C" {
 #endif
 
-#define CCSP_VERSION_MAJOR 0
-#define CCSP_VERSION_MINOR 7
+/* ccsp_version() = 1000 MAJOR + MINOR.  MAJOR changes whenever the signature or the meaning of an existing entry point changes (a binding
+ * built against another MAJOR must refuse the library: diffusion-ccsp_amd/_lib.py does, INTEGRATION.md section 2 shows the check); MINOR
+ * counts additions.  1.0 = round 4's 0.7 with ccsp_compose_chain_run's `accept` argument (added in round 4 WITHOUT a bump: the reason for
+ * the rule) + ccsp_rccl_comm_count / ccsp_rccl_allreduce_sum_f32 + ccsp_chain_margins; ccsp_plan_fused_host moved behind CCSP_EXPERIMENTS. */
+#define CCSP_VERSION_MAJOR 1
+#define CCSP_VERSION_MINOR 0
 #define CCSP_MAX_SAMPLES_PER_STEP 100000
 
 typedef struct ccsp_model ccsp_model;   /* ConstraintDiffuser weights + GaussianDiffusion schedule */
@@ -220,7 +224,7 @@ int ccsp_model_set_energy_hook(ccsp_model* model, ccsp_energy_hook hook, void* c
 /* The same reduction inside the library: with a communicator installed, every MALA inner step enqueues
  * ncclAllReduce(pair, pair, 2, ncclFloat32, ncclSum, comm, stream) on the chain's own stream between the energy evaluation at the
  * proposal and the accept step -- no callback, no host round trip (the Python trampoline of round 3 cost 10 % of a C4 chain with
- * ONE rank).  RCCL is bound at run time (dlopen "librccl.so", or CCSP_RCCL_LIB): a process that already carries an RCCL
+ * ONE rank).  RCCL is bound at run time (CCSP_RCCL_LIB, else the already-loaded "librccl.so.1" by RTLD_NOLOAD, else dlopen): a process that already carries an RCCL
  * (PyTorch-ROCm) gets that instance.  comm = an ncclComm_t; NULL removes it; a communicator takes precedence over a hook.
  * ccsp_rccl_unique_id / ccsp_rccl_comm_create / ccsp_rccl_comm_destroy wrap ncclGetUniqueId / ncclCommInitRank (on the calling
  * thread's current device; collective over the n_ranks callers) / ncclCommDestroy for hosts that have no communicator of their
@@ -230,6 +234,11 @@ int ccsp_model_set_energy_allreduce(ccsp_model* model, void* comm);
 int ccsp_rccl_unique_id(void* id /* host, CCSP_RCCL_ID_BYTES */);
 int ccsp_rccl_comm_create(int32_t n_ranks, int32_t rank, const void* id, void** comm);
 int ccsp_rccl_comm_destroy(void* comm);
+/* What the communicator itself says (ncclCommCount) and the RCCL it is bound to (ncclGetVersion's code; `version` may be NULL):
+ * bench.py prints both in its N > 1 line as the proof that RCCL joined N ranks.  ccsp_rccl_allreduce_sum_f32 = ncclAllReduce(buf, buf, n,
+ * ncclFloat32, ncclSum) on `stream` over that communicator (the same call the MALA reduction enqueues; buf = device floats). */
+int ccsp_rccl_comm_count(void* comm, int32_t* n_ranks, int32_t* version);
+int ccsp_rccl_allreduce_sum_f32(void* comm, float* buf, int64_t n, void* stream);
 
 /* Kernel-level timing of the most recent ccsp_chain_run on this graph, measured with HIP events
  * on the chain's stream (bench.py's roofline block).  evals = network evaluations executed,
@@ -238,6 +247,15 @@ int ccsp_rccl_comm_destroy(void* comm);
  * row GEMM / edge kernel (0 when profiling is off).  Synchronises on the chain's end. */
 int ccsp_profile_enable(ccsp_graph* graph, int32_t on);
 int ccsp_chain_stats(ccsp_graph* graph, int64_t* evals, float* ms_total, float* ms_ugemm, float* ms_edge);
+
+/* Debugging aid for the Metropolis samplers (AnnealedMALASampler / AnnealedMUHASampler accept tests, ddpm.py:1026-1041,1104-1121): with a
+ * buffer installed, every accept step of the following ccsp_chain_run / ccsp_compose_chain_run calls on this graph writes, per node row,
+ * margin = log(acceptance ratio) - log(u) -- the row is accepted iff margin > 0 -- to margins[k * N + n], k = index of the accept step within
+ * the call in chain order (timesteps t_first..t_last, inner steps ascending).  An accept test is a discrete decision: two correct fp32
+ * implementations decide a row with |margin| ~ 1e-6 either way, and through the batch-scalar energy every later decision follows.  The parity
+ * tests use this to assert that every decision that differs from the reference's is such a near-tie.  DEVICE buffer owned by the caller,
+ * n_floats its size (steps beyond it are not recorded); NULL removes it.  Costs one store per node row and accept step. */
+int ccsp_chain_margins(ccsp_graph* graph, float* margins, int64_t n_floats);
 /* MALA chains (ddpm.py:1012-1047; the gradient and E(x) of ddpm.py:1019,1026): an inner step that accepted NO node leaves x where it was, so E(x) and dE/dx of the next
  * inner step are the values already computed; unless CCSP_MALA_REUSE=0 the kernels of that gradient evaluation then return
  * at once (decided on the device from the accept kernel's count; every kernel is deterministic, so the chain is bitwise the
@@ -268,6 +286,7 @@ int ccsp_plan_host(int32_t N, int32_t E, int32_t C, const int64_t* edge_index, c
                    int32_t* urow_node, int32_t* urow_ts, int32_t* tile_row0, int32_t* tile_nrows,
                    int32_t* tile_ts, int32_t* node_ptr, int32_t* node_ent);
 
+#ifdef CCSP_EXPERIMENTS   /* exported by the experiments build only (libccsp_hip_exp.so; _lib.build(experiments=True)) */
 /* Host-only: the FUSED TILES of the one-launch evaluation kernels (csrc/ccsp_fused.h; the same loop over constraint types and
  * their edges, denoise_fn.py:313-371).  Every type's sorted edges are cut, in order, into runs whose distinct U rows are at most
  * rows_per_slot (<= 32; the kernels use 28 or 32) per slot and whose length is at most max_edges (<= 128; 112 or 128); a workgroup
@@ -278,6 +297,7 @@ int ccsp_plan_host(int32_t N, int32_t E, int32_t C, const int64_t* edge_index, c
  * Caller-sized HOST arrays (tiles [4 E], rows [128 E], e_lu [E]); any of them may be NULL. */
 int ccsp_plan_fused_host(int32_t N, int32_t E, int32_t C, const int64_t* edge_index, const float* edge_attr, int32_t rows_per_slot,
                          int32_t max_edges, int32_t* n_tiles, int32_t* tiles, int32_t* rows, uint16_t* e_lu);
+#endif
 
 /* Host-only: the PARTIAL ROWS of the energy backward (csrc/ccsp_plan.h build_bwdsum_plan).  The reference's autograd adds, for every
  * constraint type, the gradient of an edge's MLP input back onto the two nodes' embeddings (the backward of the gathers at

@@ -15,6 +15,8 @@ for p in (ROOT, os.path.join(ROOT, 'oracle')):
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'gpu_experiments: needs a real MI355X AND the experiments build (CCSP_EXPERIMENTS=1 python -m pytest tests '
+                                       '-m gpu_experiments): the variants that lost their A/Bs, kept out of the product library and of the default -m gpu run')
 
 
 import diffusion_ccsp_amd  # noqa: E402,F401

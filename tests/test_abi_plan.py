@@ -12,9 +12,12 @@ from conftest import ROOT, worlds
 from diffusion_ccsp_amd import _lib
 
 
-def declared_symbols():
+def declared_symbols(experiments=None):
+    """every function include/ccsp.h declares for this build (the #ifdef CCSP_EXPERIMENTS block only for the experiments library)"""
     text = open(os.path.join(ROOT, 'include', 'ccsp.h')).read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    if not (_lib.EXPERIMENTS if experiments is None else experiments):
+        text = re.sub(r'#ifdef CCSP_EXPERIMENTS.*?#endif', '', text, flags=re.S)
     return sorted(set(re.findall(r'\b(ccsp_[a-z_0-9]+)\s*\(', text)))
 
 
@@ -24,8 +27,19 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 17
     for n in names:
         assert hasattr(L, n), n
-    assert L.ccsp_version() == 7
+    assert L.ccsp_version() == 1000 * _lib.ABI_MAJOR + 0             # 1.0: include/ccsp.h CCSP_VERSION_MAJOR / _MINOR
+    assert 'ccsp_plan_fused_host' in declared_symbols(True) and 'ccsp_plan_fused_host' not in declared_symbols(False)
+    if not _lib.EXPERIMENTS:
+        assert not hasattr(L, 'ccsp_plan_fused_host')                # the product library carries none of the experiments
     assert isinstance(L.ccsp_last_error(), bytes)
+
+
+def test_stale_library_of_another_abi_major_is_refused(monkeypatch):
+    """_lib.lib() checks ccsp_version() before it binds anything: a library of another MAJOR version has other signatures"""
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'ABI_MAJOR', _lib.ABI_MAJOR + 1)
+    with pytest.raises(_lib.CcspError, match='ABI version'):
+        _lib.lib()
 
 
 def test_structs_match_header_layout():
@@ -170,6 +184,7 @@ def test_bwdsum_plan_invariants(case):
         assert (np.diff(seg) > 0).all() and (pl['urow_node'][f['prow_urow'][seg]] == n).all()
 
 
+@pytest.mark.skipif(not _lib.EXPERIMENTS, reason='ccsp_plan_fused_host is exported by the experiments build only (CCSP_EXPERIMENTS=1)')
 @pytest.mark.parametrize('shape', [(28, 112), (32, 128)])
 @pytest.mark.parametrize('case', ['qualitative', 'triangular', 'robot', 'ragged', 'shuffled'])
 def test_fused_plan_invariants(case, shape):

@@ -5,7 +5,7 @@ ROOT = os.environ.get('GRAFT_REPO_ROOT', '/root/repo'); sys.path.insert(0, ROOT)
 if sys.argv[1] == '--run':
     import torch
     from diffusion_ccsp_amd import ConstraintDiffuser, GaussianDiffusion, worlds, _lib
-    _lib.SO = os.environ['CCSP_SO']; _lib._stale = lambda: False
+    _lib.SO = os.environ['CCSP_SO']; _lib._stale = lambda *a: False
     from bench import load_weights
     dev = torch.device('cuda:0')
     den = ConstraintDiffuser(dims=worlds.MODE_DIMS['diffuse_pairwise'], hidden_dim=256, input_mode='diffuse_pairwise', EBM='MALA', energy_wrapper=True,

@@ -4,7 +4,7 @@ if len(sys.argv) > 1:
     import torch
     from diffusion_ccsp_amd import ConstraintDiffuser, GaussianDiffusion, worlds, _lib
     if os.environ.get('CCSP_SO'):
-        _lib.SO = os.environ['CCSP_SO']; _lib._stale = lambda: False
+        _lib.SO = os.environ['CCSP_SO']; _lib._stale = lambda *a: False
     from bench import load_weights
     dev = torch.device('cuda:0')
     den = ConstraintDiffuser(dims=worlds.MODE_DIMS['qualitative'], hidden_dim=256, input_mode='qualitative', device=dev, verbose=False)

@@ -4,7 +4,7 @@ ROOT = os.environ.get('GRAFT_REPO_ROOT', '/root/repo'); sys.path.insert(0, ROOT)
 import numpy as np, torch
 from diffusion_ccsp_amd import _lib
 if os.environ.get('CCSP_SO'):
-    _lib.SO = os.environ['CCSP_SO']; _lib._stale = lambda: False
+    _lib.SO = os.environ['CCSP_SO']; _lib._stale = lambda *a: False
 from conftest import golden
 import test_hip_parity as T
 from test_oracle_golden import MALA_SEGMENTS

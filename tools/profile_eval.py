@@ -13,7 +13,7 @@ from bench import CONFIGS, load_weights
 from diffusion_ccsp_amd import ConstraintDiffuser, worlds, _lib
 if os.environ.get('CCSP_SO'):          # ablation builds (tools only)
     _lib.SO = os.environ['CCSP_SO']
-    _lib._stale = lambda: False
+    _lib._stale = lambda *a: False
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 cfg = CONFIGS[sys.argv[3] if len(sys.argv) > 3 else 'c2']

@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 import torch
 from diffusion_ccsp_amd import _lib, ConstraintDiffuser, GaussianDiffusion, worlds
 if os.environ.get('CCSP_SO'):
-    _lib.SO = os.environ['CCSP_SO']; _lib._stale = lambda: False
+    _lib.SO = os.environ['CCSP_SO']; _lib._stale = lambda *a: False
 from bench import load_weights
 dev = torch.device('cuda:0')
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256

@@ -8,7 +8,7 @@ os.environ.setdefault('CCSP_LANES', '1')
 import numpy as np, torch
 import diffusion_ccsp_amd
 from diffusion_ccsp_amd import _lib, ConstraintDiffuser, GaussianDiffusion, worlds
-_lib.SO = os.environ.get('CCSP_SO') or os.path.join(ROOT, 'tools', 'abl_trace.so'); _lib._stale = lambda: False
+_lib.SO = os.environ.get('CCSP_SO') or os.path.join(ROOT, 'tools', 'abl_trace.so'); _lib._stale = lambda *a: False
 from bench import load_weights
 dev = torch.device('cuda:0')
 which = sys.argv[1] if len(sys.argv) > 1 else '256'
