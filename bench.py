@@ -64,7 +64,7 @@ S_LANGEVIN = 10
 
 CONFIGS = {
     'c2': dict(mode='qualitative', n_types=13, n_objects=8, graphs=256, EBM='ULA', energy=False, batch='qualitative_batch',
-               weights=('weights/qualitative_h256_ref30k_fp32.npz', 'weights/qualitative_h256_trained.npz', 'tests/golden/weights_qualitative_h256.npz'),
+               weights=('weights/qualitative_h256_ref30k.npz', 'tests/golden/weights_qualitative_h256.npz'),
                label='C2: RandomSplitQualitativeWorld 8 objects, T=1000 ULA S=10'),
     'c4': dict(mode='diffuse_pairwise', n_types=2, n_objects=12, graphs=256, EBM='MALA', energy=True, batch='triangular_batch',
                weights=('tests/golden/weights_diffuse_pairwise_h256_energy.npz',),
@@ -74,13 +74,13 @@ CONFIGS = {
                label='C5: 3D panda-box packing (robot_box) 10 objects, T=1000 ULA S=10'),
 }
 WEIGHT_NOTES = {
-    'weights/qualitative_h256_ref30k_fp32.npz': 'the reference recipe AS WRITTEN for input_mode qualitative (train_utils.py:87,142-156,217-218; ddpm.py:444,519-556: a fixed set of '
-                                                '30 000 worlds of 2-5 objects, shuffled epochs, batch 128, Adam 5e-4, no EMA) on one MI355X by tools/train_gpu.py TRAIN_RECIPE=reference, '
-                                                'the 30 000-step checkpoint, stored in fp32.  The recipe runs 300 000 steps; the solved rate of its checkpoints peaks at 30-40 k steps '
-                                                'and falls afterwards because the reference sampler overflows fp32 on more and more graphs (profiles/r03_solved_curve_reference_recipe*.json, '
-                                                'tests/golden/chain_q256_ref300k_B16.npz = the REFERENCE sampling with the 300 000-step weights: 16 of 16 graphs non-finite)',
-    'weights/qualitative_h256_trained.npz': '12 000 steps on one MI355X by tools/train_gpu.py with the reference recipe (p_losses l2, one t per batch, '
-                                            'Adam 5e-4, batch 128) on worlds of 2-8 objects from this package\'s generator',
+    'weights/qualitative_h256_ref30k.npz': 'the reference recipe AS WRITTEN for input_mode qualitative (train_utils.py:87,142-156,217-218; ddpm.py:444,519-556: a fixed set of '
+                                           '30 000 worlds of 2-5 objects, shuffled epochs, batch 128, Adam 5e-4, no EMA) on one MI355X by tools/train_gpu.py TRAIN_RECIPE=reference, '
+                                           'the 30 000-step checkpoint; the thirteen type-MLP matrices stored int8 per output row (round 5: 34 MB -> 10 MB of what travels to the GPU box; '
+                                           'the DEQUANTISED values are the weights -- tests/golden/chain_q256_bench_B16 is the REFERENCE sampling with exactly these).  The recipe runs '
+                                           '300 000 steps; the solved rate of its checkpoints peaks at 30-40 k steps and falls afterwards because the reference sampler overflows fp32 on '
+                                           'more and more graphs (profiles/r03_solved_curve_reference_recipe*.json, tests/golden/chain_q256_ref300k_B16.npz = the REFERENCE sampling with '
+                                           'the 300 000-step weights: 16 of 16 graphs non-finite).  tools/fetch_or_train_weights.sh re-trains any of the checkpoints',
     'tests/golden/weights_qualitative_h256.npz': 'parity fixture: 2000 CPU steps of the reference loss (oracle/ref_train.py)',
     'tests/golden/weights_diffuse_pairwise_h256_energy.npz': 'parity fixture: 1200 CPU steps of the reference loss in energy mode (oracle/ref_train.py); the weights '
                                                              'the reference-generated C4 goldens were made with',

@@ -396,6 +396,8 @@ __global__ __launch_bounds__(256, MODE == 0 ? CCSP_H2_MODE0_WGS : (MODE == 6 ? 4
                                                        float* __restrict__ U, float* __restrict__ umax, StepRef ref, size_t tau_stride) {
     static_assert(ND % 128 == 0 && KD % H2_BK == 0 && KD / H2_BK >= 4, "shape");
     constexpr bool FWD = KD < ND;                                 // <256, 512>: the forward GEMM (base, time term, row maxima); <512, 256>: the transpose
+    CCSP_TRK2_DECL
+    CCSP_TRK2(0);
     CCSP_TRK(0, 0);
     CCSP_TRK_RT(0, 30);
     if (ref.skip && *ref.skip == 0) return;                       // (uniform) MALA reuse: the state has not moved since this was computed
@@ -746,9 +748,11 @@ __global__ __launch_bounds__(256, MODE == 0 ? CCSP_H2_MODE0_WGS : (MODE == 6 ? 4
             __syncthreads();
             for (int c = 0; c < NCH; ++c) {
                 CCSP_TRK(0, 2 + (c < 8 ? c : 7));
+                CCSP_TRK2(1 + 2 * c);                             // chunk c: the stage is visible, the MFMAs begin
                 if constexpr (FWD) { if (c == NCH - 1) h2_epilogue_prefetch<ND>(bs0, 0, wr0, nrows, row0, colw, base); }
                 h2_kstep<MI>(smem, APL, smem + 2 * APL, 0, wr0, wn * 64, acc);
                 h2_kstep<MI>(smem, APL, smem + 2 * APL, 1, wr0, wn * 64, acc);
+                CCSP_TRK2(2 + 2 * c);                             // wave 0 has issued its MFMAs and waits at the barrier
                 __syncthreads();                                  // every wave is done reading the stage
                 if (c + 1 < NCH) {
                     lstore(0, 0);
@@ -759,6 +763,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? CCSP_H2_MODE0_WGS : (MODE == 6 ? 4
         }
     }
     // (every wave is past the last barrier: the stages are free for the wave-private epilogue tiles)
+    CCSP_TRK2(25);
     CCSP_TRK(0, 10);
     h2_epilogue_wave<ND, MI, FWD, PRE1>(acc, bs0, bs1, tv, reinterpret_cast<float*>(smem) + wave * H2_CW_SZ, wr0, nrows, row0, colw, sE, w_exp, base, has_tau,
                                         U, umax, 2 * NCT, 2 * ct + wn);
@@ -767,6 +772,12 @@ __global__ __launch_bounds__(256, MODE == 0 ? CCSP_H2_MODE0_WGS : (MODE == 6 ? 4
 #endif
     CCSP_TRK_RT(0, 31);
     CCSP_TRK(0, 17);
+    CCSP_TRK2(26);                                                // wave 0's epilogue has issued its last store
+#ifdef CCSP_TRACE2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CCSP_TRK2(27);                                                // ... and its stores have been acknowledged
+    CCSP_TRK2_FLUSH();
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

@@ -48,6 +48,38 @@ __device__ unsigned long long g_trace[3 * 256 * 32];
 #define CCSP_TRK_RT(kern, k) do { } while (0)
 #endif
 
+// Second profiling build (tools/trace2_build.py, -DCCSP_TRACE2; round 5): the phase boundaries of EVERY workgroup of k_rowgemm_h2 at the product
+// kernel's own residency (three workgroups per CU in MODE 0), with the hardware slot the workgroup ran on (HW_ID: shader engine, CU, SIMD of
+// wave 0; XCC_ID), so that the phases of the workgroups that SHARE a compute unit can be laid next to each other on that CU's own clock.  Stamps
+// go to LDS (one ds_write_b32 of lane 0, a dword each: the low half of s_memtime) and leave for global memory once, at the kernel's end.
+#ifdef CCSP_TRACE2
+__device__ unsigned int g_trace2[4096 * 40];
+// (scalar stores: no vector register, no exec-mask change, nothing added to the kernel's 168-VGPR budget; s_dcache_wb at the end)
+#define CCSP_TRK2_DECL unsigned int* const trk2_ptr = g_trace2 + (size_t)(blockIdx.x < 4096 ? blockIdx.x : 4095) * 40;
+#define CCSP_TRK2(k)                                                                                                              \
+    do {                                                                                                                          \
+        const unsigned int lo_ = (unsigned int)__builtin_amdgcn_s_memtime();                                                      \
+        const unsigned int off_ = 4u * (unsigned int)(k);                                                                         \
+        asm volatile("s_store_dword %0, %1, %2 glc" :: "s"(lo_), "s"(trk2_ptr), "s"(off_) : "memory");                            \
+    } while (0)
+#define CCSP_TRK2_FLUSH()                                                                                                         \
+    do {                                                                                                                          \
+        unsigned int h0_, h1_;                                                                                                    \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(h0_));                                                         \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(h1_));                                                        \
+        const unsigned int rt_ = (unsigned int)__builtin_amdgcn_s_memrealtime();                                                  \
+        const unsigned int o0_ = 4u * 36u, o1_ = 4u * 37u, o2_ = 4u * 38u;                                                        \
+        asm volatile("s_store_dword %0, %1, %2 glc" :: "s"(h0_), "s"(trk2_ptr), "s"(o0_) : "memory");                             \
+        asm volatile("s_store_dword %0, %1, %2 glc" :: "s"(h1_), "s"(trk2_ptr), "s"(o1_) : "memory");                             \
+        asm volatile("s_store_dword %0, %1, %2 glc" :: "s"(rt_), "s"(trk2_ptr), "s"(o2_) : "memory");                             \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb" ::: "memory");                                                        \
+    } while (0)
+#else
+#define CCSP_TRK2_DECL
+#define CCSP_TRK2(k) do { } while (0)
+#define CCSP_TRK2_FLUSH() do { } while (0)
+#endif
+
 namespace {
 
 thread_local char g_err[512] = "";
@@ -1087,7 +1119,10 @@ __device__ __forceinline__ void node_body(NodeArgs a, const EncW w, const EncOut
                     else u = ccsp::philox_uniform(a.noise.seed, a.noise.row_offset + (unsigned long long)n, a.noise.ucall);
                     const float accf = (u < expf(la)) ? 1.0f : 0.0f;
                     if (p == 0 && accf != 0.0f && a.acc_count) atomicAdd(a.acc_count, 1);
-                    if (p == 0 && a.margin) a.margin[n] = la - logf(u);      // > 0 accepted, < 0 rejected; |margin| small = a near-tie
+                    if (p == 0 && a.margin) {            // > 0 accepted, < 0 rejected; |margin| small against the terms it is the difference of = a near-tie
+                        a.margin[n] = la - logf(u);
+                        a.margin[a.N + n] = fabsf(logp_h) + fabsf(logp_x) + fabsf(lrev) + fabsf(lfwd);
+                    }
                     xv = accf * hc + (1.0f - accf) * xv;
                 } else {                                        // ddpm.py:273
                     xv = 0.5f * z;
@@ -2453,8 +2488,8 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
 
 // slot k (= index of the accept step within this call, chain order) of the margin buffer installed by ccsp_chain_margins, or null
 float* margin_at(const ccsp_graph* g, uint64_t k) {
-    if (!g->margin_buf || (int64_t)((k + 1) * (uint64_t)g->N) > g->margin_cap) return nullptr;
-    return g->margin_buf + (size_t)k * g->N;
+    if (!g->margin_buf || (int64_t)((k + 1) * 2 * (uint64_t)g->N) > g->margin_cap) return nullptr;
+    return g->margin_buf + (size_t)k * 2 * g->N;
 }
 
 int steps_at(const ccsp_model* m, int sampler, int t) {
@@ -3972,6 +4007,12 @@ int ccsp_chain_run(ccsp_model* m, ccsp_graph* g, int32_t sampler, const ccsp_noi
     HIP_TRY(hipEventRecord(g->ev1, s));
     return rc;
 }
+
+#ifdef CCSP_TRACE2
+int ccsp_debug_trace2(unsigned int* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace2), sizeof(unsigned int) * 4096 * 40) == hipSuccess ? 0 : 1;
+}
+#endif
 
 #ifdef CCSP_TRACE
 int ccsp_debug_trace(unsigned long long* out) {

@@ -63,7 +63,10 @@ __global__ __launch_bounds__(256) void k_hmc(HmcArgs a) {
     else u = ccsp::philox_uniform(a.noise.seed, a.noise.row_offset + (unsigned long long)n, a.noise.ucall);
     const float acc = (u < expf(la)) ? 1.0f : 0.0f;
     if (p == 0 && acc != 0.0f && a.acc_count) atomicAdd(a.acc_count, 1);
-    if (p == 0 && a.margin) a.margin[n] = la - logf(u);
+    if (p == 0 && a.margin) {
+        a.margin[n] = la - logf(u);
+        a.margin[a.N + n] = fabsf(logp_h) + fabsf(lv) + fabsf(logp_x) + fabsf(lvp);
+    }
     float xv = acc * a.xl[i] + (1.0f - acc) * a.x[i];
     const float vv = acc * a.vl[i] + (1.0f - acc) * a.vp[i];
     if (a.reset_mask && a.mask[n]) xv = a.xfeat[(size_t)n * a.F + a.pose_begin + p];

@@ -241,14 +241,14 @@ class GaussianDiffusion(object):
         return int(sps) if np.isscalar(sps) else int(np.asarray(sps)[t])
 
     def _margin_buffer(self, g, t_first, t_last):
-        """record_margins (debugging aid; ccsp_chain_margins): a [accept steps of this call, N] buffer the accept kernels fill with
-        log(acceptance ratio) - log(u) per node row -- positive = accepted, negative = rejected, |value| small = a near-tie that fp32
-        rounding may decide either way (the parity tests assert that every decision differing from the reference's is one).
-        -> self.last_margins after the chain"""
+        """record_margins (debugging aid; ccsp_chain_margins): a [accept steps of this call, 2, N] buffer the accept kernels fill with
+        [:, 0] = log(acceptance ratio) - log(u) per node row -- positive = accepted, negative = rejected -- and [:, 1] = the sum of the
+        absolute values of the terms of that ratio; |margin| <~ 1e-6 scale = a near-tie that fp32 rounding may decide either way (the
+        parity tests assert that every difference from the reference's decisions begins at one).  -> self.last_margins after the chain"""
         if not self.record_margins or self._sampler() not in ('MALA', 'HMC'):
             return None
         k = sum(self._inner_steps(t) for t in range(int(t_last), int(t_first) + 1))
-        marg = torch.full((max(k, 1), g.N), float('nan'), device=self.device, dtype=torch.float32)
+        marg = torch.full((max(k, 1), 2, g.N), float('nan'), device=self.device, dtype=torch.float32)
         _lib.check(_lib.lib().ccsp_chain_margins(g.h, _ptr(marg), marg.numel()))
         return marg
 

@@ -250,9 +250,10 @@ int ccsp_chain_stats(ccsp_graph* graph, int64_t* evals, float* ms_total, float* 
 
 /* Debugging aid for the Metropolis samplers (AnnealedMALASampler / AnnealedMUHASampler accept tests, ddpm.py:1026-1041,1104-1121): with a
  * buffer installed, every accept step of the following ccsp_chain_run / ccsp_compose_chain_run calls on this graph writes, per node row,
- * margin = log(acceptance ratio) - log(u) -- the row is accepted iff margin > 0 -- to margins[k * N + n], k = index of the accept step within
- * the call in chain order (timesteps t_first..t_last, inner steps ascending).  An accept test is a discrete decision: two correct fp32
- * implementations decide a row with |margin| ~ 1e-6 either way, and through the batch-scalar energy every later decision follows.  The parity
+ * margin = log(acceptance ratio) - log(u) -- the row is accepted iff margin > 0 -- to margins[k * 2 N + n] and scale = the sum of the absolute
+ * values of the four terms the ratio is made of (the two batch log-probabilities, the two proposal / momentum log-densities) to
+ * margins[k * 2 N + N + n], k = index of the accept step within the call in chain order (timesteps t_first..t_last, inner steps ascending).  An accept test is a discrete decision: two correct fp32
+ * implementations decide a row with |margin| <~ 1e-6 scale either way, and through the batch-scalar energy every later decision follows.  The parity
  * tests use this to assert that every decision that differs from the reference's is such a near-tie.  DEVICE buffer owned by the caller,
  * n_floats its size (steps beyond it are not recorded); NULL removes it.  Costs one store per node row and accept step. */
 int ccsp_chain_margins(ccsp_graph* graph, float* margins, int64_t n_floats);

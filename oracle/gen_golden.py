@@ -560,26 +560,84 @@ def gen_options():
     print('options.npz  randn calls %d  |final|max %.3g  |hist|max %.3g' % (pn.c, np.abs(rec['final']).max(), np.abs(rec['hist']).max()))
 
 
-def build_composed_reference(H, W_robot, W_qual, weight=(1, 1), T=1000, S=10, EBM='ULA', energy=False):
+def build_composed_reference(H, W_robot, W_qual, weight=(1, 1), T=1000, S=10, EBM='ULA', energy=False, dtype=torch.float32):
     """the reference's composed denoiser the way its code expects to be assembled (nothing in the repository does the
     assembly: pose_encoder_2 & co. are None after the constructor, denoise_fn.py:287-291): a 'robot_qualitative'
     ConstraintDiffuser holding the robot domain's weights, the qualitative model's thirteen type MLPs appended to its
     ModuleList (so that type i >= 2 is qualitative type i - 2, denoise_fn.py:24,310-311), and the qualitative model's
     encoders / decoder / time MLP as the *_2 modules."""
-    model = dfn.ConstraintDiffuser(dims=worlds.MODE_DIMS['robot_box'], hidden_dim=H, EBM=EBM, input_mode='robot_qualitative',
-                                   device='cpu', verbose=False)
-    model.load_state_dict({k: torch.from_numpy(v) for k, v in W_robot.items()})
-    qual = dfn.ConstraintDiffuser(dims=worlds.MODE_DIMS['qualitative'], hidden_dim=H, EBM=EBM, input_mode='qualitative',
-                                  device='cpu', verbose=False)
-    qual.load_state_dict({k: torch.from_numpy(v) for k, v in W_qual.items()})
-    model.mlps.extend(qual.mlps)
-    model.pose_encoder_2, model.geom_encoder_2 = qual.pose_encoder, qual.geom_encoder
-    model.pose_decoder_2, model.time_mlp_2 = qual.pose_decoder, qual.time_mlp
-    model.composing_weight = tuple(weight)
-    if energy:      # the composed model in energy mode: its forward returns (dE/dposes, E) (denoise_fn.py:539-548), wrapped like any energy model
-        model.energy_wrapper = True
-    gd = ddpm.GaussianDiffusion(dfn.ComposedEBMDenoiseFn(model) if energy else model, timesteps=T, EBM=EBM, samples_per_step=S, step_sizes='2*self.betas')
+    if dtype == torch.float64:
+        torch.set_default_dtype(torch.float64)
+    try:
+        model = dfn.ConstraintDiffuser(dims=worlds.MODE_DIMS['robot_box'], hidden_dim=H, EBM=EBM, input_mode='robot_qualitative',
+                                       device='cpu', verbose=False)
+        model.load_state_dict({k: torch.from_numpy(v).to(dtype) for k, v in W_robot.items()})
+        qual = dfn.ConstraintDiffuser(dims=worlds.MODE_DIMS['qualitative'], hidden_dim=H, EBM=EBM, input_mode='qualitative',
+                                      device='cpu', verbose=False)
+        qual.load_state_dict({k: torch.from_numpy(v).to(dtype) for k, v in W_qual.items()})
+        model.mlps.extend(qual.mlps)
+        model.pose_encoder_2, model.geom_encoder_2 = qual.pose_encoder, qual.geom_encoder
+        model.pose_decoder_2, model.time_mlp_2 = qual.pose_decoder, qual.time_mlp
+        model.composing_weight = tuple(weight)
+        if energy:      # the composed model in energy mode: its forward returns (dE/dposes, E) (denoise_fn.py:539-548), wrapped like any energy model
+            model.energy_wrapper = True
+        gd = ddpm.GaussianDiffusion(dfn.ComposedEBMDenoiseFn(model) if energy else model, timesteps=T, EBM=EBM, samples_per_step=S, step_sizes='2*self.betas')
+        if dtype == torch.float64:      # (as build_reference: the custom kappa buffer is a plain attribute, step_sizes a tensor expression of the fp32 betas)
+            gd = gd.double()
+            gd._sqrt_recipm1_alphas_cumprod_custom = gd._sqrt_recipm1_alphas_cumprod_custom.double()
+            gd.step_sizes = gd.step_sizes.double() if torch.is_tensor(gd.step_sizes) else gd.step_sizes
+    finally:
+        torch.set_default_dtype(torch.float32)
     return model, gd.eval()
+
+
+def ref_single_timestep(gd, batch, x, t, seed, dtype=torch.float32):
+    """ONE iteration of GaussianDiffusion.p_sample_loop's body from the state x, for the Metropolis samplers.  Every piece is the reference's
+    own code (p_sample, AnnealedMALASampler / AnnealedMUHASampler.sample_step, the denoiser); only the glue around them is restated, line by
+    line: the gradient / energy closures (ddpm.py:279-289), the sampler construction (:301-317), the loop body (:322-334), and the noise draws
+    keep the call numbers they have in the full chain.  Used for ONE thing: the reference's own fp32-vs-fp64 disagreement over a single
+    timestep (the noise floor a parity bar may be quoted against).  Checked where it is used: in fp32 it reproduces the recorded chain's
+    successor BIT FOR BIT."""
+    T, EBM = int(gd.num_timesteps), gd.EBM
+    S = 4 if EBM == 'HMC' else int(gd.samples_per_step)
+    per_t = 1 + S + (1 if EBM == 'HMC' else 0)
+    m = batch.mask
+    gt_features = batch.x[:, gd.dims[-1][1]:gd.dims[-1][2]].to(dtype)
+    shape = gt_features.shape
+
+    def gradient_function(xx, bb, tt):
+        return - gd.denoise_fn(xx, bb, tt, eval=True) * gd._sqrt_recipm1_alphas_cumprod_custom[tt]
+
+    def energy_function(xx, bb, tt):
+        return - gd.denoise_fn.neg_logp_unnorm(xx, bb, tt, eval=True) * gd._sqrt_recipm1_alphas_cumprod_custom[tt]
+
+    def noise_function():
+        return torch.randn(shape)
+    if EBM == 'MALA':
+        sampler = ddpm.AnnealedMALASampler(gd.samples_per_step, gd.step_sizes, gradient_function, noise_function, energy_function)
+    else:
+        sampler = ddpm.AnnealedMUHASampler(4, gd.step_sizes, 0, 9 * gd.betas, 2, gradient_function=gradient_function, energy_function=energy_function)
+    rates = []
+    orig_upd = ddpm.MetropolisSampler._update_acceptance_rate
+    ddpm.MetropolisSampler._update_acceptance_rate = lambda self, accept_rate, tt, debug=False: rates.append(float(accept_rate))
+    pn = PatchedNoise(seed, dtype)
+    pn.c, pn.uc = 1 + (T - 1 - t) * per_t, (T - 1 - t) * S
+    b = batch.clone()
+    b.x = b.x.to(dtype)
+    prev = torch.is_grad_enabled()
+    torch.set_grad_enabled(True)
+    torch.set_default_dtype(dtype)
+    try:
+        with pn, contextlib.redirect_stdout(io.StringIO()):
+            tt = torch.full((1,), t, dtype=torch.long)
+            pose = gd.p_sample(b, torch.as_tensor(x).to(dtype).clone(), tt, tag='EBM')
+            pose = sampler.sample_step(pose, b, tt)
+            pose[m.bool()] = gt_features[m.bool()].clone()
+    finally:
+        torch.set_default_dtype(torch.float32)
+        torch.set_grad_enabled(prev)
+        ddpm.MetropolisSampler._update_acceptance_rate = orig_upd
+    return pose.detach().numpy(), (rates[-1] if rates else 0.0)
 
 
 def gen_composed():
@@ -680,6 +738,69 @@ def gen_composed_energy_chains():
         print('%-24s %6.1fs  randn calls %d  |final|max %.3g  |hist|max %.3g' % (name, dt, pn.c, np.abs(out).max(), np.abs(hist).max()), flush=True)
 
 
+def gen_composed_metropolis(which=()):
+    """MALA and HMC of the REFERENCE on a composed energy model (AnnealedMALASampler / AnnealedMUHASampler, ddpm.py:999-1047,1050-1128, over
+    ComposedEBMDenoiseFn around the 'robot_qualitative' ConstraintDiffuser with energy_wrapper=True; denoise_fn.py:287-291,310-311,341-371,
+    487-503), the reference's default schedule (step_sizes '2*self.betas'), EVERY state recorded together with the reference's own
+    acceptance log (MetropolisSampler._update_acceptance_rate), like chain_t256_mala.  Unlike ULA on the same energy (chain_c*_ula_energy:
+    overflows fp32 within a dozen timesteps) the Metropolis chains stay finite: the first timesteps climb to 1e14 through the ancestral
+    step's gain on the zero column, the accept test rejects what would grow further, and from t ~ 950 on the T = 1000 MALA chain sits at
+    |x| ~ 1 with mixed acceptance.  HMC at T = 1000 never accepts (its leapfrog uses the step size and mass of index 0..3, ddpm.py:1076-1084),
+    so its fixtures use T = 20 / T = 8 like chain_t64_hmc_T20."""
+    jobs = (('chain_c64_mala', 64, 'MALA', 1000, 2, 13, 55), ('chain_c256_mala', 256, 'MALA', 200, 2, 14, 56),
+            ('chain_c64_hmc', 64, 'HMC', 20, 4, 15, 57), ('chain_c256_hmc', 256, 'HMC', 8, 4, 16, 58), ('chain_c256_hmc_T20', 256, 'HMC', 20, 4, 17, 59))
+    for name, H, EBM, T, S, seed, bseed in jobs:
+        if which and name not in which:
+            continue
+        sfx = '_energy' if H == 64 else ''          # hidden_dim 64: both domains trained in energy mode; 256: the direct-mode fixtures (as chain_c256_ula_energy)
+        Wr = oracle_mod.load_weights(os.path.join(GOLD, 'weights_robot_box_h%d%s.npz' % (H, sfx)))
+        Wq = oracle_mod.load_weights(os.path.join(GOLD, 'weights_qualitative_h%d%s.npz' % (H, sfx)))
+        model, gd = build_composed_reference(H, Wr, Wq, (1, 1), T=T, S=S, EBM=EBM, energy=True)
+        b = worlds.robot_qualitative_batch(2, 6, seed=bseed).to_torch()
+        rates = {}
+        orig_upd = ddpm.MetropolisSampler._update_acceptance_rate
+
+        def record(self, accept_rate, t, debug=False):
+            rates[int(t)] = float(accept_rate)
+            return orig_upd(self, accept_rate, t, debug)
+        ddpm.MetropolisSampler._update_acceptance_rate = record
+        t0 = time.time()
+        try:
+            with PatchedNoise(seed) as pn, contextlib.redirect_stdout(io.StringIO()):
+                out, hist = gd.sample(b.clone(), return_history=True)
+        finally:
+            ddpm.MetropolisSampler._update_acceptance_rate = orig_upd
+        dt = time.time() - t0
+        out = out.detach().numpy()
+        hist = np.stack([h.detach().numpy() for h in hist])
+        r = dict(batch_arrays(b))
+        if EBM == 'HMC':
+            # the reference's OWN sensitivity, timestep by timestep: the fp64 reference run for one timestep from each recorded fp32 state.  The leapfrog
+            # map of this energy amplifies rounding differences of the gradient evaluations several thousand-fold at hidden_dim 256; a parity bar
+            # on the successor state is quoted against THIS disagreement, not against anything an implementation under test measured.
+            _, gd32 = build_composed_reference(H, Wr, Wq, (1, 1), T=T, S=S, EBM=EBM, energy=True)
+            _, gd64 = build_composed_reference(H, Wr, Wq, (1, 1), T=T, S=S, EBM=EBM, energy=True, dtype=torch.float64)
+            nxt64, acc64 = [], []
+            for k in range(T):
+                x32, a32 = ref_single_timestep(gd32, b, hist[k], T - 1 - k, seed)
+                assert np.array_equal(x32, hist[k + 1], equal_nan=True) and abs(a32 - rates.get(T - 1 - k, 0.0)) < 1e-9, ('single-timestep glue != chain', name, k)
+                x64, a64 = ref_single_timestep(gd64, b, hist[k].astype(np.float64), T - 1 - k, seed, torch.float64)
+                nxt64.append(x64)
+                acc64.append(a64)
+            r.update(next_f64=np.stack(nxt64).astype(np.float64), accept_f64=np.asarray(acc64, dtype=np.float64))
+            fl = [float(np.abs(nxt64[k] - hist[k + 1]).max() / (1.0 + np.abs(hist[k + 1]).max())) for k in range(T)]
+            print('   fp32-vs-fp64 reference, one timestep from the same state: max relative difference %.2e (per timestep: %s); acceptance equal: %s'
+                  % (max(fl), ' '.join('%.1e' % v for v in fl), bool(np.allclose(acc64, r.get('accept', [rates.get(t, 0.0) for t in range(T - 1, -1, -1)]) if False else [rates.get(T - 1 - k, 0.0) for k in range(T)]))))
+        r.update(final=out, hist_idx=np.arange(T + 1, dtype=np.int32), hist=hist, seed=np.int64(seed), T=np.int32(T), S=np.int32(S),
+                 S_accept=np.int32(4 if EBM == 'HMC' else S), H=np.int32(H), n_randn=np.int64(pn.c), n_rand=np.int64(pn.uc),
+                 weight=np.asarray((1, 1), dtype=np.float32), accept=np.asarray([rates.get(t, 0.0) for t in range(T)], dtype=np.float32),
+                 ref_seconds=np.float64(dt), sampler=np.asarray(EBM))
+        np.savez_compressed(os.path.join(GOLD, name + '.npz'), **r)
+        print('%-20s %6.1fs  randn %d rand %d  finite %s  |hist|max %.3g  |final|max %.3g  acceptance mean %.3f  distinct rates %d' %
+              (name, dt, pn.c, pn.uc, bool(np.isfinite(hist).all()), np.nanmax(np.abs(hist)), np.nanmax(np.abs(out)), float(r['accept'].mean()),
+               len(set(np.round(r['accept'], 4)))), flush=True)
+
+
 def gen_chains(which):
     jobs = {
         'chain_sd64_ula': lambda: run_chain('chain_sd64_ula', 'qualitative', 64, 'weights_qualitative_h64_sd.npz',
@@ -726,18 +847,26 @@ def gen_chains(which):
                                              worlds.triangular_batch(4, 12, seed=44).to_torch(), 'MALA', S=10, energy=True, full_hist=True),
         'chain_r256_ula': lambda: run_chain('chain_r256_ula', 'robot_box', 256, 'weights_robot_box_h256.npz',
                                             worlds.robot_box_batch(3, 10, seed=45).to_torch(), 'ULA', S=10),
+        # HMC at the BASELINE hidden width (round 5): T = 20 where its proposals are accepted and rejected (every state + the acceptance log),
+        # and T = 100 (sparser acceptance)
+        'chain_t256_hmc_T20': lambda: run_chain('chain_t256_hmc_T20', 'diffuse_pairwise', 256, 'weights_diffuse_pairwise_h256_energy.npz',
+                                                worlds.triangular_batch(3, 12, seed=48).to_torch(), 'HMC', T=20, energy=True),
+        'chain_t256_hmc_T100': lambda: run_chain('chain_t256_hmc_T100', 'diffuse_pairwise', 256, 'weights_diffuse_pairwise_h256_energy.npz',
+                                                 worlds.triangular_batch(2, 12, seed=49).to_torch(), 'HMC', T=100, energy=True, full_hist=True),
         # bench.py's C2 weights on 8-object graphs: what the REFERENCE sampler does with them (finite rows, non-finite rows,
         # final poses for the solved check) -- the HIP path must show the same rows and the same solved mask
-        'chain_q256_bench_B16': lambda: run_chain('chain_q256_bench_B16', 'qualitative', 256, 'weights/qualitative_h256_trained.npz',
+        'chain_q256_bench_B16': lambda: run_chain('chain_q256_bench_B16', 'qualitative', 256, 'weights/qualitative_h256_ref30k.npz',
                                                   worlds.qualitative_batch(16, 8, seed=19).to_torch(), 'ULA'),
-        # a longer-trained checkpoint of the same recipe (50 000 steps): the REFERENCE sampler overflows fp32 on most 8-object
-        # graphs with it -- the better the network fits, the larger the transient of the first timesteps
-        'chain_q256_50k_B16': lambda: run_chain('chain_q256_50k_B16', 'qualitative', 256, 'weights/qualitative_h256_50k.npz',
-                                                worlds.qualitative_batch(16, 8, seed=19).to_torch(), 'ULA'),
+        # (round 1-4 kept a 50 000-step checkpoint of the earlier recipe for the MIXED case -- some graphs overflow, some do not; round 5 gets
+        # that case from the 300 000-step reference-recipe weights under the reference's documented S = 3, below, and dropped the 10 MB file)
         # the reference recipe AS WRITTEN (30 000 fixed worlds of 2-5 objects, 300 000 Adam steps, tools/train_gpu.py TRAIN_RECIPE=reference;
         # profiles/r03_train_reference_recipe_log.txt): what the REFERENCE sampler does with the final weights on 8-object graphs
         'chain_q256_ref300k_B16': lambda: run_chain('chain_q256_ref300k_B16', 'qualitative', 256, 'weights/qualitative_h256_ref300k.npz',
                                                     worlds.qualitative_batch(16, 8, seed=19).to_torch(), 'ULA'),
+        # ... and the same weights under samples_per_step = 3 (the reference's documented command line, train_ddpm.py:31-35): a MIXED batch -- most
+        # graphs come back from the transient, some overflow fp32 and stay non-finite
+        'chain_q256_ref300k_S3_B32': lambda: run_chain('chain_q256_ref300k_S3_B32', 'qualitative', 256, 'weights/qualitative_h256_ref300k.npz',
+                                                       worlds.qualitative_batch(32, 8, seed=21).to_torch(), 'ULA', S=3),
         'chain_q64_T1000_B4_f64': lambda: run_chain('chain_q64_T1000_B4_f64', 'qualitative', 64, 'weights_qualitative_h64.npz',
                                                     worlds.qualitative_batch(4, 8, seed=31).to_torch(), 'ULA', dtype=torch.float64),
     }
@@ -778,6 +907,8 @@ if __name__ == '__main__':
         gen_composed()
     if not which or 'composed_energy' in which:
         gen_composed_energy_chains()
+    if not which or 'composed_metropolis' in which or any(w.startswith('chain_c') and ('mala' in w or 'hmc' in w) for w in which):
+        gen_composed_metropolis(tuple(w for w in which if w.startswith('chain_c')))
     if not which or 'pre_transform' in which:
         gen_pre_transform()
     if not which or 'struct_diffusion' in which:

@@ -423,3 +423,74 @@ def test_hip_composed_hmc_vs_oracle(name, H, device):
                 flips += 1
                 assert abs(rate - acc_o[k]) <= 1.0 / (N * 4) + 1e-6 and rel_err(got, hist[k + 1]) < 0.2, (T, t, rate, acc_o[k])
         assert flips <= 1, T
+
+
+# ---- round 5: MALA and HMC on the composed energy model against the REFERENCE's own chains -------------------------------------------------
+# chain_c{64,256}_mala / chain_c{64,256}_hmc / chain_c256_hmc_T20 (oracle/gen_golden.py gen_composed_metropolis): the imported reference running
+# AnnealedMALASampler / AnnealedMUHASampler over ComposedEBMDenoiseFn(robot_qualitative energy model) on its default schedule, every state
+# and its own acceptance log recorded.  Both the numpy restatement (oracle/compose.py) and the HIP path are started from every recorded
+# state and must reproduce the next one (1e-4 of the state's magnitude) and the reference's mean acceptance of the timestep exactly.
+REF_METROPOLIS = [('chain_c64_mala', 64, 'MALA'), ('chain_c256_mala', 256, 'MALA'), ('chain_c64_hmc', 64, 'HMC'), ('chain_c256_hmc', 256, 'HMC'),
+                  ('chain_c256_hmc_T20', 256, 'HMC')]
+
+
+def _ref_metropolis_fixture(name):
+    z = golden(name)
+    T = int(z['T'])
+    assert z['hist'].shape[0] == T + 1 and z['accept'].shape == (T,) and str(z['sampler']) in ('MALA', 'HMC')
+    return z
+
+
+@pytest.mark.parametrize('name,H,sampler', REF_METROPOLIS)
+def test_oracle_composed_metropolis_vs_reference(name, H, sampler):
+    """oracle/compose.py's MALA / HMC on the composed energy against the reference's recorded chains (every 25th timestep of the
+    T = 1000 chain, every 8th of the T = 200 one, every timestep of the short HMC chains)"""
+    from test_oracle_golden import mala_timestep_errors
+    z = _ref_metropolis_fixture(name)
+    T, S, seed = int(z['T']), int(z['S']), int(z['seed'])
+    b = golden_batch(z)
+    N = z['x'].shape[0]
+    m1, m2 = _energy_pair(H, T, S)
+    g = compose_oracle.ComposedOracleGraph(m1, m2, b, weight=(1, 1))
+    zs = noise.normal_stream(seed, int(z['n_randn']), N, 5)
+    us = noise.uniform_stream(seed, int(z['n_rand']), N)
+    n_acc = int(z['S_accept'])
+
+    def step(x, t):
+        with np.errstate(all='ignore'):
+            _, hist = g.chain(zs, S, sampler=sampler, energy=True, history=True, uniform=us, x=x, t_first=t, t_last=t)
+        acc = np.zeros(T, dtype=np.float64)
+        acc[t] = float(np.mean(g.last_accept[-n_acc:]))
+        return hist[-1], acc
+    ts = list(range(T - 1, -1, -(25 if T == 1000 else (8 if T == 200 else 1))))
+    bad = mala_timestep_errors(step, z, ts)
+    assert len(bad) <= max(1, len(ts) // 50), bad
+    if sampler == 'MALA':
+        assert len(set(np.round(z['accept'], 3))) >= 4 and 0.0 < float(z['accept'].mean()) < 1.0       # the reference chain accepts AND rejects
+    assert np.isfinite(z['hist']).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,H,sampler', REF_METROPOLIS)
+def test_hip_composed_metropolis_vs_reference(name, H, sampler, device):
+    """ccsp_compose_chain_run with CCSP_SAMPLER_MALA / _HMC against the reference's recorded chains: EVERY timestep from the reference's
+    state.  A timestep may differ only where the accept kernel itself reports a near-tie (ccsp_chain_margins: |log acceptance ratio - log u|
+    within fp32 rounding of its terms), and at most one timestep in a hundred may."""
+    from diffusion_ccsp_amd import ComposedEBMDenoiseFn, GaussianDiffusion
+    from test_hip_parity import NEAR_TIE
+    from test_oracle_golden import mala_timestep_errors
+    z = _ref_metropolis_fixture(name)
+    T, S, seed = int(z['T']), int(z['S']), int(z['seed'])
+    b = golden_batch(z)
+    first = _composed_pair_hip(H, device, sampler)
+    gd = GaussianDiffusion(ComposedEBMDenoiseFn(first), timesteps=T, EBM=sampler, samples_per_step=S)
+    assert gd.n_normal_calls() == int(z['n_randn'])
+    gd.record_margins = True
+
+    def step(x, t):
+        out = gd.p_sample_segment(b, torch.from_numpy(x), t, t, seed=seed).cpu().numpy()
+        return out, gd.last_accept_rates.cpu().numpy(), gd.last_margins.cpu().numpy()
+    bad = mala_timestep_errors(step, z, list(range(T - 1, -1, -1)))
+    print(name, 'flagged timesteps (t, rows off, acceptance here, reference, smallest |margin| / scale):', bad)
+    assert len(bad) <= max(1, T // 100), bad
+    assert all(r[4] < NEAR_TIE for r in bad), bad

@@ -261,15 +261,36 @@ def mala_timestep_errors(run_step, z, timesteps):
     moves the batch-scalar energy that all nodes share in the S - 1 inner steps after it, so a flagged timestep can show
     several rows off; what is bounded is the NUMBER of flagged timesteps (callers assert <= 1 %)."""
     T = int(z['T'])
-    tol_acc = 0.25 / (z['x'].shape[0] * int(z['S']))
+    n_steps = int(z['S_accept']) if 'S_accept' in getattr(z, 'files', z) else int(z['S'])        # (HMC: the reference's fixed 4 inner steps, not samples_per_step)
+    tol_acc = 0.25 / (z['x'].shape[0] * n_steps)
     bad = []
     for t in timesteps:
         k = T - 1 - t
-        x, acc = run_step(z['hist'][k], t)
+        res = run_step(z['hist'][k], t)
+        x, acc = res[0], res[1]
         want = z['hist'][k + 1]
-        off = int((np.abs(x - want).max(axis=1) > 1e-4 * (1.0 + np.abs(want).max())).sum())
+        both = np.isfinite(want).all(axis=1) & np.isfinite(x).all(axis=1)
+        same_nonfinite = np.array_equal(np.isfinite(want), np.isfinite(x))
+        tol = 1e-4
+        if 'next_f64' in getattr(z, 'files', z):
+            # fixtures that carry the REFERENCE's own fp32-vs-fp64 disagreement over this very timestep (oracle/gen_golden.py ref_single_timestep:
+            # the fp64 reference run for one timestep from the same recorded state): where the map of a timestep amplifies rounding differences
+            # (HMC's leapfrog on the composed energy at hidden_dim 256: up to 1.2e-2) the bar is 8 x that disagreement, never below 1e-4
+            floor = float(np.abs(z['next_f64'][k] - want).max() / (1.0 + np.abs(want).max()))
+            tol = max(tol, 8.0 * floor)
+        off = int((np.abs(x - want)[both].max(axis=1) > tol * (1.0 + np.abs(want[both]).max())).sum()) if both.any() else 0
+        if not same_nonfinite:
+            off += int((np.isfinite(want) != np.isfinite(x)).any(axis=1).sum())
         if off or abs(float(acc[t]) - float(z['accept'][t])) > tol_acc:
-            bad.append((int(t), off, float(acc[t]), float(z['accept'][t])))
+            rec = (int(t), off, float(acc[t]), float(z['accept'][t]))
+            if len(res) > 2 and res[2] is not None:
+                # the accept kernels' margins of this timestep (log acceptance ratio - log u per node row and inner step, and the sum of
+                # the absolute values of the ratio's terms): a difference from the reference must have BEGUN at a near-tie, i.e. some decision
+                # of the timestep has a margin that is within fp32 rounding of the terms it is the difference of.  -> smallest |margin| / scale
+                marg = np.asarray(res[2], dtype=np.float64)              # [inner steps, 2, N]: margin, scale of its terms
+                rel = np.abs(marg[:, 0]) / np.maximum(marg[:, 1], 1e-30)
+                rec = rec + (float(np.nanmin(rel)) if np.isfinite(rel).any() else float('nan'),)
+            bad.append(rec)
     return bad
 
 
@@ -320,6 +341,29 @@ def hmc_T20_errors(run_step, z):
         if rel_err(x, z['hist'][k + 1]) > 2e-4 or abs(float(acc[t]) - float(z['accept'][t])) > 1e-6:
             bad.append((t, rel_err(x, z['hist'][k + 1]), float(acc[t]), float(z['accept'][t])))
     return bad
+
+
+@pytest.mark.parametrize('name', ['chain_t256_hmc_T20', 'chain_t256_hmc_T100'])
+def test_hmc_h256_vs_reference(name):
+    """the oracle's HMC at hidden_dim 256 against the reference's recorded chains (round 5): every timestep of the T = 20 chain, every fifth of
+    the T = 100 one"""
+    z = golden(name)
+    T = int(z['T'])
+    m = oracle_model('diffuse_pairwise', 256, 'weights_diffuse_pairwise_h256_energy.npz', T=T, energy=True)
+    g = m.graph(golden_batch(z))
+    assert int(z['n_randn']) == 1 + T * 6 and int(z['n_rand']) == T * 4 and np.isfinite(z['hist']).all()
+    step = lambda x, t: g.chain('HMC', seed=int(z['seed']), x=x, t_first=t, t_last=t, accept=True)
+    if T == 20:
+        assert len(set(np.round(z['accept'], 4))) >= 2 and 0.2 < float(z['accept'].mean()) < 0.8
+        bad = hmc_T20_errors(step, z)
+    else:
+        bad = []
+        for k in range(0, T, 5):
+            t = T - 1 - k
+            x, acc = step(z['hist'][k], t)
+            if rel_err(x, z['hist'][k + 1]) > 2e-4 or abs(float(acc[t]) - float(z['accept'][t])) > 1e-6:
+                bad.append((t, rel_err(x, z['hist'][k + 1]), float(acc[t]), float(z['accept'][t])))
+    assert not bad, bad
 
 
 def test_hmc_vs_reference():

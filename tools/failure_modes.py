@@ -12,7 +12,7 @@ from diffusion_ccsp_amd import ConstraintDiffuser, GaussianDiffusion, checker, w
 
 dev = torch.device('cuda:0')
 den = ConstraintDiffuser(dims=worlds.MODE_DIMS['qualitative'], hidden_dim=256, input_mode='qualitative', EBM='ULA', device=dev, verbose=False)
-den.load_state_dict(load_weights(os.path.join(ROOT, 'weights', 'qualitative_h256_trained.npz')))
+den.load_state_dict(load_weights(os.path.join(ROOT, 'weights', 'qualitative_h256_ref30k.npz')))
 gd = GaussianDiffusion(den, timesteps=1000, EBM='ULA', samples_per_step=10)
 for n in (3, 8):
     b = worlds.qualitative_batch(128, n, seed=11 + n)

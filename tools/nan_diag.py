@@ -5,7 +5,7 @@ import numpy as np, torch
 from bench import load_weights
 from diffusion_ccsp_amd import ConstraintDiffuser, GaussianDiffusion, worlds
 dev = torch.device('cuda:0')
-W = load_weights(os.path.join(ROOT, 'weights', 'qualitative_h256_trained.npz'))
+W = load_weights(os.path.join(ROOT, 'weights', 'qualitative_h256_ref30k.npz'))
 den = ConstraintDiffuser(dims=worlds.MODE_DIMS['qualitative'], hidden_dim=256, input_mode='qualitative', EBM='ULA', device=dev, verbose=False)
 den.load_state_dict(W)
 gd = GaussianDiffusion(den, timesteps=1000, EBM='ULA', samples_per_step=10)
