@@ -61,18 +61,6 @@ print('    MFMA phase of a chunk     %s   (12 MFMA 32x32x16 x 2 k-steps per wave
 print('    between chunks            %s   (barrier, 8 ds_write_b128 per thread, next loads issued, barrier)' % q(gap.ravel()))
 print('  epilogue (issue)            %s' % q(epi))
 print('  stores acknowledged         %s' % q(drain))
-# tick rate of s_memtime during this launch: end stamps (memtime, realtime at 100 MHz) of the workgroups of one shader engine
-rates = []
-for kx in set((xcc * 8 + se).tolist()):
-    sel = np.nonzero((xcc * 8 + se) == kx)[0]
-    if len(sel) < 8:
-        continue
-    a, bq = t[sel, 27].astype(np.float64), t[sel, 38].astype(np.float64)
-    a, bq = rel(a, a.min()), rel(bq, bq.min())
-    if bq.max() - bq.min() >= 200:
-        rates.append(np.polyfit(bq, a, 1)[0] * 100.0)
-if rates:
-    print('s_memtime during this launch: %.0f MHz (median over %d shader engines; tools/clock_probe: one tick = one shader cycle)' % (np.median(rates), len(rates)))
 # co-residency: how the phases of the workgroups on ONE compute unit lie against each other
 frac_any, frac_mean, span_all, phase_spread = [], [], [], []
 for k, idx in groups.items():
