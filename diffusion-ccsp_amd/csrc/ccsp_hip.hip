@@ -1834,6 +1834,7 @@ void launch_rowgemm_h2(ccsp_model* m, ccsp_graph* g, const float* tau_t, StepRef
                        (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, m->wp_exp, g->base, tau_t, g->U, g->umax, ref, tau_stride)
     if (mode == 6) CCSP_ROWGEMM_F(6); else if (mode == 4) CCSP_ROWGEMM_F(4);
 #ifdef CCSP_EXPERIMENTS
+    else if (mode == 8) CCSP_ROWGEMM_F(8);
     else if (mode == 5) CCSP_ROWGEMM_F(5); else if (mode == 3) CCSP_ROWGEMM_F(3); else if (mode == 2) CCSP_ROWGEMM_F(2); else if (mode == 1) CCSP_ROWGEMM_F(1);
 #endif
     else CCSP_ROWGEMM_F(0);
@@ -2442,6 +2443,7 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
                                (size_t)0)
             if (mode == 6) CCSP_ROWGEMM_T(6); else if (mode == 4) CCSP_ROWGEMM_T(4);
 #ifdef CCSP_EXPERIMENTS
+            else if (mode == 8) CCSP_ROWGEMM_T(8);
             else if (mode == 5) CCSP_ROWGEMM_T(5); else if (mode == 3) CCSP_ROWGEMM_T(3); else if (mode == 2) CCSP_ROWGEMM_T(2); else if (mode == 1) CCSP_ROWGEMM_T(1);
 #endif
             else CCSP_ROWGEMM_T(0);
@@ -3347,7 +3349,7 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     //           bf16x3 (three-term bf16 operands, six products), f32 (v_mfma_f32_32x32x2_f32)
     m->f16x2 = (H == 256 && d->model_kind == CCSP_MODEL_DIFFUSION_CCSP) ? 1 : 0;
 #ifdef CCSP_EXPERIMENTS
-    if (const char* e = getenv("CCSP_ROW_MODE")) { const int v = atoi(e); if (v >= 0 && v <= 7) m->row_mode = v; }
+    if (const char* e = getenv("CCSP_ROW_MODE")) { const int v = atoi(e); if (v >= 0 && v <= 8) m->row_mode = v; }
 #else
     if (const char* e = getenv("CCSP_ROW_MODE")) { const int v = atoi(e); if (v == 0 || v == 4 || v == 6) m->row_mode = v; }      // (the three forms the selection uses)
 #endif
