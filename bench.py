@@ -174,9 +174,9 @@ def _git_blob_hash(path):
 
 def pmc_traffic_file(config, symbols):
     """fabric-side bytes per launch of each kernel whose name starts with one of `symbols`, from the COMMITTED rocprofv3 --pmc
-    summary of this round (profiles/r04_pmc_<config>.txt, made by tools/pmc_run.sh).  -> ({symbol: {kernel name, bytes}}, stamp)"""
-    path = os.path.join(ROOT, 'profiles', 'r04_pmc_%s.txt' % config)
-    if not os.path.isfile(path):
+    summary of this round (profiles/r05_pmc_<config>.txt, else round 4's; made by tools/pmc_run.sh).  -> ({symbol: {kernel name, bytes}}, stamp)"""
+    path = next((q for q in (os.path.join(ROOT, 'profiles', '%s_pmc_%s.txt' % (r, config)) for r in ('r05', 'r04')) if os.path.isfile(q)), None)
+    if path is None:
         return {}, None
     cur, got = None, {}
     for line in open(path):
@@ -191,7 +191,7 @@ def pmc_traffic_file(config, symbols):
         for name, d in got.items():
             if name.startswith(sym) and len(d) == 2:
                 out[sym] = {'kernel_name': name, 'bytes': d['FETCH_SIZE'] * 1024.0 * 2.0 + d['WRITE_SIZE'] * 1024.0}
-    return out, {'source': 'profiles/r04_pmc_%s.txt' % config, 'git_blob': _git_blob_hash(path)}
+    return out, {'source': os.path.relpath(path, ROOT), 'git_blob': _git_blob_hash(path)}
 
 
 def pmc_traffic_live(config, graphs, symbols, timeout=240):
