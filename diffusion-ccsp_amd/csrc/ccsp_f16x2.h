@@ -85,6 +85,32 @@ constexpr int H2_BPL = 128 * H2_BK;          // fp16 elements per plane of the 1
 // ccsp_bf16x3.h: conflict-free ds_read_b128 fragment reads and 16-byte staging writes)
 __device__ __forceinline__ int h2_off(int row, int piece) { return row * H2_BK + ((piece ^ ((row >> 2) & 3)) << 3); }
 
+// The decoder's A operand, four elements of a row: SiLU(a + b) scaled by 2^e and split into two fp16 terms (packed hi / lo pairs ready for the LDS
+// planes).  The adds and multiplies are written on two-element vectors so that hipcc issues v_pk_add_f32 / v_pk_mul_f32 (two fp32 per lane and
+// instruction, same IEEE results per element: bitwise the scalar form silu_fast(a + b) -> ldexpf -> split2h) -- the activation is the VALU half of
+// the edge kernels' chunk (profiles/r02_findings.md: ~420 VALU cycles per chunk and wave against 384 of MFMA).
+typedef float h2_f2 __attribute__((ext_vector_type(2)));
+// (inline asm: left to itself hipcc scalarises most two-element vector operations again)
+__device__ __forceinline__ h2_f2 h2_pk_add(h2_f2 x, h2_f2 y) { h2_f2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+__device__ __forceinline__ h2_f2 h2_pk_mul(h2_f2 x, h2_f2 y) { h2_f2 r; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+__device__ __forceinline__ h2_f2 h2_pk_sub(h2_f2 x, h2_f2 y) { h2_f2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y)); return r; }
+__device__ __forceinline__ void h2_act4(const float4& a, const float4& b, int e, uint2& hi, uint2& lo) {
+    const h2_f2 z0 = h2_pk_add(h2_f2{a.x, a.y}, h2_f2{b.x, b.y}), z1 = h2_pk_add(h2_f2{a.z, a.w}, h2_f2{b.z, b.w});
+    const h2_f2 k = {-1.4426950408889634f, -1.4426950408889634f}, one = {1.0f, 1.0f};
+    const h2_f2 t0 = h2_pk_mul(z0, k), t1 = h2_pk_mul(z1, k);
+    const h2_f2 d0 = h2_pk_add(h2_f2{__builtin_amdgcn_exp2f(t0.x), __builtin_amdgcn_exp2f(t0.y)}, one);
+    const h2_f2 d1 = h2_pk_add(h2_f2{__builtin_amdgcn_exp2f(t1.x), __builtin_amdgcn_exp2f(t1.y)}, one);
+    const h2_f2 h0 = h2_pk_mul(z0, h2_f2{__builtin_amdgcn_rcpf(d0.x), __builtin_amdgcn_rcpf(d0.y)});
+    const h2_f2 h1 = h2_pk_mul(z1, h2_f2{__builtin_amdgcn_rcpf(d1.x), __builtin_amdgcn_rcpf(d1.y)});
+    const h2_f2 s0 = {ldexpf(h0.x, e), ldexpf(h0.y, e)}, s1 = {ldexpf(h1.x, e), ldexpf(h1.y, e)};
+    typedef _Float16 h2_h2 __attribute__((ext_vector_type(2)));
+    const h2_h2 a0 = __builtin_convertvector(s0, h2_h2), a1 = __builtin_convertvector(s1, h2_h2);          // v_cvt_pk_f16_f32 (round to nearest even)
+    const h2_f2 r0 = h2_pk_sub(s0, __builtin_convertvector(a0, h2_f2)), r1 = h2_pk_sub(s1, __builtin_convertvector(a1, h2_f2));
+    const h2_h2 b0 = __builtin_convertvector(r0, h2_h2), b1 = __builtin_convertvector(r1, h2_h2);
+    hi = make_uint2(__builtin_bit_cast(unsigned int, a0), __builtin_bit_cast(unsigned int, a1));
+    lo = make_uint2(__builtin_bit_cast(unsigned int, b0), __builtin_bit_cast(unsigned int, b1));
+}
+
 // one k-step (K = 16) of a staged chunk: acc[i][j] += A(rows am0 + 32 i + 0..31) . B(rows bn0 + 32 j + 0..31)^T, three
 // products each.  As / Bs: [2 planes][rows][32] fp16 (plane strides apl / H2_BPL).
 template <int MI>
@@ -1119,14 +1145,11 @@ __global__ __launch_bounds__(256, (MT == 1 && !FUSE) ? 3 : 2) void k_edge_h2(int
     };
     auto store_a = [&](int stage, int set, int i) {               // SiLU + scale + split of one pass -> the A planes of the stage
         unsigned short* As = smem + stage * STAGE;
-        const float h[4] = {silu_fast(ua[set][i].x + ub[set][i].x), silu_fast(ua[set][i].y + ub[set][i].y),
-                            silu_fast(ua[set][i].z + ub[set][i].z), silu_fast(ua[set][i].w + ub[set][i].w)};
-        unsigned short p1[4], p2[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) split2h(ldexpf(h[e], a_exp[i]), p1[e], p2[e]);
+        uint2 hi, lo;
+        h2_act4(ua[set][i], ub[set][i], a_exp[i], hi, lo);
         unsigned short* d = As + a_st[i];
-        *reinterpret_cast<uint2*>(d) = make_uint2(p1[0] | ((unsigned)p1[1] << 16), p1[2] | ((unsigned)p1[3] << 16));
-        *reinterpret_cast<uint2*>(d + APL) = make_uint2(p2[0] | ((unsigned)p2[1] << 16), p2[2] | ((unsigned)p2[3] << 16));
+        *reinterpret_cast<uint2*>(d) = hi;
+        *reinterpret_cast<uint2*>(d + APL) = lo;
     };
     auto store_b = [&](int stage) {
         unsigned short* Bs = smem + stage * STAGE + 2 * APL;
@@ -1364,14 +1387,11 @@ __global__ __launch_bounds__(256, 2) void k_edge_h2s(int E_act, int P, const int
     if (lq == 0) sE[lr] = a_exp;
     auto store_a = [&](int stage, int set) {                      // SiLU + scale + split -> the A planes of the stage
         unsigned short* As = smem + stage * STAGE;
-        const float h[4] = {silu_fast(ua[set].x + ub[set].x), silu_fast(ua[set].y + ub[set].y),
-                            silu_fast(ua[set].z + ub[set].z), silu_fast(ua[set].w + ub[set].w)};
-        unsigned short p1[4], p2[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) split2h(ldexpf(h[e], a_exp), p1[e], p2[e]);
+        uint2 hi, lo;
+        h2_act4(ua[set], ub[set], a_exp, hi, lo);
         unsigned short* d = As + a_st;
-        *reinterpret_cast<uint2*>(d) = make_uint2(p1[0] | ((unsigned)p1[1] << 16), p1[2] | ((unsigned)p1[3] << 16));
-        *reinterpret_cast<uint2*>(d + APL) = make_uint2(p2[0] | ((unsigned)p2[1] << 16), p2[2] | ((unsigned)p2[3] << 16));
+        *reinterpret_cast<uint2*>(d) = hi;
+        *reinterpret_cast<uint2*>(d + APL) = lo;
     };
     auto store_b = [&](int stage) {
         unsigned short* Bs = smem + stage * STAGE + 2 * APL;

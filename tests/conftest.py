@@ -29,6 +29,22 @@ class Batch(object):
         self.__dict__.update(kw)
 
 
+def effective_cores():
+    """cores this container may actually use: the cgroup quota if there is one (the GPU boxes report 256 CPUs and grant 16), else os.cpu_count()"""
+    n = os.cpu_count() or 8
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q != 'max':
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def golden(name):
     return np.load(os.path.join(GOLD, name + '.npz'), allow_pickle=False)
 

@@ -494,3 +494,43 @@ def test_hip_composed_metropolis_vs_reference(name, H, sampler, device):
     print(name, 'flagged timesteps (t, rows off, acceptance here, reference, smallest |margin| / scale):', bad)
     assert len(bad) <= max(1, T // 100), bad
     assert all(r[4] < NEAR_TIE for r in bad), bad
+
+
+@pytest.mark.gpu
+def test_hip_composed_mala_honours_the_shard_energy_hook(device):
+    """a composed MALA chain must reduce its batch energies across shards like ccsp_chain_run does (the hook / communicator of the FIRST
+    domain's model: sharding.enable_global_batch_energy), or the shards of a global batch decouple silently.  A one-rank "reduction" that leaves the
+    pair alone reproduces the unhooked chain bit for bit and is called once per inner step; one that scales it changes the chain; composed HMC,
+    which does not reduce, refuses a model with a hook installed."""
+    from diffusion_ccsp_amd import CcspError, ComposedEBMDenoiseFn, GaussianDiffusion, sharding
+    z = golden('chain_c64_mala')
+    b = golden_batch(z)
+    T, S, seed = 40, 2, 5
+    first = _composed_pair_hip(64, device, 'MALA')
+    gd = GaussianDiffusion(ComposedEBMDenoiseFn(first), timesteps=T, EBM='MALA', samples_per_step=S)
+    x0 = torch.from_numpy(z['hist'][990])                       # a late state of the reference chain: mixed acceptance from here
+
+    class OneRank(object):
+        def __init__(self, scale):
+            self.scale, self.calls = scale, 0
+
+        def all_reduce(self, t):
+            t.mul_(self.scale)
+            self.calls += 1
+    plain = gd.p_sample_segment(b, x0, 9, 0, seed=seed).cpu().numpy()
+    rates = gd.last_accept_rates.cpu().numpy()[:10]
+    assert 0.0 < rates.mean() < 1.0
+    out = {}
+    for scale in (1.0, 4.0):
+        hk = OneRank(scale)
+        sharding.enable_global_batch_energy(gd, hk)
+        out[scale] = gd.p_sample_segment(b, x0, 9, 0, seed=seed).cpu().numpy()
+        assert hk.calls == 10 * S
+    assert np.array_equal(out[1.0], plain, equal_nan=True)
+    assert not np.array_equal(out[4.0], plain, equal_nan=True)
+    gd_h = GaussianDiffusion(ComposedEBMDenoiseFn(first), timesteps=T, EBM='HMC', samples_per_step=4)
+    sharding.enable_global_batch_energy(gd_h, OneRank(1.0))
+    with pytest.raises(CcspError, match='HMC chain does not reduce'):
+        gd_h.p_sample_segment(b, x0, 9, 8, seed=seed)
+    sharding.enable_global_batch_energy(gd_h, None)
+    assert np.isfinite(gd_h.p_sample_segment(b, x0, 9, 8, seed=seed).cpu().numpy()).all()
