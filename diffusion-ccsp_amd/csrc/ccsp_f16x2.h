@@ -90,18 +90,23 @@ __device__ __forceinline__ int h2_off(int row, int piece) { return row * H2_BK +
 // instruction, same IEEE results per element: bitwise the scalar form silu_fast(a + b) -> ldexpf -> split2h) -- the activation is the VALU half of
 // the edge kernels' chunk (profiles/r02_findings.md: ~420 VALU cycles per chunk and wave against 384 of MFMA).
 typedef float h2_f2 __attribute__((ext_vector_type(2)));
-// (inline asm: left to itself hipcc scalarises most two-element vector operations again)
+// (inline asm: left to itself hipcc scalarises most two-element vector operations again.  The compiler's hazard recogniser does not see inside an asm
+// statement: on gfx940+ a non-transcendental VALU instruction that reads the result of v_exp_f32 / v_rcp_f32 needs one wait state after it (trans
+// forwarding hazard; hipcc inserts the s_nop for its own instructions) -- the _t forms carry it themselves and are the ones to use on such operands.
+// Without it the consumer reads the register's previous contents: tools/pk_probe.hip reproduces that.)
 __device__ __forceinline__ h2_f2 h2_pk_add(h2_f2 x, h2_f2 y) { h2_f2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
 __device__ __forceinline__ h2_f2 h2_pk_mul(h2_f2 x, h2_f2 y) { h2_f2 r; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+__device__ __forceinline__ h2_f2 h2_pk_add_t(h2_f2 x, h2_f2 y) { h2_f2 r; asm("s_nop 0\n\tv_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+__device__ __forceinline__ h2_f2 h2_pk_mul_t(h2_f2 x, h2_f2 y) { h2_f2 r; asm("s_nop 0\n\tv_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
 __device__ __forceinline__ h2_f2 h2_pk_sub(h2_f2 x, h2_f2 y) { h2_f2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y)); return r; }
 __device__ __forceinline__ void h2_act4(const float4& a, const float4& b, int e, uint2& hi, uint2& lo) {
     const h2_f2 z0 = h2_pk_add(h2_f2{a.x, a.y}, h2_f2{b.x, b.y}), z1 = h2_pk_add(h2_f2{a.z, a.w}, h2_f2{b.z, b.w});
     const h2_f2 k = {-1.4426950408889634f, -1.4426950408889634f}, one = {1.0f, 1.0f};
     const h2_f2 t0 = h2_pk_mul(z0, k), t1 = h2_pk_mul(z1, k);
-    const h2_f2 d0 = h2_pk_add(h2_f2{__builtin_amdgcn_exp2f(t0.x), __builtin_amdgcn_exp2f(t0.y)}, one);
-    const h2_f2 d1 = h2_pk_add(h2_f2{__builtin_amdgcn_exp2f(t1.x), __builtin_amdgcn_exp2f(t1.y)}, one);
-    const h2_f2 h0 = h2_pk_mul(z0, h2_f2{__builtin_amdgcn_rcpf(d0.x), __builtin_amdgcn_rcpf(d0.y)});
-    const h2_f2 h1 = h2_pk_mul(z1, h2_f2{__builtin_amdgcn_rcpf(d1.x), __builtin_amdgcn_rcpf(d1.y)});
+    const h2_f2 d0 = h2_pk_add_t(h2_f2{__builtin_amdgcn_exp2f(t0.x), __builtin_amdgcn_exp2f(t0.y)}, one);
+    const h2_f2 d1 = h2_pk_add_t(h2_f2{__builtin_amdgcn_exp2f(t1.x), __builtin_amdgcn_exp2f(t1.y)}, one);
+    const h2_f2 h0 = h2_pk_mul_t(z0, h2_f2{__builtin_amdgcn_rcpf(d0.x), __builtin_amdgcn_rcpf(d0.y)});
+    const h2_f2 h1 = h2_pk_mul_t(z1, h2_f2{__builtin_amdgcn_rcpf(d1.x), __builtin_amdgcn_rcpf(d1.y)});
     const h2_f2 s0 = {ldexpf(h0.x, e), ldexpf(h0.y, e)}, s1 = {ldexpf(h1.x, e), ldexpf(h1.y, e)};
     typedef _Float16 h2_h2 __attribute__((ext_vector_type(2)));
     const h2_h2 a0 = __builtin_convertvector(s0, h2_h2), a1 = __builtin_convertvector(s1, h2_h2);          // v_cvt_pk_f16_f32 (round to nearest even)

@@ -505,10 +505,11 @@ def test_hip_composed_mala_honours_the_shard_energy_hook(device):
     from diffusion_ccsp_amd import CcspError, ComposedEBMDenoiseFn, GaussianDiffusion, sharding
     z = golden('chain_c64_mala')
     b = golden_batch(z)
-    T, S, seed = 40, 2, 5
+    T, S, seed = int(z['T']), int(z['S']), int(z['seed'])
+    t0 = 500                                                    # the reference accepts 0.3 .. 0.96 of the proposals at timesteps 500 .. 491
     first = _composed_pair_hip(64, device, 'MALA')
     gd = GaussianDiffusion(ComposedEBMDenoiseFn(first), timesteps=T, EBM='MALA', samples_per_step=S)
-    x0 = torch.from_numpy(z['hist'][990])                       # a late state of the reference chain: mixed acceptance from here
+    x0 = torch.from_numpy(z['hist'][T - 1 - t0])
 
     class OneRank(object):
         def __init__(self, scale):
@@ -517,14 +518,14 @@ def test_hip_composed_mala_honours_the_shard_energy_hook(device):
         def all_reduce(self, t):
             t.mul_(self.scale)
             self.calls += 1
-    plain = gd.p_sample_segment(b, x0, 9, 0, seed=seed).cpu().numpy()
-    rates = gd.last_accept_rates.cpu().numpy()[:10]
-    assert 0.0 < rates.mean() < 1.0
+    plain = gd.p_sample_segment(b, x0, t0, t0 - 9, seed=seed).cpu().numpy()
+    rates = gd.last_accept_rates.cpu().numpy()[t0 - 9:t0 + 1]
+    assert 0.2 < rates.mean() < 0.9
     out = {}
     for scale in (1.0, 4.0):
         hk = OneRank(scale)
         sharding.enable_global_batch_energy(gd, hk)
-        out[scale] = gd.p_sample_segment(b, x0, 9, 0, seed=seed).cpu().numpy()
+        out[scale] = gd.p_sample_segment(b, x0, t0, t0 - 9, seed=seed).cpu().numpy()
         assert hk.calls == 10 * S
     assert np.array_equal(out[1.0], plain, equal_nan=True)
     assert not np.array_equal(out[4.0], plain, equal_nan=True)
