@@ -100,6 +100,15 @@ __device__ __forceinline__ h2_f2 h2_pk_add_t(h2_f2 x, h2_f2 y) { h2_f2 r; asm("s
 __device__ __forceinline__ h2_f2 h2_pk_mul_t(h2_f2 x, h2_f2 y) { h2_f2 r; asm("s_nop 0\n\tv_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
 __device__ __forceinline__ h2_f2 h2_pk_sub(h2_f2 x, h2_f2 y) { h2_f2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y)); return r; }
 __device__ __forceinline__ void h2_act4(const float4& a, const float4& b, int e, uint2& hi, uint2& lo) {
+#ifdef CCSP_ACT_SCALAR                       // the scalar form the packed one is measured against (tools/mkvariant.py act_scalar); same bits
+    const float h[4] = {silu_fast(a.x + b.x), silu_fast(a.y + b.y), silu_fast(a.z + b.z), silu_fast(a.w + b.w)};
+    unsigned short p1[4], p2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split2h(ldexpf(h[i], e), p1[i], p2[i]);
+    hi = make_uint2(p1[0] | (unsigned int)p1[1] << 16, p1[2] | (unsigned int)p1[3] << 16);
+    lo = make_uint2(p2[0] | (unsigned int)p2[1] << 16, p2[2] | (unsigned int)p2[3] << 16);
+    return;
+#endif
     const h2_f2 z0 = h2_pk_add(h2_f2{a.x, a.y}, h2_f2{b.x, b.y}), z1 = h2_pk_add(h2_f2{a.z, a.w}, h2_f2{b.z, b.w});
     const h2_f2 k = {-1.4426950408889634f, -1.4426950408889634f}, one = {1.0f, 1.0f};
     const h2_f2 t0 = h2_pk_mul(z0, k), t1 = h2_pk_mul(z1, k);

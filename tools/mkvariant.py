@@ -8,6 +8,7 @@ SRC = os.path.join(ROOT, 'diffusion-ccsp_amd', 'csrc')
 
 # name -> (patches [(file, old, new)], defines [-D...])
 VARIANTS = {
+    'act_scalar': ([], ['CCSP_ACT_SCALAR']),                     # edge kernels' activation producer without the packed fp32 instructions
     'cb22': ([], ['CCSP_H2_CB0=2', 'CCSP_H2_CB1=2']),          # row GEMM MODE 2: base of both row tiles requested under chunk NCH - 2
     'cb88': ([], ['CCSP_H2_CB0=8', 'CCSP_H2_CB1=8']),          # ... under chunk 0
     'cb11': ([], ['CCSP_H2_CB0=1', 'CCSP_H2_CB1=1']),          # ... under the last chunk
