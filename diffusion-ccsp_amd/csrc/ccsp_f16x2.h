@@ -502,6 +502,12 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
     CCSP_TRK(0, 0);
     CCSP_TRK_RT(0, 30);
     if (ref.skip && *ref.skip == 0) return;                       // (uniform) MALA reuse: the state has not moved since this was computed
+    gate_wait(ref.gate);
+    const int n_work = (int)gridDim.x - ref.na.blocks;
+    if ((int)blockIdx.x >= n_work) {                              // (workgroup-uniform) the evaluation's normal draws: NoiseAhead
+        noise_ahead_block(ref.na, (int)blockIdx.x - n_work);
+        return;
+    }
     constexpr int NCT = ND / 128, NCH = KD / H2_BK;
     constexpr int MI = (MODE == 4 || MODE == 6) ? 1 : 2, TM = 64 * MI;           // 32-row MFMA tiles per wave, rows per workgroup tile (MODE 6: MODE 0's staging on 64-row tiles)
     constexpr int APL = TM * H2_BK, STAGE = MODE == 5 ? 2 * H2_BPL : (MODE == 8 ? 2 * APL + 4 * H2_BPL : 2 * APL + 2 * H2_BPL);   // 32 KB per stage (24 KB for 64-row tiles; MODE 5: the B planes only, 16 KB; MODE 8: one A stage + two B stages, 48 KB)
@@ -513,7 +519,7 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
     __shared__ __attribute__((aligned(16))) unsigned short smem[SMEM_US + 256];      // stages (epilogue tiles on top) + 128 row exponents
     int* sE = reinterpret_cast<int*>(smem + SMEM_US);
     if (ref.tab) tau_t += (size_t)ref.tab[*ref.counter].t * tau_stride;      // hipGraph mode: timestep from the device table
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bid = xcd_remap(blockIdx.x, n_work);
     const int tile = bid / NCT, ct = bid % NCT;
     const int4 td = tile_desc[tile];
     const int row0 = td.x, nrows = td.y, ts = td.z;
@@ -981,6 +987,7 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
     CCSP_TRK2(27);                                                // ... and its stores have been acknowledged
     CCSP_TRK2_FLUSH();
 #endif
+    gate_done(ref.gate);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1085,6 +1092,7 @@ __global__ __launch_bounds__(256, (MT == 1 && !FUSE) ? 3 : 2) void k_edge_h2(int
     static_assert(!NG || (!ENERGY && !FUSE && MT == 1), "the node-grouped form: direct mode, 64-row tiles");
     if constexpr (ENERGY) { if (en.skip && *en.skip == 0) return; }                        // (uniform) MALA reuse
     if (counter_inc && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(counter_inc, 1);     // hipGraph mode: next table entry
+    gate_wait(en.gate);
     CCSP_TRK(1, 0);
     CCSP_TRK_RT(1, 30);
     constexpr int H = 256, BN = 128, NCH = H / H2_BK;
@@ -1338,6 +1346,7 @@ __global__ __launch_bounds__(256, (MT == 1 && !FUSE) ? 3 : 2) void k_edge_h2(int
         const float tot = block_sum_256(e2, reinterpret_cast<float*>(smem));
         if (tid == 0) en.partial[blockIdx.x] = tot;
     }
+    gate_done(en.gate);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1358,6 +1367,9 @@ __global__ __launch_bounds__(256, 2) void k_edge_h2s(int E_act, int P, const int
     static_assert(!(FUSE && ENERGY), "the fused node update is the direct-mode one");
     if constexpr (ENERGY) { if (en.skip && *en.skip == 0) return; }                        // (uniform) MALA reuse
     if (counter_inc && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(counter_inc, 1);     // hipGraph mode: next table entry
+    gate_wait(en.gate);
+    CCSP_TRK(1, 0);
+    CCSP_TRK_RT(1, 30);
     constexpr int H = 256, BN = 128, NCH = H / H2_BK;
     constexpr int ME = 16, ROWS = 2 * ME;
     constexpr int APL = ROWS * H2_BK, STAGE = 2 * APL + 2 * H2_BPL;       // 4 KB of A planes + 16 KB of B planes
@@ -1422,7 +1434,15 @@ __global__ __launch_bounds__(256, 2) void k_edge_h2s(int E_act, int P, const int
     store_b(0);
     gload_b(1);
     gload_a(2, 0);
-    __syncthreads();
+    // (bare barriers through the K loop: __syncthreads() carries a fence that waits for EVERY outstanding load -- the operands requested two and
+    // three chunks ahead were drained at each chunk's barrier, one full memory round trip per chunk in a kernel that is one workgroup's latency
+    // chain.  The LDS side is all the barrier has to order: lgkmcnt(0) for this wave's stage stores; hipcc counts the loads where they are used.)
+    auto stage_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    stage_barrier();
+    CCSP_TRK(1, 2);
     auto kstep = [&](const unsigned short* st, int ks) {          // 32 x 32 of the wave: rows 0..31, columns 32 wave .. + 31
         const int piece = (lane >> 5) + 2 * ks;
         half8 a[2], b[2];
@@ -1445,7 +1465,8 @@ __global__ __launch_bounds__(256, 2) void k_edge_h2s(int E_act, int P, const int
         if (c + 1 < NCH) store_b(nx);
         if (c + 2 < NCH) gload_b(c + 2);
         if (c + 3 < NCH) gload_a(c + 3, nx);
-        __syncthreads();
+        stage_barrier();
+        CCSP_TRK(1, 3 + c);
     }
     // epilogue: 32 rows (half = row / 16, edge e0 + row % 16)
     float* S1 = reinterpret_cast<float*>(smem);
@@ -1465,10 +1486,12 @@ __global__ __launch_bounds__(256, 2) void k_edge_h2s(int E_act, int P, const int
         }
     }
     __syncthreads();
+    CCSP_TRK(1, 11);
     if (P == 4) h2_decoder_l2<4, ROWS>(S1, S1_LD, Wd2, P, RED, wave, lane);
     else if (P == 5) h2_decoder_l2<5, ROWS>(S1, S1_LD, Wd2, P, RED, wave, lane);
     else h2_decoder_l2<0, ROWS>(S1, S1_LD, Wd2, P, RED, wave, lane);
     __syncthreads();
+    CCSP_TRK(1, 12);
     float e2 = 0.0f;
     for (int idx = tid; idx < ROWS * P; idx += 256) {
         const int row = idx & (ROWS - 1), p = idx / ROWS;
@@ -1500,6 +1523,9 @@ __global__ __launch_bounds__(256, 2) void k_edge_h2s(int E_act, int P, const int
         const float tot = block_sum_256(e2, reinterpret_cast<float*>(smem));
         if (tid == 0) en.partial[blockIdx.x] = tot;
     }
+    CCSP_TRK(1, 13);
+    CCSP_TRK_RT(1, 31);
+    gate_done(en.gate);
 }
 
 // ------------------------------------------------------------------------------------------

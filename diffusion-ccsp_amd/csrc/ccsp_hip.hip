@@ -769,6 +769,50 @@ template <> struct EdgeCfg<256> { static constexpr int WM = 1, WN = 4, TN = 1; }
 template <> struct EdgeCfg<128> { static constexpr int WM = 2, WN = 2, TN = 1; };
 template <> struct EdgeCfg<64> { static constexpr int WM = 4, WN = 1, TN = 1; };
 
+// Relay mode (EXPERIMENTS build, CCSP_RELAY=1; profiles/r05_findings.md section 5 -- slower than stream order): the three kernels of an evaluation are enqueued on three streams of their own and
+// handed over through device counters instead of stream order, so that the launch boundary, the start-up of a kernel and everything it can
+// load without its producer's results run UNDER the producer.  A workgroup polls `wait` until it has reached `target` (one lane, agent-scope
+// acquire; then the workgroup's L1 / this XCD's L2 are invalidated like at a kernel start) and adds 1 to `done` once its own stores have been
+// written back (agent-scope release, like a kernel end).  A wait that outlasts GATE_TIMEOUT (100 MHz ticks) raises *fault and goes on: a chain
+// with a fault is reported as failed by the host, the GPU never hangs on a counter.
+struct Gate {
+    const unsigned int* wait;      // or null: no wait
+    unsigned int target;
+    unsigned int* done;            // or null: no signal
+    unsigned int* fault;
+};
+constexpr long long GATE_TIMEOUT = 200000000LL;          // 2 s
+#ifndef CCSP_EXPERIMENTS
+__device__ __forceinline__ void gate_wait(const Gate&) {}
+__device__ __forceinline__ void gate_done(const Gate&) {}
+#else
+__device__ __forceinline__ void gate_wait(const Gate& g) {
+    if (g.wait == nullptr) return;
+    if (threadIdx.x == 0) {
+        const long long t0 = wall_clock64();
+        unsigned int spins = 0;
+        while ((int)(__hip_atomic_load(g.wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g.target) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 255u) == 0 && wall_clock64() - t0 > GATE_TIMEOUT) { __hip_atomic_store(g.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+    }
+    __syncthreads();
+#ifndef CCSP_GATE_NOFENCE
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+}
+__device__ __forceinline__ void gate_done(const Gate& g) {
+    if (g.done == nullptr) return;
+#ifndef CCSP_GATE_NOFENCE
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // this thread's stores: acknowledged and written back
+#else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(g.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
+
 // ENERGY = true (denoise_fn.py:373-375): the CSR slot receives -2 d = -2 (o - pose) (the direct term of
 // dE/dpose), the decoder pre-activations go to Q (when non-null, for k_edge_bwd) and the workgroup's
 // share of sum d^2 to partial[blockIdx.x].
@@ -779,6 +823,7 @@ struct EdgeEnergyArgs {
     float* Q;                // [2 E_act, H/2] or null
     float* partial;          // [gridDim.x]
     const int* skip;         // MALA reuse: if non-null and *skip == 0 the launch returns at once
+    Gate gate;               // relay mode
 };
 
 template <int H, bool ENERGY>
@@ -932,10 +977,31 @@ struct ChainHeader {
     const float* normal;
     int noise_mode, pad;
 };
+// Noise ahead (round 5, profiles/r05_findings.md section 6): the normal draws of an evaluation's node update need no data, but Philox + Box-Muller
+// is ~500 dependent VALU instructions -- with one wave per SIMD 5-6 k cycles, the longest single piece of the node kernel (13 k), which sits on the
+// chain of every evaluation.  The row GEMM that opens the evaluation carries them out instead: `blocks` extra workgroups behind its tile list write
+// z[N, P] (256 elements each, the same ccsp::philox_normal call per element), and the node kernel reads z like an injected stream.
+struct NoiseAhead {
+    float* z;               // [N, P] or null
+    int N, P, blocks;
+    unsigned int call;
+    unsigned long long seed, row_offset;
+};
+__device__ __forceinline__ void noise_ahead_block(const NoiseAhead& na, int blk) {
+    const long idx = (long)blk * 256 + threadIdx.x;
+    if (idx >= (long)na.N * na.P) return;
+    const int n = (int)(idx / na.P), p = (int)(idx - (long)n * na.P);
+    na.z[idx] = ccsp::philox_normal(na.seed, na.row_offset + (unsigned long long)n, na.call, p);
+}
+
+__global__ void k_noise_ahead(NoiseAhead na) { noise_ahead_block(na, (int)blockIdx.x); }      // (experiment paths without k_rowgemm_h2)
+
 struct StepRef {
     const StepEntry* tab;
     int* counter;
     const int* skip;        // MALA reuse (CCSP_MALA_REUSE): if non-null and *skip == 0 the launch returns at once
+    Gate gate;              // relay mode
+    NoiseAhead na;          // forward GEMM of a direct-mode chain: the evaluation's normal draws (or z == null)
 };
 
 struct NodeArgs {
@@ -970,6 +1036,7 @@ struct NodeArgs {
     const StepEntry* tab;
     const int* counter;
     const ChainHeader* hdr;
+    Gate gate;              // relay mode
 };
 
 // The two update formulas of the direct-mode chain, shared by k_node and k_node_direct.  Every product and sum is rounded on
@@ -1158,7 +1225,7 @@ __device__ __forceinline__ void node_body(NodeArgs a, const EncW w, const EncOut
     CCSP_TRK_RT(2, 31);
 }
 template <int H, bool ENCH>
-__global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, EncOut eo) { node_body<H, ENCH>(a, w, eo); }
+__global__ __launch_bounds__(256) void k_node(NodeArgs a, EncW w, EncOut eo) { gate_wait(a.gate); node_body<H, ENCH>(a, w, eo); gate_done(a.gate); }
 
 // ------------------------------------------------------------------------------------------
 // k_node_direct: k_node for what a direct-mode chain runs 11 000 times -- CSR reduce (src 0), ancestral or ULA step, f16
@@ -1348,6 +1415,10 @@ __device__ __forceinline__ void node_block_direct(const NodeArgs& a, const EncW&
         if constexpr (FUSED) return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else return *ptr;
     };
+#ifdef CCSP_TRACE
+    asm volatile("" :: "v"(csr_cnt));
+    CCSP_TRK(2, 7);
+#endif
     float v[32];
     {
         const float* op = a.O + pc;
@@ -1362,8 +1433,12 @@ __device__ __forceinline__ void node_block_direct(const NodeArgs& a, const EncW&
     EncPrefetchH pfh;
     if constexpr (!STREAM) enc_prefetch_h2(w, pfh);                       // behind the chain: in flight under the update
     // ---- the noise draw needs no data: computed while the loads are in flight
-    float z = ccsp::philox_normal(a.noise.seed, a.noise.row_offset + (unsigned long long)nc, a.noise.call, pc);
-    z = injected ? z_inj : z;
+    float z = z_inj;                                                      // (a uniform branch: an injected / drawn-ahead stream skips ~500 instructions)
+    if (!injected) z = ccsp::philox_normal(a.noise.seed, a.noise.row_offset + (unsigned long long)nc, a.noise.call, pc);
+#ifdef CCSP_TRACE
+    asm volatile("" :: "v"(z));
+    CCSP_TRK(2, 8);
+#endif
     // ---- CSR sum in the reference's order, count-normalise, mask fill
     float acc = 0.0f;
 #pragma unroll
@@ -1377,6 +1452,10 @@ __device__ __forceinline__ void node_block_direct(const NodeArgs& a, const EncW&
         for (int j = 0; j < 16; ++j) acc = q0 + j < csr_cnt ? acc + u[j] : acc;
     }
     if (a.normalize) acc = acc / sqrtf((float)csr_cnt);                   // 0/0 -> NaN like the reference
+#ifdef CCSP_TRACE
+    asm volatile("" :: "v"(acc));
+    CCSP_TRK(2, 9);
+#endif
     const bool masked = mk != 0;
     const float eps = masked ? xf_fill : acc;
     float xv = a.step == STEP_ANCESTRAL ? step_ancestral(x_old, eps, z, a.a_t, a.b_t, a.c1, a.c2, a.sigma)
@@ -1395,6 +1474,7 @@ __device__ __forceinline__ void node_block_direct(const NodeArgs& a, const EncW&
         amax = fmaxf(amax, __shfl_xor(amax, 4));
         if (p == 0) lds.sexp[nl] = h2_scale_exp(fmaf(w.c1, amax, w.c2));
     }
+    CCSP_TRK(2, 6);
     __syncthreads();
     CCSP_TRK(2, 1);
     if constexpr (STREAM) encode_tile_h2_stream(w, lds.xs, lds.s1h, lds.sexp, lds.smax, node0, a.N, eo);
@@ -1406,9 +1486,11 @@ __global__ __launch_bounds__(256) void k_node_direct(NodeArgs a, EncW w, EncOut 
     CCSP_TRK(2, 0);
     CCSP_TRK_RT(2, 30);
     __builtin_amdgcn_s_setprio(3);
+    gate_wait(a.gate);
     node_block_direct<false>(a, w, eo, n_ent, blockIdx.x * NODE_TILE, node_lds(lds_raw));
     CCSP_TRK(2, 5);
     CCSP_TRK_RT(2, 31);
+    gate_done(a.gate);
 }
 #ifdef CCSP_EXPERIMENTS
 // the same with the encoder's weights streamed (CCSP_NODE=stream, A/B): a third of the registers, so that its waves fit next to
@@ -1608,6 +1690,7 @@ struct ccsp_model {
     int energy_bwd_h2 = 1;            // CCSP_ENERGY_BWD=bf16x3 keeps the backward GEMMs on the six-product bf16 kernels
     int fuse_node = 0;                // CCSP_FUSE_NODE=1: fold the node update into the edge kernel's tail (FuseArgs).  Measured slower than
                                       // the separate launch (C2 467 -> 383, C5 250 -> 182 samples/s, profiles/r03_findings.md), so off by default
+    int relay = 0;                    // CCSP_RELAY=1: relay mode for small batches (Gate)
     int node_generic = 0;             // CCSP_NODE=generic: k_node instead of k_node_direct in direct-mode chains (A/B runs)
     int node_stream = 0;              // CCSP_NODE=stream: k_node_direct_s
     int valu_node_energy = 0;         // CCSP_NODE_ENERGY_VALU: the pre-MFMA node-energy kernel (A/B runs; never combined with the reuse below)
@@ -1704,6 +1787,10 @@ struct ccsp_graph {
     float *Q = nullptr, *GZ = nullptr, *GZR = nullptr, *GP = nullptr, *xhat = nullptr, *partial = nullptr, *Escal = nullptr;
     int *acc_count = nullptr, *acc_denom = nullptr;
     int* mala_changed = nullptr;       // MALA reuse: nodes accepted by the last accept step
+    float* zbuf = nullptr;             // [N, P] normal draws of the evaluation in flight (NoiseAhead)
+    unsigned int* relay_ctr = nullptr; // relay mode: {row GEMM, edge, node} workgroups done since the chain began, fault flag
+    hipEvent_t relay_ev[3] = {nullptr, nullptr, nullptr};
+    int64_t relay_chains = 0;          // chains of this graph that ran in relay mode (ccsp_graph_variant)
     float* margin_buf = nullptr;       // ccsp_chain_margins: caller-owned [accept steps of a call][N] buffer, or null
     int64_t margin_cap = 0;            // its size in floats
     float *hmc_vk = nullptr, *hmc_vp = nullptr, *hmc_vl = nullptr;   // HMC momenta (allocated on first use)
@@ -1816,20 +1903,21 @@ int rowgemm_h2_mode(const ccsp_model* m, const ccsp_graph* g, int nct, int n_til
     return 0;
 }
 
-void launch_rowgemm_h2(ccsp_model* m, ccsp_graph* g, const float* tau_t, StepRef ref, size_t tau_stride, hipStream_t s) {
+int launch_rowgemm_h2(ccsp_model* m, ccsp_graph* g, const float* tau_t, StepRef ref, size_t tau_stride, hipStream_t s) {   // -> workgroups
     constexpr int H = 256;
     const int mode = rowgemm_h2_mode(m, g, 2 * H / 128);
 #ifdef CCSP_EXPERIMENTS
     if (mode == 7 && m->WpF) {                          // resident A planes, weight fragments straight from global memory (ccsp_fused.h)
+        if (ref.na.z) hipLaunchKernelGGL(k_noise_ahead, dim3(ref.na.blocks), dim3(256), 0, s, ref.na);
         hipLaunchKernelGGL(k_rowgemm_h2d, dim3(g->n_tiles * 4), dim3(256), 0, s, g->pembH, (size_t)g->N * H, g->pexp, g->urow_node, g->td64, m->WpF,
                            m->wp_exp, g->base, tau_t, g->U, g->umax, ref, tau_stride);
-        return;
+        return g->n_tiles * 4;
     }
 #endif
     const bool small = mode == 4 || mode == 6;          // 64-row plan tiles instead of their 128-row pairs
     const int work = (small ? g->n_tiles : g->n_tiles2) * (2 * H / 128);
 #define CCSP_ROWGEMM_F(MODE)                                                                                                                          \
-    hipLaunchKernelGGL((k_rowgemm_h2<H, 2 * H, MODE>), dim3(work), dim3(256), 0, s, g->pembH, (size_t)g->N * H, g->pexp, g->urow_node,                  \
+    hipLaunchKernelGGL((k_rowgemm_h2<H, 2 * H, MODE>), dim3(work + ref.na.blocks), dim3(256), 0, s, g->pembH, (size_t)g->N * H, g->pexp, g->urow_node,                  \
                        small ? g->td64 : g->td128, m->WpH,                                                                                              \
                        (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, m->wp_exp, g->base, tau_t, g->U, g->umax, ref, tau_stride)
     if (mode == 6) CCSP_ROWGEMM_F(6); else if (mode == 4) CCSP_ROWGEMM_F(4);
@@ -1839,6 +1927,7 @@ void launch_rowgemm_h2(ccsp_model* m, ccsp_graph* g, const float* tau_t, StepRef
 #endif
     else CCSP_ROWGEMM_F(0);
 #undef CCSP_ROWGEMM_F
+    return work;
 }
 
 // edges per workgroup of the f16x2 edge kernel for a batch of E_act active edges: 16 (k_edge_h2s) when most of the chip would
@@ -1996,7 +2085,8 @@ int fuse2_prepare(ccsp_model* m, ccsp_graph* g, hipStream_t s) {
 // fused: if non-null (direct-mode chain, f16x2 kernels), the node update with these arguments is folded into the edge kernel's
 // tail and *did_fuse is set; the caller then launches no node kernel
 template <int H>
-int launch_eval(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s, bool tabled = false, const NodeArgs* fused = nullptr, bool* did_fuse = nullptr) {
+int launch_eval(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s, bool tabled = false, const NodeArgs* fused = nullptr, bool* did_fuse = nullptr,
+                const NoiseAhead* na = nullptr /*H = 256, f16x2 only: the evaluation's normal draws, see NoiseAhead*/) {
     // U = pose_emb . Wp^T ; O = decoder(...)
     // tabled (hipGraph mode): the timestep comes from the device step table, see StepEntry
     const ccsp::Plan& p = g->plan;
@@ -2005,12 +2095,14 @@ int launch_eval(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s, bool tabled 
     const int nw_u = g->n_tiles * rowgemm_col_tiles<H, 2 * H>();
     const size_t tau_stride = (size_t)m->d.n_types * 2 * H;
     const float* tau_t = m->tau + (tabled ? 0 : (size_t)t * tau_stride);
-    const StepRef ref{tabled ? g->d_tab : nullptr, tabled ? g->d_counter : nullptr};
+    StepRef ref{tabled ? g->d_tab : nullptr, tabled ? g->d_counter : nullptr};
+    if (na) ref.na = *na;
     int* const cinc = tabled ? g->d_counter : nullptr;
     if constexpr (H == 256) {
 #ifdef CCSP_EXPERIMENTS
         if (m->f16x2 && m->eval_fused && !tabled && g->n_ftiles > 0 && fused == nullptr) {
             prof_mark(g, s, CCSP_K_EVAL_FUSED);
+            if (ref.na.z) hipLaunchKernelGGL(k_noise_ahead, dim3(ref.na.blocks), dim3(256), 0, s, ref.na);
             FusedArgs fa;
             fa.order = g->ft_order; fa.n_items = 2 * g->n_ftiles;
             fa.tiles = g->ft_tiles; fa.rows = g->ft_rows; fa.e_lu = g->ft_elu; fa.ent_pos = g->ent_pos;
@@ -2536,12 +2628,88 @@ int lane_stream_get(size_t k, hipStream_t* out) {
     return 0;
 }
 
+// the event behind the device's last relay chain (Relay)
+int relay_tail_get(hipEvent_t* out) {
+    static std::mutex mu;
+    static std::map<int, hipEvent_t> tail;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = tail.find(dev);
+    if (it == tail.end()) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        it = tail.emplace(dev, e).first;
+    }
+    *out = it->second;
+    return 0;
+}
+
 // one concurrently running sub-batch of a chain
 struct Lane {
     ccsp_graph* g;
     hipStream_t s;
     int node0;          // global index of the lane's first node (noise rows, output slices)
+    int idx = 0;        // lane index (relay mode: which pair of pooled streams)
+    int relay_slots = 0;   // relay mode: workgroup slots this lane may hold at once (0 = relay off), see relay_begin
 };
+
+// Relay mode of one lane (Gate).  Safe only while EVERY workgroup of the lane's three kernels can be resident at once -- a workgroup that
+// polls a counter holds its slot, so a producer that found no room would never run.  Slot model: any mix of two workgroups of these kernels fits
+// a CU (LDS <= 74 KB, <= 248 VGPRs per wave, one wave per SIMD each), so 2 x CUs workgroups of any mix are always placeable (if one were not,
+// every CU would hold two already); the lanes of a chain share that budget and relay chains of a device run one after the other (relay_tail in
+// ccsp_chain_run).  Lists above the budget run the stream-ordered launches.
+struct Relay {
+    bool on = false;
+    hipStream_t sE = nullptr, sN = nullptr;
+    unsigned int nR = 0, nE = 0, nN = 0, ev = 0;
+};
+__global__ void k_relay_fault(const unsigned int* ctr, float* x, long n) {      // a gate timed out: the chain's result is void
+    if (ctr[3] == 0) return;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = __builtin_nanf("");
+}
+int relay_begin(ccsp_model* m, const Lane& L, Relay* r) {
+    ccsp_graph* g = L.g;
+    r->on = false;
+#ifndef CCSP_EXPERIMENTS
+    (void)m; (void)g;
+    return 0;
+#else
+    if (L.relay_slots <= 0 || !m->f16x2 || !m->bf16x3 || !m->pe2_wH || m->node_generic || m->d.model_kind != CCSP_MODEL_DIFFUSION_CCSP ||
+        m->d.energy_wrapper || g->plan.E_act <= 0 || g->profile || m->d.hidden_dim != 256) return 0;
+    constexpr int H = 256;
+    const int mode = rowgemm_h2_mode(m, g, 2 * H / 128);
+    if (mode != 0 && mode != 4 && mode != 6) return 0;
+    r->nR = (unsigned int)(((mode == 4 || mode == 6) ? g->n_tiles : g->n_tiles2) * (2 * H / 128));
+    r->nE = (unsigned int)nblk(g->plan.E_act, edge_tile_edges(m, g->plan.E_act));
+    r->nN = (unsigned int)nblk(g->N, NODE_TILE);
+    if ((long)r->nR + r->nE + r->nN > (long)L.relay_slots) return 0;
+    if (!g->relay_ctr) {
+        if (dev_alloc(g->allocs, &g->relay_ctr, 4)) return 1;
+        for (int i = 0; i < 3; ++i) HIP_TRY(hipEventCreateWithFlags(&g->relay_ev[i], hipEventDisableTiming));
+    }
+    if (lane_stream_get(8 + 2 * (size_t)L.idx, &r->sE) || lane_stream_get(9 + 2 * (size_t)L.idx, &r->sN)) return 1;
+    HIP_TRY(hipMemsetAsync(g->relay_ctr, 0, 4 * sizeof(unsigned int), L.s));
+    HIP_TRY(hipEventRecord(g->relay_ev[0], L.s));            // (behind the chain's first node launch: the state and its embeddings)
+    HIP_TRY(hipStreamWaitEvent(r->sE, g->relay_ev[0], 0));
+    HIP_TRY(hipStreamWaitEvent(r->sN, g->relay_ev[0], 0));
+    r->ev = 0;
+    r->on = true;
+    g->relay_chains++;
+    return 0;
+#endif
+}
+int relay_end(const ccsp_model* m, const Lane& L, const Relay& r) {
+    ccsp_graph* g = L.g;
+    HIP_TRY(hipEventRecord(g->relay_ev[1], r.sE));
+    HIP_TRY(hipEventRecord(g->relay_ev[2], r.sN));
+    HIP_TRY(hipStreamWaitEvent(L.s, g->relay_ev[1], 0));
+    HIP_TRY(hipStreamWaitEvent(L.s, g->relay_ev[2], 0));
+    const long n = (long)g->N * m->d.pose_dim;
+    hipLaunchKernelGGL(k_relay_fault, dim3(nblk(n, 256)), dim3(256), 0, L.s, g->relay_ctr, g->x, n);
+    return 0;
+}
 
 // Enqueues timesteps t_first..t_last for every lane, interleaved kernel by kernel so that all lane
 // streams advance together.  NP_total = rows x P of the whole batch (history / injected-noise stride).
@@ -2851,10 +3019,16 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
             }
         }
 #endif
+        // relay mode (Gate): lanes whose three grids fit their share of the chip's workgroup slots all at once
+        std::vector<Relay> relay(lanes.size());
+        if constexpr (H == 256)
+            for (size_t li = 0; li < lanes.size(); ++li)
+                if (relay_begin(m, lanes[li], &relay[li])) return 1;
         for (int t = t_first; t >= t_last; --t) {
             const int S = steps_at(m, sampler, t);
             for (int e = 0; e <= S; ++e) {
-                for (const Lane& L : lanes) {
+                for (size_t li = 0; li < lanes.size(); ++li) {
+                    const Lane& L = lanes[li];
                     ccsp_graph* g = L.g;
                     NodeArgs a = node_args(m, g);
                     a.do_encode = 1;
@@ -2863,18 +3037,50 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
                     a.hist = e == S ? hist_at(L, T - t) : nullptr;
                     sched(a, t);
                     if (noise_for(L, call0[t] + (uint64_t)e, a.noise)) return 1;
+                    if constexpr (H == 256) {
+                        Relay& r = relay[li];
+                        if (r.on) {
+                            // row GEMM i+1 waits for node update i, edge kernel i for row GEMM i, node update i for edge kernel i; every
+                            // buffer of an evaluation is dead before its next writer passes its gate (the waits form one cycle)
+                            unsigned int* c = g->relay_ctr;
+                            StepRef ref{nullptr, nullptr, nullptr, Gate{r.ev ? c + 2 : nullptr, r.ev * r.nN, c + 0, c + 3}};
+                            const size_t tau_stride = (size_t)m->d.n_types * 2 * H;
+                            launch_rowgemm_h2(m, g, m->tau + (size_t)t * tau_stride, ref, tau_stride, L.s);
+                            EdgeEnergyArgs en{};
+                            en.gate = Gate{c + 0, (r.ev + 1) * r.nR, c + 1, c + 3};
+                            launch_edge_h2<false>(m, g, en, nullptr, r.sE, nullptr);
+                            a.src = 0;
+                            a.gate = Gate{c + 1, (r.ev + 1) * r.nE, c + 2, c + 3};
+                            launch_node<H>(m, g, a, r.sN);
+                            r.ev++;
+                            g->evals++;
+                            continue;
+                        }
+                    }
                     bool fused = false;
                     if (m->d.model_kind == CCSP_MODEL_STRUCT_DIFFUSION) {
                         if (launch_eval_sd<H>(m, g, t, L.s)) return 1;
                         a.src = 1; a.eps_buf = g->eps;
                     } else {
                         a.src = 0;
-                        if (launch_eval<H>(m, g, t, L.s, false, (g->fuse_me > 0 || g->ng_use) ? &a : nullptr, &fused)) return 1;
+                        NoiseAhead na{};
+                        if constexpr (H == 256) {
+                            if (m->f16x2 && m->bf16x3 && nz->mode != CCSP_NOISE_INJECTED && g->plan.E_act > 0) {
+                                if (!g->zbuf && dev_alloc(g->allocs, &g->zbuf, (size_t)g->N * P)) return 1;
+                                na.z = g->zbuf; na.N = g->N; na.P = P; na.blocks = nblk((long)g->N * P, 256);
+                                na.call = a.noise.call; na.seed = a.noise.seed; na.row_offset = a.noise.row_offset;
+                                a.noise.mode = CCSP_NOISE_INJECTED;          // the node update reads the draws the row GEMM's extra workgroups wrote
+                                a.noise.normal = g->zbuf;
+                            }
+                        }
+                        if (launch_eval<H>(m, g, t, L.s, false, (g->fuse_me > 0 || g->ng_use) ? &a : nullptr, &fused, na.z ? &na : nullptr)) return 1;
                     }
                     if (!fused) launch_node<H>(m, g, a, L.s);
                 }
             }
         }
+        for (size_t li = 0; li < lanes.size(); ++li)
+            if (relay[li].on && relay_end(m, lanes[li], relay[li])) return 1;
     }
     for (const Lane& L : lanes)
         HIP_TRY(hipMemcpyAsync(x_io + (size_t)L.node0 * P, L.g->x, (size_t)L.g->N * P * sizeof(float), hipMemcpyDeviceToDevice, L.s));
@@ -3344,6 +3550,7 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     if (const char* e = getenv("CCSP_LANE_MIN_EDGES")) m->lane_min_edges = atoi(e);
     m->lane_min_tokens = 1024;
     if (const char* e = getenv("CCSP_LANE_MIN_TOKENS")) m->lane_min_tokens = atoi(e);
+    if (const char* e = exp_env("CCSP_RELAY")) m->relay = atoi(e);
     if (const char* e = getenv("CCSP_LANES")) { const int v = atoi(e); if (v >= 1 && v <= 8) m->lanes = v; }
     // CCSP_MMA: f16x2 (default at hidden_dim 256: two-term fp16 operands, three MFMA products per fp32 product),
     //           bf16x3 (three-term bf16 operands, six products), f32 (v_mfma_f32_32x32x2_f32)
@@ -3958,6 +4165,13 @@ int ccsp_chain_run(ccsp_model* m, ccsp_graph* g, int32_t sampler, const ccsp_noi
         }
     }
     if (!g->have_events) { HIP_TRY(hipEventCreate(&g->ev0)); HIP_TRY(hipEventCreate(&g->ev1)); g->have_events = true; }
+    // relay chains of a device run one after the other: each may then count on the whole chip's workgroup slots (Relay)
+    hipEvent_t relay_tail = nullptr;
+    const bool relay = m->relay && !m->d.energy_wrapper && m->d.model_kind == CCSP_MODEL_DIFFUSION_CCSP && !g->profile;
+    if (relay) {
+        if (relay_tail_get(&relay_tail)) return 1;
+        HIP_TRY(hipStreamWaitEvent(s, relay_tail, 0));
+    }
     HIP_TRY(hipEventRecord(g->ev0, s));
     const bool forked = !lanes.empty();
     if (forked) {
@@ -3965,6 +4179,10 @@ int ccsp_chain_run(ccsp_model* m, ccsp_graph* g, int32_t sampler, const ccsp_noi
         for (const Lane& L : lanes) HIP_TRY(hipStreamWaitEvent(L.s, m->fork_event, 0));
     } else {
         lanes.push_back(Lane{g, s, 0});
+    }
+    for (size_t i = 0; i < lanes.size(); ++i) {
+        lanes[i].idx = (int)i;
+        lanes[i].relay_slots = relay ? 2 * m->ncu / (int)lanes.size() : 0;
     }
     int rc = 0;
     auto run = [&](const std::vector<Lane>& ls) -> int {
@@ -4007,6 +4225,7 @@ int ccsp_chain_run(ccsp_model* m, ccsp_graph* g, int32_t sampler, const ccsp_noi
         g->kev_used = 0;
     }
     HIP_TRY(hipEventRecord(g->ev1, s));
+    if (relay) HIP_TRY(hipEventRecord(relay_tail, s));
     return rc;
 }
 

@@ -19,6 +19,12 @@ def pytest_configure(config):
                                        '-m gpu_experiments): the variants that lost their A/Bs, kept out of the product library and of the default -m gpu run')
 
 
+def pytest_collection_modifyitems(config, items):
+    """the full-size parity tests wait for CPU oracle chains that full_size_oracle_prefetch (below) starts with the session: they go last, so
+    that the chains run under every other GPU test instead of inside their own"""
+    items.sort(key=lambda it: it.name.startswith('test_full_size'))            # (stable: nothing else moves)
+
+
 import diffusion_ccsp_amd  # noqa: E402,F401
 from diffusion_ccsp_amd import worlds  # noqa: E402
 import oracle  # noqa: E402  (tests are allowed to use the checker)
@@ -84,6 +90,16 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / (1.0 + np.abs(b).max()))
+
+
+@pytest.fixture(scope='session', autouse=True)
+def full_size_oracle_prefetch(request):
+    """a GPU session that will run the full-size tests of test_hip_parity.py starts their oracle work (worker threads, ctypes releases the GIL) now"""
+    import torch
+    if torch.cuda.is_available() and any(it.name.startswith('test_full_size') for it in request.session.items):
+        import test_hip_parity
+        test_hip_parity.start_full_size_oracle_work(torch.device('cuda:0'))
+    yield
 
 
 @pytest.fixture(scope='session')

@@ -256,3 +256,32 @@ def test_energy_launch_forms_are_bitwise_identical(device, monkeypatch):
             assert np.array_equal(a, c, equal_nan=True)
 
 
+
+
+def test_relay_mode_is_bitwise_identical(device, monkeypatch):
+    """CCSP_RELAY=1 (round 5, csrc Gate; profiles/r05_findings.md section 5): on small batches the three kernels of an evaluation go to three
+    streams and are handed over through device counters (a workgroup polls its producer's counter at entry, adds to its own at exit, with an
+    agent-scope release / acquire around it) instead of stream order.  Same kernels, same arithmetic: bit-equal chains, histories and segments --
+    one lane and two, a batch above the slot budget (falls back to stream order), and no gate may time out (a fault turns the state into NaN)."""
+    out = {}
+    for relay in ('0', '1'):
+        monkeypatch.setenv('CCSP_RELAY', relay)
+        res = []
+        for name in ('chain_q256_T100_B1', 'chain_q256_T1000_B4'):
+            z = golden(name)
+            den, gd, b = _golden_chain_model(device, z)
+            x, hist = gd.sample(b, return_history=True, seed=int(z['seed']))
+            assert np.abs(x.cpu().numpy() - z['final']).max() < 1e-4, (relay, name)
+            res += [x.cpu().numpy(), torch.stack(hist).cpu().numpy()]
+            T = int(z['T'])
+            res.append(gd.p_sample_segment(b, torch.from_numpy(z['hist'][1]), T - 2, T - 5, seed=int(z['seed'])).cpu().numpy())
+        for lanes, graphs in (('1', 24), ('2', 48), ('1', 200)):
+            monkeypatch.setenv('CCSP_LANES', lanes)
+            monkeypatch.setenv('CCSP_LANE_MIN_EDGES', '1')
+            den, gd = hip_model(device, 'qualitative', 256, 'weights_qualitative_h256.npz', T=30, S=3)
+            x = gd.sample(worlds.qualitative_batch(graphs, 8, seed=3).to_torch(), seed=11).cpu().numpy()
+            assert np.isfinite(x).all()
+            res.append(x)
+        out[relay] = res
+    for a, c in zip(out['0'], out['1']):
+        assert np.array_equal(a, c, equal_nan=True)

@@ -30,7 +30,7 @@ names = {0: ['entry', 'index setup'] + ['chunk %d landed' % c for c in range(8)]
              'row tile 0 stores issued', 'row tile 1 in LDS', 'row tile 1 stores issued', 'stores drained'] +
             ['tile %d group %d computed' % (i, st) for i in range(2) for st in range(4)] + ['tile 0 bt formed', 'tile 1 bt formed'],
          1: ['entry', 'indices+umax', 'stage 0 built'] + ['chunk %d done' % c for c in range(8)] + ['S1 written', 'layer-2 partials', 'O stored'],
-         2: ['entry', 'CSR sum + update', 'layer 1', 'layer 2 MFMA', 'row max', 'planes stored']}
+         2: ['entry', 'CSR sum + update', 'layer 1', 'layer 2 MFMA', 'row max', 'planes stored', 'update computed (in front of the barrier)', 'node_ptr here', 'noise drawn', 'CSR sum done']}
 for kern, title in ((0, 'k_rowgemm_h2'), (1, 'k_edge_h2'), (2, 'k_node')):
     tk = t[kern]
     tk = tk[tk[:, 0] > 0]
