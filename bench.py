@@ -434,7 +434,7 @@ def sd_main(args):
             og.denoise(poses, 500 - n_ev % 400)
             n_ev += 1
         dt = (time.perf_counter() - t1) / n_ev
-        rec['cpu_baseline'] = {'value': nb / (dt * T_STEPS * (1 + S)), 'unit': 'samples/s', 'cores': os.cpu_count(), 'threads_used': 1, 'kind': 'port',
+        rec['cpu_baseline'] = {'value': nb / (dt * T_STEPS * (1 + S)), 'unit': 'samples/s', 'cores': 1, 'threads_used': 1, 'host_cpus': os.cpu_count(), 'host_cpu_quota': effective_cores(), 'kind': 'port',
                                'sample': '%d single evaluations of a %d-graph batch by the C oracle (oracle/ccsp_oracle.c, one thread), extrapolated x %d evaluations per chain'
                                          % (n_ev, nb, T_STEPS * (1 + S)), 'sec_per_evaluation_per_graph': dt / nb}
     if rank == 0:
@@ -445,6 +445,22 @@ def sd_main(args):
     if rank == 0:
         print(json.dumps(rec), flush=True)
 
+
+
+def effective_cores():
+    """cores this container may actually use: the cgroup quota if there is one (the GPU boxes report 256 CPUs and grant 16), else os.cpu_count()"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q != 'max':
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 def world_label(cfg):
     """'RandomSplitQualitativeWorld 8-obj' from the configuration's label"""
@@ -962,9 +978,11 @@ def main():
         cpu_batch.num_graphs = B
         r = torch_proxy.time_baseline(load_weights(wpath), dims, HIDDEN, cfg['n_types'], cpu_batch, T=T_STEPS, S=S,
                                       n_timesteps=3, budget_s=25.0, sampler=cfg['EBM'])
-        rec['cpu_baseline'] = {'value': r['samples_per_s'], 'unit': 'samples/s', 'cores': os.cpu_count(), 'threads_used': r['cores'], 'kind': 'port',
-                               'cores_note': 'cores = host cores of this box (os.cpu_count()); threads_used = the PyTorch thread count the value was taken at, '
-                                             'the fastest of sec_per_eval_by_threads (these small matrices do not scale to every core)',
+        rec['cpu_baseline'] = {'value': r['samples_per_s'], 'unit': 'samples/s', 'cores': r['cores'], 'threads_used': r['cores'], 'host_cpus': os.cpu_count(),
+                               'host_cpu_quota': effective_cores(), 'kind': 'port',
+                               'cores_note': 'cores = threads_used = the PyTorch thread count the value was taken at, the fastest of sec_per_eval_by_threads '
+                                             '(these small matrices do not scale to every core); host_cpus = os.cpu_count(), host_cpu_quota = what the '
+                                             "container's cgroup grants of them",
                                'sample': r['sample'], 'sec_per_timestep': r['sec_per_timestep'],
                                'sec_per_eval_by_threads': r['sec_per_eval_by_threads'],
                                'speedup_gpu_over_cpu': value / r['samples_per_s']}
