@@ -187,6 +187,44 @@ __device__ __forceinline__ void h2_chunk_ahead(const unsigned short* __restrict_
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][i][PA[q]], b[ks][j][PB[q]], acc[i][j], 0, 0, 0);
 }
 
+// h2_chunk_ahead with the NEXT ring stage's direct-to-LDS loads issued BETWEEN its MFMA pairs (between(k), k = 0 .. 6 MI - 1).  A wave issues in
+// order: six global_load_lds pieces in front of the chunk's reads cost their whole issue time (60-185 cycles each inside a busy phase) before the
+// first MFMA can go -- 0.85 k cycles per chunk for 0.38 k of matrix work in the small-batch traces (profiles/r05_findings.md section 6).  Behind an
+// MFMA pair the same issue slots are free: the pair occupies the matrix pipe for 64 cycles while the wave moves on.  Same reads, same MFMA order.
+template <int MI, typename F>
+__device__ __forceinline__ void h2_chunk_ahead_with(const unsigned short* __restrict__ As, int apl, const unsigned short* __restrict__ Bs,
+                                                    int am0, int bn0, floatx16 (&acc)[MI][2], F&& between) {
+    const int lane = threadIdx.x & 63;
+    half8 a[2][MI][2], b[2][2][2];                               // [k-step][tile][plane]
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int piece = (lane >> 5) + 2 * ks;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[ks][i][1] = *reinterpret_cast<const half8*>(As + apl + h2_off(am0 + 32 * i + (lane & 31), piece));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[ks][j][0] = *reinterpret_cast<const half8*>(Bs + h2_off(bn0 + 32 * j + (lane & 31), piece));
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[ks][i][0] = *reinterpret_cast<const half8*>(As + h2_off(am0 + 32 * i + (lane & 31), piece));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[ks][j][1] = *reinterpret_cast<const half8*>(Bs + H2_BPL + h2_off(bn0 + 32 * j + (lane & 31), piece));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][i][PA[q]], b[ks][j][PB[q]], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                between((ks * 3 + q) * MI + i);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+}
+
 // Both k-steps of a staged chunk with the fragment reads of k-step 1 issued UNDER the MFMAs of k-step 0 (MODE 8 of k_rowgemm_h2; MI = 2).  The three
 // products of a k-step use (a lo, b hi), (a hi, b lo), (a hi, b hi): a lo is dead after the first group, b lo after the second, so k-step 1's
 // a lo / b lo go into the SAME registers behind those groups and only its two hi fragments need registers of their own (16 VGPRs).  The LDS
@@ -842,9 +880,17 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
                 __builtin_amdgcn_s_barrier();                         // chunk c has landed for every wave; stage (c-1) % NST is free
                 __builtin_amdgcn_sched_barrier(0);
                 CCSP_TRK(0, 2 + (c < 8 ? c : 7));
-                if (c + D < NCH) glds(c + D, (c + D) % NST);
                 const unsigned short* st = smem + (c % NST) * STAGE;
-                h2_chunk_ahead<MI>(st, APL, st + 2 * APL, wr0, wn * 64, acc);
+                if (c + D < NCH) {
+                    // the next ring stage's loads go out between this chunk's MFMA pairs (h2_chunk_ahead_with): A pieces first, then the weights
+                    unsigned short* nst = smem + ((c + D) % NST) * STAGE;
+                    h2_chunk_ahead_with<MI>(st, APL, st + 2 * APL, wr0, wn * 64, acc, [&](int k) {
+                        if (k < NA) __builtin_amdgcn_global_load_lds((gptr)(ga[k] + (c + D) * H2_BK), (lptr)(nst + loa[k]), 16, 0, 0);
+                        else if (k < NA + 4) __builtin_amdgcn_global_load_lds((gptr)(gb[k - NA] + (c + D) * H2_BK), (lptr)(nst + 2 * APL + lob[k - NA]), 16, 0, 0);
+                    });
+                } else {
+                    h2_chunk_ahead<MI>(st, APL, st + 2 * APL, wr0, wn * 64, acc);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             exps_wait();

@@ -33,7 +33,7 @@ names = {0: ['entry', 'index setup'] + ['chunk %d landed' % c for c in range(8)]
          2: ['entry', 'CSR sum + update', 'layer 1', 'layer 2 MFMA', 'row max', 'planes stored', 'update computed (in front of the barrier)', 'node_ptr here', 'noise drawn', 'CSR sum done']}
 for kern, title in ((0, 'k_rowgemm_h2'), (1, 'k_edge_h2'), (2, 'k_node')):
     tk = t[kern]
-    tk = tk[tk[:, 0] > 0]
+    tk = tk[(tk[:, 0] > 0) & ((tk[:, :30] > 0).sum(axis=1) >= 4)]          # (the row GEMM's noise-ahead workgroups stamp their entry only)
     if not len(tk):
         continue
     nn = names[kern]
