@@ -42,8 +42,11 @@ def build(name, spec, trace=False):
     hip = hip.replace('#include "../../include/ccsp.h"', '#include "%s"' % os.path.join(ROOT, 'include', 'ccsp.h'))
     open(os.path.join(tmp, 'ccsp_hip.hip'), 'w').write(hip)
     out = os.path.join(ROOT, 'tools', 'abl_%s%s.so' % (name, '_trace' if trace else ''))
-    subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-pthread'] + (['-DCCSP_TRACE'] if trace else []) + ['-D' + d for d in defines] +
-                          ['-I', os.path.join(ROOT, 'include'), '-I', SRC, '-o', out, os.path.join(tmp, 'ccsp_hip.hip')])
+    # (the product build's flags, diffusion-ccsp_amd/_lib.py: -save-temps changes the pipeline the device code goes through, and an A/B must not
+    # measure that)
+    subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-pthread', '-save-temps', '--offload-compress'] +
+                          (['-DCCSP_TRACE'] if trace else []) + ['-D' + d for d in defines] +
+                          ['-I', os.path.join(ROOT, 'include'), '-I', SRC, '-o', out, os.path.join(tmp, 'ccsp_hip.hip'), '-ldl'], cwd=tmp)
     shutil.rmtree(tmp, ignore_errors=True)
     print('built', out)
 
