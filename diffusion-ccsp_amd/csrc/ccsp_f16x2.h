@@ -498,6 +498,15 @@ __device__ __forceinline__ void h2_wait_vm_lgkm0(int n) {
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
+// s_waitcnt vmcnt(N) for the row indices requested at kernel entry (h2_ld4), N = loads issued since
+template <int N, int NI>
+__device__ __forceinline__ void h2_idx_wait(int (&v)[NI]) {
+    static_assert(NI == 1 || NI == 2 || NI == 4, "index count");
+    if constexpr (NI == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v[0]) : "n"(N) : "memory");
+    else if constexpr (NI == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(v[0]), "+v"(v[1]) : "n"(N) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : "n"(N) : "memory");
+}
+
 // ------------------------------------------------------------------------------------------
 // k_rowgemm_h2<KD, ND, MODE>:  U[row0 + r, col0 + c] = 2^-(ea[r] + ew) * sum_k A[src(r), k] W[ts][col0 + c, k]  + base + tau
 //   A planes [2][n_src][KD] fp16 bits scaled by 2^a_exp[src], rows gathered by urow_node; W planes [2][n_ts][ND][KD]
@@ -559,6 +568,25 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
     if (ref.tab) tau_t += (size_t)ref.tab[*ref.counter].t * tau_stride;      // hipGraph mode: timestep from the device table
     const int bid = xcd_remap(blockIdx.x, n_work);
     const int tile = bid / NCT, ct = bid % NCT;
+    // Forward GEMM: the plane rows of this thread's tile rows come from a table padded per tile (StepRef::tile_rows): its address needs the
+    // workgroup index only, so the gather is requested HERE, next to the tile descriptor, and not behind it -- descriptor -> row indices ->
+    // operand rows was three dependent round trips of ~2 k cycles each in front of the first MFMA (profiles/r05_findings.md section 1), now two.
+    // asm loads (the compiler neither moves nor waits for them); the wait is h2_idx_wait<N> in each mode, N = the loads issued behind them.
+    constexpr bool RINGIDX = MODE >= 2 && MODE != 5 && MODE != 6 && MODE != 8;       // the direct-to-LDS forms: a lane's rows are those of its 1 KB blocks
+    constexpr int TM_ = ((MODE == 4 || MODE == 6) ? 1 : 2) * 64;
+    constexpr int NIDX = RINGIDX ? TM_ / 32 : TM_ / 64;
+    int srcx[NIDX];
+    if constexpr (KD < ND) {
+        const int* trp = ref.tile_rows + (size_t)tile * TM_;
+#pragma unroll
+        for (int j = 0; j < NIDX; ++j) {
+            int row;
+            if constexpr (RINGIDX) row = (((TM_ / 32) * (int)(threadIdx.x >> 6) + j) % (TM_ / 16)) * 16 + (int)((threadIdx.x & 63) >> 2);
+            else if constexpr (MODE == 5) row = (int)((threadIdx.x >> 7) * 64) + 32 * j + (int)(threadIdx.x & 31);
+            else row = (int)(threadIdx.x >> 2) + 64 * j;
+            h2_ld4(srcx[j], trp + row);
+        }
+    }
     const int4 td = tile_desc[tile];
     const int row0 = td.x, nrows = td.y, ts = td.z;
     const int col0 = ct * 128;
@@ -614,14 +642,15 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
         for (int i = 0; i < 2; ++i) {
             const int row = wr0 + 32 * i + (lane & 31);
             const int r = row < nrows ? row : nrows - 1;
-            if (urow_node) h2_ld4(src[i], urow_node + row0 + r); else src[i] = row0 + r;
+            if constexpr (FWD) src[i] = srcx[i];                     // (requested at kernel entry)
+            else if (urow_node) h2_ld4(src[i], urow_node + row0 + r); else src[i] = row0 + r;
         }
         __builtin_amdgcn_sched_barrier(0);
         glds_b(0);
         glds_b(1);
         glds_b(2);
         __builtin_amdgcn_sched_barrier(0);
-        if (urow_node) asm volatile("s_waitcnt vmcnt(12)" : "+v"(src[0]), "+v"(src[1]) :: "memory");      // (the twelve weight loads stay in flight)
+        if (FWD || urow_node) asm volatile("s_waitcnt vmcnt(12)" : "+v"(src[0]), "+v"(src[1]) :: "memory");      // (the twelve weight loads stay in flight)
         const unsigned short* ap[2][2];                               // [tile][plane]
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -718,7 +747,8 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
         for (int i = 0; i < 2; ++i) {
             int r = lrow + 64 * i;
             r = r < nrows ? r : nrows - 1;
-            srcr[i] = urow_node ? urow_node[row0 + r] : row0 + r;
+            if constexpr (FWD) { if (i == 0) h2_idx_wait<4>(srcx); srcr[i] = srcx[i]; }      // (behind them: the four weight pieces of chunk 0)
+            else srcr[i] = urow_node ? urow_node[row0 + r] : row0 + r;
             a_ptr[i] = A + (size_t)srcr[i] * KD + lq * 8;
         }
         const int st_off = h2_off(lrow, lq);
@@ -819,11 +849,16 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
             const int blk = NA * wave + j, rb16 = blk % ARB;
             const int row = rb16 * 16 + (lane >> 2);
             const int r = row < nrows ? row : nrows - 1;
-            src[j] = urow_node ? urow_node[row0 + r] : row0 + r;
+            if constexpr (!FWD) src[j] = urow_node ? urow_node[row0 + r] : row0 + r;
         }
         __builtin_amdgcn_sched_barrier(0);
         glds_b(0, 0);                                             // the weights of chunk 0 are on their way while the row indices arrive
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (FWD) {                                      // (requested at kernel entry; behind them: the two time-term loads and the four weight pieces)
+            h2_idx_wait<6>(srcx);
+#pragma unroll
+            for (int j = 0; j < NA; ++j) src[j] = srcx[j];
+        }
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int blk = NA * wave + j, plane = blk / ARB, rb16 = blk % ARB;
@@ -940,7 +975,8 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
         for (int i = 0; i < MI; ++i) {
             int r = lrow + 64 * i;
             r = r < nrows ? r : nrows - 1;
-            srcr[i] = urow_node ? urow_node[row0 + r] : row0 + r;
+            if constexpr (FWD) { if (i == 0) h2_idx_wait<2>(srcx); srcr[i] = srcx[i]; }      // (requested at kernel entry; behind them: the two time-term loads)
+            else srcr[i] = urow_node ? urow_node[row0 + r] : row0 + r;
             a_ptr[i] = A + (size_t)srcr[i] * KD + lq * 8;
         }
         auto row_exps = [&]() {                                   // (epilogue only) behind the first operands, by the lanes that hold the row's index

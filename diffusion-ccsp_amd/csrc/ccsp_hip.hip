@@ -1002,6 +1002,8 @@ struct StepRef {
     const int* skip;        // MALA reuse (CCSP_MALA_REUSE): if non-null and *skip == 0 the launch returns at once
     Gate gate;              // relay mode
     NoiseAhead na;          // forward GEMM of a direct-mode chain: the evaluation's normal draws (or z == null)
+    const int* tile_rows;   // forward GEMM: the plane row of every tile row, padded per tile ([tile][TM]; rows past the tile's end repeat its last row) --
+                            // its address needs the workgroup index only, so the gather goes out WITH the tile descriptor instead of behind it
 };
 
 struct NodeArgs {
@@ -1765,7 +1767,9 @@ struct ccsp_graph {
     std::vector<int> h_forder;
     int n_ftiles = 0;
     ccsp::FusedPlan fplan;                    // kept alive for the async upload
+    int *tr64 = nullptr, *tr128 = nullptr;    // urow_node per tile row, padded per tile (StepRef::tile_rows)
     int4 *td64 = nullptr, *td128 = nullptr;   // the same tile lists as {row0, nrows, 2 type + slot, 0} records (k_rowgemm_h2: one scalar load per tile)
+    std::vector<int> h_tr;                    // (kept alive for the asynchronous upload, like h_td)
     std::vector<int4> h_td;                   // kept alive for the async upload
     int* urow_ts;
     // energy mode (allocated on first use)
@@ -1916,6 +1920,7 @@ int launch_rowgemm_h2(ccsp_model* m, ccsp_graph* g, const float* tau_t, StepRef 
 #endif
     const bool small = mode == 4 || mode == 6;          // 64-row plan tiles instead of their 128-row pairs
     const int work = (small ? g->n_tiles : g->n_tiles2) * (2 * H / 128);
+    ref.tile_rows = small ? g->tr64 : g->tr128;
 #define CCSP_ROWGEMM_F(MODE)                                                                                                                          \
     hipLaunchKernelGGL((k_rowgemm_h2<H, 2 * H, MODE>), dim3(work + ref.na.blocks), dim3(256), 0, s, g->pembH, (size_t)g->N * H, g->pexp, g->urow_node,                  \
                        small ? g->td64 : g->td128, m->WpH,                                                                                              \
@@ -3237,6 +3242,18 @@ int graph_build(ccsp_model* m, int N, int E, int F, const float* x, const signed
         int4* td = nullptr;
         TRY(dev_upload(reg, &td, g->h_td, s));
         g->td64 = td; g->td128 = td + p.tile_row0.size();
+        // the forward row GEMM's gather per tile row (64-row tiles, then their 128-row pairs): one dependent round trip less in front of its first operands
+        std::vector<int>& tr = g->h_tr;
+        tr.reserve((p.tile_row0.size() * 64 + r0.size() * 128));
+        for (size_t i = 0; i < p.tile_row0.size(); ++i)
+            for (int r = 0; r < 64; ++r) tr.push_back(p.tile_nrows[i] > 0 ? p.urow_node[p.tile_row0[i] + std::min(r, p.tile_nrows[i] - 1)] : 0);
+        for (size_t i = 0; i < r0.size(); ++i)
+            for (int r = 0; r < 128; ++r) tr.push_back(nr[i] > 0 ? p.urow_node[r0[i] + std::min(r, nr[i] - 1)] : 0);
+        if (!tr.empty()) {
+            int* trd = nullptr;
+            TRY(dev_upload(reg, &trd, tr, s));
+            g->tr64 = trd; g->tr128 = trd + p.tile_row0.size() * 64;
+        }
     }
 #ifdef CCSP_EXPERIMENTS
     if (m->f16x2 && m->WpF && m->eval_fused && p.E_act > 0) {   // fused tiles: <= 28 (32) U rows per slot, <= 112 (128) edges
