@@ -79,6 +79,18 @@ __global__ void k_absmax_bits(long n, const float* __restrict__ src, unsigned in
     if ((threadIdx.x & 63) == 0 && v) atomicMax(out, v);
 }
 
+// planar fp16 planes [2][rows][K] -> the forward row GEMM's weight layout [rows][K / 32][2][32] (both planes of a row's 32-element K chunk in one
+// 128-byte line: k_rowgemm_h2, ILW)
+__global__ void k_interleave_planes(long n /*rows * K*/, int K, const unsigned short* __restrict__ src, unsigned short* __restrict__ dst) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long row = i / K;
+    const int k = (int)(i - row * K);
+    const long o = row * 2 * K + (long)(k >> 5) * 64 + (k & 31);
+    dst[o] = src[i];
+    dst[o + 32] = src[n + i];
+}
+
 constexpr int H2_BK = 32;                    // K chunk: two MFMA k-steps of 16
 constexpr int H2_BPL = 128 * H2_BK;          // fp16 elements per plane of the 128-row B operand stage
 // rows are unpadded 64-byte K chunks, the 16-byte piece index XOR-swizzled by (row >> 2) & 3 (rb2_off of
@@ -280,6 +292,78 @@ __device__ __forceinline__ void h2_chunk_pipe(const unsigned short* __restrict__
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi1[i], blo[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi1[i], bhi1[j], acc[i][j], 0, 0, 0);
+}
+
+// h2_chunk_pipe with a hook behind each of its six MFMA groups (between(k), k = 0 .. 5): MODE 9 of k_rowgemm_h2 issues the NEXT chunk's staging
+// stores (into the other LDS stage) and the global loads two chunks further on there, where the matrix pipe is busy for 128 cycles per group and
+// the wave's issue slots are free.  Same reads, same MFMA order per accumulator: bitwise the sums of h2_kstep.
+template <typename F>
+__device__ __forceinline__ void h2_chunk_pipe_with(const unsigned short* __restrict__ As, int apl, const unsigned short* __restrict__ Bs,
+                                                   int am0, int bn0, floatx16 (&acc)[2][2], F&& between) {
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 31, p0 = lane >> 5;
+    int oa[2], ob[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { oa[i] = am0 + 32 * i + r; ob[i] = bn0 + 32 * i + r; }
+    half8 alo[2], ahi[2], blo[2], bhi[2], ahi1[2], bhi1[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) alo[i] = *reinterpret_cast<const half8*>(As + apl + h2_off(oa[i], p0));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bhi[j] = *reinterpret_cast<const half8*>(Bs + h2_off(ob[j], p0));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ahi[i] = *reinterpret_cast<const half8*>(As + h2_off(oa[i], p0));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) blo[j] = *reinterpret_cast<const half8*>(Bs + H2_BPL + h2_off(ob[j], p0));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ahi1[i] = *reinterpret_cast<const half8*>(As + h2_off(oa[i], p0 + 2));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bhi1[j] = *reinterpret_cast<const half8*>(Bs + h2_off(ob[j], p0 + 2));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[i], bhi[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) alo[i] = *reinterpret_cast<const half8*>(As + apl + h2_off(oa[i], p0 + 2));          // k-step 1's a lo
+    __builtin_amdgcn_sched_barrier(0);
+    between(0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[i], blo[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) blo[j] = *reinterpret_cast<const half8*>(Bs + H2_BPL + h2_off(ob[j], p0 + 2));      // k-step 1's b lo
+    __builtin_amdgcn_sched_barrier(0);
+    between(1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[i], bhi[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    between(2);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[i], bhi1[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    between(3);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi1[i], blo[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    between(4);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -544,6 +628,13 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
                                                        float* __restrict__ U, float* __restrict__ umax, StepRef ref, size_t tau_stride) {
     static_assert(ND % 128 == 0 && KD % H2_BK == 0 && KD / H2_BK >= 4, "shape");
     constexpr bool FWD = KD < ND;                                 // <256, 512>: the forward GEMM (base, time term, row maxima); <512, 256>: the transpose
+    // Operand layout of the FORWARD GEMM's weights (round 5): the two fp16 planes of a row's 32-element K chunk side by side -- [row][chunk][plane][32],
+    // 128 bytes = ONE L2 -> L1 line per (row, chunk).  In the planar layout ([plane][row][K]) a chunk of a row is HALF a line of each plane, the
+    // other halves belong to the next chunk, and by then (32 KB of other lines per workgroup and chunk through a 32 KB L1) they are gone: every
+    // operand line crossed the CU's L2 port twice.  WROW / WCH / WPL: element strides of a row, a chunk, a plane.
+    constexpr bool ILW = KD < ND;
+    constexpr int WROW = ILW ? 2 * KD : KD, WCH = ILW ? 2 * H2_BK : H2_BK;
+    const size_t WPL = ILW ? (size_t)H2_BK : w_plane, WTS = ILW ? 2 * w_stride : w_stride;
     CCSP_TRK2_DECL
     CCSP_TRK2(0);
     CCSP_TRK(0, 0);
@@ -559,9 +650,10 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
     constexpr int MI = (MODE == 4 || MODE == 6) ? 1 : 2, TM = 64 * MI;           // 32-row MFMA tiles per wave, rows per workgroup tile (MODE 6: MODE 0's staging on 64-row tiles)
     constexpr int APL = TM * H2_BK, STAGE = MODE == 5 ? 2 * H2_BPL : (MODE == 8 ? 2 * APL + 4 * H2_BPL : 2 * APL + 2 * H2_BPL);   // 32 KB per stage (24 KB for 64-row tiles; MODE 5: the B planes only, 16 KB; MODE 8: one A stage + two B stages, 48 KB)
     constexpr bool DB = MODE == 1;
+    constexpr bool DBP = MODE == 9;                               // two stages + two register sets like MODE 1, the staging under the MFMAs (below)
     constexpr int NST = (MODE == 0 || MODE == 6 || MODE == 8) ? 1 : ((MODE == 3 || MODE == 5) ? 4 : (MODE == 4 ? 3 : 2));      // LDS stages
-    constexpr int NRS = MODE == 1 ? 2 : 1;                        // register sets (MODE 2 and above use none)
-    constexpr bool PRE1 = FWD && MI == 2 && MODE >= 2 && MODE != 6 && MODE != 8;            // row tile 1's base values requested under the K loop (VGPRs to spare)
+    constexpr int NRS = (MODE == 1 || MODE == 9) ? 2 : 1;                        // register sets (MODE 2 and above use none)
+    constexpr bool PRE1 = FWD && MI == 2 && MODE >= 2 && MODE != 6 && MODE != 8 && MODE != 9;            // row tile 1's base values requested under the K loop (VGPRs to spare)
     constexpr int SMEM_US = (NST * STAGE * 2 > 4 * H2_CW_SZ * 4 ? NST * STAGE : 4 * H2_CW_SZ * 2);
     __shared__ __attribute__((aligned(16))) unsigned short smem[SMEM_US + 256];      // stages (epilogue tiles on top) + 128 row exponents
     int* sE = reinterpret_cast<int*>(smem + SMEM_US);
@@ -572,7 +664,7 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
     // workgroup index only, so the gather is requested HERE, next to the tile descriptor, and not behind it -- descriptor -> row indices ->
     // operand rows was three dependent round trips of ~2 k cycles each in front of the first MFMA (profiles/r05_findings.md section 1), now two.
     // asm loads (the compiler neither moves nor waits for them); the wait is h2_idx_wait<N> in each mode, N = the loads issued behind them.
-    constexpr bool RINGIDX = MODE >= 2 && MODE != 5 && MODE != 6 && MODE != 8;       // the direct-to-LDS forms: a lane's rows are those of its 1 KB blocks
+    constexpr bool RINGIDX = MODE >= 2 && MODE != 5 && MODE != 6 && MODE != 8 && MODE != 9;       // the direct-to-LDS forms: a lane's rows are those of its 1 KB blocks
     constexpr int TM_ = ((MODE == 4 || MODE == 6) ? 1 : 2) * 64;
     constexpr int NIDX = RINGIDX ? TM_ / 32 : TM_ / 64;
     int srcx[NIDX];
@@ -628,13 +720,13 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
             const int blk = 4 * wave + j, plane = blk >> 3, rb16 = blk & 7;
             const int row = rb16 * 16 + (lane >> 2);
             const int piece = (lane & 3) ^ ((row >> 2) & 3);
-            gb[j] = W + (size_t)plane * w_plane + (size_t)ts * w_stride + (size_t)(col0 + row) * KD + piece * 8;
+            gb[j] = W + (size_t)plane * WPL + (size_t)ts * WTS + (size_t)(col0 + row) * WROW + piece * 8;
             lob[j] = __builtin_amdgcn_readfirstlane(plane * H2_BPL + rb16 * 16 * H2_BK);
         }
         auto glds_b = [&](int c) {
             unsigned short* st = smem + (c % NST) * STAGE;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds((gptr)(gb[j] + c * H2_BK), (lptr)(st + lob[j]), 16, 0, 0);
+            for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds((gptr)(gb[j] + c * WCH), (lptr)(st + lob[j]), 16, 0, 0);
         };
         // the lane's two A rows (tile i = 0, 1): one dependent gather, requested first
         int src[2];
@@ -732,13 +824,13 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
             const int blk = 4 * wave + j, plane = blk >> 3, rb16 = blk & 7;
             const int row = rb16 * 16 + (lane >> 2);
             const int piece = (lane & 3) ^ ((row >> 2) & 3);
-            gb[j] = W + (size_t)plane * w_plane + (size_t)ts * w_stride + (size_t)(col0 + row) * KD + piece * 8;
+            gb[j] = W + (size_t)plane * WPL + (size_t)ts * WTS + (size_t)(col0 + row) * WROW + piece * 8;
             lob[j] = __builtin_amdgcn_readfirstlane(plane * H2_BPL + rb16 * 16 * H2_BK);
         }
         auto glds_b = [&](int c) {
             unsigned short* st = Bs0 + (c & 1) * 2 * H2_BPL;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds((gptr)(gb[j] + c * H2_BK), (lptr)(st + lob[j]), 16, 0, 0);
+            for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds((gptr)(gb[j] + c * WCH), (lptr)(st + lob[j]), 16, 0, 0);
         };
         glds_b(0);                                                // needs the tile descriptor only: on its way while the row indices arrive
         const unsigned short* a_ptr[2];
@@ -815,7 +907,7 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-    } else if constexpr (MODE >= 2 && MODE != 6) {
+    } else if constexpr (MODE >= 2 && MODE != 6 && MODE != 9) {
         // a wave-instruction fills one 1 KB block = (plane, sixteen rows); wave w owns blocks NA w .. NA w + NA - 1 of the A
         // planes (2 x TM / 16 blocks) and 4 w .. 4 w + 3 of the B planes
         using gptr = const __attribute__((address_space(1))) void*;
@@ -829,13 +921,13 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
             const int blk = 4 * wave + j, plane = blk >> 3, rb16 = blk & 7;
             const int row = rb16 * 16 + (lane >> 2);
             const int piece = (lane & 3) ^ ((row >> 2) & 3);
-            gb[j] = W + (size_t)plane * w_plane + (size_t)ts * w_stride + (size_t)(col0 + row) * KD + piece * 8;
+            gb[j] = W + (size_t)plane * WPL + (size_t)ts * WTS + (size_t)(col0 + row) * WROW + piece * 8;
             lob[j] = __builtin_amdgcn_readfirstlane(plane * H2_BPL + rb16 * 16 * H2_BK);
         }
         auto glds_b = [&](int c, int stage) {
             unsigned short* st = smem + stage * STAGE;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds((gptr)(gb[j] + c * H2_BK), (lptr)(st + 2 * APL + lob[j]), 16, 0, 0);
+            for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds((gptr)(gb[j] + c * WCH), (lptr)(st + 2 * APL + lob[j]), 16, 0, 0);
         };
         auto glds_a = [&](int c, int stage) {
             unsigned short* st = smem + stage * STAGE;
@@ -921,7 +1013,7 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
                     unsigned short* nst = smem + ((c + D) % NST) * STAGE;
                     h2_chunk_ahead_with<MI>(st, APL, st + 2 * APL, wr0, wn * 64, acc, [&](int k) {
                         if (k < NA) __builtin_amdgcn_global_load_lds((gptr)(ga[k] + (c + D) * H2_BK), (lptr)(nst + loa[k]), 16, 0, 0);
-                        else if (k < NA + 4) __builtin_amdgcn_global_load_lds((gptr)(gb[k - NA] + (c + D) * H2_BK), (lptr)(nst + 2 * APL + lob[k - NA]), 16, 0, 0);
+                        else if (k < NA + 4) __builtin_amdgcn_global_load_lds((gptr)(gb[k - NA] + (c + D) * WCH), (lptr)(nst + 2 * APL + lob[k - NA]), 16, 0, 0);
                     });
                 } else {
                     h2_chunk_ahead<MI>(st, APL, st + 2 * APL, wr0, wn * 64, acc);
@@ -988,7 +1080,7 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
                 for (int i = 0; i < MI; ++i) sE[lrow + 64 * i] = e[i];
             }
         };
-        const unsigned short* b_ptr = W + (size_t)ts * w_stride + (size_t)(col0 + lrow) * KD + lq * 8;
+        const unsigned short* b_ptr = W + (size_t)ts * WTS + (size_t)(col0 + lrow) * WROW + lq * 8;
         const int st_off = h2_off(lrow, lq);                      // (row + 64 has the same swizzle: + 64 * H2_BK)
         ushort8 ra[NRS][2 * MI], rb[NRS][4];                      // [register set][row half * 2 + plane]
         auto gload = [&](int c, int set) {
@@ -996,7 +1088,7 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
-                    rb[set][i * 2 + p] = *reinterpret_cast<const ushort8*>(b_ptr + (size_t)i * 64 * KD + (size_t)p * w_plane + c * H2_BK);
+                    rb[set][i * 2 + p] = *reinterpret_cast<const ushort8*>(b_ptr + (size_t)i * 64 * WROW + (size_t)p * WPL + c * WCH);
                     if (i < MI) ra[set][(i < MI ? i : 0) * 2 + p] = *reinterpret_cast<const ushort8*>(a_ptr[i < MI ? i : 0] + (size_t)p * a_plane + c * H2_BK);
                 }
         };
@@ -1012,7 +1104,99 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
                 }
         };
         CCSP_TRK(0, 1);
-        if constexpr (DB) {
+        if constexpr (DBP) {
+            // MODE 9 (round 5; tile lists of at most two workgroups per CU -- the lanes of a C2 batch).  With ONE wave per SIMD nothing overlaps a
+            // wave's LDS traffic with its MFMAs: per chunk a wave reads 16 KB of fragments and stores 8 KB of staging (~ 930 cycles of the CU's LDS
+            // for its four waves) and multiplies for 768 cycles, one after the other -- the 2.5 k-cycle chunk period of every earlier form, however
+            // its pieces were arranged (profiles/r05_findings.md sections 1, 2, 7).  Here the wave is its own second wave: two fragment sets, the
+            // reads of the NEXT k-step always in flight under the twelve MFMAs of the current one; two LDS stages and two register sets, the
+            // eight staging stores of chunk c + 1 (into the other stage) and the eight global loads of chunk c + 3 issued ONE per MFMA pair; one
+            // bare barrier per chunk, in its MIDDLE (behind k-step 0's MFMAs: the other stage is then visible for the reads of chunk c + 1's first
+            // k-step, which go out under k-step 1's MFMAs).  Same MFMA order per accumulator as h2_kstep: bitwise the same sums.  248 VGPRs.
+            static_assert(MI == 2, "MODE 9 runs 128-row tiles");
+            auto gload_one = [&](int c, int set, int k) {             // k: bit 0 plane, bit 1 row half, bit 2 weight / A row
+                const int pl = k & 1, i = (k >> 1) & 1;
+                if (k & 4) rb[set][i * 2 + pl] = *reinterpret_cast<const ushort8*>(b_ptr + (size_t)i * 64 * WROW + (size_t)pl * WPL + c * WCH);
+                else ra[set][i * 2 + pl] = *reinterpret_cast<const ushort8*>(a_ptr[i] + (size_t)pl * a_plane + c * H2_BK);
+            };
+            auto lstore_one = [&](int stage, int set, int k) {
+                const int pl = k & 1, i = (k >> 1) & 1;
+                unsigned short* As = smem + stage * STAGE;
+                if (k & 4) *reinterpret_cast<ushort8*>(As + 2 * APL + pl * H2_BPL + st_off + i * 64 * H2_BK) = rb[set][i * 2 + pl];
+                else *reinterpret_cast<ushort8*>(As + pl * APL + st_off + i * 64 * H2_BK) = ra[set][i * 2 + pl];
+            };
+            const int fr = lane & 31, fp0 = lane >> 5;
+            half8 fa[2][2][2], fb[2][2][2];                           // [fragment set = k-step][tile][plane: 0 hi, 1 lo]
+            auto fread = [&](const unsigned short* st, int ks) {      // in the order the products consume them: (a lo, b hi), (a hi, b lo)
+                const unsigned short* Bs = st + 2 * APL;
+                const int piece = fp0 + 2 * ks;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[ks][i][1] = *reinterpret_cast<const half8*>(st + APL + h2_off(wr0 + 32 * i + fr, piece));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[ks][j][0] = *reinterpret_cast<const half8*>(Bs + h2_off(wn * 64 + 32 * j + fr, piece));
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[ks][i][0] = *reinterpret_cast<const half8*>(st + h2_off(wr0 + 32 * i + fr, piece));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[ks][j][1] = *reinterpret_cast<const half8*>(Bs + H2_BPL + h2_off(wn * 64 + 32 * j + fr, piece));
+            };
+            gload(0, 0);
+            gload(1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            row_exps();
+            lstore(0, 0);
+            gload(2, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            fread(smem, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};       // smallest terms first (h2_kstep's order)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {                           // fully unrolled: register-set indices are constants
+                CCSP_TRK(0, 2 + (c < 8 ? c : 7));
+                CCSP_TRK2(1 + 2 * (c < 8 ? c : 7));
+                if constexpr (FWD) { if (c == NCH - 1) h2_epilogue_prefetch<ND>(bs0, 0, wr0, nrows, row0, colw, base); }
+                const unsigned short* st = smem + (c & 1) * STAGE;
+                const int ns = (c + 1) & 1;                           // the other stage = the register set that holds chunk c + 1
+                __builtin_amdgcn_sched_barrier(0);
+                fread(st, 1);                                         // k-step 1's fragments: in flight under k-step 0's MFMAs
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i][PA[q]], fb[0][j][PB[q]], acc[i][j], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int k = q * 2 + i;                      // behind MFMA pair k: two of chunk c + 1's eight staging stores (pairs 0 .. 3)
+                        if (c + 1 < NCH && k < 4) { lstore_one(ns, ns, 2 * k); lstore_one(ns, ns, 2 * k + 1); }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                CCSP_TRK2(2 + 2 * (c < 8 ? c : 7));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // k-step 1's fragments have landed, this wave's stores too
+                __builtin_amdgcn_s_barrier();                         // every wave is done reading stage c & 1; stage ns is visible
+                __builtin_amdgcn_sched_barrier(0);
+                if (c + 1 < NCH) fread(smem + ns * STAGE, 0);         // chunk c + 1's first k-step: in flight under k-step 1's MFMAs
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][i][PA[q]], fb[1][j][PB[q]], acc[i][j], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int k = q * 2 + i;                      // behind MFMA pair k: chunk c + 3's eight global loads (2, 2, 1, 1, 1, 1)
+                        if (c + 3 < NCH) {
+                            if (k < 2) { gload_one(c + 3, ns, 2 * k); gload_one(c + 3, ns, 2 * k + 1); }
+                            else gload_one(c + 3, ns, k + 2);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                             // every wave is done reading the stages (the epilogue tiles go on top)
+            __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr (DB) {
             gload(0, 0);
             gload(1, 1);
             row_exps();

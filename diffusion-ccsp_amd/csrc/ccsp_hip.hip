@@ -1672,6 +1672,7 @@ struct ccsp_model {
     unsigned short* WpTS;   // [3][C][2][H][2H] planes of WpT (transpose row GEMM of the energy backward)
     int f16x2 = 0;          // 1: evaluation GEMMs on the f16 matrix cores with 2-way split, exactly scaled operands (ccsp_f16x2.h; H = 256)
     unsigned short* WpH = nullptr;    // [2][C][2][2H][H] fp16 planes of Wp * 2^wp_exp
+    unsigned short* WpHI = nullptr;   // the same planes as [C][2][2H][H / 32][2][32]: the forward row GEMM's operand (k_interleave_planes)
     unsigned short* Wd1H = nullptr;   // [2][H/2][H]      fp16 planes of pose_decoder.0.weight * 2^wd_exp
     int wp_exp = 0, wd_exp = 0;
     unsigned short* WpF = nullptr;    // the planes of WpH in MFMA fragment order (k_pack_wp_frag): k_eval_fused reads them straight into registers
@@ -1923,9 +1924,9 @@ int launch_rowgemm_h2(ccsp_model* m, ccsp_graph* g, const float* tau_t, StepRef 
     ref.tile_rows = small ? g->tr64 : g->tr128;
 #define CCSP_ROWGEMM_F(MODE)                                                                                                                          \
     hipLaunchKernelGGL((k_rowgemm_h2<H, 2 * H, MODE>), dim3(work + ref.na.blocks), dim3(256), 0, s, g->pembH, (size_t)g->N * H, g->pexp, g->urow_node,                  \
-                       small ? g->td64 : g->td128, m->WpH,                                                                                              \
+                       small ? g->td64 : g->td128, m->WpHI,                                                                                             \
                        (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, m->wp_exp, g->base, tau_t, g->U, g->umax, ref, tau_stride)
-    if (mode == 6) CCSP_ROWGEMM_F(6); else if (mode == 4) CCSP_ROWGEMM_F(4);
+    if (mode == 6) CCSP_ROWGEMM_F(6); else if (mode == 4) CCSP_ROWGEMM_F(4); else if (mode == 9) CCSP_ROWGEMM_F(9);
 #ifdef CCSP_EXPERIMENTS
     else if (mode == 8) CCSP_ROWGEMM_F(8);
     else if (mode == 5) CCSP_ROWGEMM_F(5); else if (mode == 3) CCSP_ROWGEMM_F(3); else if (mode == 2) CCSP_ROWGEMM_F(2); else if (mode == 1) CCSP_ROWGEMM_F(1);
@@ -3573,9 +3574,9 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     //           bf16x3 (three-term bf16 operands, six products), f32 (v_mfma_f32_32x32x2_f32)
     m->f16x2 = (H == 256 && d->model_kind == CCSP_MODEL_DIFFUSION_CCSP) ? 1 : 0;
 #ifdef CCSP_EXPERIMENTS
-    if (const char* e = getenv("CCSP_ROW_MODE")) { const int v = atoi(e); if (v >= 0 && v <= 8) m->row_mode = v; }
+    if (const char* e = getenv("CCSP_ROW_MODE")) { const int v = atoi(e); if (v >= 0 && v <= 9) m->row_mode = v; }
 #else
-    if (const char* e = getenv("CCSP_ROW_MODE")) { const int v = atoi(e); if (v == 0 || v == 4 || v == 6) m->row_mode = v; }      // (the three forms the selection uses)
+    if (const char* e = getenv("CCSP_ROW_MODE")) { const int v = atoi(e); if (v == 0 || v == 4 || v == 6 || v == 9) m->row_mode = v; }      // (the three forms the selection uses)
 #endif
     if (const char* e = getenv("CCSP_EDGE_MT")) m->edge_mt = atoi(e) == 2 ? 2 : 1;
     if (const char* e = getenv("CCSP_EDGE_SMALL")) m->edge_small = atoi(e) != 0;
@@ -3792,6 +3793,8 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
             TRY(dev_alloc(reg, &m->WpH, (size_t)2 * nwp));
             TRY(dev_alloc(reg, &m->Wd1H, (size_t)2 * nwd));
             hipLaunchKernelGGL(k_split2h, dim3(nblk(nwp, 256)), dim3(256), 0, s, nwp, m->Wp, m->wp_exp, m->WpH);
+            TRY(dev_alloc(reg, &m->WpHI, (size_t)2 * nwp));
+            hipLaunchKernelGGL(k_interleave_planes, dim3(nblk(nwp, 256)), dim3(256), 0, s, (long)nwp, H, m->WpH, m->WpHI);
             hipLaunchKernelGGL(k_split2h, dim3(nblk(nwd, 256)), dim3(256), 0, s, nwd, m->pd0_w, m->wd_exp, m->Wd1H);
 #ifdef CCSP_EXPERIMENTS
             if (m->eval_fused || m->row_mode == 7) {   // the same planes in MFMA fragment order for the fused evaluation kernel (ccsp_fused.h)
