@@ -632,9 +632,14 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
     // 128 bytes = ONE L2 -> L1 line per (row, chunk).  In the planar layout ([plane][row][K]) a chunk of a row is HALF a line of each plane, the
     // other halves belong to the next chunk, and by then (32 KB of other lines per workgroup and chunk through a 32 KB L1) they are gone: every
     // operand line crossed the CU's L2 port twice.  WROW / WCH / WPL: element strides of a row, a chunk, a plane.
-    constexpr bool ILW = KD < ND;
+    constexpr bool ILW = true;                                    // (the transpose GEMM's weights too: WpTHI)
     constexpr int WROW = ILW ? 2 * KD : KD, WCH = ILW ? 2 * H2_BK : H2_BK;
     const size_t WPL = ILW ? (size_t)H2_BK : w_plane, WTS = ILW ? 2 * w_stride : w_stride;
+    // ... and of its A operand, the pose-embedding planes the node kernels' encoder epilogue writes (enc_store_tile; CCSP_A_INTERLEAVED: the product
+    // build -- the experiments build keeps the planar planes its other consumers read)
+    constexpr bool ILA = CCSP_A_INTERLEAVED;                      // (transpose GEMM: the partial-row planes k_edge_bwd_h2 writes)
+    constexpr int AROW = ILA ? 2 * KD : KD, ACH = ILA ? 2 * H2_BK : H2_BK;
+    const size_t APLN = ILA ? (size_t)H2_BK : a_plane;
     CCSP_TRK2_DECL
     CCSP_TRK2(0);
     CCSP_TRK(0, 0);
@@ -747,7 +752,7 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) ap[i][pl] = A + (size_t)pl * a_plane + (size_t)src[i] * KD + 8 * (lane >> 5);
+            for (int pl = 0; pl < 2; ++pl) ap[i][pl] = A + (size_t)pl * APLN + (size_t)src[i] * AROW + 8 * (lane >> 5);
         half8 af[2][2][2][2];                                         // [register set][k-step][tile][plane]
         auto aload = [&](int c, int set) {
 #pragma unroll
@@ -756,7 +761,7 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int pl = 0; pl < 2; ++pl)
-                        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(af[set][ks][i][pl]) : "v"(ap[i][pl] + c * H2_BK + 16 * ks) : "memory");
+                        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(af[set][ks][i][pl]) : "v"(ap[i][pl] + c * ACH + 16 * ks) : "memory");
         };
         auto await_set = [&](int set) {                               // names the set's registers as read-write: the compiler keeps its uses behind the wait
 #pragma unroll
@@ -841,7 +846,7 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
             r = r < nrows ? r : nrows - 1;
             if constexpr (FWD) { if (i == 0) h2_idx_wait<4>(srcx); srcr[i] = srcx[i]; }      // (behind them: the four weight pieces of chunk 0)
             else srcr[i] = urow_node ? urow_node[row0 + r] : row0 + r;
-            a_ptr[i] = A + (size_t)srcr[i] * KD + lq * 8;
+            a_ptr[i] = A + (size_t)srcr[i] * AROW + lq * 8;
         }
         const int st_off = h2_off(lrow, lq);
         ushort8 ra[4];                                            // [row half * 2 + plane]
@@ -849,7 +854,7 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl) ra[i * 2 + pl] = *reinterpret_cast<const ushort8*>(a_ptr[i] + (size_t)pl * a_plane + c * H2_BK);
+                for (int pl = 0; pl < 2; ++pl) ra[i * 2 + pl] = *reinterpret_cast<const ushort8*>(a_ptr[i] + (size_t)pl * APLN + c * ACH);
         };
         auto lstore_a = [&]() {
 #pragma unroll
@@ -932,7 +937,7 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
         auto glds_a = [&](int c, int stage) {
             unsigned short* st = smem + stage * STAGE;
 #pragma unroll
-            for (int j = 0; j < NA; ++j) __builtin_amdgcn_global_load_lds((gptr)(ga[j] + c * H2_BK), (lptr)(st + loa[j]), 16, 0, 0);
+            for (int j = 0; j < NA; ++j) __builtin_amdgcn_global_load_lds((gptr)(ga[j] + c * ACH), (lptr)(st + loa[j]), 16, 0, 0);
         };
         auto glds = [&](int c, int stage) { glds_a(c, stage); glds_b(c, stage); };
         int src[NA];
@@ -956,7 +961,7 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
             const int blk = NA * wave + j, plane = blk / ARB, rb16 = blk % ARB;
             const int row = rb16 * 16 + (lane >> 2);
             const int piece = (lane & 3) ^ ((row >> 2) & 3);
-            ga[j] = A + (size_t)plane * a_plane + (size_t)src[j] * KD + piece * 8;
+            ga[j] = A + (size_t)plane * APLN + (size_t)src[j] * AROW + piece * 8;
             loa[j] = __builtin_amdgcn_readfirstlane(plane * APL + rb16 * 16 * H2_BK);
         }
         // the row exponents (epilogue only) come from the lanes that hold a row's plane index: no second dependent gather
@@ -1012,7 +1017,7 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
                     // the next ring stage's loads go out between this chunk's MFMA pairs (h2_chunk_ahead_with): A pieces first, then the weights
                     unsigned short* nst = smem + ((c + D) % NST) * STAGE;
                     h2_chunk_ahead_with<MI>(st, APL, st + 2 * APL, wr0, wn * 64, acc, [&](int k) {
-                        if (k < NA) __builtin_amdgcn_global_load_lds((gptr)(ga[k] + (c + D) * H2_BK), (lptr)(nst + loa[k]), 16, 0, 0);
+                        if (k < NA) __builtin_amdgcn_global_load_lds((gptr)(ga[k] + (c + D) * ACH), (lptr)(nst + loa[k]), 16, 0, 0);
                         else if (k < NA + 4) __builtin_amdgcn_global_load_lds((gptr)(gb[k - NA] + (c + D) * WCH), (lptr)(nst + 2 * APL + lob[k - NA]), 16, 0, 0);
                     });
                 } else {
@@ -1069,7 +1074,7 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
             r = r < nrows ? r : nrows - 1;
             if constexpr (FWD) { if (i == 0) h2_idx_wait<2>(srcx); srcr[i] = srcx[i]; }      // (requested at kernel entry; behind them: the two time-term loads)
             else srcr[i] = urow_node ? urow_node[row0 + r] : row0 + r;
-            a_ptr[i] = A + (size_t)srcr[i] * KD + lq * 8;
+            a_ptr[i] = A + (size_t)srcr[i] * AROW + lq * 8;
         }
         auto row_exps = [&]() {                                   // (epilogue only) behind the first operands, by the lanes that hold the row's index
             int e[MI];
@@ -1089,7 +1094,7 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     rb[set][i * 2 + p] = *reinterpret_cast<const ushort8*>(b_ptr + (size_t)i * 64 * WROW + (size_t)p * WPL + c * WCH);
-                    if (i < MI) ra[set][(i < MI ? i : 0) * 2 + p] = *reinterpret_cast<const ushort8*>(a_ptr[i < MI ? i : 0] + (size_t)p * a_plane + c * H2_BK);
+                    if (i < MI) ra[set][(i < MI ? i : 0) * 2 + p] = *reinterpret_cast<const ushort8*>(a_ptr[i < MI ? i : 0] + (size_t)p * APLN + c * ACH);
                 }
         };
         auto lstore = [&](int stage, int set) {
@@ -1117,7 +1122,7 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
             auto gload_one = [&](int c, int set, int k) {             // k: bit 0 plane, bit 1 row half, bit 2 weight / A row
                 const int pl = k & 1, i = (k >> 1) & 1;
                 if (k & 4) rb[set][i * 2 + pl] = *reinterpret_cast<const ushort8*>(b_ptr + (size_t)i * 64 * WROW + (size_t)pl * WPL + c * WCH);
-                else ra[set][i * 2 + pl] = *reinterpret_cast<const ushort8*>(a_ptr[i] + (size_t)pl * a_plane + c * H2_BK);
+                else ra[set][i * 2 + pl] = *reinterpret_cast<const ushort8*>(a_ptr[i] + (size_t)pl * APLN + c * ACH);
             };
             auto lstore_one = [&](int stage, int set, int k) {
                 const int pl = k & 1, i = (k >> 1) & 1;
@@ -1350,7 +1355,7 @@ __device__ __forceinline__ void edge_node_tail(const FuseArgs& fu, int wg, void*
 template <bool ENERGY, int MT, int L2, bool FUSE = false, bool NG = false>
 __global__ __launch_bounds__(256, (MT == 1 && !FUSE) ? 3 : 2) void k_edge_h2(int E_act, int P, const int* __restrict__ e_u0, const int* __restrict__ e_u1,
                                                     const float* __restrict__ U, const float* __restrict__ umax /*[R][8]*/,
-                                                    const unsigned short* __restrict__ Wd1H /*[2][128][256]*/, int wd_exp,
+                                                    const unsigned short* __restrict__ Wd1H /*[128][256 / 32][2][32]: both planes of a row's K chunk in one line*/, int wd_exp,
                                                     const float* __restrict__ bd1, const float* __restrict__ Wd2,
                                                     const float* __restrict__ bd2, const int* __restrict__ ent_pos, float* __restrict__ O,
                                                     EdgeEnergyArgs en, int* __restrict__ counter_inc, FuseArgs fu) {
@@ -1413,7 +1418,7 @@ __global__ __launch_bounds__(256, (MT == 1 && !FUSE) ? 3 : 2) void k_edge_h2(int
         a_st[i] = h2_off(row, lq >> 1) + (lq & 1) * 4;
     }
     const int brow = tid >> 2, bq = tid & 3;                      // B copy: rows brow, brow + 64, piece bq, both planes
-    const unsigned short* b_ptr = Wd1H + (size_t)brow * H + bq * 8;
+    const unsigned short* b_ptr = Wd1H + (size_t)brow * (2 * H) + bq * 8;       // (chunk-interleaved planes [128][H / 32][2][32]: k_interleave_planes)
     const int b_st = h2_off(brow, bq);
     float4 ua[2][NPASS], ub[2][NPASS];                            // [register set][pass]
     ushort8 rb[4];
@@ -1429,7 +1434,7 @@ __global__ __launch_bounds__(256, (MT == 1 && !FUSE) ? 3 : 2) void k_edge_h2(int
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int p = 0; p < 2; ++p)
-                rb[i * 2 + p] = *reinterpret_cast<const ushort8*>(b_ptr + (size_t)p * BN * H + (size_t)i * 64 * H + c * H2_BK);
+                rb[i * 2 + p] = *reinterpret_cast<const ushort8*>(b_ptr + (size_t)p * H2_BK + (size_t)i * 64 * (2 * H) + c * (2 * H2_BK));
     };
     auto store_a = [&](int stage, int set, int i) {               // SiLU + scale + split of one pass -> the A planes of the stage
         unsigned short* As = smem + stage * STAGE;
@@ -1626,7 +1631,7 @@ __global__ __launch_bounds__(256, (MT == 1 && !FUSE) ? 3 : 2) void k_edge_h2(int
 template <bool ENERGY, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void k_edge_h2s(int E_act, int P, const int* __restrict__ e_u0, const int* __restrict__ e_u1,
                                                      const float* __restrict__ U, const float* __restrict__ umax /*[R][8]*/,
-                                                     const unsigned short* __restrict__ Wd1H /*[2][128][256]*/, int wd_exp,
+                                                     const unsigned short* __restrict__ Wd1H /*[128][256 / 32][2][32]: both planes of a row's K chunk in one line*/, int wd_exp,
                                                      const float* __restrict__ bd1, const float* __restrict__ Wd2,
                                                      const float* __restrict__ bd2, const int* __restrict__ ent_pos, float* __restrict__ O,
                                                      EdgeEnergyArgs en, int* __restrict__ counter_inc, FuseArgs fu) {
@@ -1655,7 +1660,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_h2s(int E_act, int P, const int
     const float4 m0 = *reinterpret_cast<const float4*>(umax + (size_t)r0 * 8 + 4 * hs);
     const float4 m1 = *reinterpret_cast<const float4*>(umax + (size_t)r1 * 8 + 4 * hs);
     const int brow = tid >> 2, bq = tid & 3;                      // B copy: rows brow, brow + 64, piece bq, both planes
-    const unsigned short* b_ptr = Wd1H + (size_t)brow * H + bq * 8;
+    const unsigned short* b_ptr = Wd1H + (size_t)brow * (2 * H) + bq * 8;       // (chunk-interleaved planes [128][H / 32][2][32]: k_interleave_planes)
     const int b_st = h2_off(brow, bq);
     const int a_st = h2_off(lr, lq >> 1) + (lq & 1) * 4;
     float4 ua[2], ub[2];                                          // [register set]
@@ -1669,7 +1674,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_h2s(int E_act, int P, const int
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int p = 0; p < 2; ++p)
-                rb[i * 2 + p] = *reinterpret_cast<const ushort8*>(b_ptr + (size_t)p * BN * H + (size_t)i * 64 * H + c * H2_BK);
+                rb[i * 2 + p] = *reinterpret_cast<const ushort8*>(b_ptr + (size_t)p * H2_BK + (size_t)i * 64 * (2 * H) + c * (2 * H2_BK));
     };
     gload_a(0, 0);
     gload_b(0);
@@ -1873,7 +1878,7 @@ __global__ __launch_bounds__(256, 3) void k_edge_bwd_h2(int E_act, int P_rt, con
         a_st[i] = h2_off(lr + 32 * i, lq >> 1) + (lq & 1) * 4;
     }
     const int brow = tid >> 2, bq = tid & 3;
-    const unsigned short* b_ptr = Wd1TH + (size_t)(n0 + brow) * KD + bq * 8;
+    const unsigned short* b_ptr = Wd1TH + (size_t)(n0 + brow) * (2 * KD) + bq * 8;       // (chunk-interleaved planes [256][128 / 32][2][32])
     const int b_st = h2_off(brow, bq);
     float4 rq[2][2];                                              // [register set][pass]: decoder pre-activations
     ushort8 rb[4];
@@ -1886,7 +1891,7 @@ __global__ __launch_bounds__(256, 3) void k_edge_bwd_h2(int E_act, int P_rt, con
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int p = 0; p < 2; ++p)
-                rb[i * 2 + p] = *reinterpret_cast<const ushort8*>(b_ptr + (size_t)p * H * KD + (size_t)i * 64 * KD + c * H2_BK);
+                rb[i * 2 + p] = *reinterpret_cast<const ushort8*>(b_ptr + (size_t)p * H2_BK + (size_t)i * 64 * (2 * KD) + c * (2 * H2_BK));
     };
     auto store_a = [&](int stage, int c, int set, int i) {
         unsigned short* As = smem + stage * STAGE;
@@ -2066,11 +2071,20 @@ __global__ __launch_bounds__(256, 3) void k_edge_bwd_h2(int E_act, int P_rt, con
             unsigned short p1[8], p2[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) split2h(ldexpf(h[k], e), p1[k], p2[k]);
+#if CCSP_A_INTERLEAVED                                              // [NP][512 / 32][2][32]: both planes of a row's K chunk in one line (k_rowgemm_h2, ILA)
+            const int col = s * H + n0 + cg * 4;
+            const size_t o = (size_t)gid * (4 * H) + (size_t)(col >> 5) * 64 + (col & 31);
+            *reinterpret_cast<uint2*>(bs.GZPH + o) = make_uint2(p1[0] | ((unsigned)p1[1] << 16), p1[2] | ((unsigned)p1[3] << 16));
+            *reinterpret_cast<uint2*>(bs.GZPH + o + 128) = make_uint2(p1[4] | ((unsigned)p1[5] << 16), p1[6] | ((unsigned)p1[7] << 16));      // (column + 64 = two chunks on)
+            *reinterpret_cast<uint2*>(bs.GZPH + o + 32) = make_uint2(p2[0] | ((unsigned)p2[1] << 16), p2[2] | ((unsigned)p2[3] << 16));
+            *reinterpret_cast<uint2*>(bs.GZPH + o + 160) = make_uint2(p2[4] | ((unsigned)p2[5] << 16), p2[6] | ((unsigned)p2[7] << 16));
+#else
             const size_t o = (size_t)gid * (2 * H) + s * H + n0 + cg * 4;
             *reinterpret_cast<uint2*>(bs.GZPH + o) = make_uint2(p1[0] | ((unsigned)p1[1] << 16), p1[2] | ((unsigned)p1[3] << 16));
             *reinterpret_cast<uint2*>(bs.GZPH + o + 64) = make_uint2(p1[4] | ((unsigned)p1[5] << 16), p1[6] | ((unsigned)p1[7] << 16));
             *reinterpret_cast<uint2*>(bs.GZPH + bs.plane + o) = make_uint2(p2[0] | ((unsigned)p2[1] << 16), p2[2] | ((unsigned)p2[3] << 16));
             *reinterpret_cast<uint2*>(bs.GZPH + bs.plane + o + 64) = make_uint2(p2[4] | ((unsigned)p2[5] << 16), p2[6] | ((unsigned)p2[7] << 16));
+#endif
         }
     }
 }

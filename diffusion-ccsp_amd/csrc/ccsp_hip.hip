@@ -294,10 +294,18 @@ __device__ __forceinline__ void split2h(float xs, unsigned short& h1, unsigned s
     h2 = __builtin_bit_cast(unsigned short, b);
 }
 
+// The f16x2 operand planes of the pose embeddings (EncOut::h2): product build = both planes of a row's 32-column chunk side by side, [N][H / 32][2][32]
+// (one 128-byte L2 -> L1 line per (row, K chunk) of the forward row GEMM: k_rowgemm_h2, ILA); experiments build = planar [2][N][H], which its
+// other consumers (k_rowgemm_h2d, the fused evaluation kernels) read.
+#ifdef CCSP_EXPERIMENTS
+#define CCSP_A_INTERLEAVED 0
+#else
+#define CCSP_A_INTERLEAVED 1
+#endif
 struct EncOut {
     float* f32;                 // [N, H] embeddings, or null
     unsigned short* bf3;        // [3][N][H] bf16 planes (ccsp_bf16x3.h), or null
-    unsigned short* h2;         // [2][N][H] fp16 planes of the row scaled by 2^h2_exp[n] (ccsp_f16x2.h), or null
+    unsigned short* h2;         // fp16 planes of the row scaled by 2^h2_exp[n] (ccsp_f16x2.h; layout: CCSP_A_INTERLEAVED), or null
     int* h2_exp;                // [N]
 };
 
@@ -348,8 +356,14 @@ __device__ __forceinline__ void enc_store_tile(const float (&v)[H / 64][4], floa
                 unsigned short h1[4], h2[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) split2h(ldexpf(v[j][r], e2), h1[r], h2[r]);
+#if CCSP_A_INTERLEAVED
+                const size_t oi = (size_t)n * (2 * H) + (size_t)(c0 >> 5) * 64 + (c0 & 31);
+                *reinterpret_cast<uint2*>(out.h2 + oi) = make_uint2(h1[0] | ((unsigned)h1[1] << 16), h1[2] | ((unsigned)h1[3] << 16));
+                *reinterpret_cast<uint2*>(out.h2 + oi + 32) = make_uint2(h2[0] | ((unsigned)h2[1] << 16), h2[2] | ((unsigned)h2[3] << 16));
+#else
                 *reinterpret_cast<uint2*>(out.h2 + o) = make_uint2(h1[0] | ((unsigned)h1[1] << 16), h1[2] | ((unsigned)h1[3] << 16));
                 *reinterpret_cast<uint2*>(out.h2 + pl + o) = make_uint2(h2[0] | ((unsigned)h2[1] << 16), h2[2] | ((unsigned)h2[3] << 16));
+#endif
             }
         }
     }
@@ -1674,6 +1688,7 @@ struct ccsp_model {
     unsigned short* WpH = nullptr;    // [2][C][2][2H][H] fp16 planes of Wp * 2^wp_exp
     unsigned short* WpHI = nullptr;   // the same planes as [C][2][2H][H / 32][2][32]: the forward row GEMM's operand (k_interleave_planes)
     unsigned short* Wd1H = nullptr;   // [2][H/2][H]      fp16 planes of pose_decoder.0.weight * 2^wd_exp
+    unsigned short* Wd1HI = nullptr;  // [H/2][H/32][2][32] the same planes chunk-interleaved: the edge kernels' B operand
     int wp_exp = 0, wd_exp = 0;
     unsigned short* WpF = nullptr;    // the planes of WpH in MFMA fragment order (k_pack_wp_frag): k_eval_fused reads them straight into registers
     unsigned short* Wd1F = nullptr;   // likewise pose_decoder.0.weight (k_pack_wd1_frag)
@@ -1681,6 +1696,7 @@ struct ccsp_model {
                                       // 256-thread workgroups per CU; 2 = CCSP_EVAL=fused8, the persistent 512-thread form); split: two launches
     unsigned short* WpTH = nullptr;   // [2][C][2][H][2H] fp16 planes of WpT * 2^wp_exp (energy backward; energy_wrapper models only)
     unsigned short* Wd1TH = nullptr;  // [2][H][H/2]      fp16 planes of pose_decoder.0.weight^T * 2^wd_exp
+    unsigned short *WpTHI = nullptr, *Wd1THI = nullptr;      // the two above chunk-interleaved ([row][K / 32][2][32]): what the backward kernels read
     float wd2_absmax = 0.0f;          // max |pose_decoder.2.weight| (row-exponent bound of k_edge_bwd_h2)
     float bwd_bound_c = 0.0f;         // 1.21 max|Wd2| max_n sum_j |Wd1[j, n]|: |g_z[k, s H + n]| <= bwd_bound_c sum_p |go[k, s, p]| (k_edge_bwd_h2<true>)
     int bwd_rowsum_fused = 1;         // (CCSP_ENERGY_ROWSUM=kernel turns it off) row sums of g_z inside the decoder backward, transpose GEMM on partial rows
@@ -1963,7 +1979,7 @@ int launch_edge_h2(ccsp_model* m, ccsp_graph* g, EdgeEnergyArgs en, int* cinc, h
         const int nws = nblk(E_act, 16);
 #define CCSP_EDGE_S(FUSE)                                                                                                                            \
         hipLaunchKernelGGL((k_edge_h2s<ENERGY, FUSE>), dim3(nws), dim3(256), 0, s, E_act, m->d.pose_dim, FUSE ? g->fuse_u0 : g->e_u0,                     \
-                           FUSE ? g->fuse_u1 : g->e_u1, g->U, g->umax, m->Wd1H, m->wd_exp, m->pd0_b, m->pd2_w, m->pd2_b, FUSE ? g->fuse_pos : g->ent_pos, \
+                           FUSE ? g->fuse_u1 : g->e_u1, g->U, g->umax, m->Wd1HI, m->wd_exp, m->pd0_b, m->pd2_w, m->pd2_b, FUSE ? g->fuse_pos : g->ent_pos, \
                            g->O, en, cinc, fa)
 #ifdef CCSP_EXPERIMENTS
         if constexpr (!ENERGY) { if (fuse) CCSP_EDGE_S(true); else CCSP_EDGE_S(false); }
@@ -1978,7 +1994,7 @@ int launch_edge_h2(ccsp_model* m, ccsp_graph* g, EdgeEnergyArgs en, int* cinc, h
     const int nwg = nblk(E_act, me);
 #define CCSP_EDGE_F(MT, L2, FUSE)                                                                                                                    \
     hipLaunchKernelGGL((k_edge_h2<ENERGY, MT, L2, FUSE>), dim3(nwg), dim3(256), 0, s, E_act, m->d.pose_dim, FUSE ? g->fuse_u0 : g->e_u0,                \
-                       FUSE ? g->fuse_u1 : g->e_u1, g->U, g->umax, m->Wd1H, m->wd_exp, m->pd0_b, m->pd2_w, m->pd2_b, FUSE ? g->fuse_pos : g->ent_pos,     \
+                       FUSE ? g->fuse_u1 : g->e_u1, g->U, g->umax, m->Wd1HI, m->wd_exp, m->pd0_b, m->pd2_w, m->pd2_b, FUSE ? g->fuse_pos : g->ent_pos,     \
                        g->O, en, cinc, fa)
 #ifdef CCSP_EXPERIMENTS
     if constexpr (!ENERGY) {
@@ -2141,10 +2157,10 @@ int launch_eval(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s, bool tabled 
                 const EdgeEnergyArgs en0{};
                 if (nblk(p.E_act, 32) <= m->ncu)      // (the second decoder layer in the form the three-launch path picks for this batch: same sums, bit for bit)
                     hipLaunchKernelGGL((k_edge_h2<false, 1, 1, false, true>), dim3(g->ng_wgs), dim3(256), 0, s, p.E_act, m->d.pose_dim, g->e_u0, g->e_u1, g->U, g->umax,
-                                       m->Wd1H, m->wd_exp, m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, en0, cinc, fu);
+                                       m->Wd1HI, m->wd_exp, m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, en0, cinc, fu);
                 else
                     hipLaunchKernelGGL((k_edge_h2<false, 1, 0, false, true>), dim3(g->ng_wgs), dim3(256), 0, s, p.E_act, m->d.pose_dim, g->e_u0, g->e_u1, g->U, g->umax,
-                                       m->Wd1H, m->wd_exp, m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, en0, cinc, fu);
+                                       m->Wd1HI, m->wd_exp, m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, en0, cinc, fu);
                 if (did_fuse) *did_fuse = true;
                 prof_mark(g, s, -1);
                 g->evals++;
@@ -2490,7 +2506,7 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
                                                : BwdSumArgs{nullptr, nullptr, 0, nullptr, 0.0f};
 #define CCSP_EDGE_BWD(SUM, PP)                                                                                                                      \
             hipLaunchKernelGGL((k_edge_bwd_h2<SUM, PP>), dim3(nblk(p.E_act, 64) * 4), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->ent_pos, g->U, g->O, \
-                               g->Q, m->Wd1TH, m->wd_exp, m->wd2_absmax, m->pd2_w, g->GZ, skip, bsa)
+                               g->Q, m->Wd1THI, m->wd_exp, m->wd2_absmax, m->pd2_w, g->GZ, skip, bsa)
             const bool p4 = P == 4 && !m->bwd_generic_p;
 #ifdef CCSP_EXPERIMENTS
             if (!g->bs_ready) { if (p4) CCSP_EDGE_BWD(false, 4); else CCSP_EDGE_BWD(false, 0); }      // (CCSP_ENERGY_ROWSUM=kernel: round 3's k_rowsum_h2 downstream)
@@ -2536,7 +2552,7 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
             const int4* tdesc = small ? (psum ? g->bs_td64 : g->td64) : (psum ? g->bs_td128 : g->td128);
             float* gp_out = psum ? g->GPP : g->GP;
 #define CCSP_ROWGEMM_T(MODE)                                                                                                                        \
-            hipLaunchKernelGGL((k_rowgemm_h2<2 * H, H, MODE>), dim3(work), dim3(256), 0, s, a_pl, a_stride, a_ex, no_map, tdesc, m->WpTH,               \
+            hipLaunchKernelGGL((k_rowgemm_h2<2 * H, H, MODE>), dim3(work), dim3(256), 0, s, a_pl, a_stride, a_ex, no_map, tdesc, m->WpTHI,              \
                                (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, m->wp_exp, nof, nof, gp_out, nou, StepRef{nullptr, nullptr, skip}, \
                                (size_t)0)
             if (mode == 6) CCSP_ROWGEMM_T(6); else if (mode == 4) CCSP_ROWGEMM_T(4);
@@ -3796,6 +3812,8 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
             TRY(dev_alloc(reg, &m->WpHI, (size_t)2 * nwp));
             hipLaunchKernelGGL(k_interleave_planes, dim3(nblk(nwp, 256)), dim3(256), 0, s, (long)nwp, H, m->WpH, m->WpHI);
             hipLaunchKernelGGL(k_split2h, dim3(nblk(nwd, 256)), dim3(256), 0, s, nwd, m->pd0_w, m->wd_exp, m->Wd1H);
+            TRY(dev_alloc(reg, &m->Wd1HI, (size_t)2 * nwd));
+            hipLaunchKernelGGL(k_interleave_planes, dim3(nblk(nwd, 256)), dim3(256), 0, s, (long)nwd, H, m->Wd1H, m->Wd1HI);
 #ifdef CCSP_EXPERIMENTS
             if (m->eval_fused || m->row_mode == 7) {   // the same planes in MFMA fragment order for the fused evaluation kernel (ccsp_fused.h)
                 const long n16 = (long)d->n_types * 2 * 32768;
@@ -3827,6 +3845,10 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
                 TRY(dev_alloc(reg, &m->Wd1TH, (size_t)2 * nwd));
                 hipLaunchKernelGGL(k_split2h, dim3(nblk(nwp, 256)), dim3(256), 0, s, nwp, m->WpT, m->wp_exp, m->WpTH);
                 hipLaunchKernelGGL(k_split2h, dim3(nblk(nwd, 256)), dim3(256), 0, s, nwd, m->pd0_wT, m->wd_exp, m->Wd1TH);
+                TRY(dev_alloc(reg, &m->WpTHI, (size_t)2 * nwp));
+                TRY(dev_alloc(reg, &m->Wd1THI, (size_t)2 * nwd));
+                hipLaunchKernelGGL(k_interleave_planes, dim3(nblk(nwp, 256)), dim3(256), 0, s, (long)nwp, 2 * H, m->WpTH, m->WpTHI);
+                hipLaunchKernelGGL(k_interleave_planes, dim3(nblk(nwd, 256)), dim3(256), 0, s, (long)nwd, H / 2, m->Wd1TH, m->Wd1THI);
             }
         }
     }
