@@ -237,139 +237,6 @@ __device__ __forceinline__ void h2_chunk_ahead_with(const unsigned short* __rest
             }
 }
 
-// Both k-steps of a staged chunk with the fragment reads of k-step 1 issued UNDER the MFMAs of k-step 0 (MODE 8 of k_rowgemm_h2; MI = 2).  The three
-// products of a k-step use (a lo, b hi), (a hi, b lo), (a hi, b hi): a lo is dead after the first group, b lo after the second, so k-step 1's
-// a lo / b lo go into the SAME registers behind those groups and only its two hi fragments need registers of their own (16 VGPRs).  The LDS
-// latency of a chunk is then paid once (the first eight reads) instead of twice.  Same MFMA order per accumulator as h2_kstep: bitwise the same sums.
-__device__ __forceinline__ void h2_chunk_pipe(const unsigned short* __restrict__ As, int apl, const unsigned short* __restrict__ Bs,
-                                              int am0, int bn0, floatx16 (&acc)[2][2]) {
-    const int lane = threadIdx.x & 63;
-    const int r = lane & 31, p0 = lane >> 5;
-    int oa[2], ob[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) { oa[i] = am0 + 32 * i + r; ob[i] = bn0 + 32 * i + r; }
-    half8 alo[2], ahi[2], blo[2], bhi[2], ahi1[2], bhi1[2];
-    // k-step 0, in the order the products consume them; then k-step 1's hi fragments
-#pragma unroll
-    for (int i = 0; i < 2; ++i) alo[i] = *reinterpret_cast<const half8*>(As + apl + h2_off(oa[i], p0));
-#pragma unroll
-    for (int j = 0; j < 2; ++j) bhi[j] = *reinterpret_cast<const half8*>(Bs + h2_off(ob[j], p0));
-#pragma unroll
-    for (int i = 0; i < 2; ++i) ahi[i] = *reinterpret_cast<const half8*>(As + h2_off(oa[i], p0));
-#pragma unroll
-    for (int j = 0; j < 2; ++j) blo[j] = *reinterpret_cast<const half8*>(Bs + H2_BPL + h2_off(ob[j], p0));
-#pragma unroll
-    for (int i = 0; i < 2; ++i) ahi1[i] = *reinterpret_cast<const half8*>(As + h2_off(oa[i], p0 + 2));
-#pragma unroll
-    for (int j = 0; j < 2; ++j) bhi1[j] = *reinterpret_cast<const half8*>(Bs + h2_off(ob[j], p0 + 2));
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[i], bhi[j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) alo[i] = *reinterpret_cast<const half8*>(As + apl + h2_off(oa[i], p0 + 2));          // k-step 1's a lo
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[i], blo[j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) blo[j] = *reinterpret_cast<const half8*>(Bs + H2_BPL + h2_off(ob[j], p0 + 2));      // k-step 1's b lo
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[i], bhi[j], acc[i][j], 0, 0, 0);
-    // k-step 1: every fragment was requested at least four MFMAs ago
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[i], bhi1[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi1[i], blo[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi1[i], bhi1[j], acc[i][j], 0, 0, 0);
-}
-
-// h2_chunk_pipe with a hook behind each of its six MFMA groups (between(k), k = 0 .. 5): MODE 9 of k_rowgemm_h2 issues the NEXT chunk's staging
-// stores (into the other LDS stage) and the global loads two chunks further on there, where the matrix pipe is busy for 128 cycles per group and
-// the wave's issue slots are free.  Same reads, same MFMA order per accumulator: bitwise the sums of h2_kstep.
-template <typename F>
-__device__ __forceinline__ void h2_chunk_pipe_with(const unsigned short* __restrict__ As, int apl, const unsigned short* __restrict__ Bs,
-                                                   int am0, int bn0, floatx16 (&acc)[2][2], F&& between) {
-    const int lane = threadIdx.x & 63;
-    const int r = lane & 31, p0 = lane >> 5;
-    int oa[2], ob[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) { oa[i] = am0 + 32 * i + r; ob[i] = bn0 + 32 * i + r; }
-    half8 alo[2], ahi[2], blo[2], bhi[2], ahi1[2], bhi1[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) alo[i] = *reinterpret_cast<const half8*>(As + apl + h2_off(oa[i], p0));
-#pragma unroll
-    for (int j = 0; j < 2; ++j) bhi[j] = *reinterpret_cast<const half8*>(Bs + h2_off(ob[j], p0));
-#pragma unroll
-    for (int i = 0; i < 2; ++i) ahi[i] = *reinterpret_cast<const half8*>(As + h2_off(oa[i], p0));
-#pragma unroll
-    for (int j = 0; j < 2; ++j) blo[j] = *reinterpret_cast<const half8*>(Bs + H2_BPL + h2_off(ob[j], p0));
-#pragma unroll
-    for (int i = 0; i < 2; ++i) ahi1[i] = *reinterpret_cast<const half8*>(As + h2_off(oa[i], p0 + 2));
-#pragma unroll
-    for (int j = 0; j < 2; ++j) bhi1[j] = *reinterpret_cast<const half8*>(Bs + h2_off(ob[j], p0 + 2));
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[i], bhi[j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) alo[i] = *reinterpret_cast<const half8*>(As + apl + h2_off(oa[i], p0 + 2));          // k-step 1's a lo
-    __builtin_amdgcn_sched_barrier(0);
-    between(0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[i], blo[j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) blo[j] = *reinterpret_cast<const half8*>(Bs + H2_BPL + h2_off(ob[j], p0 + 2));      // k-step 1's b lo
-    __builtin_amdgcn_sched_barrier(0);
-    between(1);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[i], bhi[j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    between(2);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[i], bhi1[j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    between(3);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi1[i], blo[j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    between(4);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi1[i], bhi1[j], acc[i][j], 0, 0, 0);
-}
-
 // A chunk whose A fragments are already in registers (MODE 5 of k_rowgemm_h2: loaded straight from global memory in the MFMA
 // operand layout), B from the staged planes.  Same MFMA order per accumulator as h2_kstep / h2_chunk_ahead: bitwise the same sums.
 template <int MI>
@@ -621,7 +488,7 @@ __device__ __forceinline__ void h2_idx_wait(int (&v)[NI]) {
 #define CCSP_H2_MODE0_WGS 3
 #endif
 template <int KD, int ND, int MODE>
-__global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS : (MODE == 6 ? 4 : (MODE == 3 ? 1 : 2))) void k_rowgemm_h2(const unsigned short* __restrict__ A, size_t a_plane, const int* __restrict__ a_exp,
+__global__ __launch_bounds__(256, MODE == 0 ? CCSP_H2_MODE0_WGS : (MODE == 6 ? 4 : (MODE == 3 ? 1 : 2))) void k_rowgemm_h2(const unsigned short* __restrict__ A, size_t a_plane, const int* __restrict__ a_exp,
                                                        const int* __restrict__ urow_node, const int4* __restrict__ tile_desc,
                                                        const unsigned short* __restrict__ W, size_t w_plane, size_t w_stride, int w_exp,
                                                        const float* __restrict__ base, const float* __restrict__ tau_t,
@@ -653,12 +520,12 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
     }
     constexpr int NCT = ND / 128, NCH = KD / H2_BK;
     constexpr int MI = (MODE == 4 || MODE == 6) ? 1 : 2, TM = 64 * MI;           // 32-row MFMA tiles per wave, rows per workgroup tile (MODE 6: MODE 0's staging on 64-row tiles)
-    constexpr int APL = TM * H2_BK, STAGE = MODE == 5 ? 2 * H2_BPL : (MODE == 8 ? 2 * APL + 4 * H2_BPL : 2 * APL + 2 * H2_BPL);   // 32 KB per stage (24 KB for 64-row tiles; MODE 5: the B planes only, 16 KB; MODE 8: one A stage + two B stages, 48 KB)
+    constexpr int APL = TM * H2_BK, STAGE = MODE == 5 ? 2 * H2_BPL : 2 * APL + 2 * H2_BPL;   // 32 KB per stage (24 KB for 64-row tiles; MODE 5: the B planes only, 16 KB)
     constexpr bool DB = MODE == 1;
     constexpr bool DBP = MODE == 9;                               // two stages + two register sets like MODE 1, the staging under the MFMAs (below)
-    constexpr int NST = (MODE == 0 || MODE == 6 || MODE == 8) ? 1 : ((MODE == 3 || MODE == 5) ? 4 : (MODE == 4 ? 3 : 2));      // LDS stages
+    constexpr int NST = (MODE == 0 || MODE == 6) ? 1 : ((MODE == 3 || MODE == 5) ? 4 : (MODE == 4 ? 3 : 2));      // LDS stages
     constexpr int NRS = (MODE == 1 || MODE == 9) ? 2 : 1;                        // register sets (MODE 2 and above use none)
-    constexpr bool PRE1 = FWD && MI == 2 && MODE >= 2 && MODE != 6 && MODE != 8 && MODE != 9;            // row tile 1's base values requested under the K loop (VGPRs to spare)
+    constexpr bool PRE1 = FWD && MI == 2 && MODE >= 2 && MODE != 6 && MODE != 9;            // row tile 1's base values requested under the K loop (VGPRs to spare)
     constexpr int SMEM_US = (NST * STAGE * 2 > 4 * H2_CW_SZ * 4 ? NST * STAGE : 4 * H2_CW_SZ * 2);
     __shared__ __attribute__((aligned(16))) unsigned short smem[SMEM_US + 256];      // stages (epilogue tiles on top) + 128 row exponents
     int* sE = reinterpret_cast<int*>(smem + SMEM_US);
@@ -669,7 +536,7 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
     // workgroup index only, so the gather is requested HERE, next to the tile descriptor, and not behind it -- descriptor -> row indices ->
     // operand rows was three dependent round trips of ~2 k cycles each in front of the first MFMA (profiles/r05_findings.md section 1), now two.
     // asm loads (the compiler neither moves nor waits for them); the wait is h2_idx_wait<N> in each mode, N = the loads issued behind them.
-    constexpr bool RINGIDX = MODE >= 2 && MODE != 5 && MODE != 6 && MODE != 8 && MODE != 9;       // the direct-to-LDS forms: a lane's rows are those of its 1 KB blocks
+    constexpr bool RINGIDX = MODE >= 2 && MODE != 5 && MODE != 6 && MODE != 9;       // the direct-to-LDS forms: a lane's rows are those of its 1 KB blocks
     constexpr int TM_ = ((MODE == 4 || MODE == 6) ? 1 : 2) * 64;
     constexpr int NIDX = RINGIDX ? TM_ / 32 : TM_ / 64;
     int srcx[NIDX];
@@ -704,7 +571,7 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
     // discard them: a select instead of a branch).  The first loads of the kernel: older than every counted wait below.
     const bool has_tau = FWD && tau_t && (ts & 1) == 0;
     h2_f4 tv[2] = {h2_f4{0.f, 0.f, 0.f, 0.f}, h2_f4{0.f, 0.f, 0.f, 0.f}};
-    if constexpr (FWD && MODE != 8) {                             // (MODE 8 requests them with the base values, under its last chunk: 8 VGPRs less through the K loop)
+    if constexpr (FWD) {
         const float* tp = (has_tau ? tau_t + (size_t)(ts >> 1) * ND : base) + colw + 4 * (lane & 7);
         h2_ld16(tv[0], tp);
         h2_ld16(tv[1], tp + 32);
@@ -809,109 +676,6 @@ __global__ __launch_bounds__(256, (MODE == 0 || MODE == 8) ? CCSP_H2_MODE0_WGS :
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                 // every wave is done reading the stages; the row exponents are visible
         __builtin_amdgcn_sched_barrier(0);
-    } else if constexpr (MODE == 8) {
-        // MODE 8 (round 5, experiments build; profiles/r05_findings.md section 2: the MFMA phase of a chunk shrinks by a quarter, the phase between
-        // chunks grows by as much -- four LDS-DMA requests cost more issue time than the four ds_write_b128 they replace): the WEIGHT planes of a chunk go
-        // straight to LDS (global_load_lds_dwordx4: no staging registers, no ds_write) into one of TWO B stages, requested two chunks ahead;
-        // the A rows (gathered by node) keep MODE 0's register staging into ONE A stage, requested two chunks ahead as well.  Per chunk that
-        // is four ds_write_b128 per thread between the barriers instead of eight, 16 VGPRs less of staging -- spent on h2_chunk_pipe's
-        // fragment prefetch -- and 48 KB of LDS: three workgroups per CU like MODE 0.  Bare s_barrier (a __syncthreads() would drain the
-        // requests in flight); the compiler's own vmcnt(0) in front of the A stores is also what the landing of the weights needs.
-        using gptr = const __attribute__((address_space(1))) void*;
-        using lptr = __attribute__((address_space(3))) void*;
-        static_assert(MI == 2, "MODE 8 runs 128-row tiles");
-        unsigned short* const As = smem;
-        unsigned short* const Bs0 = smem + 2 * APL;
-        const unsigned short* gb[4];
-        int lob[4];                                               // wave-uniform offsets of the wave's four 1 KB blocks inside a B stage
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int blk = 4 * wave + j, plane = blk >> 3, rb16 = blk & 7;
-            const int row = rb16 * 16 + (lane >> 2);
-            const int piece = (lane & 3) ^ ((row >> 2) & 3);
-            gb[j] = W + (size_t)plane * WPL + (size_t)ts * WTS + (size_t)(col0 + row) * WROW + piece * 8;
-            lob[j] = __builtin_amdgcn_readfirstlane(plane * H2_BPL + rb16 * 16 * H2_BK);
-        }
-        auto glds_b = [&](int c) {
-            unsigned short* st = Bs0 + (c & 1) * 2 * H2_BPL;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds((gptr)(gb[j] + c * WCH), (lptr)(st + lob[j]), 16, 0, 0);
-        };
-        glds_b(0);                                                // needs the tile descriptor only: on its way while the row indices arrive
-        const unsigned short* a_ptr[2];
-        int srcr[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int r = lrow + 64 * i;
-            r = r < nrows ? r : nrows - 1;
-            if constexpr (FWD) { if (i == 0) h2_idx_wait<4>(srcx); srcr[i] = srcx[i]; }      // (behind them: the four weight pieces of chunk 0)
-            else srcr[i] = urow_node ? urow_node[row0 + r] : row0 + r;
-            a_ptr[i] = A + (size_t)srcr[i] * AROW + lq * 8;
-        }
-        const int st_off = h2_off(lrow, lq);
-        ushort8 ra[4];                                            // [row half * 2 + plane]
-        auto gload_a = [&](int c) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) ra[i * 2 + pl] = *reinterpret_cast<const ushort8*>(a_ptr[i] + (size_t)pl * APLN + c * ACH);
-        };
-        auto lstore_a = [&]() {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) *reinterpret_cast<ushort8*>(As + pl * APL + st_off + i * 64 * H2_BK) = ra[i * 2 + pl];
-        };
-        gload_a(0);
-        __builtin_amdgcn_sched_barrier(0);
-        {                                                         // (epilogue only) the row exponents, by the lanes that hold the row's index
-            int e[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) e[i] = a_exp[srcr[i]];
-            if (lq == 0) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) sE[lrow + 64 * i] = e[i];
-            }
-        }
-        lstore_a();                                               // (the compiler's wait in front of it: A(0) and B(0) have landed for this wave)
-        gload_a(1);
-        glds_b(1);
-        CCSP_TRK(0, 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            CCSP_TRK(0, 2 + (c < 8 ? c : 7));
-            CCSP_TRK2(1 + 2 * (c < 8 ? c : 7));
-            if (FWD && c == NCH - 1) {                             // (the last chunk carries the 32 registers of row tile 0's base values: MODE 0's k-steps)
-                // (an opaque copy of the column offset: the addresses below are formed HERE -- hoisted above the K loop they were eighteen
-                //  registers that hipcc spilled to scratch, next to asm loads with counted waits)
-                int colw_l = colw, wr0_l = wr0;
-                asm volatile("" : "+v"(colw_l), "+v"(wr0_l));
-                const float* tp = (has_tau ? tau_t + (size_t)(ts >> 1) * ND : base) + colw_l + 4 * (lane & 7);
-                h2_ld16(tv[0], tp);
-                h2_ld16(tv[1], tp + 32);
-                h2_epilogue_prefetch<ND>(bs0, 0, wr0_l, nrows, row0, colw_l, base);
-                h2_kstep<MI>(As, APL, Bs0 + (c & 1) * 2 * H2_BPL, 0, wr0, wn * 64, acc);
-                h2_kstep<MI>(As, APL, Bs0 + (c & 1) * 2 * H2_BPL, 1, wr0, wn * 64, acc);
-            } else {
-                h2_chunk_pipe(As, APL, Bs0 + (c & 1) * 2 * H2_BPL, wr0, wn * 64, acc);
-            }
-            CCSP_TRK2(2 + 2 * (c < 8 ? c : 7));
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                         // every wave is done reading the A stage and B stage c & 1
-            __builtin_amdgcn_sched_barrier(0);
-            if (c + 1 < NCH) {
-                lstore_a();                                       // chunk c + 1's rows (requested a whole chunk ago) -> the A stage; B(c + 1) has landed with them
-                if (c + 2 < NCH) { gload_a(c + 2); glds_b(c + 2); }
-                __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
     } else if constexpr (MODE >= 2 && MODE != 6 && MODE != 9) {
         // a wave-instruction fills one 1 KB block = (plane, sixteen rows); wave w owns blocks NA w .. NA w + NA - 1 of the A
         // planes (2 x TM / 16 blocks) and 4 w .. 4 w + 3 of the B planes

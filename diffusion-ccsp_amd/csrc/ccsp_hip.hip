@@ -1725,7 +1725,7 @@ struct ccsp_model {
     // StructDiffusion baseline (model_kind 1): transformer weights as given ([out, in] row-major)
     struct SdLayer {
         float *in_w, *in_b, *out_w, *out_b, *ln1_g, *ln1_b, *fc_w, *fc_b, *proj_w, *proj_b, *ln2_g, *ln2_b;
-        unsigned short *in_wH = nullptr, *out_wH = nullptr, *fc_wH = nullptr, *proj_wH = nullptr;    // fp16 planes [2][N][K] * 2^exp (k_sd_gemm_h2)
+        unsigned short *in_wH = nullptr, *out_wH = nullptr, *fc_wH = nullptr, *proj_wH = nullptr;    // fp16 planes [N][K / 32][2][32] * 2^exp (k_sd_gemm_h2)
         int in_e = 0, out_e = 0, fc_e = 0, proj_e = 0;
     };
     int sd_h2 = 0;         // 1: the transformer's GEMMs on the f16 pipe (f16x2; Wd a multiple of 128, CCSP_MMA unset or f16x2)
@@ -1942,9 +1942,9 @@ int launch_rowgemm_h2(ccsp_model* m, ccsp_graph* g, const float* tau_t, StepRef 
     hipLaunchKernelGGL((k_rowgemm_h2<H, 2 * H, MODE>), dim3(work + ref.na.blocks), dim3(256), 0, s, g->pembH, (size_t)g->N * H, g->pexp, g->urow_node,                  \
                        small ? g->td64 : g->td128, m->WpHI,                                                                                             \
                        (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, m->wp_exp, g->base, tau_t, g->U, g->umax, ref, tau_stride)
-    if (mode == 6) CCSP_ROWGEMM_F(6); else if (mode == 4) CCSP_ROWGEMM_F(4); else if (mode == 9) CCSP_ROWGEMM_F(9);
+    if (mode == 6) CCSP_ROWGEMM_F(6); else if (mode == 4) CCSP_ROWGEMM_F(4);
 #ifdef CCSP_EXPERIMENTS
-    else if (mode == 8) CCSP_ROWGEMM_F(8);
+    else if (mode == 9) CCSP_ROWGEMM_F(9);
     else if (mode == 5) CCSP_ROWGEMM_F(5); else if (mode == 3) CCSP_ROWGEMM_F(3); else if (mode == 2) CCSP_ROWGEMM_F(2); else if (mode == 1) CCSP_ROWGEMM_F(1);
 #endif
     else CCSP_ROWGEMM_F(0);
@@ -2557,7 +2557,6 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
                                (size_t)0)
             if (mode == 6) CCSP_ROWGEMM_T(6); else if (mode == 4) CCSP_ROWGEMM_T(4);
 #ifdef CCSP_EXPERIMENTS
-            else if (mode == 8) CCSP_ROWGEMM_T(8);
             else if (mode == 5) CCSP_ROWGEMM_T(5); else if (mode == 3) CCSP_ROWGEMM_T(3); else if (mode == 2) CCSP_ROWGEMM_T(2); else if (mode == 1) CCSP_ROWGEMM_T(1);
 #endif
             else CCSP_ROWGEMM_T(0);
@@ -3590,9 +3589,9 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     //           bf16x3 (three-term bf16 operands, six products), f32 (v_mfma_f32_32x32x2_f32)
     m->f16x2 = (H == 256 && d->model_kind == CCSP_MODEL_DIFFUSION_CCSP) ? 1 : 0;
 #ifdef CCSP_EXPERIMENTS
-    if (const char* e = getenv("CCSP_ROW_MODE")) { const int v = atoi(e); if (v >= 0 && v <= 9) m->row_mode = v; }
+    if (const char* e = getenv("CCSP_ROW_MODE")) { const int v = atoi(e); if (v >= 0 && v <= 9 && v != 8) m->row_mode = v; }
 #else
-    if (const char* e = getenv("CCSP_ROW_MODE")) { const int v = atoi(e); if (v == 0 || v == 4 || v == 6 || v == 9) m->row_mode = v; }      // (the three forms the selection uses)
+    if (const char* e = getenv("CCSP_ROW_MODE")) { const int v = atoi(e); if (v == 0 || v == 4 || v == 6) m->row_mode = v; }      // (the three forms the selection uses)
 #endif
     if (const char* e = getenv("CCSP_EDGE_MT")) m->edge_mt = atoi(e) == 2 ? 2 : 1;
     if (const char* e = getenv("CCSP_EDGE_SMALL")) m->edge_small = atoi(e) != 0;
@@ -3696,6 +3695,8 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
                 HIP_TRY(hipMemcpyAsync(h_mx, mx, sizeof(h_mx), hipMemcpyDeviceToHost, s));
                 HIP_TRY(hipStreamSynchronize(s));
                 auto host_exp = [](unsigned int bits) { const int be = (int)((bits >> 23) & 0xffu); return (be == 0 || be == 255) ? 0 : 140 - be; };
+                unsigned short* tmp = nullptr;                 // (planar planes of one tensor on their way to the interleaved layout)
+                TRY(dev_alloc(reg, &tmp, (size_t)2 * n_fc));
                 for (int l = 0; l < SD_LAYERS; ++l) {
                     ccsp_model::SdLayer& w = m->sd[l];
                     w.in_e = host_exp(h_mx[4 * l]); w.out_e = host_exp(h_mx[4 * l + 1]); w.fc_e = host_exp(h_mx[4 * l + 2]); w.proj_e = host_exp(h_mx[4 * l + 3]);
@@ -3705,6 +3706,13 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
                     hipLaunchKernelGGL(k_split2h, dim3(nblk(n_out, 256)), dim3(256), 0, s, n_out, w.out_w, w.out_e, w.out_wH);
                     hipLaunchKernelGGL(k_split2h, dim3(nblk(n_fc, 256)), dim3(256), 0, s, n_fc, w.fc_w, w.fc_e, w.fc_wH);
                     hipLaunchKernelGGL(k_split2h, dim3(nblk(n_fc, 256)), dim3(256), 0, s, n_fc, w.proj_w, w.proj_e, w.proj_wH);
+                    {   // ... chunk-interleaved ([N][K / 32][2][32]): what k_sd_gemm_h2 reads
+                        struct { unsigned short* p; long n; int K; } ws[4] = {{w.in_wH, n_in, Wd}, {w.out_wH, n_out, Wd}, {w.fc_wH, n_fc, Wd}, {w.proj_wH, n_fc, 4 * Wd}};
+                        for (auto& e : ws) {
+                            HIP_TRY(hipMemcpyAsync(tmp, e.p, (size_t)2 * e.n * sizeof(unsigned short), hipMemcpyDeviceToDevice, s));
+                            hipLaunchKernelGGL(k_interleave_planes, dim3(nblk(e.n, 256)), dim3(256), 0, s, e.n, e.K, tmp, e.p);
+                        }
+                    }
                 }
             }
         }

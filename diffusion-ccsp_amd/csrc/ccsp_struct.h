@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void k_sd_ln2ln1(int M, int Wd, float* __restr
 // K chunks of 32 double-buffered through LDS, operands requested PD (2 or 4) chunks ahead into PD register sets (with one chunk of
 // lead every iteration waited an L2 round trip: 1.5 k cycles per chunk against 0.4 k of MFMA work, first build of this round).
 // A is fp32 in memory: a row's exponent comes from amax (bits of its largest magnitude, left by the producer), the split into two
-// fp16 planes happens while the chunk is staged.  W: planes [2][N][K] scaled by 2^w_exp.  Epilogue per wave through a wave-private
+// fp16 planes happens while the chunk is staged.  W: planes [N][K / 32][2][32] scaled by 2^w_exp.  Epilogue per wave through a wave-private
 // LDS tile (rows re-read as 16-byte segments): bias, residual / QuickGELU, 16-byte stores, and -- cmax non-null -- the row maxima
 // of the result for the next GEMM (DPP maximum over the lanes of a row, one atomicMax on the float bits per row and wave).
 // K % 64 == 0, N % TN == 0; M arbitrary (rows clamped).
@@ -273,7 +273,8 @@ __global__ __launch_bounds__(256, 2) void k_sd_gemm_h2(int M, int K, int N, cons
         a_st[i] = h2_off(lr + 32 * i, lq >> 1) + (lq & 1) * 4;
     }
     const int brow = tid >> 2, bq = tid & 3;                      // B copy: rows brow (+ 64), piece bq, both planes
-    const unsigned short* b_ptr = WH + (size_t)(col0 + brow) * K + k_first + bq * 8;
+    // (W: chunk-interleaved planes [N][K / 32][2][32] -- both fp16 planes of a row's K chunk in ONE 128-byte line, k_interleave_planes)
+    const unsigned short* b_ptr = WH + (size_t)(col0 + brow) * (2 * K) + 2 * k_first + bq * 8;
     const int b_st = h2_off(brow, bq);
     // operand loads by inline asm, waited for by counted s_waitcnt (h2_ld16): hipcc sinks an ordinary load to its first use -- the
     // ds_write of the NEXT trip -- which puts a memory round trip into every chunk (measured: 1.8 k cycles per chunk against 0.2 k of
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void k_sd_gemm_h2(int M, int K, int N, cons
     // hipcc merge the two paths' register sets with v_mov copies placed BEFORE the s_waitcnt of one path -- copies of registers whose
     // loads were in flight (second build of this round: NaN in every transformer parity test).
     const float* const a_dummy = A + (size_t)row0 * K + k_first;
-    const unsigned short* const b_dummy = WH + (size_t)col0 * K + k_first;
+    const unsigned short* const b_dummy = WH + (size_t)col0 * (2 * K) + 2 * k_first;
     auto gload = [&](int c, int set) {
         const bool real = c < Ks / H2_BK;
 #pragma unroll
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void k_sd_gemm_h2(int M, int K, int N, cons
         for (int i = 0; i < NB; ++i)
 #pragma unroll
             for (int p = 0; p < 2; ++p)
-                h2_ld16(rb[set][i * 2 + p], reinterpret_cast<const float*>(real ? b_ptr + (size_t)p * w_plane + (size_t)i * 64 * K + c * H2_BK : b_dummy));
+                h2_ld16(rb[set][i * 2 + p], reinterpret_cast<const float*>(real ? b_ptr + (size_t)p * H2_BK + (size_t)i * 64 * (2 * K) + c * (2 * H2_BK) : b_dummy));
     };
     // the set's loads have landed; the PD - 1 sets requested after it stay in flight
     auto gwait = [&](int set) {

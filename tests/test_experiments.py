@@ -18,7 +18,7 @@ pytestmark = [pytest.mark.gpu_experiments,
 
 
 @pytest.mark.parametrize('env', [{'CCSP_ROW_MODE': '1', 'CCSP_EDGE_MT': '2'}, {'CCSP_ROW_MODE': '2', 'CCSP_EDGE_MT': '1'}, {'CCSP_ROW_MODE': '3', 'CCSP_EDGE_MT': '2'},
-                                 {'CCSP_ROW_MODE': '5', 'CCSP_EDGE_MT': '1'}, {'CCSP_ROW_MODE': '7', 'CCSP_EDGE_MT': '1'}, {'CCSP_ROW_MODE': '8'}, {'CCSP_NODE': 'stream'},
+                                 {'CCSP_ROW_MODE': '5', 'CCSP_EDGE_MT': '1'}, {'CCSP_ROW_MODE': '7', 'CCSP_EDGE_MT': '1'}, {'CCSP_ROW_MODE': '9'}, {'CCSP_NODE': 'stream'},
                                  {'CCSP_ENERGY_ROWSUM': 'kernel'}])
 def test_f16x2_experimental_variants_meet_the_same_bars(device, monkeypatch, env):
     """(see tests/test_hip_parity.py::test_f16x2_residency_variants_meet_the_same_bars) the f16x2 kernels pick a variant by tile count (row GEMM: MODE 0 three workgroups per CU register-staged on 128-row tiles, MODE 6 the
