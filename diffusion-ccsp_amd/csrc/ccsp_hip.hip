@@ -1943,6 +1943,10 @@ int launch_rowgemm_h2(ccsp_model* m, ccsp_graph* g, const float* tau_t, StepRef 
                        small ? g->td64 : g->td128, m->WpHI,                                                                                             \
                        (size_t)m->d.n_types * 2 * 2 * H * H, (size_t)2 * H * H, m->wp_exp, g->base, tau_t, g->U, g->umax, ref, tau_stride)
     if (mode == 6) CCSP_ROWGEMM_F(6); else if (mode == 4) CCSP_ROWGEMM_F(4);
+#ifdef CCSP_TRY_MODE2
+    else if (mode == 2) CCSP_ROWGEMM_F(2);
+    else if (mode == 9) CCSP_ROWGEMM_F(9);
+#endif
 #ifdef CCSP_EXPERIMENTS
     else if (mode == 9) CCSP_ROWGEMM_F(9);
     else if (mode == 5) CCSP_ROWGEMM_F(5); else if (mode == 3) CCSP_ROWGEMM_F(3); else if (mode == 2) CCSP_ROWGEMM_F(2); else if (mode == 1) CCSP_ROWGEMM_F(1);
@@ -3591,7 +3595,11 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
 #ifdef CCSP_EXPERIMENTS
     if (const char* e = getenv("CCSP_ROW_MODE")) { const int v = atoi(e); if (v >= 0 && v <= 9 && v != 8) m->row_mode = v; }
 #else
-    if (const char* e = getenv("CCSP_ROW_MODE")) { const int v = atoi(e); if (v == 0 || v == 4 || v == 6) m->row_mode = v; }      // (the three forms the selection uses)
+    if (const char* e = getenv("CCSP_ROW_MODE")) { const int v = atoi(e); if (v == 0 || v == 4 || v == 6
+#ifdef CCSP_TRY_MODE2
+            || v == 2 || v == 9
+#endif
+            ) m->row_mode = v; }      // (the three forms the selection uses)
 #endif
     if (const char* e = getenv("CCSP_EDGE_MT")) m->edge_mt = atoi(e) == 2 ? 2 : 1;
     if (const char* e = getenv("CCSP_EDGE_SMALL")) m->edge_small = atoi(e) != 0;

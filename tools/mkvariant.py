@@ -10,7 +10,8 @@ SRC = os.path.join(ROOT, 'diffusion-ccsp_amd', 'csrc')
 VARIANTS = {
     'base': ([], []),                                            # the sources as they are (build it from a stash / an older checkout for a same-call A/B)
     'gate_nofence': ([], ['CCSP_GATE_NOFENCE']),                 # relay gates without the cache-wide release / acquire (TIMING ONLY: results are stale)
-    'act_scalar': ([], ['CCSP_ACT_SCALAR']),                     # edge kernels' activation producer without the packed fp32 instructions
+    'act_scalar': ([], ['CCSP_ACT_SCALAR']),
+    'try_mode2': ([], ['CCSP_TRY_MODE2']),                       # the product build + row GEMM MODEs 2 / 9 selectable by CCSP_ROW_MODE (direct-to-LDS staging and the software-pipelined form on the product's interleaved A planes)                     # edge kernels' activation producer without the packed fp32 instructions
     'cb22': ([], ['CCSP_H2_CB0=2', 'CCSP_H2_CB1=2']),          # row GEMM MODE 2: base of both row tiles requested under chunk NCH - 2
     'cb88': ([], ['CCSP_H2_CB0=8', 'CCSP_H2_CB1=8']),          # ... under chunk 0
     'cb11': ([], ['CCSP_H2_CB0=1', 'CCSP_H2_CB1=1']),          # ... under the last chunk
