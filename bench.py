@@ -353,6 +353,7 @@ def sd_main(args):
     B = args.graphs_per_gpu or 256
     S = args.samples_per_step
     dims = worlds.MODE_DIMS['qualitative']
+    host_budget = apply_lanes_rule(world)
     den = ConstraintDiffuser(dims=dims, hidden_dim=HIDDEN, input_mode='qualitative', EBM='ULA', device=dev, verbose=False, model='StructDiffusion')
     den.reset_parameters(0)
     # nn.Linear default init everywhere except the last pose-decoder layer, scaled by 1/20: with the default there the untrained network's
@@ -376,14 +377,19 @@ def sd_main(args):
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    cpu0 = host_cpu_seconds()
     t0 = time.perf_counter()
     for k in range(args.steps):
         x = one_step(args.warmup + k)
     torch.cuda.synchronize()
+    local_elapsed = time.perf_counter() - t0
+    cpu_s = host_cpu_seconds() - cpu0
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    times = rank_times(local_elapsed, world, dist, dev)
+    cpu_per_rank = gather_floats(cpu_s, world, dist, dev)
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -396,6 +402,9 @@ def sd_main(args):
     rec = {'metric': 'samples/sec, T=1000 ULA, StructDiffusion transformer baseline, 7-obj (all chains per second; not a BASELINE.json configuration)',
            'value': value, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+           'lanes': gd.chain_lanes(), 'host_cpu_s_per_step': [c / args.steps for c in cpu_per_rank],
+           'host_cores_busy_per_rank': [c / max(1e-9, t) for c, t in zip(cpu_per_rank, times)], 'host_budget': host_budget,
+           'per_rank_ms_per_step': [1e3 * v / args.steps for v in times],
            'dtype': 'f32 (f16x2 split operands: 3 fp16 MFMA products per fp32 product, fp32 accumulate)' if mma == 'f16x2' else 'f32',
            'data': 'synthetic (random-init weights: nn.Linear default init, last pose-decoder layer x 0.05 so that the chain stays finite)',
            'config': {'workload': 'StructDiffusion baseline (denoise_fn.py:391-451): %d graphs x 7 objects per GPU, 8-token sequences, width %d, 4 blocks, 2 heads, '
@@ -461,6 +470,50 @@ def effective_cores():
     except (OSError, ValueError):
         pass
     return n
+
+def host_cpu_seconds():
+    """user + system CPU seconds of this process so far (getrusage(RUSAGE_SELF): the library's lane threads, RCCL's proxy threads and the Python
+    thread included; child processes -- the rocprofv3 sub-runs -- are not)"""
+    import resource
+    r = resource.getrusage(resource.RUSAGE_SELF)
+    return r.ru_utime + r.ru_stime
+
+
+# A rank with two lanes keeps two enqueueing threads busy for the whole chain (33 000 launches per lane) next to the Python thread that waits in
+# ccsp_chain_run: measured 2.0-2.1 core-seconds per second of chain (profiles/r06_host_budget.txt); one lane needs 1.0 and runs the C2 chain 6-8 % slower.
+# The reference is ONE process for the whole node (ddpm.py:342-351), so this cost is the port's own and the launcher budgets it.
+CORES_PER_RANK_TWO_LANES = 2.5
+
+
+def select_lanes(world, cores, env_lanes=None):
+    """-> (value for CCSP_LANES or None = the library's default of two lanes, reason).  An explicit CCSP_LANES always wins; otherwise one lane per rank
+    when the container grants fewer than CORES_PER_RANK_TWO_LANES cores per rank (8 ranks on the GPU boxes' 16-core quota: 16 < 20 -> one lane)."""
+    if env_lanes not in (None, ''):
+        return None, 'CCSP_LANES=%s set by the caller' % env_lanes
+    if cores < CORES_PER_RANK_TWO_LANES * world:
+        return 1, ('one lane per rank: %d usable cores < %.1f x %d ranks (two lanes keep two enqueueing threads busy per rank; starved enqueue threads '
+                   'stall the chain silently)' % (cores, CORES_PER_RANK_TWO_LANES, world))
+    return None, 'library default (two lanes above 6144 active edges): %d usable cores >= %.1f x %d ranks' % (cores, CORES_PER_RANK_TWO_LANES, world)
+
+
+def apply_lanes_rule(world):
+    """decide CCSP_LANES for this rank BEFORE the model is created (the library reads it at ccsp_model_create); -> dict for the JSON line"""
+    cores = int(os.environ.get('CCSP_BENCH_HOST_CORES', '0') or 0) or effective_cores()      # (the override: tests of the rule, tools/host_budget.sh)
+    lanes, why = select_lanes(world, cores, os.environ.get('CCSP_LANES'))
+    if lanes is not None:
+        os.environ['CCSP_LANES'] = str(lanes)
+    return {'usable_cores': cores, 'cores_per_rank_needed_for_two_lanes': CORES_PER_RANK_TWO_LANES, 'ccsp_lanes_env': os.environ.get('CCSP_LANES'), 'rule': why}
+
+
+def gather_floats(v, world, dist, dev):
+    """one double per rank, on every rank"""
+    if dist is None or world == 1:
+        return [float(v)]
+    t = torch.tensor([v], device=dev, dtype=torch.float64)
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    return [float(q.item()) for q in parts]
+
 
 def world_label(cfg):
     """'RandomSplitQualitativeWorld 8-obj' from the configuration's label"""
@@ -550,6 +603,7 @@ def dry_run_main(args):
     os.environ.setdefault('MASTER_PORT', '29533')
     dist.init_process_group(args.backend, rank=rank, world_size=world)
     from diffusion_ccsp_amd import sharding, worlds
+    host_budget = apply_lanes_rule(world)
     cname = 'c2' if args.config in ('c3', 'sd') else args.config
     cfg = CONFIGS[cname]
     B = args.graphs_per_gpu or cfg['graphs']
@@ -574,10 +628,12 @@ def dry_run_main(args):
     for k in range(args.warmup):
         one_step(k)
     dist.barrier()
+    cpu0 = host_cpu_seconds()
     t0 = time.perf_counter()
     for k in range(args.steps):
         full = one_step(args.warmup + k)
     local = time.perf_counter() - t0
+    cpu_per_rank = gather_floats(host_cpu_seconds() - cpu0, world, dist, dev)
     dist.barrier()
     elapsed = time.perf_counter() - t0
     times = rank_times(local, world, dist, dev)
@@ -592,6 +648,7 @@ def dry_run_main(args):
            'dtype': 'none (dry run: no kernels)', 'data': 'synthetic',
            'world': world, 'rccl_ranks': proof.get('rccl_ranks'), 'communicator': proof,
            'per_rank_ms_per_step': [1e3 * v / max(1, args.steps) for v in times],
+           'lanes': None, 'host_cpu_s_per_step': [c / max(1, args.steps) for c in cpu_per_rank], 'host_budget': host_budget,
            'config': {'workload': 'DRY RUN of the N > 1 host path of: %s, %d graphs per GPU' % (cfg['label'], B), 'name': args.config, 'graphs_per_gpu': B,
                       'nodes_per_rank': sizes, 'weights': wrel, 'weights_broadcast_equal_to_file_on_every_rank': None,
                       'gathered_rows_in_rank_order': gathered_ok,
@@ -664,6 +721,7 @@ def main():
 
     from diffusion_ccsp_amd import (ComposedEBMDenoiseFn, ConstraintDiffuser, GaussianDiffusion, device_info, sharding, worlds)
     from diffusion_ccsp_amd import _lib
+    host_budget = apply_lanes_rule(world)           # (CCSP_LANES is read by ccsp_model_create: decided here, per rank, before any model exists)
     B = args.graphs_per_gpu or cfg['graphs']
     if args.scaling == 'strong':
         total = 8 * cfg['graphs']
@@ -703,16 +761,20 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    cpu0 = host_cpu_seconds()
     t0 = time.perf_counter()
     for k in range(args.steps):
         x = one_step(args.warmup + k)
     torch.cuda.synchronize()
     local_elapsed = time.perf_counter() - t0          # this rank's own K steps (before it waits for the others)
+    cpu_s = host_cpu_seconds() - cpu0                 # user + sys of this rank over its own K steps: the lane threads' enqueue work is in here
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     times = rank_times(local_elapsed, world, dist, dev)
+    cpu_per_rank = gather_floats(cpu_s, world, dist, dev)
+    lanes_used = gd.chain_lanes()
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -738,6 +800,12 @@ def main():
         'value_per_gpu': value / world, 'world': world, 'rccl_ranks': (proof or {}).get('rccl_ranks'),
         'per_rank_ms_per_step': [1e3 * v / args.steps for v in times],
         'per_rank_ms_per_step_min_max': [1e3 * min(times) / args.steps, 1e3 * max(times) / args.steps],
+        # what a rank costs its host: CPU-seconds (user + sys, every thread of the process) per step and per second of its own chain time.  A rank whose
+        # busy-cores figure falls below what one rank alone shows (profiles/r06_host_budget.txt) while its ms_per_step rises is starved of host cores.
+        'lanes': lanes_used,
+        'host_cpu_s_per_step': [c / args.steps for c in cpu_per_rank],
+        'host_cores_busy_per_rank': [c / max(1e-9, t) for c, t in zip(cpu_per_rank, times)],
+        'host_budget': host_budget,
         'dtype': {'f16x2': 'f32 (f16x2 split operands: 3 fp16 MFMA products per fp32 product, fp32 accumulate)',
                   'bf16x3': 'f32 (bf16x3 split operands: 6 bf16 MFMA products per fp32 product, fp32 accumulate)'}.get(os.environ.get('CCSP_MMA', 'f16x2'), 'f32'),
         'data': 'synthetic',
@@ -816,6 +884,15 @@ def main():
         rec['solved_fraction'] = solved_fraction
         rec['solved_metric'] = 'solved samples/sec, T=1000 ULA, RandomSplitQualitativeWorld 8-obj (BASELINE.json metric)'
         rec['solved_samples_per_s'] = value * solved_fraction
+        # BASELINE.json's metric under BASELINE.json's name, with what bounds it (the reader gets value / value_strict_fp32 / this from `parsed` alone)
+        rec['baseline_metric'] = {
+            'name': 'solved samples/sec, T=1000 ULA, RandomSplitQualitativeWorld 8-obj',
+            'value': value * solved_fraction, 'unit': 'solved samples/s', 'solved_fraction': solved_fraction,
+            'solved_of': [int(n_solved[0].item()), int(n_solved[1].item())],
+            'arithmetic': 'the headline mode (see dtype); one try per graph, no rejection sampling',
+            'bounded_by': 'weights, not the sampler port: no reference checkpoint exists offline, the committed weights are the reference recipe (trained on 2-5 objects) at '
+                          '30 000 steps, and the REFERENCE sampler with exactly these weights solves 0 of 16 8-object graphs (tests/golden/chain_q256_bench_B16, '
+                          'test_bench_weights_vs_reference_golden: same final poses, same solved mask)'}
         rec['config']['solved_note'] = ('solved_fraction = share of the last timed batch (one try per graph, no rejection) passing the collision + '
                                         'qualitative-constraint check of diffusion-ccsp_amd/checker.py; the reference sampler itself overflows fp32 in its '
                                         'first timesteps on some graphs (ULA step 2*beta with beta -> 0.999; Trainer.evaluate skips them, ddpm.py:644), see DESIGN.md section 7')
@@ -971,6 +1048,15 @@ def main():
             'chain_ms_event': st['ms_total'], 'chain_evals': st['evals'],
             'profile_note': 'the profiled chain runs as one lane with an event per launch; its ms is not the timed value above',
         }
+        if 'value_strict_fp32' in rec:
+            # the number measured on the reference's own arithmetic width, priced against the fp32 matrix peak over the WHOLE evaluation:
+            # executed fp32 flops of one evaluation (after the row factorisation) x evaluations per chain x chains per second / 157.3 TFLOP/s
+            ex = sum(k.get('executed_flops_fp32_equiv', 0.0) for k in kernels if k['kernel'] in ('row GEMM (forward)', 'edge decoder (forward)', 'node update + pose encoder'))
+            rec['roofline']['value_strict_fp32'] = rec['value_strict_fp32']
+            rec['roofline']['frac_fp32_peak'] = rec['value_strict_fp32'] / B * evals_per_chain * ex / 1e12 / PEAKS['f32']
+            rec['roofline']['strict_fp32_note'] = ('value_strict_fp32 = the same step with CCSP_MMA=f32 (v_mfma_f32_32x32x2_f32, no operand split): samples/s on the reference\'s own '
+                                                   'arithmetic; frac_fp32_peak = its executed fp32 flops per second / the dense fp32 matrix peak (%.1f TFLOP/s), whole evaluation; '
+                                                   '`frac` above is the headline mode\'s dominant kernel on the f16 pipe (three fp16 products per fp32 product)' % PEAKS['f32'])
         if cname == 'c2' and world == 1 and mma == 'f16x2' and not args.no_throughput_regime and not args.graphs_per_gpu:
             try:
                 rec['roofline']['throughput_regime'] = throughput_regime(gd, cfg, worlds, dev, args)

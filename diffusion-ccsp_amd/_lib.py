@@ -13,8 +13,7 @@ CSRC = os.path.join(HERE, 'csrc')
 # ...) and the switches that select them.  The product build has none of that code (`pytest -m gpu_experiments` covers it, outside the default run).
 EXPERIMENTS = os.environ.get('CCSP_EXPERIMENTS', '0') not in ('', '0')
 SO = os.path.join(CSRC, 'libccsp_hip_exp.so' if EXPERIMENTS else 'libccsp_hip.so')
-SOURCES = ['ccsp_hip.hip', 'ccsp_philox.h', 'ccsp_plan.h', 'ccsp_energy_pre.h', 'ccsp_energy.h', 'ccsp_bf16x3.h', 'ccsp_f16x2.h', 'ccsp_fused.h',
-           'ccsp_struct.h', 'ccsp_hmc.h', os.path.join('..', '..', 'include', 'ccsp.h')]
+SOURCES = sorted(f for f in os.listdir(CSRC) if f.endswith(('.h', '.hip'))) + [os.path.join('..', '..', 'include', 'ccsp.h')]     # the one translation unit ccsp_hip.hip and the fragments / kernel headers it includes
 ABI_MAJOR = 1         # CCSP_VERSION_MAJOR of include/ccsp.h this binding was written against: lib() refuses a library of another major version
 
 K_COUNT = 11          # CCSP_K_COUNT of include/ccsp.h
@@ -199,6 +198,7 @@ def lib():
     L.ccsp_kernel_stats.argtypes = [vp, i32, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.c_char_p, i32]
     L.ccsp_chain_skipped.argtypes = [vp, C.POINTER(C.c_int64)]
     L.ccsp_chain_margins.argtypes = [vp, vp, C.c_int64]
+    L.ccsp_chain_lanes.argtypes = [vp, C.POINTER(i32)]
     L.ccsp_graph_variant.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.ccsp_compose_denoise.argtypes = [vp, vp, vp, vp, C.POINTER(Compose), vp, i32, vp, vp]
     L.ccsp_compose_energy_grad.argtypes = [vp, vp, vp, vp, C.POINTER(Compose), vp, i32, vp, vp, vp]

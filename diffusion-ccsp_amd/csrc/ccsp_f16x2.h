@@ -571,10 +571,16 @@ __global__ __launch_bounds__(256, MODE == 0 ? CCSP_H2_MODE0_WGS : (MODE == 6 ? 4
     // discard them: a select instead of a branch).  The first loads of the kernel: older than every counted wait below.
     const bool has_tau = FWD && tau_t && (ts & 1) == 0;
     h2_f4 tv[2] = {h2_f4{0.f, 0.f, 0.f, 0.f}, h2_f4{0.f, 0.f, 0.f, 0.f}};
+    // The counted waits for the row indices requested at kernel entry (h2_idx_wait<N>) name how many vector loads are issued BEHIND the indices
+    // before the wait: the constants below sit next to the loads they count, and the waits are written in terms of them -- a load added or removed
+    // here changes the wait with it instead of silently letting it return before the indices have arrived.
+    constexpr int N_TV = 2;                                       // the two time-term loads right below (FWD only; always issued: a select, not a branch, picks tau or base)
+    constexpr int N_GLDS_B = 4;                                   // 16-byte pieces per lane of one weight chunk in the direct-to-LDS forms (glds_b)
     if constexpr (FWD) {
         const float* tp = (has_tau ? tau_t + (size_t)(ts >> 1) * ND : base) + colw + 4 * (lane & 7);
         h2_ld16(tv[0], tp);
         h2_ld16(tv[1], tp + 32);
+        static_assert(N_TV == 2, "N_TV counts the h2_ld16(tv[...]) loads above");
     }
     if constexpr (MODE == 5) {
         // MODE 5 (tile lists of at most two workgroups per CU: the lanes of a C2 batch).  The K loop of the other modes is bound by
@@ -598,7 +604,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? CCSP_H2_MODE0_WGS : (MODE == 6 ? 4
         auto glds_b = [&](int c) {
             unsigned short* st = smem + (c % NST) * STAGE;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds((gptr)(gb[j] + c * WCH), (lptr)(st + lob[j]), 16, 0, 0);
+            for (int j = 0; j < N_GLDS_B; ++j) __builtin_amdgcn_global_load_lds((gptr)(gb[j] + c * WCH), (lptr)(st + lob[j]), 16, 0, 0);
         };
         // the lane's two A rows (tile i = 0, 1): one dependent gather, requested first
         int src[2];
@@ -614,7 +620,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? CCSP_H2_MODE0_WGS : (MODE == 6 ? 4
         glds_b(1);
         glds_b(2);
         __builtin_amdgcn_sched_barrier(0);
-        if (FWD || urow_node) asm volatile("s_waitcnt vmcnt(12)" : "+v"(src[0]), "+v"(src[1]) :: "memory");      // (the twelve weight loads stay in flight)
+        if (FWD || urow_node) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(src[0]), "+v"(src[1]) : "n"(3 * N_GLDS_B) : "memory");      // (the three chunks of weight loads issued since stay in flight)
         const unsigned short* ap[2][2];                               // [tile][plane]
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -696,7 +702,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? CCSP_H2_MODE0_WGS : (MODE == 6 ? 4
         auto glds_b = [&](int c, int stage) {
             unsigned short* st = smem + stage * STAGE;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds((gptr)(gb[j] + c * WCH), (lptr)(st + 2 * APL + lob[j]), 16, 0, 0);
+            for (int j = 0; j < N_GLDS_B; ++j) __builtin_amdgcn_global_load_lds((gptr)(gb[j] + c * WCH), (lptr)(st + 2 * APL + lob[j]), 16, 0, 0);
         };
         auto glds_a = [&](int c, int stage) {
             unsigned short* st = smem + stage * STAGE;
@@ -716,7 +722,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? CCSP_H2_MODE0_WGS : (MODE == 6 ? 4
         glds_b(0, 0);                                             // the weights of chunk 0 are on their way while the row indices arrive
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (FWD) {                                      // (requested at kernel entry; behind them: the two time-term loads and the four weight pieces)
-            h2_idx_wait<6>(srcx);
+            h2_idx_wait<N_TV + N_GLDS_B>(srcx);
 #pragma unroll
             for (int j = 0; j < NA; ++j) src[j] = srcx[j];
         }
@@ -836,7 +842,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? CCSP_H2_MODE0_WGS : (MODE == 6 ? 4
         for (int i = 0; i < MI; ++i) {
             int r = lrow + 64 * i;
             r = r < nrows ? r : nrows - 1;
-            if constexpr (FWD) { if (i == 0) h2_idx_wait<2>(srcx); srcr[i] = srcx[i]; }      // (requested at kernel entry; behind them: the two time-term loads)
+            if constexpr (FWD) { if (i == 0) h2_idx_wait<N_TV>(srcx); srcr[i] = srcx[i]; }      // (requested at kernel entry; behind them: the two time-term loads)
             else srcr[i] = urow_node ? urow_node[row0 + r] : row0 + r;
             a_ptr[i] = A + (size_t)srcr[i] * AROW + lq * 8;
         }

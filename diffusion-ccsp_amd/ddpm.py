@@ -11,6 +11,7 @@ is drawn from torch's global generator, so ``torch.manual_seed`` keeps runs repr
 ``sample(batch, noise=(normal[, uniform]))`` injects recorded draws instead (parity runs).
 """
 import ctypes as C
+import sys
 import time
 
 import numpy as np
@@ -202,12 +203,13 @@ class GaussianDiffusion(object):
             c = core._compose_struct()
             acc = torch.zeros(T, device=dev, dtype=torch.float32) if self._sampler() in ('MALA', 'HMC') else None
             marg = self._margin_buffer(g1, t_first, t_last)
-            with torch.cuda.device(dev):
-                _lib.check(L.ccsp_compose_chain_run(h, g1.h, second._h, g2.h, C.byref(c), _lib.SAMPLERS[self._sampler()], C.byref(nz), _ptr(x),
-                                                    int(init), int(t_first), int(t_last), None if hist is None else _ptr(hist),
-                                                    None if acc is None else _ptr(acc), _stream_ptr(dev)))
-            if marg is not None:
-                _lib.check(L.ccsp_chain_margins(g1.h, None, 0))
+            try:
+                with torch.cuda.device(dev):
+                    _lib.check(L.ccsp_compose_chain_run(h, g1.h, second._h, g2.h, C.byref(c), _lib.SAMPLERS[self._sampler()], C.byref(nz), _ptr(x),
+                                                        int(init), int(t_first), int(t_last), None if hist is None else _ptr(hist),
+                                                        None if acc is None else _ptr(acc), _stream_ptr(dev)))
+            finally:
+                self._release_margins(g1, marg)
             self._last_graph = g1
             self._keepalive = keep + [g2]
             self.last_accept_rates = acc
@@ -217,12 +219,13 @@ class GaussianDiffusion(object):
         hist = torch.empty((T + 1, g.N, self.dims[-1][0]), device=dev, dtype=torch.float32) if return_history else None
         acc = torch.zeros(T, device=dev, dtype=torch.float32) if self._sampler() in ('MALA', 'HMC') else None
         marg = self._margin_buffer(g, t_first, t_last)
-        with torch.cuda.device(dev):
-            _lib.check(L.ccsp_chain_run(h, g.h, _lib.SAMPLERS[self._sampler()], C.byref(nz), _ptr(x), int(init), int(t_first),
-                                        int(t_last), None if hist is None else _ptr(hist), None if acc is None else _ptr(acc),
-                                        _stream_ptr(dev)))
-        if marg is not None:
-            _lib.check(L.ccsp_chain_margins(g.h, None, 0))
+        try:
+            with torch.cuda.device(dev):
+                _lib.check(L.ccsp_chain_run(h, g.h, _lib.SAMPLERS[self._sampler()], C.byref(nz), _ptr(x), int(init), int(t_first),
+                                            int(t_last), None if hist is None else _ptr(hist), None if acc is None else _ptr(acc),
+                                            _stream_ptr(dev)))
+        finally:
+            self._release_margins(g, marg)
         self._last_graph = g
         self._keepalive = keep
         self.last_accept_rates = acc          # MetropolisSampler's per-timestep acceptance (ddpm.py:979-996)
@@ -251,6 +254,21 @@ class GaussianDiffusion(object):
         marg = torch.full((max(k, 1), 2, g.N), float('nan'), device=self.device, dtype=torch.float32)
         _lib.check(_lib.lib().ccsp_chain_margins(g.h, _ptr(marg), marg.numel()))
         return marg
+
+    def _release_margins(self, g, marg):
+        """uninstall the margin buffer from the (cached) graph on EVERY exit of a chain call: a chain that raised -- an exhausted injected noise
+        stream, a HIP error -- would otherwise leave the graph pointing at `marg`, which is freed when the exception unwinds, and the next MALA /
+        HMC chain on that graph would write into freed memory.  What was already enqueued may still write into the buffer: wait for it first."""
+        if marg is None:
+            return
+        if sys.exc_info()[0] is not None:
+            try:
+                torch.cuda.synchronize(self.device)
+            except Exception:                    # noqa: BLE001 -- the original error is the one to report
+                pass
+        rc = _lib.lib().ccsp_chain_margins(g.h, None, 0)
+        if sys.exc_info()[0] is None:
+            _lib.check(rc)
 
     def p_sample_loop(self, batch, return_history=False, seed=None, noise=None, row_offset=0, **kwargs):
         """GaussianDiffusion.p_sample_loop (ddpm.py:260-340)"""
@@ -290,6 +308,15 @@ class GaussianDiffusion(object):
         sk = C.c_int64()
         _lib.check(_lib.lib().ccsp_chain_skipped(g.h, C.byref(sk)))
         return dict(evals=ev.value, ms_total=ms.value, ms_ugemm=mu.value, ms_edge=me.value, evals_skipped=sk.value)
+
+    def chain_lanes(self):
+        """concurrent lanes (sub-batches on streams of their own, one enqueueing host thread each) the last chain ran as (ccsp_chain_lanes)"""
+        g = getattr(self, '_last_graph', None)
+        if g is None:
+            raise _lib.CcspError('no chain has run')
+        n = C.c_int32()
+        _lib.check(_lib.lib().ccsp_chain_lanes(g.h, C.byref(n)))
+        return int(n.value)
 
     def kernel_stats(self):
         """per-kernel launch counts and mean durations (ms) of the last PROFILED chain: {label: (calls, ms_mean)}"""

@@ -22,7 +22,10 @@
  *    have enqueued everything, i.e. it blocks for the enqueue time but not for the chain.  Host cost measured on an MI355X
  *    box (profiles/r03_findings.md): pinned to two cores (`taskset -c 0-1`) the C2 chain runs at the unpinned rate; with one
  *    lane (CCSP_LANES=1: no threads) pinned to ONE core likewise.  Energy mode, the transformer baseline and profiled runs
- *    use the caller's stream only;
+ *    use the caller's stream only.  The lane streams are shared by every model of the process (one pool per device): chains of DIFFERENT
+ *    models -- or of one model enqueued from different caller streams -- serialise per lane on them, and their fork / join events couple the
+ *    caller streams involved (each waits for the other's lane work in front of its own).  ccsp_model_destroy waits for the destroyed model's
+ *    own last chains (its join events), not for other models' work on the shared streams;
  *  - return value 0 = ok, non-zero = error; ccsp_last_error() gives the thread-local message;
  *  - no exceptions cross the boundary; handles are not thread-safe (one per device & stream);
  *  - NaN is data, not an error (isolated nodes give 0/0 exactly like the reference,
@@ -40,9 +43,10 @@ extern "C" {
 /* ccsp_version() = 1000 MAJOR + MINOR.  MAJOR changes whenever the signature or the meaning of an existing entry point changes (a binding
  * built against another MAJOR must refuse the library: diffusion-ccsp_amd/_lib.py does, INTEGRATION.md section 2 shows the check); MINOR
  * counts additions.  1.0 = round 4's 0.7 with ccsp_compose_chain_run's `accept` argument (added in round 4 WITHOUT a bump: the reason for
- * the rule) + ccsp_rccl_comm_count / ccsp_rccl_allreduce_sum_f32 + ccsp_chain_margins; ccsp_plan_fused_host moved behind CCSP_EXPERIMENTS. */
+ * the rule) + ccsp_rccl_comm_count / ccsp_rccl_allreduce_sum_f32 + ccsp_chain_margins; ccsp_plan_fused_host moved behind CCSP_EXPERIMENTS.
+ * 1.1 (round 6) adds ccsp_chain_lanes. */
 #define CCSP_VERSION_MAJOR 1
-#define CCSP_VERSION_MINOR 0
+#define CCSP_VERSION_MINOR 1
 #define CCSP_MAX_SAMPLES_PER_STEP 100000
 
 typedef struct ccsp_model ccsp_model;   /* ConstraintDiffuser weights + GaussianDiffusion schedule */
@@ -263,6 +267,11 @@ int ccsp_chain_margins(ccsp_graph* graph, float* margins, int64_t n_floats);
  * one that recomputes -- tests/test_hip_parity.py::test_mala_rejected_step_reuse_is_bitwise_identical).  `evals` of
  * ccsp_chain_stats counts the evaluations ENQUEUED; this returns how many of them the last chain skipped.  Synchronises. */
 int ccsp_chain_skipped(ccsp_graph* graph, int64_t* evaluations_skipped);
+/* How many concurrent lanes the last ccsp_chain_run on this graph was cut into (1 = the caller's stream only, no library threads; 2 = the
+ * default above 6144 active edges in direct mode: two pooled streams and two enqueueing std::thread workers, i.e. two busy host cores for
+ * the duration of the call -- what a launcher that places several ranks on one host has to budget, bench.py `host_budget`).  The reference
+ * is one process and one stream (networks/ddpm.py:342-351); this is the port's own degree of freedom (CCSP_LANES).  Does not synchronise. */
+int ccsp_chain_lanes(ccsp_graph* graph, int32_t* lanes);
 /* Per-kernel timing of a profiled chain (ccsp_profile_enable): while profiling, an event is recorded before every
  * launch of the kernels below (the first CCSP_PROFILE_MARKS marks of a chain); which = CCSP_K_*; calls = launches
  * seen, ms_mean = their mean duration, launch to next mark on the stream; name = a short label (may be NULL). */

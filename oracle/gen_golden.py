@@ -452,16 +452,20 @@ def sd_batch(sizes, seed, shuffled=False):
     return b
 
 
-def gen_struct_diffusion():
+def gen_struct_diffusion(H=64, out_name='struct_diffusion'):
     """single evaluations of the StructDiffusion baseline (denoise_fn.py:391-451): ragged graphs (3, 6, 8
-    tokens -> padded and unpadded masks, head/graph mask mix-up with B = 3 and B = 2), batch.shuffled"""
+    tokens -> padded and unpadded masks, head/graph mask mix-up with B = 3 and B = 2), batch.shuffled.
+    H = 256 (round 6, struct_diffusion_h256.npz): the width bench.py --config sd runs (transformer width 512: the f16x2 GEMM path), weights
+    trained 1500 steps with the reference's loss (oracle/ref_train.py qualitative 256 1500 --model StructDiffusion --quantise --batch 64)"""
     rec = {}
-    rng = np.random.default_rng(123)
-    wfile = 'weights_qualitative_h64_sd.npz'
+    rng = np.random.default_rng(123 if H == 64 else 124)
+    wfile = 'weights_qualitative_h%d_sd.npz' % H
     W = oracle_mod.load_weights(os.path.join(GOLD, wfile))
-    model, gd = build_reference('qualitative', 64, W, model_name='StructDiffusion')
+    model, gd = build_reference('qualitative', H, W, model_name='StructDiffusion')
     cases = [('ragged3', sd_batch((2, 5, 7), 51)), ('full2', sd_batch((7, 7), 52)), ('single', sd_batch((3,), 53)),
              ('shuffled', sd_batch((4, 7, 2, 6), 54, shuffled=True))]
+    if H != 64:
+        cases.append(('ragged8', sd_batch((1, 7, 3, 6, 2, 5, 7, 4), 55)))
     for tag, b in cases:
         for key, val in batch_arrays(b).items():
             rec['%s/%s' % (tag, key)] = val
@@ -477,8 +481,8 @@ def gen_struct_diffusion():
         rec['%s/t' % tag] = np.asarray(ts, dtype=np.int32)
         rec['%s/poses' % tag] = poses
         rec['%s/out' % tag] = np.stack(outs)
-    np.savez_compressed(os.path.join(GOLD, 'struct_diffusion.npz'), **rec)
-    print('struct_diffusion.npz')
+    np.savez_compressed(os.path.join(GOLD, out_name + '.npz'), **rec)
+    print(out_name + '.npz')
 
 
 def gen_stability():
@@ -807,6 +811,18 @@ def gen_chains(which):
                                             sd_batch((3, 7, 5), 61), 'ULA', S=4, model_name='StructDiffusion'),
         'chain_sd64_noebm': lambda: run_chain('chain_sd64_noebm', 'qualitative', 64, 'weights_qualitative_h64_sd.npz',
                                               sd_batch((6, 2), 62), False, model_name='StructDiffusion'),
+        # round 6: what was oracle-only at the benchmark width -- the transformer baseline at hidden_dim 256 (width 512: the
+        # f16x2 GEMM k_sd_gemm_h2) under the bench's sampler setting, ULA+ and ebm_per_steps = 2 (ddpm.py:297-299,330) at hidden_dim 256
+        'chain_sd256_ula': lambda: run_chain('chain_sd256_ula', 'qualitative', 256, 'weights_qualitative_h256_sd.npz',
+                                             sd_batch((3, 7, 5, 6), 71), 'ULA', S=10, model_name='StructDiffusion'),
+        'chain_q256_ulaplus': lambda: run_chain('chain_q256_ulaplus', 'qualitative', 256, 'weights_qualitative_h256.npz',
+                                                worlds.qualitative_batch(2, 6, seed=72).to_torch(), 'ULA+'),
+        'chain_t256_ula_energy_eps2': lambda: run_chain('chain_t256_ula_energy_eps2', 'diffuse_pairwise', 256, 'weights_diffuse_pairwise_h256_energy.npz',
+                                                        worlds.triangular_batch(3, 12, seed=73).to_torch(), 'ULA', T=200, S=5, energy=True,
+                                                        ebm_per_steps=2),
+        'chain_t256_mala_eps2': lambda: run_chain('chain_t256_mala_eps2', 'diffuse_pairwise', 256, 'weights_diffuse_pairwise_h256_energy.npz',
+                                                  worlds.triangular_batch(2, 12, seed=74).to_torch(), 'MALA', T=100, S=4, energy=True,
+                                                  ebm_per_steps=2, full_hist=True),
         'chain_q64_T1000_B4': lambda: run_chain('chain_q64_T1000_B4', 'qualitative', 64, 'weights_qualitative_h64.npz',
                                                 worlds.qualitative_batch(4, 8, seed=31).to_torch(), 'ULA'),
         'chain_q64_T100_B1': lambda: run_chain('chain_q64_T100_B1', 'qualitative', 64, 'weights_qualitative_h64.npz',
@@ -913,6 +929,8 @@ if __name__ == '__main__':
         gen_pre_transform()
     if not which or 'struct_diffusion' in which:
         gen_struct_diffusion()
+    if not which or 'struct_diffusion_h256' in which:
+        gen_struct_diffusion(256, 'struct_diffusion_h256')
     if not which or 'stability' in which:
         gen_stability()
     if not which or 'robot_energy' in which:

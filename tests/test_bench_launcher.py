@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(*argv, **kw):
-    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'CCSP_LANES')}
+    env.update(kw.get('env', {}))
     return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(argv), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                           universal_newlines=True, env=env, timeout=kw.get('timeout', 600), cwd=ROOT)
 
@@ -46,3 +47,30 @@ def test_world_size_mismatch_is_refused():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--dry-run'], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, universal_newlines=True, env=env, timeout=300, cwd=ROOT)
     assert r.returncode != 0 and 'WORLD_SIZE=1' in (r.stderr + r.stdout)
+
+
+def test_lanes_rule_budgets_the_host_for_n_ranks():
+    """bench.select_lanes: a rank with two lanes keeps two enqueueing threads busy (profiles/r06_host_budget.txt), so the launcher falls back to
+    one lane per rank when the container grants fewer than 2.5 cores per rank -- the GPU boxes' 16-core quota under 8 ranks -- and says so"""
+    sys.path.insert(0, ROOT)
+    import bench
+    lanes, why = bench.select_lanes(8, 16)
+    assert lanes == 1 and '16 usable cores' in why and '8 ranks' in why
+    assert bench.select_lanes(8, 20)[0] is None                 # 20 >= 2.5 x 8: the library default (two lanes)
+    assert bench.select_lanes(4, 16)[0] is None and bench.select_lanes(1, 16)[0] is None and bench.select_lanes(2, 8)[0] is None
+    assert bench.select_lanes(1, 2)[0] == 1 and bench.select_lanes(2, 4)[0] == 1
+    lanes, why = bench.select_lanes(8, 16, '2')                  # an explicit CCSP_LANES always wins
+    assert lanes is None and 'set by the caller' in why
+
+
+def test_dry_run_line_carries_the_host_budget():
+    """the N > 1 line shows what each rank cost its host and which lane count the rule chose (here: 4 usable cores for 2 ranks -> one lane)"""
+    r = _run('--gpus', '2', '--backend', 'gloo', '--dry-run', '--steps', '2', '--warmup', '1', env={'CCSP_BENCH_HOST_CORES': '4'})
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    hb = rec['host_budget']
+    assert hb['usable_cores'] == 4 and hb['ccsp_lanes_env'] == '1' and 'one lane per rank' in hb['rule']
+    assert len(rec['host_cpu_s_per_step']) == 2 and all(v >= 0 for v in rec['host_cpu_s_per_step'])
+    r = _run('--gpus', '2', '--backend', 'gloo', '--dry-run', '--steps', '1', '--warmup', '0', env={'CCSP_BENCH_HOST_CORES': '16'})
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert rec['host_budget']['ccsp_lanes_env'] is None and 'library default' in rec['host_budget']['rule']

@@ -18,8 +18,8 @@ VARIANTS = {
     'cb42': ([], ['CCSP_H2_CB0=4', 'CCSP_H2_CB1=2']),
     # bisecting the one-ulp difference between k_node and k_node_direct
     'ni_philox': ([('ccsp_philox.h', '__device__ __forceinline__ float philox_normal(', '__device__ __attribute__((noinline)) float philox_normal(')], []),
-    'pin_norm': ([('ccsp_hip.hip', '    if (a.normalize) acc = acc / sqrtf((float)csr_cnt);                   // 0/0 -> NaN like the reference', '    if (a.normalize) acc = __fdiv_rn(acc, __fsqrt_rn((float)csr_cnt));'),
-                  ('ccsp_hip.hip', '                if (a.normalize) acc = acc / sqrtf((float)csr_cnt);            // 0/0 -> NaN like the reference', '                if (a.normalize) acc = __fdiv_rn(acc, __fsqrt_rn((float)csr_cnt));')], []),
+    'pin_norm': ([('ccsp_kernels_node.h', '    if (a.normalize) acc = acc / sqrtf((float)csr_cnt);                   // 0/0 -> NaN like the reference', '    if (a.normalize) acc = __fdiv_rn(acc, __fsqrt_rn((float)csr_cnt));'),
+                  ('ccsp_kernels_node.h', '                if (a.normalize) acc = acc / sqrtf((float)csr_cnt);            // 0/0 -> NaN like the reference', '                if (a.normalize) acc = __fdiv_rn(acc, __fsqrt_rn((float)csr_cnt));')], []),
     # finer stamps inside the epilogue's store loop (trace builds)
     'epi_stamps': ([('ccsp_f16x2.h', '                if constexpr (FWD) m = h2_max8(m);', '                CCSP_TRK(0, 18 + 4 * i + st);\n                if constexpr (FWD) m = h2_max8(m);'),
                     ('ccsp_f16x2.h', '        float4 cv[4][2];                                          // the lane', '        CCSP_TRK(0, 26 + i);\n        float4 cv[4][2];                                          // the lane')], []),
