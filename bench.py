@@ -1080,6 +1080,10 @@ def main():
                                'speedup_gpu_over_cpu': value / r['samples_per_s']}
     if rank == 0:
         rec['device'] = device_info()
+        try:
+            rec['host_budget']['affinity_cpus_at_end'] = len(os.sched_getaffinity(0))      # (a `taskset` in front of the run shows here if it held)
+        except (AttributeError, OSError):
+            pass
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -16,7 +16,7 @@ SO = os.path.join(CSRC, 'libccsp_hip_exp.so' if EXPERIMENTS else 'libccsp_hip.so
 SOURCES = sorted(f for f in os.listdir(CSRC) if f.endswith(('.h', '.hip'))) + [os.path.join('..', '..', 'include', 'ccsp.h')]     # the one translation unit ccsp_hip.hip and the fragments / kernel headers it includes
 ABI_MAJOR = 1         # CCSP_VERSION_MAJOR of include/ccsp.h this binding was written against: lib() refuses a library of another major version
 
-K_COUNT = 11          # CCSP_K_COUNT of include/ccsp.h
+K_COUNT = 12          # CCSP_K_COUNT of include/ccsp.h (a 1.0 library has 11: kernel_stats asks it for its own count)
 SAMPLERS = {False: 0, None: 0, 'NONE': 0, 'ULA': 1, 'ULA+': 2, 'MALA': 3, 'HMC': 4}
 SCHEDULE_KEYS = ['betas', 'alphas_cumprod', 'alphas_cumprod_prev', 'sqrt_recip_alphas_cumprod',
                  'sqrt_recipm1_alphas_cumprod', 'posterior_log_variance_clipped', 'posterior_mean_coef1',
@@ -198,7 +198,8 @@ def lib():
     L.ccsp_kernel_stats.argtypes = [vp, i32, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.c_char_p, i32]
     L.ccsp_chain_skipped.argtypes = [vp, C.POINTER(C.c_int64)]
     L.ccsp_chain_margins.argtypes = [vp, vp, C.c_int64]
-    L.ccsp_chain_lanes.argtypes = [vp, C.POINTER(i32)]
+    if ver % 1000 >= 1:
+        L.ccsp_chain_lanes.argtypes = [vp, C.POINTER(i32)]
     L.ccsp_graph_variant.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.ccsp_compose_denoise.argtypes = [vp, vp, vp, vp, C.POINTER(Compose), vp, i32, vp, vp]
     L.ccsp_compose_energy_grad.argtypes = [vp, vp, vp, vp, C.POINTER(Compose), vp, i32, vp, vp, vp]

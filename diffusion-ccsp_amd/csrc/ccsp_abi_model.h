@@ -344,6 +344,7 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
             if (d->energy_wrapper) {    // the backward GEMMs' weights: the same tensors transposed, the same exponents
                 if (const char* e = getenv("CCSP_ENERGY_BWD")) m->energy_bwd_h2 = strcmp(e, "bf16x3") != 0;
                 if (const char* e = getenv("CCSP_MALA_REUSE")) m->mala_reuse = atoi(e) != 0;
+                if (const char* e = getenv("CCSP_EDGE_FB")) { const int v = atoi(e); if (v >= 0 && v <= 2) m->edge_fb = v; }
                 if (const char* e = exp_env("CCSP_ENERGY_ROWSUM")) m->bwd_rowsum_fused = strcmp(e, "kernel") != 0;
                 if (const char* e = exp_env("CCSP_ENERGY_NODE")) m->node_energy_fused = strcmp(e, "split") != 0;
                 if (const char* e = exp_env("CCSP_ENERGY_BWD_P")) m->bwd_generic_p = strcmp(e, "generic") == 0;

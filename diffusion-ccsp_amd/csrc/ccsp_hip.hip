@@ -38,6 +38,7 @@ namespace {
 #include "ccsp_energy.h"
 #include "ccsp_bf16x3.h"
 #include "ccsp_f16x2.h"
+#include "ccsp_edge_fb.h"    // energy mode, round 6: decoder forward + backward in one kernel
 #ifdef CCSP_EXPERIMENTS
 #include "ccsp_fused.h"      // the one-launch evaluation (k_eval_fused*, k_rowgemm_h2d): bitwise equal, slower at every batch size
 #endif

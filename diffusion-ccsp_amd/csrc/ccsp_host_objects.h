@@ -48,6 +48,8 @@ struct ccsp_model {
     float bwd_bound_c = 0.0f;         // 1.21 max|Wd2| max_n sum_j |Wd1[j, n]|: |g_z[k, s H + n]| <= bwd_bound_c sum_p |go[k, s, p]| (k_edge_bwd_h2<true>)
     int bwd_rowsum_fused = 1;         // (CCSP_ENERGY_ROWSUM=kernel turns it off) row sums of g_z inside the decoder backward, transpose GEMM on partial rows
     int bwd_generic_p = 0;            // (CCSP_ENERGY_BWD_P=generic) k_edge_bwd_h2 with the run-time pose_dim even where it is 4 (A/B runs)
+    int edge_fb = 2;                  // (CCSP_EDGE_FB) energy mode's decoder: 2 = forward + backward in one kernel (k_edge_fb_h2, ccsp_edge_fb.h), 1 = the backward alone
+                                      // on that kernel's 32-edge tiles (k_edge_bwd2_h2), 0 = round 4's k_edge_bwd_h2 on 64-edge blocks (four workgroups per block)
     int node_energy_fused = 1;        // (CCSP_ENERGY_NODE=split turns it off) k_node_energy_h2_update: the update that consumes the gradient in the same launch
     unsigned short* pe2_wH = nullptr; // pose_encoder.2.weight * 2^pe2_exp, fp16 planes in fragment order (k_pack_enc_frag_h2); CCSP_ENC=f32 leaves it null
     unsigned short* pe2_wTH = nullptr;    // the same tensor transposed, for the energy backward (k_pack_enc_frag_h2t; energy_wrapper models)
@@ -146,6 +148,7 @@ struct ccsp_graph {
     // row sums inside the decoder backward (ccsp::BwdSumPlan): partial rows instead of U rows downstream of it
     ccsp::BwdSumPlan bsplan;           // kept alive for the async upload
     bool bs_ready = false;
+    int bs_fb = 0;                     // the decoder form the partial-row plan was built for (ccsp_model::edge_fb at energy_prepare)
     int *bs_blocks = nullptr, *bs_nrow_ptr = nullptr, *bs_nrow_idx = nullptr, *bs_gexp = nullptr;
     unsigned short* GZPH = nullptr;    // [2][NP][2H] fp16 planes of the partial rows scaled by 2^bs_gexp
     float* GPP = nullptr;              // [NP][H]

@@ -3,7 +3,7 @@
 
 const char* const kKernelNames[CCSP_K_COUNT] = {"row GEMM (forward)", "edge decoder (forward)", "node update + pose encoder", "edge decoder backward",
                                                "row sum of g_z", "row GEMM (transpose)", "node energy backward", "energy sum", "HMC elementwise",
-                                               "StructDiffusion evaluation", "fused evaluation (row GEMM + edge decoder)"};
+                                               "StructDiffusion evaluation", "fused evaluation (row GEMM + edge decoder)", "edge decoder forward + backward"};
 
 inline void prof_mark(ccsp_graph* g, hipStream_t s, int id) {
     if (!g->profile || g->kev_used >= g->kev.size()) return;

@@ -27,7 +27,10 @@ int energy_prepare(ccsp_model* m, ccsp_graph* g, hipStream_t s) {
     HIP_TRY(hipMemsetAsync(g->Escal, 0, 4 * sizeof(float), s));
     HIP_TRY(hipMemsetAsync(g->partial, 0, n_partial * sizeof(float), s));
     if (partial_rows) {
-        ccsp::build_bwdsum_plan(p, TILE_M, g->bsplan);
+        // (the fused decoder kernel and its stand-alone backward work on 32-edge blocks, round 4's backward on 64-edge blocks)
+        if (m->edge_fb > 0) ccsp::build_bwdsum_plan(p, TILE_M, g->bsplan, FB_EDGES, FB_MAXP);
+        else ccsp::build_bwdsum_plan(p, TILE_M, g->bsplan);
+        g->bs_fb = m->edge_fb;
         const ccsp::BwdSumPlan& b = g->bsplan;
         if (dev_upload(reg, &g->bs_blocks, b.blocks, s) || dev_upload(reg, &g->bs_nrow_ptr, b.nrow_ptr, s) || dev_upload(reg, &g->bs_nrow_idx, b.nrow_idx, s) ||
             dev_alloc(reg, &g->GZPH, (size_t)2 * b.NP * 2 * H) || dev_alloc(reg, &g->bs_gexp, (size_t)b.NP) || dev_alloc(reg, &g->GPP, (size_t)b.NP * H))
@@ -81,11 +84,23 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
     else
     hipLaunchKernelGGL((k_rowgemm<H, 2 * H>), dim3(nw_u < m->max_wgs ? nw_u : m->max_wgs), dim3(256), 0, s, nw_u, g->pemb, g->urow_node, g->tile_row0,
                        g->tile_nrows, g->tile_ts, m->Wp, (size_t)2 * H * H, g->base, tau_t, g->U);
-    prof_mark(g, s, CCSP_K_EDGE);
-    EdgeEnergyArgs en{g->e_a, g->e_b, xeval, with_grad ? g->Q : nullptr, g->partial, skip};
+    // round 6: a gradient evaluation on the f16x2 kernels runs the decoder forward and backward as ONE kernel (ccsp_edge_fb.h)
+    const int fb = (h2 && with_grad && g->bs_ready && m->WpTH != nullptr && m->energy_bwd_h2) ? g->bs_fb : 0;
+    prof_mark(g, s, fb == 2 ? CCSP_K_EDGE_FB : CCSP_K_EDGE);
+    EdgeEnergyArgs en{g->e_a, g->e_b, xeval, (with_grad && fb != 2) ? g->Q : nullptr, g->partial, skip};
     int n_part = g->n_edge_blocks;                                                           // one energy partial per workgroup
     bool edge_done = false;
+    bool bwd_done = false;
     if constexpr (H == 256) {
+        if (fb == 2) {
+            const EdgeFbArgs fa{m->Wd1THI, m->wd2_absmax, BwdSumArgs{g->bs_blocks, g->GZPH, (size_t)g->bsplan.NP * 2 * H, g->bs_gexp, m->bwd_bound_c}};
+            n_part = nblk(p.E_act, FB_EDGES);
+            if (P == 4) hipLaunchKernelGGL(k_edge_fb_h2<4>, dim3(n_part), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->U, g->umax, m->Wd1HI, m->wd_exp,
+                                           m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, en, fa);
+            else hipLaunchKernelGGL(k_edge_fb_h2<0>, dim3(n_part), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->U, g->umax, m->Wd1HI, m->wd_exp,
+                                    m->pd0_b, m->pd2_w, m->pd2_b, g->ent_pos, g->O, en, fa);
+            edge_done = bwd_done = true;
+        } else
         if (h2) {
             n_part = launch_edge_h2<true>(m, g, en, (int*)nullptr, s);
             edge_done = true;
@@ -108,9 +123,8 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
         prof_mark(g, s, -1);
         return 0;
     }
-    prof_mark(g, s, CCSP_K_EDGE_BWD);
+    if (!bwd_done) prof_mark(g, s, CCSP_K_EDGE_BWD);
     constexpr int BMB = 32 * BwdCfg<H>::WM, NCTB = H / (32 * BwdCfg<H>::TN * BwdCfg<H>::WN);
-    bool bwd_done = false;
     const bool h2_bwd = h2 && m->WpTH != nullptr && m->energy_bwd_h2;      // backward GEMMs on the f16x2 scheme as well
 #ifndef CCSP_EXPERIMENTS
     // The product build's f16x2 backward forms the row sums inside the decoder backward (k_edge_bwd_h2<true>: partial rows, energy_prepare) and has
@@ -119,7 +133,15 @@ int launch_eval_energy(ccsp_model* m, ccsp_graph* g, int t, const float* xeval, 
                                             "energy_bwd_h2 %d) -- set CCSP_ENERGY_BWD=bf16x3 or CCSP_MMA=f32 for this model", m->d.hidden_dim, m->f16x2, m->energy_bwd_h2);
 #endif
     if constexpr (H == 256) {
-        if (h2_bwd) {
+        if (bwd_done) {}
+        else if (fb == 1) {                 // the backward alone on the fused kernel's tiles (q from the Q array, go from the CSR slots)
+            const EdgeFbArgs fa{m->Wd1THI, m->wd2_absmax, BwdSumArgs{g->bs_blocks, g->GZPH, (size_t)g->bsplan.NP * 2 * H, g->bs_gexp, m->bwd_bound_c}};
+            if (P == 4) hipLaunchKernelGGL(k_edge_bwd2_h2<4>, dim3(nblk(p.E_act, FB_EDGES)), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->ent_pos, g->U, g->O,
+                                           g->Q, m->wd_exp, m->pd2_w, skip, fa);
+            else hipLaunchKernelGGL(k_edge_bwd2_h2<0>, dim3(nblk(p.E_act, FB_EDGES)), dim3(256), 0, s, p.E_act, P, g->e_u0, g->e_u1, g->ent_pos, g->U, g->O,
+                                    g->Q, m->wd_exp, m->pd2_w, skip, fa);
+            bwd_done = true;
+        } else if (h2_bwd) {
             const BwdSumArgs bsa = g->bs_ready ? BwdSumArgs{g->bs_blocks, g->GZPH, (size_t)g->bsplan.NP * 2 * H, g->bs_gexp, m->bwd_bound_c}
                                                : BwdSumArgs{nullptr, nullptr, 0, nullptr, 0.0f};
 #define CCSP_EDGE_BWD(SUM, PP)                                                                                                                      \

@@ -177,23 +177,28 @@ inline void build_fused_plan(const Plan& p, int rows_per_slot, int max_edges, Fu
 //   edge's row in the kernel's LDS tile (edge * BS_CLD * 4); an odd entry count is padded with the tile's all-zero row BS_EDGES.
 constexpr int BS_EDGES = 64, BS_CLD = 132, BS_BLK = 1 + 2 * 128 + 2 * 128;
 struct BwdSumPlan {
-    int n_blocks = 0, NP = 0;
-    std::vector<int32_t> blocks;                            // [n_blocks][BS_BLK]
+    int n_blocks = 0, NP = 0, blk_stride = BS_BLK;
+    std::vector<int32_t> blocks;                            // [n_blocks][blk_stride]
     std::vector<int32_t> prow_urow, prow_ts;                // [NP]
     std::vector<int32_t> tile_row0, tile_nrows, tile_ts;    // tile_m-row tiles of partial rows, never straddling a (type, slot) group
     std::vector<int32_t> nrow_ptr, nrow_idx;                // [N+1], [NP]  partial rows of each node (ascending)
 };
 
-inline void build_bwdsum_plan(const Plan& p, int tile_m, BwdSumPlan& b) {
+// block_edges / max_parts: edges per block and the most partial rows a block can have (2 per edge).  Round 6's fused decoder kernel
+// (k_edge_fb_h2, ccsp_edge_fb.h) works on 32-edge blocks: (32, 64) -> blocks of 1 + 2 * 64 + 2 * 64 ints, same layout with max_parts in
+// place of 128; the padding entry stays row BS_EDGES (= 64: that kernel's tile has 64 rows too, 32 edges x both halves).
+inline void build_bwdsum_plan(const Plan& p, int tile_m, BwdSumPlan& b, int block_edges = BS_EDGES, int max_parts = 128) {
     b = BwdSumPlan();
-    b.n_blocks = (p.E_act + BS_EDGES - 1) / BS_EDGES;
+    const int blk_stride = 1 + 2 * max_parts + 2 * max_parts;
+    b.blk_stride = blk_stride;
+    b.n_blocks = (p.E_act + block_edges - 1) / block_edges;
     struct Part { int32_t urow, block, local; };
     std::vector<Part> parts;
     std::vector<std::vector<int32_t>> refs;                 // per (block, local partial): block-local edges
     std::vector<int32_t> stamp(p.R, -1), loc(p.R, 0), first(b.n_blocks + 1, 0);
     for (int t = 0; t < b.n_blocks; ++t) {
         first[t] = (int32_t)parts.size();
-        const int k0 = t * BS_EDGES, k1 = k0 + BS_EDGES < p.E_act ? k0 + BS_EDGES : p.E_act;
+        const int k0 = t * block_edges, k1 = k0 + block_edges < p.E_act ? k0 + block_edges : p.E_act;
         for (int k = k0; k < k1; ++k)
             for (int s = 0; s < 2; ++s) {
                 const int r = s == 0 ? p.e_u0[k] : p.e_u1[k];
@@ -219,18 +224,19 @@ inline void build_bwdsum_plan(const Plan& p, int tile_m, BwdSumPlan& b) {
     b.prow_urow.assign(b.NP, 0);
     b.prow_ts.assign(b.NP, 0);
     for (int i = 0; i < b.NP; ++i) { b.prow_urow[gid[i]] = parts[i].urow; b.prow_ts[gid[i]] = p.urow_ts[parts[i].urow]; }
-    b.blocks.assign((size_t)b.n_blocks * BS_BLK, 0);
+    b.blocks.assign((size_t)b.n_blocks * blk_stride, 0);
+    const int o_span = 1 + max_parts, o_pairs = 1 + 2 * max_parts;
     for (int t = 0; t < b.n_blocks; ++t) {
-        int32_t* blk = b.blocks.data() + (size_t)t * BS_BLK;
+        int32_t* blk = b.blocks.data() + (size_t)t * blk_stride;
         const int np = first[t + 1] - first[t];
         blk[0] = np;
         int q = 0;                                          // entries written (even at every partial row's start)
         for (int j = 0; j < np; ++j) {
             blk[1 + j] = gid[first[t] + j];
             const int q0 = q;
-            for (int32_t le : refs[first[t] + j]) blk[257 + q++] = le * BS_CLD * 4;
-            if (q & 1) blk[257 + q++] = BS_EDGES * BS_CLD * 4;
-            blk[129 + j] = ((q0 / 2) << 16) | (q / 2);
+            for (int32_t le : refs[first[t] + j]) blk[o_pairs + q++] = le * BS_CLD * 4;
+            if (q & 1) blk[o_pairs + q++] = BS_EDGES * BS_CLD * 4;
+            blk[o_span + j] = ((q0 / 2) << 16) | (q / 2);
         }
     }
     for (int g0 = 0; g0 < b.NP;) {

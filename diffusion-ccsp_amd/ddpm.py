@@ -315,7 +315,11 @@ class GaussianDiffusion(object):
         if g is None:
             raise _lib.CcspError('no chain has run')
         n = C.c_int32()
-        _lib.check(_lib.lib().ccsp_chain_lanes(g.h, C.byref(n)))
+        try:
+            fn = _lib.lib().ccsp_chain_lanes
+        except AttributeError:                  # (ABI 1.0 library: tools/mkcommit.sh builds of earlier commits)
+            return None
+        _lib.check(fn(g.h, C.byref(n)))
         return int(n.value)
 
     def kernel_stats(self):
@@ -326,7 +330,10 @@ class GaussianDiffusion(object):
         out = {}
         for k in range(_lib.K_COUNT):
             n, ms, name = C.c_int64(), C.c_float(), C.create_string_buffer(64)
-            _lib.check(_lib.lib().ccsp_kernel_stats(g.h, k, C.byref(n), C.byref(ms), name, 64))
+            rc = _lib.lib().ccsp_kernel_stats(g.h, k, C.byref(n), C.byref(ms), name, 64)
+            if rc != 0 and k >= 11:             # (an ABI 1.0 library -- tools/mkcommit.sh builds of earlier commits -- has eleven selectors)
+                continue
+            _lib.check(rc)
             if n.value:
                 out[name.value.decode()] = (int(n.value), float(ms.value))
         return out

@@ -276,7 +276,8 @@ int ccsp_chain_lanes(ccsp_graph* graph, int32_t* lanes);
  * launch of the kernels below (the first CCSP_PROFILE_MARKS marks of a chain); which = CCSP_K_*; calls = launches
  * seen, ms_mean = their mean duration, launch to next mark on the stream; name = a short label (may be NULL). */
 enum { CCSP_K_ROWGEMM = 0, CCSP_K_EDGE = 1, CCSP_K_NODE = 2, CCSP_K_EDGE_BWD = 3, CCSP_K_ROWSUM = 4, CCSP_K_ROWGEMM_T = 5,
-       CCSP_K_NODE_ENERGY = 6, CCSP_K_ENERGY_SUM = 7, CCSP_K_HMC = 8, CCSP_K_SD_EVAL = 9, CCSP_K_EVAL_FUSED = 10, CCSP_K_COUNT = 11 };
+       CCSP_K_NODE_ENERGY = 6, CCSP_K_ENERGY_SUM = 7, CCSP_K_HMC = 8, CCSP_K_SD_EVAL = 9, CCSP_K_EVAL_FUSED = 10, CCSP_K_EDGE_FB = 11 /* 1.1 */,
+       CCSP_K_COUNT = 12 };
 #define CCSP_PROFILE_MARKS 16384
 int ccsp_kernel_stats(ccsp_graph* graph, int32_t which, int64_t* calls, float* ms_mean, char* name, int32_t name_len);
 /* Which variants of the f16x2 evaluation kernels a ONE-lane launch on this graph runs (they are chosen by tile count, see

@@ -605,6 +605,7 @@ def ref_single_timestep(gd, batch, x, t, seed, dtype=torch.float32):
     T, EBM = int(gd.num_timesteps), gd.EBM
     S = 4 if EBM == 'HMC' else int(gd.samples_per_step)
     per_t = 1 + S + (1 if EBM == 'HMC' else 0)
+    eps = int(getattr(gd.denoise_fn, 'ebm_per_steps', 1))
     m = batch.mask
     gt_features = batch.x[:, gd.dims[-1][1]:gd.dims[-1][2]].to(dtype)
     shape = gt_features.shape
@@ -619,13 +620,17 @@ def ref_single_timestep(gd, batch, x, t, seed, dtype=torch.float32):
         return torch.randn(shape)
     if EBM == 'MALA':
         sampler = ddpm.AnnealedMALASampler(gd.samples_per_step, gd.step_sizes, gradient_function, noise_function, energy_function)
+    elif EBM == 'ULA':                                             # (round 6; ddpm.py:291-300)
+        sampler = ddpm.AnnealedULASampler(gd.samples_per_step, gd.step_sizes, gradient_function, noise_function)
     else:
         sampler = ddpm.AnnealedMUHASampler(4, gd.step_sizes, 0, 9 * gd.betas, 2, gradient_function=gradient_function, energy_function=energy_function)
     rates = []
     orig_upd = ddpm.MetropolisSampler._update_acceptance_rate
     ddpm.MetropolisSampler._update_acceptance_rate = lambda self, accept_rate, tt, debug=False: rates.append(float(accept_rate))
     pn = PatchedNoise(seed, dtype)
-    pn.c, pn.uc = 1 + (T - 1 - t) * per_t, (T - 1 - t) * S
+    # draws consumed before timestep t: the initial state, one per ancestral step, the sampler's own on the timesteps where it ran (j % eps == 0, ddpm.py:330)
+    ran = sum(1 for j in range(t + 1, T) if j % eps == 0)
+    pn.c, pn.uc = 1 + (T - 1 - t) + ran * (per_t - 1), ran * S
     b = batch.clone()
     b.x = b.x.to(dtype)
     prev = torch.is_grad_enabled()
@@ -635,13 +640,44 @@ def ref_single_timestep(gd, batch, x, t, seed, dtype=torch.float32):
         with pn, contextlib.redirect_stdout(io.StringIO()):
             tt = torch.full((1,), t, dtype=torch.long)
             pose = gd.p_sample(b, torch.as_tensor(x).to(dtype).clone(), tt, tag='EBM')
-            pose = sampler.sample_step(pose, b, tt)
+            if t % eps == 0:
+                pose = sampler.sample_step(pose, b, tt)
             pose[m.bool()] = gt_features[m.bool()].clone()
     finally:
         torch.set_default_dtype(torch.float32)
         torch.set_grad_enabled(prev)
         ddpm.MetropolisSampler._update_acceptance_rate = orig_upd
     return pose.detach().numpy(), (rates[-1] if rates else 0.0)
+
+
+def gen_eps2_h256():
+    """ebm_per_steps = 2 (ddpm.py:330; ComposedEBMDenoiseFn(model, 2), train_utils.py:284) at hidden_dim 256, energy-mode ULA S = 5, T = 200, three
+    12-triangle graphs.  The chain passes a 2e22 transient and is CHAOTIC in the reference itself (its own fp32 and fp64 runs end 4e-3 apart and are
+    unrelated at timestep 150), so the fixture records EVERY state and, per timestep, the reference's own fp64 successor of the recorded fp32 state
+    (next_f64): an implementation is checked timestep by timestep from the recorded states, with a bar quoted against the reference's own
+    fp32-vs-fp64 disagreement over that timestep.  The single-timestep glue is checked to reproduce the recorded fp32 chain bit for bit."""
+    name, wfile, T, S, seed = 'chain_t256_ula_energy_eps2', 'weights_diffuse_pairwise_h256_energy.npz', 200, 5, 7
+    batch = worlds.triangular_batch(3, 12, seed=73).to_torch()
+    # ONE thread: with several, PyTorch-CPU's autograd of the energy (the scatter of the gather's backward) is not run-to-run deterministic at this
+    # size -- two runs of the reference differ by ~1e-6 relative after one timestep (measured here: 1.5e-5 at |x| = 15), which this chain's gain
+    # turns into unrelated states -- and the bit-for-bit check of the single-timestep glue below could not hold
+    torch.set_num_threads(1)
+    run_chain(name, 'diffuse_pairwise', 256, wfile, batch, 'ULA', T=T, S=S, seed=seed, energy=True, ebm_per_steps=2, full_hist=True)
+    z = dict(np.load(os.path.join(GOLD, name + '.npz')))
+    W = oracle_mod.load_weights(os.path.join(GOLD, wfile))
+    _, gd32 = build_reference('diffuse_pairwise', 256, W, energy=True, EBM='ULA', T=T, S=S, ebm_per_steps=2)
+    _, gd64 = build_reference('diffuse_pairwise', 256, W, energy=True, EBM='ULA', T=T, S=S, ebm_per_steps=2, dtype=torch.float64)
+    nxt = []
+    for k in range(T):
+        x32, _ = ref_single_timestep(gd32, batch, z['hist'][k], T - 1 - k, seed)
+        assert np.array_equal(x32, z['hist'][k + 1], equal_nan=True), ('single-timestep glue != chain', k)
+        x64, _ = ref_single_timestep(gd64, batch, z['hist'][k].astype(np.float64), T - 1 - k, seed, torch.float64)
+        nxt.append(x64)
+    z['next_f64'] = np.stack(nxt).astype(np.float64)
+    fl = [float(np.abs(nxt[k] - z['hist'][k + 1]).max() / (1.0 + np.abs(z['hist'][k + 1]).max())) for k in range(T)]
+    np.savez_compressed(os.path.join(GOLD, name + '.npz'), **z)
+    print('   fp32-vs-fp64 reference over ONE timestep from the same state: max %.2e, median %.2e, first ten: %s' %
+          (max(fl), float(np.median(fl)), ' '.join('%.1e' % v for v in fl[:10])))
 
 
 def gen_composed():
@@ -815,11 +851,12 @@ def gen_chains(which):
         # f16x2 GEMM k_sd_gemm_h2) under the bench's sampler setting, ULA+ and ebm_per_steps = 2 (ddpm.py:297-299,330) at hidden_dim 256
         'chain_sd256_ula': lambda: run_chain('chain_sd256_ula', 'qualitative', 256, 'weights_qualitative_h256_sd.npz',
                                              sd_batch((3, 7, 5, 6), 71), 'ULA', S=10, model_name='StructDiffusion'),
+        # the reference's own fp32-vs-fp64 disagreement along that chain: the first timesteps' Langevin steps have gain > 1, so its history
+        # checkpoints are compared with a bar derived from this (tests: max(2e-3, 8 x the reference's own disagreement))
+        'chain_sd256_ula_f64': lambda: run_chain('chain_sd256_ula_f64', 'qualitative', 256, 'weights_qualitative_h256_sd.npz',
+                                                 sd_batch((3, 7, 5, 6), 71), 'ULA', S=10, model_name='StructDiffusion', dtype=torch.float64),
         'chain_q256_ulaplus': lambda: run_chain('chain_q256_ulaplus', 'qualitative', 256, 'weights_qualitative_h256.npz',
                                                 worlds.qualitative_batch(2, 6, seed=72).to_torch(), 'ULA+'),
-        'chain_t256_ula_energy_eps2': lambda: run_chain('chain_t256_ula_energy_eps2', 'diffuse_pairwise', 256, 'weights_diffuse_pairwise_h256_energy.npz',
-                                                        worlds.triangular_batch(3, 12, seed=73).to_torch(), 'ULA', T=200, S=5, energy=True,
-                                                        ebm_per_steps=2),
         'chain_t256_mala_eps2': lambda: run_chain('chain_t256_mala_eps2', 'diffuse_pairwise', 256, 'weights_diffuse_pairwise_h256_energy.npz',
                                                   worlds.triangular_batch(2, 12, seed=74).to_torch(), 'MALA', T=100, S=4, energy=True,
                                                   ebm_per_steps=2, full_hist=True),
@@ -937,4 +974,6 @@ if __name__ == '__main__':
         gen_robot_energy()
     if not which or 'options' in which:
         gen_options()
+    if not which or 'chain_t256_ula_energy_eps2' in which:
+        gen_eps2_h256()
     gen_chains(which)

@@ -515,7 +515,21 @@ def test_ulaplus_h256_segments():
     assert all(e[2] < 1e-4 for e in errs), errs
 
 
-EPS2_256_SEGMENTS = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 10), (50, 100)]
+def chaotic_timestep_errors(run_step, z, timesteps):
+    """A chain that is chaotic IN THE REFERENCE (chain_t256_ula_energy_eps2: its own fp32 and fp64 runs are unrelated half-way) is compared timestep by
+    timestep from the reference's recorded states; the fixture carries, per timestep, the reference's own fp64 successor of the recorded fp32 state
+    (next_f64, oracle/gen_golden.py ref_single_timestep), and a timestep's bar is max(1e-4, 8 x the reference's own fp32-vs-fp64 disagreement over it)
+    -- the rule of the HMC fixtures.  -> [(t, error, bar)] of the timesteps over their bar"""
+    T = int(z['T'])
+    bad = []
+    for t in timesteps:
+        k = T - 1 - t
+        want = z['hist'][k + 1]
+        bar = max(1e-4, 8.0 * rel_err(z['next_f64'][k], want))
+        err = rel_err(run_step(z['hist'][k], t), want)
+        if not err < bar:
+            bad.append((int(t), err, bar))
+    return bad
 
 
 def eps2_h256_model(z, sampler_steps):
@@ -526,10 +540,11 @@ def eps2_h256_model(z, sampler_steps):
 def test_ebm_per_steps_h256_vs_reference():
     """ebm_per_steps = 2 (ddpm.py:330) at hidden_dim 256, energy-mode ULA: Langevin steps on even timesteps only"""
     z = golden('chain_t256_ula_energy_eps2')
-    assert int(z['T']) == 200 and int(z['n_randn']) == 1 + 200 + 100 * 5
+    assert int(z['T']) == 200 and int(z['n_randn']) == 1 + 200 + 100 * 5 and len(z['hist_idx']) == 201
     g = eps2_h256_model(z, 5).graph(golden_batch(z))
-    errs = segment_errors(lambda x, tf, tl: g.chain('ULA', seed=int(z['seed']), x=x, t_first=tf, t_last=tl), z, EPS2_256_SEGMENTS)
-    assert all(e[2] < 1e-4 for e in errs), errs
+    ts = list(range(199, 179, -1)) + list(range(179, -1, -7)) + [1, 0]        # the transient's first twenty timesteps, then every seventh (odd and even)
+    bad = chaotic_timestep_errors(lambda x, t: g.chain('ULA', seed=int(z['seed']), x=x, t_first=t, t_last=t), z, ts)
+    assert not bad, bad
 
 
 def test_mala_ebm_per_steps_h256_every_timestep_vs_reference():
