@@ -148,6 +148,7 @@ def executed_work(label, N, E, R, H, mma):
         'node update + pose encoder': (2.0 * N * H * (H // 2),) + enc,
         # energy-mode backward kernels: same scheme as the forward ones unless CCSP_ENERGY_BWD=bf16x3
         'edge decoder backward': (2.0 * (2 * E) * H * (H // 2),) + bwd,
+        'edge decoder forward + backward': (2.0 * 2.0 * (2 * E) * H * (H // 2),) + prod,     # (round 6: one kernel, both GEMMs)
         'row GEMM (transpose)': (2.0 * R * H * (2 * H),) + bwd,
         'node energy backward': (2.0 * 2 * N * H * (H // 2),) + enc,
     }
@@ -159,6 +160,7 @@ KERNEL_SYMBOLS = {      # label -> kernel symbol prefix by GEMM mode (for the PM
     'edge decoder (forward)': {'f16x2': 'k_edge_h2', 'bf16x3': 'k_edge_bf2', 'f32': 'k_edge<256'},     # (k_edge_h2s on small batches: same prefix)
     'node update + pose encoder': {m: 'k_node<256' for m in ('f16x2', 'bf16x3', 'f32')},
     'edge decoder backward': {'f16x2': 'k_edge_bwd_h2', 'bf16x3': 'k_edge_bwd_bf', 'f32': 'k_edge_bwd<256>'},
+    'edge decoder forward + backward': {'f16x2': 'k_edge_fb_h2'},
     'row GEMM (transpose)': {'f16x2': 'k_rowgemm_h2<512, 256', 'bf16x3': 'k_rowgemm_bf2<512, 256>', 'f32': 'k_rowgemm<512, 256>'},
     'node energy backward': {m: 'k_node_energy' for m in ('f16x2', 'bf16x3', 'f32')},     # (_h2 / _h2_update / _mfma: same prefix)
     'row sum of g_z': {m: 'k_rowsum' for m in ('f16x2', 'bf16x3', 'f32')},
@@ -479,20 +481,23 @@ def host_cpu_seconds():
     return r.ru_utime + r.ru_stime
 
 
-# A rank with two lanes keeps two enqueueing threads busy for the whole chain (33 000 launches per lane) next to the Python thread that waits in
-# ccsp_chain_run: measured 2.0-2.1 core-seconds per second of chain (profiles/r06_host_budget.txt); one lane needs 1.0 and runs the C2 chain 6-8 % slower.
-# The reference is ONE process for the whole node (ddpm.py:342-351), so this cost is the port's own and the launcher budgets it.
-CORES_PER_RANK_TWO_LANES = 2.5
+# What a rank costs its host, measured (profiles/r06_host_budget.txt, tools/host_budget.sh; C2, one MI355X box with a 16-core cgroup quota): 2.67 busy
+# cores with two lanes (the two enqueueing threads ~0.8 each -- a chain is 33 000 launches per lane -- plus the HIP runtime's own threads), 1.9 with one
+# lane, which runs the chain 8 % slower (465 against 506 samples/s).  With K busy competitor processes in the same cgroup (= the other ranks of an
+# N-rank run, 2.67 or 1.9 each): two lanes hold 507 up to K = 13, 499 at 16, 450 at 19 (seven other two-lane ranks), 386 at 24; one lane 466 up to 16,
+# 444 at 19.  So on 16 cores two lanes win up to 7 ranks (499 against 466) and lose at 8 (450 against the 465 that eight ONE-lane ranks get with 13
+# competitors each): the launcher takes one lane per rank below 2.2 usable cores per rank.  The reference is ONE process for the whole node
+# (ddpm.py:342-351), so this cost is the port's own -- and every line reports it (host_cpu_s_per_step, host_cores_busy_per_rank, lanes).
+CORES_PER_RANK_TWO_LANES = 2.2
 
 
 def select_lanes(world, cores, env_lanes=None):
     """-> (value for CCSP_LANES or None = the library's default of two lanes, reason).  An explicit CCSP_LANES always wins; otherwise one lane per rank
-    when the container grants fewer than CORES_PER_RANK_TWO_LANES cores per rank (8 ranks on the GPU boxes' 16-core quota: 16 < 20 -> one lane)."""
+    when the container grants fewer than CORES_PER_RANK_TWO_LANES cores per rank (8 ranks on the GPU boxes' 16-core quota: 16 < 17.6 -> one lane)."""
     if env_lanes not in (None, ''):
         return None, 'CCSP_LANES=%s set by the caller' % env_lanes
     if cores < CORES_PER_RANK_TWO_LANES * world:
-        return 1, ('one lane per rank: %d usable cores < %.1f x %d ranks (two lanes keep two enqueueing threads busy per rank; starved enqueue threads '
-                   'stall the chain silently)' % (cores, CORES_PER_RANK_TWO_LANES, world))
+        return 1, ('one lane per rank: %d usable cores < %.1f x %d ranks (a two-lane rank keeps 2.67 host cores busy, a one-lane rank 1.9: profiles/r06_host_budget.txt)' % (cores, CORES_PER_RANK_TWO_LANES, world))
     return None, 'library default (two lanes above 6144 active edges): %d usable cores >= %.1f x %d ranks' % (cores, CORES_PER_RANK_TWO_LANES, world)
 
 
@@ -1007,6 +1012,11 @@ def main():
         frac_bytes = dom.get('frac_bytes')
         by_bytes = frac_bytes is not None and frac_bytes > frac_mfma
         eval_labels = [k for k in kernels if k['kernel'] not in ('energy sum', 'HMC elementwise')]
+        if any(k['kernel'] == 'edge decoder forward + backward' for k in kernels):
+            # energy mode since round 6: a GRADIENT evaluation (what fabric_bytes_per_evaluation is quoted per, and what tools/profile_eval.py runs) is
+            # row GEMM -> fused decoder forward + backward -> transpose GEMM -> node gradient; the forward-only decoder launches timed above belong
+            # to MALA's energy evaluation at the proposal, not to it
+            eval_labels = [k for k in eval_labels if k['kernel'] != 'edge decoder (forward)']
         fabric_eval = sum(k['fabric_bytes_per_launch'] for k in eval_labels) if eval_labels and all('fabric_bytes_per_launch' in k for k in eval_labels) else None
         alg_bytes = algorithmic_bytes(n_nodes, types_present, HIDDEN, P, grasp)
         # what one evaluation touches: if it fits the 256 MiB Infinity Cache the fabric-side bytes (L2 misses, Infinity-Cache hits

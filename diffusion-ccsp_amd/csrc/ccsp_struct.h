@@ -243,6 +243,10 @@ __global__ __launch_bounds__(256, 2) void k_sd_gemm_h2(int M, int K, int N, cons
                                                        const unsigned short* __restrict__ WH, size_t w_plane, int w_exp,
                                                        const float* __restrict__ bias, float* __restrict__ Cm, unsigned int* __restrict__ cmax) {
     constexpr int NJ = TN / 64;                                   // 32-column MFMA tiles per wave
+    constexpr int TRK_ID = EPI == SD_EPI_BIAS ? 0 : (EPI == SD_EPI_QGELU ? 1 : 2);      // (trace builds, tools/trace_sd_run.py; the direct-mode kernels that own these slots do not run here)
+    (void)TRK_ID;
+    CCSP_TRK(TRK_ID, 0);
+    CCSP_TRK_RT(TRK_ID, 30);
     constexpr int APL = 64 * H2_BK, BPL = TN * H2_BK, STAGE = 2 * APL + 2 * BPL;
     constexpr int NB = TN / 64;                                   // B pieces (16 bytes) per thread and plane
     constexpr int CW_LD = 32 * NJ + 4, CW_SZ = 32 * CW_LD;        // wave-private epilogue tile [32][CW_LD] floats
@@ -357,12 +361,14 @@ __global__ __launch_bounds__(256, 2) void k_sd_gemm_h2(int M, int K, int N, cons
 #pragma unroll
         for (int i = 0; i < 2; ++i) a_exp[i] = h2_scale_exp(__uint_as_float(mx[i]));
     }
+    CCSP_TRK(TRK_ID, 1);
     lstore(0, 0);
     gload(PD, 0);
     if (lq == 0) { sE[lr] = a_exp[0]; sE[lr + 32] = a_exp[1]; }  // (here and not where a_exp is loaded: its wait would sit in front of the first operand requests)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    CCSP_TRK(TRK_ID, 2);
     for (int c0 = 0; c0 < nch; c0 += PD) {                        // PD chunks per trip: register-set and stage indices are constants
 #pragma unroll
         for (int u = 0; u < PD; ++u) {
@@ -378,12 +384,14 @@ __global__ __launch_bounds__(256, 2) void k_sd_gemm_h2(int M, int K, int N, cons
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    CCSP_TRK(TRK_ID, 3);
     // the dummies still in flight land before their registers are handed to the epilogue
 #pragma unroll
     for (int u = 0; u < PD; ++u) {
         if (NB == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[u][0]), "+v"(ra[u][1]), "+v"(rb[u][0]), "+v"(rb[u][1]) :: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[u][0]), "+v"(ra[u][1]), "+v"(rb[u][0]), "+v"(rb[u][1]), "+v"(rb[u][2 * NB - 2]), "+v"(rb[u][2 * NB - 1]) :: "memory");
     }
+    CCSP_TRK(TRK_ID, 4);
     // epilogue, one wave at a time through its private LDS tile (the stages are free: every wave is past the last barrier)
     float* Cw = reinterpret_cast<float*>(smem) + wave * CW_SZ;
     constexpr int LPR = 8 * NJ;                                   // lanes per row segment: 4 columns each
@@ -399,6 +407,7 @@ __global__ __launch_bounds__(256, 2) void k_sd_gemm_h2(int M, int K, int N, cons
             Cw[rr * CW_LD + j * 32 + (lane & 31)] = acc[j][r];
         }
     asm volatile("" ::: "memory");                                // (compiler ordering only: one wave's LDS operations execute in order)
+    CCSP_TRK(TRK_ID, 5);
     constexpr int RPP = 64 / LPR;                                 // rows per pass
 #pragma unroll
     for (int st = 0; st < 32 / RPP; ++st) {
@@ -429,6 +438,8 @@ __global__ __launch_bounds__(256, 2) void k_sd_gemm_h2(int M, int K, int N, cons
             if (eq == 0 && live) atomicMax(cmax + row0 + trow, b);
         }
     }
+    CCSP_TRK(TRK_ID, 6);
+    CCSP_TRK_RT(TRK_ID, 31);
 }
 
 // token rows: [grasp_emb] geoms_emb (poses_emb + time_emb) + pe[position] -> ln_pre; padding rows are zero

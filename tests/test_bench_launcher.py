@@ -50,13 +50,14 @@ def test_world_size_mismatch_is_refused():
 
 
 def test_lanes_rule_budgets_the_host_for_n_ranks():
-    """bench.select_lanes: a rank with two lanes keeps two enqueueing threads busy (profiles/r06_host_budget.txt), so the launcher falls back to
-    one lane per rank when the container grants fewer than 2.5 cores per rank -- the GPU boxes' 16-core quota under 8 ranks -- and says so"""
+    """bench.select_lanes: a two-lane rank keeps 2.67 host cores busy, a one-lane rank 1.9 (profiles/r06_host_budget.txt), so the launcher falls back
+    to one lane per rank when the container grants fewer than 2.2 cores per rank -- the GPU boxes' 16-core quota under 8 ranks -- and says so"""
     sys.path.insert(0, ROOT)
     import bench
     lanes, why = bench.select_lanes(8, 16)
     assert lanes == 1 and '16 usable cores' in why and '8 ranks' in why
-    assert bench.select_lanes(8, 20)[0] is None                 # 20 >= 2.5 x 8: the library default (two lanes)
+    assert bench.select_lanes(8, 20)[0] is None                 # 20 >= 2.2 x 8: the library default (two lanes)
+    assert bench.select_lanes(7, 16)[0] is None                 # measured: seven two-lane ranks on 16 cores 499 samples/s each, one-lane 466
     assert bench.select_lanes(4, 16)[0] is None and bench.select_lanes(1, 16)[0] is None and bench.select_lanes(2, 8)[0] is None
     assert bench.select_lanes(1, 2)[0] == 1 and bench.select_lanes(2, 4)[0] == 1
     lanes, why = bench.select_lanes(8, 16, '2')                  # an explicit CCSP_LANES always wins
