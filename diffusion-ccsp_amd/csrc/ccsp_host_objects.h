@@ -17,6 +17,8 @@ struct ccsp_model {
     float* WpT;    // [C][2][H][2H]   their transposes (energy-mode backward)
     int lanes;     // concurrent sub-batch chains per ccsp_chain_run (direct mode), default 2
     int lane_min_edges;   // batches with fewer active edges run as one lane
+    int sd_pipe = 1;      // (CCSP_SD_PIPE=0) k_sd_gemm_h2w without the staging interleaved between its MFMA pairs
+    int sd_tile = -1;     // (CCSP_SD_TILE) StructDiffusion GEMM tiles: 0 = 64-row tiles everywhere (round 4), 1 = 128 x 128 wherever the shape allows, -1 = by shape
     int lane_min_tokens;  // StructDiffusion: batches with fewer token rows run as one lane
     std::vector<hipStream_t> lane_streams;   // taken from the process-wide pool (lane_stream_get): new HIP streams are expensive to create
     std::vector<char> lane_stream_owned;     // (1: created for this model alone -- the CU-mask experiment -- and destroyed with it)

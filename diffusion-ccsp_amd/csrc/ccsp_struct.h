@@ -238,7 +238,12 @@ __global__ __launch_bounds__(256) void k_sd_ln2ln1(int M, int Wd, float* __restr
 // of the result for the next GEMM (DPP maximum over the lanes of a row, one atomicMax on the float bits per row and wave).
 // K % 64 == 0, N % TN == 0; M arbitrary (rows clamped).
 // ------------------------------------------------------------------------------------------
-template <int EPI, int TN, int PD>
+// KS (round 6): K chunks per STEP of the loop.  A phase trace of this kernel (tools/trace_sd_run.py, profiles/r06_trace_sd_gemm_*.txt) puts 80 % of a
+// workgroup's life in the K loop at 820 .. 1760 cycles per 32-wide chunk for 190 .. 380 cycles of MFMA issue: with one wave per SIMD every chunk
+// pays its own chain -- wait for the set, split, ds_write, barrier, fragment reads, six dependent MFMAs -- in full.  KS = 2 stages TWO chunks per
+// step (a stage is two sub-stages of the KS = 1 layout): half the barriers and waits, twice the MFMAs behind each, the fragment reads of four
+// k-steps free to be issued ahead of the first MFMA.  Same products in the same order per accumulator.
+template <int EPI, int TN, int PD, int KS = 1>
 __global__ __launch_bounds__(256, 2) void k_sd_gemm_h2(int M, int K, int N, const float* __restrict__ A, const unsigned int* __restrict__ amax,
                                                        const unsigned short* __restrict__ WH, size_t w_plane, int w_exp,
                                                        const float* __restrict__ bias, float* __restrict__ Cm, unsigned int* __restrict__ cmax) {
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void k_sd_gemm_h2(int M, int K, int N, cons
     (void)TRK_ID;
     CCSP_TRK(TRK_ID, 0);
     CCSP_TRK_RT(TRK_ID, 30);
-    constexpr int APL = 64 * H2_BK, BPL = TN * H2_BK, STAGE = 2 * APL + 2 * BPL;
+    constexpr int APL = 64 * H2_BK, BPL = TN * H2_BK, SUB = 2 * APL + 2 * BPL, STAGE = KS * SUB;
     constexpr int NB = TN / 64;                                   // B pieces (16 bytes) per thread and plane
     constexpr int CW_LD = 32 * NJ + 4, CW_SZ = 32 * CW_LD;        // wave-private epilogue tile [32][CW_LD] floats
     constexpr int SMEM_US = 2 * STAGE * 2 > 4 * CW_SZ * 4 ? 2 * STAGE : 4 * CW_SZ * 2;
@@ -283,49 +288,63 @@ __global__ __launch_bounds__(256, 2) void k_sd_gemm_h2(int M, int K, int N, cons
     // operand loads by inline asm, waited for by counted s_waitcnt (h2_ld16): hipcc sinks an ordinary load to its first use -- the
     // ds_write of the NEXT trip -- which puts a memory round trip into every chunk (measured: 1.8 k cycles per chunk against 0.2 k of
     // MFMA work, whatever the prefetch distance written in the source)
-    h2_f4 ra[PD][2];                                              // [register set][row]
-    h2_f4 rb[PD][2 * NB];
-    constexpr int NLD = 2 + 2 * NB;                               // loads per chunk and thread
+    h2_f4 ra[PD][2 * KS];                                         // [register set][chunk of the step][row]
+    h2_f4 rb[PD][2 * NB * KS];
+    constexpr int NLD = KS * (2 + 2 * NB);                        // loads per step and thread
     // Every step of the chain issues the same loads and the same wait, with NO branch around either: chunks past the end of the slice are
     // requested as dummies (every lane the slice's first 16 bytes: one request per instruction).  A wait inside `if (more chunks)` made
     // hipcc merge the two paths' register sets with v_mov copies placed BEFORE the s_waitcnt of one path -- copies of registers whose
     // loads were in flight (second build of this round: NaN in every transformer parity test).
     const float* const a_dummy = A + (size_t)row0 * K + k_first;
     const unsigned short* const b_dummy = WH + (size_t)col0 * (2 * K) + 2 * k_first;
+    // (c: index of the STEP -- KS consecutive chunks)
     auto gload = [&](int c, int set) {
-        const bool real = c < Ks / H2_BK;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) h2_ld16(ra[set][i], real ? a_ptr[i] + c * H2_BK : a_dummy);
+        for (int q = 0; q < KS; ++q) {
+            const int ch = c * KS + q;
+            const bool real = ch < Ks / H2_BK;
 #pragma unroll
-        for (int i = 0; i < NB; ++i)
+            for (int i = 0; i < 2; ++i) h2_ld16(ra[set][q * 2 + i], real ? a_ptr[i] + ch * H2_BK : a_dummy);
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
-                h2_ld16(rb[set][i * 2 + p], reinterpret_cast<const float*>(real ? b_ptr + (size_t)p * H2_BK + (size_t)i * 64 * (2 * K) + c * (2 * H2_BK) : b_dummy));
-    };
-    // the set's loads have landed; the PD - 1 sets requested after it stay in flight
-    auto gwait = [&](int set) {
-        if (NB == 1) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ra[set][0]), "+v"(ra[set][1]), "+v"(rb[set][0]), "+v"(rb[set][1]) : "n"((PD - 1) * NLD) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%6)" : "+v"(ra[set][0]), "+v"(ra[set][1]), "+v"(rb[set][0]), "+v"(rb[set][1]), "+v"(rb[set][2 * NB - 2]), "+v"(rb[set][2 * NB - 1]) : "n"((PD - 1) * NLD) : "memory");
-    };
-    static_assert(PD == 2 || PD == 4, "prefetch depth");
-    static_assert(NB <= 2, "gwait names four B registers");
-    auto lstore = [&](int stage, int set) {
-        unsigned short* As = smem + stage * STAGE;
-        unsigned short* Bs = As + 2 * APL;
+            for (int i = 0; i < NB; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float h[4] = {ra[set][i][0], ra[set][i][1], ra[set][i][2], ra[set][i][3]};
-            unsigned short p1[4], p2[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) split2h(ldexpf(h[e], a_exp[i]), p1[e], p2[e]);
-            unsigned short* d = As + a_st[i];
-            *reinterpret_cast<uint2*>(d) = make_uint2(p1[0] | ((unsigned)p1[1] << 16), p1[2] | ((unsigned)p1[3] << 16));
-            *reinterpret_cast<uint2*>(d + APL) = make_uint2(p2[0] | ((unsigned)p2[1] << 16), p2[2] | ((unsigned)p2[3] << 16));
+                for (int p = 0; p < 2; ++p)
+                    h2_ld16(rb[set][q * 2 * NB + i * 2 + p], reinterpret_cast<const float*>(real ? b_ptr + (size_t)p * H2_BK + (size_t)i * 64 * (2 * K) + ch * (2 * H2_BK) : b_dummy));
         }
+    };
+    // the set's loads have landed (N younger loads may stay in flight); every register of the set is named: the compiler must not touch one before
+#define CCSP_SD_GWAIT(set, N)                                                                                                                        \
+    do {                                                                                                                                             \
+        _Pragma("unroll") for (int q_ = 0; q_ < KS; ++q_) {                                                                                          \
+            if (NB == 1) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ra[set][q_ * 2]), "+v"(ra[set][q_ * 2 + 1]), "+v"(rb[set][q_ * 2]), "+v"(rb[set][q_ * 2 + 1]) : "n"(N) : "memory"); \
+            else asm volatile("s_waitcnt vmcnt(%6)" : "+v"(ra[set][q_ * 2]), "+v"(ra[set][q_ * 2 + 1]), "+v"(rb[set][(q_ * 4) % (2 * NB * KS)]), "+v"(rb[set][(q_ * 4 + 1) % (2 * NB * KS)]), \
+                              "+v"(rb[set][(q_ * 4 + 2) % (2 * NB * KS)]), "+v"(rb[set][(q_ * 4 + 3) % (2 * NB * KS)]) : "n"(N) : "memory");        \
+        }                                                                                                                                            \
+    } while (0)
+    // ... with the PD - 1 sets requested after it still in flight
+    auto gwait = [&](int set) { CCSP_SD_GWAIT(set, (PD - 1) * NLD); };
+    static_assert(PD == 2 || PD == 4, "prefetch depth");
+    static_assert(NB <= 2, "gwait names four B registers per chunk");
+    auto lstore = [&](int stage, int set) {
 #pragma unroll
-        for (int i = 0; i < NB; ++i)
+        for (int q = 0; q < KS; ++q) {
+            unsigned short* As = smem + stage * STAGE + q * SUB;
+            unsigned short* Bs = As + 2 * APL;
 #pragma unroll
-            for (int p = 0; p < 2; ++p) *reinterpret_cast<h2_f4*>(Bs + p * BPL + b_st + i * 64 * H2_BK) = rb[set][i * 2 + p];
+            for (int i = 0; i < 2; ++i) {
+                const float h[4] = {ra[set][q * 2 + i][0], ra[set][q * 2 + i][1], ra[set][q * 2 + i][2], ra[set][q * 2 + i][3]};
+                unsigned short p1[4], p2[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split2h(ldexpf(h[e], a_exp[i]), p1[e], p2[e]);
+                unsigned short* d = As + a_st[i];
+                *reinterpret_cast<uint2*>(d) = make_uint2(p1[0] | ((unsigned)p1[1] << 16), p1[2] | ((unsigned)p1[3] << 16));
+                *reinterpret_cast<uint2*>(d + APL) = make_uint2(p2[0] | ((unsigned)p2[1] << 16), p2[2] | ((unsigned)p2[3] << 16));
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) *reinterpret_cast<h2_f4*>(Bs + p * BPL + b_st + i * 64 * H2_BK) = rb[set][q * 2 * NB + i * 2 + p];
+        }
     };
     floatx16 acc[NJ];
 #pragma unroll
@@ -348,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void k_sd_gemm_h2(int M, int K, int N, cons
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[PA[q]], b[j][PB[q]], acc[j], 0, 0, 0);
     };
-    const int nch = Ks / H2_BK;                                   // (a multiple of PD: the host picks PD)
+    const int nch = Ks / (H2_BK * KS);                            // steps (a multiple of PD: the host picks PD and KS)
 #pragma unroll
     for (int u = 0; u < PD; ++u) gload(u, u);
     {   // the rows' maxima ride behind the first operand requests (as an ordinary load in front of them they cost every workgroup a
@@ -356,8 +375,8 @@ __global__ __launch_bounds__(256, 2) void k_sd_gemm_h2(int M, int K, int N, cons
         unsigned int mx[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) asm volatile("global_load_dword %0, %1, off" : "=v"(mx[i]) : "v"(a_mx[i]) : "memory");
-        if (NB == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(mx[0]), "+v"(mx[1]), "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(rb[0][0]), "+v"(rb[0][1]) :: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(mx[0]), "+v"(mx[1]), "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[0][2 * NB - 2]), "+v"(rb[0][2 * NB - 1]) :: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(mx[0]), "+v"(mx[1]) :: "memory");
+        CCSP_SD_GWAIT(0, 0);
 #pragma unroll
         for (int i = 0; i < 2; ++i) a_exp[i] = h2_scale_exp(__uint_as_float(mx[i]));
     }
@@ -372,9 +391,12 @@ __global__ __launch_bounds__(256, 2) void k_sd_gemm_h2(int M, int K, int N, cons
     for (int c0 = 0; c0 < nch; c0 += PD) {                        // PD chunks per trip: register-set and stage indices are constants
 #pragma unroll
         for (int u = 0; u < PD; ++u) {
-            const int c = c0 + u;                                 // chunk multiplied now, from stage u & 1; chunk c + 1 is staged behind it
-            kstep(smem + (u & 1) * STAGE, 0);                     // (behind the last chunk: a dummy, into the stage nobody reads again)
-            kstep(smem + (u & 1) * STAGE, 1);
+            const int c = c0 + u;                                 // step multiplied now, from stage u & 1; step c + 1 is staged behind it
+#pragma unroll
+            for (int q = 0; q < KS; ++q) {
+                kstep(smem + (u & 1) * STAGE + q * SUB, 0);       // (behind the last step: a dummy, into the stage nobody reads again)
+                kstep(smem + (u & 1) * STAGE + q * SUB, 1);
+            }
             __builtin_amdgcn_sched_barrier(0);
             gwait((u + 1) % PD);
             lstore((u + 1) & 1, (u + 1) % PD);
@@ -387,10 +409,8 @@ __global__ __launch_bounds__(256, 2) void k_sd_gemm_h2(int M, int K, int N, cons
     CCSP_TRK(TRK_ID, 3);
     // the dummies still in flight land before their registers are handed to the epilogue
 #pragma unroll
-    for (int u = 0; u < PD; ++u) {
-        if (NB == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[u][0]), "+v"(ra[u][1]), "+v"(rb[u][0]), "+v"(rb[u][1]) :: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[u][0]), "+v"(ra[u][1]), "+v"(rb[u][0]), "+v"(rb[u][1]), "+v"(rb[u][2 * NB - 2]), "+v"(rb[u][2 * NB - 1]) :: "memory");
-    }
+    for (int u = 0; u < PD; ++u) CCSP_SD_GWAIT(u, 0);
+#undef CCSP_SD_GWAIT
     CCSP_TRK(TRK_ID, 4);
     // epilogue, one wave at a time through its private LDS tile (the stages are free: every wave is past the last barrier)
     float* Cw = reinterpret_cast<float*>(smem) + wave * CW_SZ;
@@ -442,39 +462,268 @@ __global__ __launch_bounds__(256, 2) void k_sd_gemm_h2(int M, int K, int N, cons
     CCSP_TRK_RT(TRK_ID, 31);
 }
 
+#ifdef CCSP_EXPERIMENTS
+// ------------------------------------------------------------------------------------------
+// k_sd_gemm_h2w<EPI> (round 6): the same GEMM on 128 x 128 tiles -- 4 waves as 2 x 2, 64 x 64 per wave (k_rowgemm_h2's wave tile).
+// Why: the 64 x 64 tile of k_sd_gemm_h2 asks the CU's address unit for 16 KB of operands and its LDS for 16 KB of stores + 32 KB of fragment
+// reads per 64 x 64 x 32 chunk -- with three workgroups per CU that is ~1200 address-unit cycles (four 16-byte requests per wave at ~25 cycles
+// each, profiles/r05_ta_probe.txt) and ~1080 LDS cycles per chunk and CU against 576 of MFMA, and the measured chunk is 1040 cycles
+// (profiles/r06_trace_sd_gemm_1lane.txt, r06_findings.md section 3).  A 128 x 128 tile moves twice the bytes for four times the products:
+// 8 requests, 8 staging stores and 16 fragment reads per wave and chunk for 24 MFMAs (768 cycles).  Same split, same scaling, same order of the
+// three products per accumulator as k_sd_gemm_h2; the tile lists of a 2048-row batch are 192 .. 256 workgroups (c_proj: four K slices).
+// K % 64 == 0, N % 128 == 0; M arbitrary (rows clamped).
+// MEASURED SLOWER than the narrow kernel it was built to replace (same call, 256 graphs x 8 tokens, two lanes): 60.3 samples/s narrow, 51.0 wide,
+// 57.0 wide + PIPE; per launch 22.8 us (21.1 with PIPE) against 23.0 for in_proj / c_proj -- i.e. a workgroup of four times the products lives four
+// times as long: with ONE workgroup per CU nothing overlaps a wave's own chain, and interleaving the staging between the MFMA pairs recovers 8 % of it.
+// Experiments build only (CCSP_SD_TILE=wide); tests/test_experiments.py keeps it correct.  profiles/r06_findings.md section 4.
+// ------------------------------------------------------------------------------------------
+// PIPE: the staging of chunk c + 1 (wait for its registers, split, LDS stores) and the requests for chunk c + 3 are issued BETWEEN the MFMA pairs of
+// chunk c (h2_chunk_ahead_with: every fragment read of the chunk up front, twelve slots of two MFMAs each).  With one workgroup per CU -- 192 .. 256
+// tiles on 256 CUs -- a wave has nobody to overlap with but itself: without PIPE a chunk is requests + wait + 96 VALU instructions + stores +
+// barrier + fragment reads + 24 MFMAs one after the other, 3.0 k cycles for 768 of matrix work (same duration as the narrow kernel: measured).
+template <int EPI, bool PIPE = false>
+__global__ __launch_bounds__(256, 2) void k_sd_gemm_h2w(int M, int K, int N, const float* __restrict__ A, const unsigned int* __restrict__ amax,
+                                                        const unsigned short* __restrict__ WH, size_t w_plane, int w_exp,
+                                                        const float* __restrict__ bias, float* __restrict__ Cm, unsigned int* __restrict__ cmax) {
+    constexpr int TM = 128, TN = 128, MI = 2, NJ = 2, PD = 2;
+    constexpr int APL = TM * H2_BK, BPL = TN * H2_BK, STAGE = 2 * APL + 2 * BPL;
+    constexpr int NA = TM / 32;                                   // A rows per thread and chunk
+    constexpr int CW_LD = 32 * NJ + 4, CW_SZ = 32 * CW_LD;        // wave-private epilogue tile [32][CW_LD] floats
+    static_assert(2 * STAGE * 2 >= 4 * CW_SZ * 4, "epilogue tiles fit the stages");
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * STAGE + 2 * TM];
+    int* sE = reinterpret_cast<int*>(smem + 2 * STAGE);
+    (void)w_plane;
+    const int nct = N / TN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int row0 = (bid / nct) * TM, col0 = (bid % nct) * TN;
+    const int nrows = M - row0 < TM ? M - row0 : TM;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int Ks = K / (int)gridDim.y, k_first = (int)blockIdx.y * Ks;      // split K as in k_sd_gemm_h2
+    Cm += (size_t)blockIdx.y * M * N;
+    const int lr = tid >> 3, lq = tid & 7;                        // A producer: rows lr + 32 i, fp32 columns 4 lq .. + 3 of the chunk
+    const float* a_ptr[NA];
+    const unsigned int* a_mx[NA];
+    int a_exp[NA], a_st[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        int r = lr + 32 * i;
+        r = r < nrows ? r : nrows - 1;
+        a_ptr[i] = A + (size_t)(row0 + r) * K + k_first + lq * 4;
+        a_mx[i] = amax + row0 + r;
+        a_st[i] = h2_off(lr + 32 * i, lq >> 1) + (lq & 1) * 4;
+    }
+    const int brow = tid >> 2, bq = tid & 3;                      // B copy: rows brow, brow + 64, piece bq, both planes
+    const unsigned short* b_ptr = WH + (size_t)(col0 + brow) * (2 * K) + 2 * k_first + bq * 8;
+    const int b_st = h2_off(brow, bq);
+    h2_f4 ra[PD][NA];
+    h2_f4 rb[PD][4];
+    constexpr int NLD = NA + 4;
+    const float* const a_dummy = A + (size_t)row0 * K + k_first;
+    const unsigned short* const b_dummy = WH + (size_t)col0 * (2 * K) + 2 * k_first;
+    auto gload = [&](int c, int set) {                            // (no branch around a load or a wait: see k_sd_gemm_h2)
+        const bool real = c < Ks / H2_BK;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) h2_ld16(ra[set][i], real ? a_ptr[i] + c * H2_BK : a_dummy);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                h2_ld16(rb[set][i * 2 + p], reinterpret_cast<const float*>(real ? b_ptr + (size_t)p * H2_BK + (size_t)i * 64 * (2 * K) + c * (2 * H2_BK) : b_dummy));
+    };
+#define CCSP_SDW_GWAIT(set, NN)                                                                                                                      \
+    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(ra[set][0]), "+v"(ra[set][1]), "+v"(ra[set][2]), "+v"(ra[set][3]), "+v"(rb[set][0]), "+v"(rb[set][1]), \
+                 "+v"(rb[set][2]), "+v"(rb[set][3]) : "n"(NN) : "memory")
+    auto lstore_a = [&](int stage, int set, int i) {              // one A row of the set: split, two 8-byte stores
+        unsigned short* As = smem + stage * STAGE;
+        const float h[4] = {ra[set][i][0], ra[set][i][1], ra[set][i][2], ra[set][i][3]};
+        unsigned short p1[4], p2[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split2h(ldexpf(h[e], a_exp[i]), p1[e], p2[e]);
+        unsigned short* d = As + a_st[i];
+        *reinterpret_cast<uint2*>(d) = make_uint2(p1[0] | ((unsigned)p1[1] << 16), p1[2] | ((unsigned)p1[3] << 16));
+        *reinterpret_cast<uint2*>(d + APL) = make_uint2(p2[0] | ((unsigned)p2[1] << 16), p2[2] | ((unsigned)p2[3] << 16));
+    };
+    auto lstore_b = [&](int stage, int set, int i) {              // both planes of weight rows brow + 64 i
+        unsigned short* Bs = smem + stage * STAGE + 2 * APL;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) *reinterpret_cast<h2_f4*>(Bs + p * BPL + b_st + i * 64 * H2_BK) = rb[set][i * 2 + p];
+    };
+    auto lstore = [&](int stage, int set) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) lstore_a(stage, set, i);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) lstore_b(stage, set, i);
+    };
+    auto gload_part = [&](int c, int set, int part) {             // a quarter of gload(c, set): A row `part`, and weight piece `part`
+        const bool real = c < Ks / H2_BK;
+        h2_ld16(ra[set][part], real ? a_ptr[part] + c * H2_BK : a_dummy);
+        const int i = part >> 1, pl = part & 1;
+        h2_ld16(rb[set][part], reinterpret_cast<const float*>(real ? b_ptr + (size_t)pl * H2_BK + (size_t)i * 64 * (2 * K) + c * (2 * H2_BK) : b_dummy));
+    };
+    floatx16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const int nch = Ks / H2_BK;                                   // (even: K % 64 == 0)
+    gload(0, 0);
+    gload(1, 1);
+    {
+        unsigned int mx[NA];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) asm volatile("global_load_dword %0, %1, off" : "=v"(mx[i]) : "v"(a_mx[i]) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(mx[0]), "+v"(mx[1]), "+v"(mx[2]), "+v"(mx[3]) :: "memory");
+        CCSP_SDW_GWAIT(0, 0);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) a_exp[i] = h2_scale_exp(__uint_as_float(mx[i]));
+    }
+    lstore(0, 0);
+    gload(2, 0);
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+        if (lq == 0) sE[lr + 32 * i] = a_exp[i];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    for (int c0 = 0; c0 < nch; c0 += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const unsigned short* st = smem + (u & 1) * STAGE;
+            if constexpr (PIPE) {
+                h2_chunk_ahead_with<MI>(st, APL, st + 2 * APL, wm * 64, wn * 64, acc, [&](int k) {
+                    // (k and u are constants after unrolling: every slot is straight-line code, no branch around a wait or a load)
+                    if (k == 0) { if (u == 0) CCSP_SDW_GWAIT(1, NLD); else CCSP_SDW_GWAIT(0, NLD); }
+                    else if (k <= 4) lstore_a((u + 1) & 1, (u + 1) & 1, k - 1);
+                    else if (k <= 6) lstore_b((u + 1) & 1, (u + 1) & 1, k - 5);
+                    else if (k <= 10) gload_part(c0 + u + 3, (u + 1) & 1, k - 7);
+                });
+            } else {
+                h2_kstep<MI>(st, APL, st + 2 * APL, 0, wm * 64, wn * 64, acc);
+                h2_kstep<MI>(st, APL, st + 2 * APL, 1, wm * 64, wn * 64, acc);
+                __builtin_amdgcn_sched_barrier(0);
+                if (u == 0) CCSP_SDW_GWAIT(1, NLD); else CCSP_SDW_GWAIT(0, NLD);
+                lstore((u + 1) & 1, (u + 1) & 1);
+                gload(c0 + u + 3, (u + 1) & 1);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (not __syncthreads(): its fence is a vmcnt(0) that drains the prefetch)
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    CCSP_SDW_GWAIT(0, 0);
+    CCSP_SDW_GWAIT(1, 0);
+#undef CCSP_SDW_GWAIT
+    // epilogue, one wave at a time through its private LDS tile, one 32-row tile after the other
+    float* Cw = reinterpret_cast<float*>(smem) + wave * CW_SZ;
+    constexpr int LPR = 8 * NJ;
+    const int er = lane / LPR, eq = lane % LPR;
+    const int colw = col0 + wn * 32 * NJ;
+    float4 bv = *reinterpret_cast<const float4*>(bias + colw + 4 * eq);
+    if (blockIdx.y != 0) bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int RPP = 64 / LPR;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                Cw[rr * CW_LD + j * 32 + (lane & 31)] = acc[mi][j][r];
+            }
+        asm volatile("" ::: "memory");                            // (compiler ordering only: one wave's LDS operations execute in order)
+#pragma unroll
+        for (int st = 0; st < 32 / RPP; ++st) {
+            const int trow = wm * 64 + 32 * mi + er + RPP * st;
+            const int e = -(sE[trow] + w_exp);
+            const bool live = trow < nrows;
+            float* dst = Cm + (size_t)(row0 + (live ? trow : 0)) * N + colw + 4 * eq;
+            const float4 v = *reinterpret_cast<const float4*>(Cw + (er + RPP * st) * CW_LD + 4 * eq);
+            float o[4] = {ldexpf(v.x, e) + bv.x, ldexpf(v.y, e) + bv.y, ldexpf(v.z, e) + bv.z, ldexpf(v.w, e) + bv.w};
+            if (EPI == SD_EPI_RESID) {
+                const float4 x = *reinterpret_cast<const float4*>(dst);
+                o[0] += x.x; o[1] += x.y; o[2] += x.z; o[3] += x.w;
+            }
+            if (EPI == SD_EPI_QGELU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = o[q] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.44269504088896341f * o[q]));
+            }
+            if (live) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            if (cmax) {
+                unsigned int b = 0u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const unsigned int ob = __float_as_uint(o[q]) & 0x7fffffffu; b = b > ob ? b : ob; }
+                unsigned int t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)b, 0xB1, 0xF, 0xF, true); b = b > t ? b : t;
+                t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)b, 0x4E, 0xF, 0xF, true); b = b > t ? b : t;
+                t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)b, 0x141, 0xF, 0xF, true); b = b > t ? b : t;
+                t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)b, 0x140, 0xF, 0xF, true); b = b > t ? b : t;      // LPR == 16
+                if (eq == 0 && live) atomicMax(cmax + row0 + trow, b);
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+}
+
+#endif  // CCSP_EXPERIMENTS
+
 // token rows: [grasp_emb] geoms_emb (poses_emb + time_emb) + pe[position] -> ln_pre; padding rows are zero
 // (denoise_fn.py:397-423)
+template <int NV = 0>
 __global__ __launch_bounds__(256) void k_sd_embed(int M, int H, int Wd, int grasp, const int* __restrict__ tok_node,
                                                   const int* __restrict__ tok_pos, const float* __restrict__ gemb,
                                                   const float* __restrict__ remb, const float* __restrict__ pemb,
                                                   const float* __restrict__ temb_t, const float* __restrict__ pe,
-                                                  const float* __restrict__ gam, const float* __restrict__ bet, float* __restrict__ X) {
+                                                  const float* __restrict__ gam, const float* __restrict__ bet, float* __restrict__ X,
+                                                  // round 6: ln_1 of the FIRST block in the same pass over the row (k_sd_ln<0> of round 4: one launch less per
+                                                  // evaluation; same arithmetic in the same order).  Y == nullptr: ln_pre only
+                                                  const float* __restrict__ g1, const float* __restrict__ b1, float* __restrict__ Y, unsigned int* __restrict__ ymax,
+                                                  unsigned int* __restrict__ z0, unsigned int* __restrict__ z1, unsigned int* __restrict__ z2) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
+    if (Y && lane == 0) { if (z0) z0[row] = 0u; if (z1) z1[row] = 0u; if (z2) z2[row] = 0u; }
     const int n = tok_node[row];
-    float v[SD_MAXV];
+    constexpr int N = NV ? NV : SD_MAXV;                          // (NV > 0: the width is 64 NV at compile time, as in k_sd_ln)
+    float v[N];
     if (n < 0) {
 #pragma unroll
-        for (int i = 0; i < SD_MAXV; ++i) if (lane + 64 * i < Wd) X[(size_t)row * Wd + lane + 64 * i] = 0.0f;
-        return;
-    }
-    const int off = grasp ? H : 0;
-    const float* per = pe + (size_t)tok_pos[row] * Wd;
+        for (int i = 0; i < N; ++i) { v[i] = 0.0f; if (NV || lane + 64 * i < Wd) X[(size_t)row * Wd + lane + 64 * i] = 0.0f; }
+        if (!Y) return;
+    } else {
+        const int off = grasp ? H : 0;
+        const float* per = pe + (size_t)tok_pos[row] * Wd;
 #pragma unroll
-    for (int i = 0; i < SD_MAXV; ++i) {
-        const int c = lane + 64 * i;
-        float e = 0.0f;
-        if (c < Wd) {
-            if (c < off) e = remb[(size_t)n * H + c];
-            else if (c < off + H) e = gemb[(size_t)n * H + c - off];
-            else e = pemb[(size_t)n * H + c - off - H] + temb_t[c - off - H];
-            e += per[c];
+        for (int i = 0; i < N; ++i) {
+            const int c = lane + 64 * i;
+            float e = 0.0f;
+            if (NV || c < Wd) {
+                if (c < off) e = remb[(size_t)n * H + c];
+                else if (c < off + H) e = gemb[(size_t)n * H + c - off];
+                else e = pemb[(size_t)n * H + c - off - H] + temb_t[c - off - H];
+                e += per[c];
+            }
+            v[i] = e;
         }
-        v[i] = e;
-    }
-    ln_row(v, Wd, lane, gam, bet);
+        ln_row<NV>(v, Wd, lane, gam, bet);
 #pragma unroll
-    for (int i = 0; i < SD_MAXV; ++i) if (lane + 64 * i < Wd) X[(size_t)row * Wd + lane + 64 * i] = v[i];
+        for (int i = 0; i < N; ++i) if (NV || lane + 64 * i < Wd) X[(size_t)row * Wd + lane + 64 * i] = v[i];
+        if (!Y) return;
+    }
+    ln_row<NV>(v, Wd, lane, g1, b1);                                   // (a padding row is all zeros: its ln_1 is the bias, as k_sd_ln computes it)
+    unsigned int b = 0u;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        if (NV || lane + 64 * i < Wd) {
+            Y[(size_t)row * Wd + lane + 64 * i] = v[i];
+            const unsigned int ob = __float_as_uint(v[i]) & 0x7fffffffu;
+            b = b > ob ? b : ob;
+        }
+    if (ymax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const unsigned int t = (unsigned int)__shfl_xor((int)b, o); b = b > t ? b : t; }
+        if (lane == 0) ymax[row] = b;
+    }
 }
 
 // nn.MultiheadAttention core for one (graph, head): 8 x 8 scores, the FLOAT pad mask added to them
@@ -588,44 +837,73 @@ __global__ __launch_bounds__(256) void k_sd_attn(int Wd, const float* __restrict
 }
 
 // per node: ln_post of its token row, last H channels -> pose_decoder -> eps; masked nodes take
-// batch.x[:, -P:] (denoise_fn.py:437-449).  One wave per node.
-template <int H>
+// batch.x[:, -P:] (denoise_fn.py:437-449).
+// Round 6: one wave per node in the row phases as before, but the first decoder layer is shared by the workgroup's four nodes: a thread owns one
+// hidden unit for all four, so one weight load feeds four accumulators (round 1: every wave streamed the whole [H, H/2] weight for its own node
+// through 2 H dependent load-multiply steps; 18.6 us per evaluation, as long as a GEMM -- profiles/r06_kernel_stats_sd_before.csv).  NV > 0: the
+// width at compile time (no bounds tests next to the row loads, as in k_sd_ln).  Every sum keeps its order (c ascending per unit; the second layer's
+// lane-strided partials and butterfly): results are bitwise those of the old kernel.  (Eight nodes per workgroup -- two per wave in the row
+// phases -- was slower, 24.5 us: the row phase is the latency chain of this kernel.)
+template <int H, int NV = 0>
 __global__ __launch_bounds__(256) void k_sd_decode(int N, int Wd, int P, int F, const int* __restrict__ node_tok, const float* __restrict__ X,
                                                    const float* __restrict__ gam, const float* __restrict__ bet,
                                                    const float* __restrict__ pd0_wT /*[H][H/2]*/, const float* __restrict__ pd0_b,
                                                    const float* __restrict__ pd2_w /*[P][H/2]*/, const float* __restrict__ pd2_b,
                                                    const float* __restrict__ xfeat, const signed char* __restrict__ mask,
-                                                   float* __restrict__ eps) {
-    __shared__ float ys[4][H];
-    __shared__ float hs[4][H / 2];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + w;
+                                                   float* __restrict__ eps,
+                                                   // the last block's  x = x + ln_2(mlp(x))  (k_sd_ln<1>, transformer.py:66) for the rows decoded here -- nobody else reads
+                                                   // that x.  Ymlp: the c_proj output as `yparts` split-K partial products [yparts][M][Wd], added in order; null: X is final
+                                                   const float* __restrict__ Ymlp, int yparts, int M, const float* __restrict__ g2, const float* __restrict__ b2) {
+    constexpr int NPW = 4, HH = H / 2, NR = NV ? NV : SD_MAXV;
+    __shared__ float ys[NPW][H];
+    __shared__ float hs[NPW][HH];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
+    const int n = blockIdx.x * NPW + w;
     const bool live = n < N;
-    float v[SD_MAXV];
-    if (live) {
-        const int row = node_tok[n];
+    {
+        float v[NR];
+        const int row = node_tok[live ? n : 0];
 #pragma unroll
-        for (int i = 0; i < SD_MAXV; ++i) v[i] = lane + 64 * i < Wd ? X[(size_t)row * Wd + lane + 64 * i] : 0.0f;
-        ln_row(v, Wd, lane, gam, bet);
+        for (int i = 0; i < NR; ++i) v[i] = (NV || lane + 64 * i < Wd) ? X[(size_t)row * Wd + ((NV || lane + 64 * i < Wd) ? lane + 64 * i : 0)] : 0.0f;
+        if (Ymlp) {
+            float y[NR];
 #pragma unroll
-        for (int i = 0; i < SD_MAXV; ++i) {
+            for (int i = 0; i < NR; ++i) y[i] = (NV || lane + 64 * i < Wd) ? Ymlp[(size_t)row * Wd + ((NV || lane + 64 * i < Wd) ? lane + 64 * i : 0)] : 0.0f;
+            for (int k = 1; k < yparts; ++k) {
+#pragma unroll
+                for (int i = 0; i < NR; ++i)
+                    y[i] += (NV || lane + 64 * i < Wd) ? Ymlp[((size_t)k * M + row) * Wd + ((NV || lane + 64 * i < Wd) ? lane + 64 * i : 0)] : 0.0f;
+            }
+            ln_row<NV>(y, Wd, lane, g2, b2);
+#pragma unroll
+            for (int i = 0; i < NR; ++i) v[i] = v[i] + y[i];
+        }
+        ln_row<NV>(v, Wd, lane, gam, bet);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
             const int c = lane + 64 * i;
-            if (c < Wd && c >= Wd - H) ys[w][c - (Wd - H)] = v[i];
+            if ((NV || c < Wd) && c >= Wd - H) ys[w][c - (Wd - H)] = live ? v[i] : 0.0f;
         }
     }
     __syncthreads();
-    if (live) {
-        for (int k = lane; k < H / 2; k += 64) {
-            float q = pd0_b[k];
-            for (int c = 0; c < H; ++c) q += ys[w][c] * pd0_wT[(size_t)c * (H / 2) + k];
-            hs[w][k] = silu_f(q);
+    for (int u = tid; u < HH; u += 256) {                          // one hidden unit, all four nodes
+        const float b0 = pd0_b[u];
+        float q[NPW] = {b0, b0, b0, b0};
+        const float* wp = pd0_wT + u;
+#pragma unroll 8
+        for (int c = 0; c < H; ++c) {
+            const float wv = wp[(size_t)c * HH];
+#pragma unroll
+            for (int j = 0; j < NPW; ++j) q[j] += ys[j][c] * wv;
         }
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) hs[j][u] = silu_f(q[j]);
     }
     __syncthreads();
     if (!live) return;
     for (int p = 0; p < P; ++p) {
         float part = 0.0f;
-        for (int k = lane; k < H / 2; k += 64) part += hs[w][k] * pd2_w[(size_t)p * (H / 2) + k];
+        for (int k = lane; k < HH; k += 64) part += hs[w][k] * pd2_w[(size_t)p * HH + k];
         const float o = wave_sum(part) + pd2_b[p];
         if (lane == 0) eps[(size_t)n * P + p] = mask[n] ? xfeat[(size_t)n * F + F - P + p] : o;
     }

@@ -4,11 +4,11 @@ Certifies oracle/torch_proxy.py as a stand-in for "the reference's PyTorch-CPU p
 with the same weights, the same thread count and interleaved repetitions, the imported reference and the proxy must
   * give the same outputs (<= 1e-6 relative; observed: bit-identical), and
   * cost the same per network evaluation within +-5 %.
-Both the direct mode (C2-shaped batch: 256 x 8-object qualitative graphs) and the energy mode (C4-shaped: 12-triangle graphs,
-forward + autograd backward) are checked.  The GPU box cannot run the reference (only /root/repo travels), so bench.py's
+The direct mode (C2-shaped batch: 256 x 8-object qualitative graphs), the energy mode (C4-shaped: 12-triangle graphs,
+forward + autograd backward) and, since round 6, the StructDiffusion transformer baseline (256 x 7-object graphs, width 512) are checked.  The GPU box cannot run the reference (only /root/repo travels), so bench.py's
 cpu_baseline times the proxy there; this script is what ties that number to the reference.
 
-usage: python oracle/certify_proxy.py [--graphs 256] [--threads 8] [--reps 5]      -> profiles/r02_certify_proxy.txt
+usage: python oracle/certify_proxy.py [--graphs 256] [--threads 8] [--reps 5] [--out profiles/r06_certify_proxy.txt]
 """
 import argparse
 import os
@@ -32,9 +32,9 @@ from diffusion_ccsp_amd import worlds  # noqa: E402
 GOLD = os.path.join(ROOT, 'tests', 'golden')
 
 
-def reference_model(dfn, mode, H, W, energy):
+def reference_model(dfn, mode, H, W, energy, model='Diffusion-CCSP'):
     m = dfn.ConstraintDiffuser(dims=worlds.MODE_DIMS[mode], hidden_dim=H, EBM='MALA' if energy else 'ULA', input_mode=mode,
-                               energy_wrapper=energy, device='cpu', verbose=False)
+                               energy_wrapper=energy, device='cpu', verbose=False, model=model)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()})
     return m.eval()
 
@@ -44,18 +44,21 @@ def main():
     ap.add_argument('--graphs', type=int, default=256)
     ap.add_argument('--threads', type=int, default=8)
     ap.add_argument('--reps', type=int, default=5)
+    ap.add_argument('--out', default=os.path.join(ROOT, 'profiles', 'r06_certify_proxy.txt'))
     args = ap.parse_args()
     ddpm, dfn = ref_import.load()
     torch.set_num_threads(args.threads)
     lines = ['certify_proxy: torch %s, %d threads, %d interleaved repetitions per arm' % (torch.__version__, args.threads, args.reps)]
     ok = True
-    cases = [('direct  C2-shaped', 'qualitative', 13, 'weights_qualitative_h256.npz', False, worlds.qualitative_batch(args.graphs, 8, seed=5)),
+    cases = [('direct  C2-shaped', 'qualitative', 13, 'weights_qualitative_h256.npz', False, worlds.qualitative_batch(args.graphs, 8, seed=5), 'Diffusion-CCSP'),
              ('energy  C4-shaped', 'diffuse_pairwise', 2, 'weights_diffuse_pairwise_h256_energy.npz', True,
-              worlds.triangular_batch(max(1, args.graphs // 4), 12, seed=5))]
-    for tag, mode, C, wfile, energy, batch in cases:
+              worlds.triangular_batch(max(1, args.graphs // 4), 12, seed=5), 'Diffusion-CCSP'),
+             # round 6: the transformer baseline (bench.py --config sd: 256 graphs x 7 objects = 8-token sequences, width 512)
+             ('transformer baseline', 'qualitative', 13, 'weights_qualitative_h256_sd.npz', False, worlds.qualitative_batch(args.graphs, 7, seed=5), 'StructDiffusion')]
+    for tag, mode, C, wfile, energy, batch, kind in cases:
         W = oracle_mod.load_weights(os.path.join(GOLD, wfile))
-        ref = reference_model(dfn, mode, 256, W, energy)
-        prx = torch_proxy.ProxyDiffuser(W, worlds.MODE_DIMS[mode], 256, C)
+        ref = reference_model(dfn, mode, 256, W, energy, kind)
+        prx = (torch_proxy.ProxyStructDiffuser if kind == 'StructDiffusion' else torch_proxy.ProxyDiffuser)(W, worlds.MODE_DIMS[mode], 256, C)
         b = batch.to_torch()
         N, P = b.x.shape[0], worlds.MODE_DIMS[mode][-1][0]
         poses = (torch.randn(N, P, generator=torch.Generator().manual_seed(1)) * 0.6)
@@ -89,7 +92,7 @@ def main():
     out = '\n'.join(lines)
     print(out)
     os.makedirs(os.path.join(ROOT, 'profiles'), exist_ok=True)
-    with open(os.path.join(ROOT, 'profiles', 'r02_certify_proxy.txt'), 'w') as f:
+    with open(args.out, 'w') as f:
         f.write(out + '\n')
     sys.exit(0 if ok else 1)
 

@@ -97,6 +97,98 @@ class ProxyDiffuser(object):
         return out
 
 
+class ProxyStructDiffuser(ProxyDiffuser):
+    """cost-faithful port of the StructDiffusion baseline (reference denoise_fn.py:391-451, transformer.py:43-82), op for op:
+    the geometry and pose encoders on every call, the time MLP on [N, 1, H] rows, a Python loop over the graphs that slices each sequence, adds the
+    positional encoding, applies ln_pre, pads to 8 tokens and builds the FLOAT pad mask (+1.0 on padded rows / columns; `[-0:]` marks everything of
+    an unpadded graph), the masks repeated graph-major while nn.MultiheadAttention reads them head-major, four pre-LN blocks
+    (x + MHA(ln_1 x); x + ln_2(c_proj(QuickGELU(c_fc x)))), ln_post, the last H channels, a second Python loop that gathers the real tokens, the
+    pose decoder, the mask fill.  nn.MultiheadAttention.forward in eval mode is F.multi_head_attention_forward with need_weights=True (the
+    reference keeps the attention weights of every block): called here with the same arguments."""
+    L, HEADS, LAYERS = 8, 2, 4
+
+    def __init__(self, weights, dims, hidden_dim, n_types=0, normalize=True):
+        ProxyDiffuser.__init__(self, weights, dims, hidden_dim, n_types, normalize)
+        self.width = hidden_dim * (3 if self.grasp else 2)
+        pe = torch.zeros(5000, self.width)
+        position = torch.arange(0, 5000).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, self.width, 2) * -(math.log(10000.0) / self.width))
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        self.pe = pe.unsqueeze(0)
+        # the transformer is made of stock torch modules in the reference (nn.LayerNorm, nn.MultiheadAttention, nn.Linear): the same stock modules here,
+        # so that what a module call costs in Python -- 256 ln_pre calls per evaluation, MultiheadAttention's fast-path checks -- is in the baseline too
+        nn = torch.nn
+
+        def ln(name):
+            m = nn.LayerNorm(self.width)
+            m.weight, m.bias = nn.Parameter(self.W[name + '.weight'].detach().clone()), nn.Parameter(self.W[name + '.bias'].detach().clone())
+            return m.eval()
+
+        def lin(name, n_in, n_out):
+            m = nn.Linear(n_in, n_out)
+            m.weight, m.bias = nn.Parameter(self.W[name + '.weight'].detach().clone()), nn.Parameter(self.W[name + '.bias'].detach().clone())
+            return m.eval()
+        self.ln_pre, self.ln_post = ln('ln_pre'), ln('ln_post')
+        self.blocks = []
+        for l in range(self.LAYERS):
+            pre = 'transformer.resblocks.%d.' % l
+            attn = nn.MultiheadAttention(self.width, self.HEADS)
+            attn.in_proj_weight = nn.Parameter(self.W[pre + 'attn.in_proj_weight'].detach().clone())
+            attn.in_proj_bias = nn.Parameter(self.W[pre + 'attn.in_proj_bias'].detach().clone())
+            attn.out_proj.weight = nn.Parameter(self.W[pre + 'attn.out_proj.weight'].detach().clone())
+            attn.out_proj.bias = nn.Parameter(self.W[pre + 'attn.out_proj.bias'].detach().clone())
+            self.blocks.append(dict(ln_1=ln(pre + 'ln_1'), ln_2=ln(pre + 'ln_2'), attn=attn.eval(), c_fc=lin(pre + 'mlp.c_fc', self.width, 4 * self.width),
+                                    c_proj=lin(pre + 'mlp.c_proj', 4 * self.width, self.width), dropout=nn.Dropout(p=0.1).eval()))
+
+    def __call__(self, poses_in, batch, t, energy=False):
+        from einops import rearrange, repeat          # (the reference's own helpers: ~30 us of Python per call, 256 calls per evaluation -- part of its cost)
+        H, P, W = self.H, self.P, self.W
+        x = batch.x.clone()
+        geoms_emb = self._mlp2('geom_encoder', x[:, :self.dims[0][2]])
+        poses_emb = self._mlp2('pose_encoder', poses_in)
+        time_emb = self.time_mlp(t.unsqueeze(0).expand(geoms_emb.shape[0], *t.shape))[:, 0]
+        poses_emb = poses_emb + time_emb
+        obj_emb = torch.cat([geoms_emb, poses_emb], dim=-1)
+        if self.grasp:
+            obj_emb = torch.cat([self._mlp2('grasp_encoder', x[:, self.dims[1][1]:self.dims[1][2]]), obj_emb], dim=-1)
+        sequences, attn_masks, indices = [], [], []
+        for j in range(batch.batch.max().item() + 1):
+            seq = obj_emb[batch.batch == j]
+            pe = self.pe[:, :seq.shape[0], :]
+            if hasattr(batch, 'shuffled'):
+                pe = pe[:, batch.shuffled[batch.batch == j], :]
+            seq += rearrange(pe, 'b n c -> (b n) c')
+            xs = self.ln_pre(seq)
+            padding_len = self.L - xs.shape[0]
+            indices.append(xs.shape[0])
+            sequences.append(F.pad(xs, (0, 0, 0, padding_len), 'constant', 0))
+            attn_mask = torch.zeros(self.L, self.L)
+            attn_mask[:, -padding_len:] = True
+            attn_mask[-padding_len:, :] = True
+            attn_masks.append(attn_mask)
+        xs = torch.stack(sequences, dim=1)                                  # [8, B, width]
+        masks = torch.stack(attn_masks)
+        masks = repeat(masks, 'b l1 l2 -> (repeat b) l1 l2', repeat=self.HEADS)
+        weights = None
+        for blk in self.blocks:
+            y = blk['ln_1'](xs)
+            attn, attn_w = blk['attn'](y, y, y, attn_mask=masks)
+            weights = attn_w.unsqueeze(1) if weights is None else torch.cat([weights, attn_w.unsqueeze(1)], dim=1)
+            xs = xs + attn
+            h = blk['c_fc'](xs)
+            h = h * torch.sigmoid(1.702 * h)
+            h = blk['c_proj'](h)
+            xs = xs + blk['ln_2'](blk['dropout'](h))
+        xs = self.ln_post(xs)
+        xs = xs[:, :, -H:]
+        poses_out = torch.cat([xs[:indices[j], j] for j in range(len(indices))], dim=0)
+        poses_out = self._mlp2('pose_decoder', poses_out, last_act=False)
+        m = batch.mask.bool()
+        poses_out[m] = x[:, -P:][m]
+        return poses_out
+
+
 def cosine_schedule(T):
     steps = T + 1
     xs = np.linspace(0, steps, steps)
@@ -171,13 +263,13 @@ def sample(model, batch, T, S, noise_fn):
 
 
 def time_baseline(weights, dims, hidden_dim, n_types, batch, T=1000, S=10, n_timesteps=3, budget_s=25.0,
-                  thread_candidates=(8, 16, 32, 64), sampler='ULA'):
+                  thread_candidates=(8, 16, 32, 64), sampler='ULA', model_kind='Diffusion-CCSP'):
     """times full timesteps (1+S evaluations each) of the proxy on the host cores and extrapolates x T.
     PyTorch-CPU does not scale to every core of a large host on these small matrices (128 threads were
     4x slower than 8 on the GPU box), so one timestep is timed per candidate thread count first and the
     fastest setting is used -- the baseline is the best the CPU path does on this box.
     Returns dict(samples_per_s, sec_per_timestep, cores, sample)."""
-    model = ProxyDiffuser(weights, dims, hidden_dim, n_types)
+    model = (ProxyStructDiffuser if model_kind == 'StructDiffusion' else ProxyDiffuser)(weights, dims, hidden_dim, n_types)
     sch = cosine_schedule(T)
     g = torch.Generator().manual_seed(0)
     N, P = batch.x.shape[0], dims[-1][0]

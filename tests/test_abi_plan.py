@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 17
     for n in names:
         assert hasattr(L, n), n
-    assert L.ccsp_version() == 1000 * _lib.ABI_MAJOR + 0             # 1.0: include/ccsp.h CCSP_VERSION_MAJOR / _MINOR
+    assert L.ccsp_version() == 1000 * _lib.ABI_MAJOR + 1             # 1.1: include/ccsp.h CCSP_VERSION_MAJOR / _MINOR (round 6 added ccsp_chain_lanes, CCSP_K_EDGE_FB)
     assert 'ccsp_plan_fused_host' in declared_symbols(True) and 'ccsp_plan_fused_host' not in declared_symbols(False)
     if not _lib.EXPERIMENTS:
         assert not hasattr(L, 'ccsp_plan_fused_host')                # the product library carries none of the experiments
