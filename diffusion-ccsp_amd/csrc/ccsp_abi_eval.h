@@ -152,7 +152,11 @@ int ccsp_chain_run(ccsp_model* m, ccsp_graph* g, int32_t sampler, const ccsp_noi
     // below ~6000 edges the half-batch kernels are too small to overlap usefully (C2-shaped batches: 64 graphs / 5.1 k
     // edges 143 vs 132 samples/s with 1 vs 2 lanes, 96 graphs / 7.6 k edges 167 vs 188); CCSP_LANE_MIN_EDGES overrides
     const bool small = m->d.model_kind == CCSP_MODEL_STRUCT_DIFFUSION ? g->sd_M < m->lane_min_tokens : g->plan.E_act < m->lane_min_edges;
-    if (m->d.energy_wrapper || g->profile || small || g->N < 2 * want) want = 1;
+    // energy mode: MALA may run as TWO coupled lanes (MalaCouple, ccsp_chain.h); everything else that evaluates energies stays on one stream
+    const bool mala2 = m->d.energy_wrapper && sampler == CCSP_SAMPLER_MALA && m->mala_lanes == 2 && m->d.model_kind == CCSP_MODEL_DIFFUSION_CCSP &&
+                       m->d.hidden_dim == 256 && m->f16x2 && m->energy_hook == nullptr && m->rccl_comm == nullptr && g->margin_buf == nullptr;
+    if ((m->d.energy_wrapper && !mala2) || g->profile || small || g->N < 2 * want) want = 1;
+    if (mala2 && want > 2) want = 2;
     std::vector<Lane> lanes;
     if (want > 1) {
         if (ensure_children(m, g, want, s)) return 1;
@@ -177,7 +181,21 @@ int ccsp_chain_run(ccsp_model* m, ccsp_graph* g, int32_t sampler, const ccsp_noi
         lanes.push_back(Lane{g, s, 0});
     }
     g->lanes_last = (int)lanes.size();
+    MalaCouple couple;
+    const bool coupled = forked && m->d.energy_wrapper && lanes.size() == 2;
+    if (forked && m->d.energy_wrapper && !coupled) return fail("chain_run: an energy-mode chain runs as one lane or as two coupled MALA lanes");
+    if (coupled) {
+        for (int i = 0; i < 2; ++i) {
+            couple.recF[i].store(0); couple.recA[i].store(0);
+            couple.E_x[i] = nullptr; couple.hat_partial[i] = nullptr; couple.n_hat[i] = 0;
+        }
+        couple.failed.store(0);
+        if (!m->mala_ev[0])
+            for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreateWithFlags(&m->mala_ev[i], hipEventDisableTiming));
+        couple.evF[0] = m->mala_ev[0]; couple.evF[1] = m->mala_ev[1]; couple.evA[0] = m->mala_ev[2]; couple.evA[1] = m->mala_ev[3];
+    }
     for (size_t i = 0; i < lanes.size(); ++i) {
+        lanes[i].couple = coupled ? &couple : nullptr;
         lanes[i].idx = (int)i;
         lanes[i].relay_slots = relay ? 2 * m->ncu / (int)lanes.size() : 0;
     }
@@ -205,7 +223,7 @@ int ccsp_chain_run(ccsp_model* m, ccsp_graph* g, int32_t sampler, const ccsp_noi
                 if (stagger_us > 0 && i > 0) hipLaunchKernelGGL(k_delay, dim3(1), dim3(1), 0, lanes[i].s, (long long)stagger_us * 100 * (long long)i);
 #endif
                 rcs[i] = run(std::vector<Lane>{lanes[i]});
-                if (rcs[i]) errs[i] = g_err;
+                if (rcs[i]) { errs[i] = g_err; if (coupled) couple.failed.store(1); }       // (the other lane's hand-shake stops waiting)
             });
         for (auto& t : th) t.join();
         for (size_t i = 0; i < lanes.size(); ++i)
@@ -220,6 +238,9 @@ int ccsp_chain_run(ccsp_model* m, ccsp_graph* g, int32_t sampler, const ccsp_noi
         }
         g->evals = ev;
         g->kev_used = 0;
+        if (coupled && accept && rc == 0)
+            hipLaunchKernelGGL(k_accept_rates2, dim3(nblk(T, 256)), dim3(256), 0, s, T, lanes[0].g->acc_count, lanes[0].g->acc_denom, lanes[1].g->acc_count,
+                               lanes[1].g->acc_denom, accept);
     }
     HIP_TRY(hipEventRecord(g->ev1, s));
     if (relay) HIP_TRY(hipEventRecord(relay_tail, s));
@@ -298,7 +319,13 @@ int ccsp_chain_skipped(ccsp_graph* g, int64_t* evaluations_skipped) {
     if (!g->have_events) return fail("chain_skipped: no chain has run on this graph");
     HIP_TRY(hipEventSynchronize(g->ev1));
     int n = 0;
-    if (g->mala_changed) HIP_TRY(hipMemcpy(&n, g->mala_changed + 2, sizeof(int), hipMemcpyDeviceToHost));
+    if (g->lanes_last > 1) {                       // coupled MALA lanes: each lane skips on its own state
+        for (ccsp_graph* c : g->children) {
+            int k = 0;
+            if (c->mala_changed) HIP_TRY(hipMemcpy(&k, c->mala_changed + 2, sizeof(int), hipMemcpyDeviceToHost));
+            n += k;
+        }
+    } else if (g->mala_changed) HIP_TRY(hipMemcpy(&n, g->mala_changed + 2, sizeof(int), hipMemcpyDeviceToHost));
     *evaluations_skipped = n;
     return 0;
 }

@@ -346,6 +346,7 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
             if (d->energy_wrapper) {    // the backward GEMMs' weights: the same tensors transposed, the same exponents
                 if (const char* e = getenv("CCSP_ENERGY_BWD")) m->energy_bwd_h2 = strcmp(e, "bf16x3") != 0;
                 if (const char* e = getenv("CCSP_MALA_REUSE")) m->mala_reuse = atoi(e) != 0;
+                if (const char* e = getenv("CCSP_MALA_LANES")) m->mala_lanes = atoi(e) == 2 ? 2 : 1;
                 if (const char* e = getenv("CCSP_EDGE_FB")) { const int v = atoi(e); if (v >= 0 && v <= 2) m->edge_fb = v; }
                 if (const char* e = exp_env("CCSP_ENERGY_ROWSUM")) m->bwd_rowsum_fused = strcmp(e, "kernel") != 0;
                 if (const char* e = exp_env("CCSP_ENERGY_NODE")) m->node_energy_fused = strcmp(e, "split") != 0;
@@ -394,6 +395,7 @@ void ccsp_model_destroy(ccsp_model* m) {
         if (m->lane_stream_owned[i]) { (void)hipStreamSynchronize(m->lane_streams[i]); (void)hipStreamDestroy(m->lane_streams[i]); }
     }
     for (hipEvent_t e : m->lane_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : m->mala_ev) if (e) (void)hipEventDestroy(e);
     if (m->fork_event) (void)hipEventDestroy(m->fork_event);
     if (m->capture_stream) (void)hipStreamDestroy(m->capture_stream);
     for (void* p : m->allocs) (void)hipFree(p);

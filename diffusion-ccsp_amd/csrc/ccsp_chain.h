@@ -67,12 +67,33 @@ int relay_tail_get(hipEvent_t* out) {
 }
 
 // one concurrently running sub-batch of a chain
+// Two coupled MALA lanes (round 6; VERDICT r03-r05 "two MALA lanes with the pair {E(x), E(x_hat)} exchanged through events").  The reference's
+// accept test uses ONE scalar energy for the whole batch (ddpm.py:1026-1038), so two sub-batches on two streams are independent except at the
+// accept step, which needs both lanes' E(x) and E(x_hat).  Each lane's accept kernel reads the other lane's E(x) scalar and proposal-energy
+// partials straight from its buffers and adds lane 0's sum + lane 1's sum (both lanes the same order: the same decision inputs).  Ordering:
+//   evF[l]: recorded by lane l behind its forward pass at the proposal (its E(x), written by the gradient evaluation before, and its partials are
+//           final); the OTHER lane's accept kernel waits for it;
+//   evA[l]: recorded behind lane l's accept kernel (it has read the other lane's buffers); the other lane waits for it before the next kernel
+//           that rewrites them (its next gradient evaluation -- ancestral or Langevin).
+// An event must have been RECORDED (host call) before another thread's hipStreamWaitEvent can name that record, so the two enqueueing threads
+// shake hands through recF / recA (how many records each has made); a lane can never be a whole inner step ahead of the other, which is also
+// what makes two events per lane enough.  Nothing waits on the device for anything that is not already enqueued: no hang is possible.
+struct MalaCouple {
+    std::atomic<long> recF[2], recA[2];
+    std::atomic<int> failed;
+    hipEvent_t evF[2], evA[2];
+    const float* E_x[2];            // each lane's E(x) device scalar
+    const float* hat_partial[2];    // ... and proposal-energy partials (per workgroup of its forward decoder kernel)
+    int n_hat[2];
+};
+
 struct Lane {
     ccsp_graph* g;
     hipStream_t s;
     int node0;          // global index of the lane's first node (noise rows, output slices)
     int idx = 0;        // lane index (relay mode: which pair of pooled streams)
     int relay_slots = 0;   // relay mode: workgroup slots this lane may hold at once (0 = relay off), see relay_begin
+    MalaCouple* couple = nullptr;   // MALA on two coupled lanes
 };
 
 // Relay mode of one lane (Gate).  Safe only while EVERY workgroup of the lane's three kernels can be resident at once -- a workgroup that
@@ -196,6 +217,27 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
             if (sampler == CCSP_SAMPLER_MALA || sampler == CCSP_SAMPLER_HMC) { uc0 += (uint64_t)steps_at(m, sampler, t); g->h_denom[t] = N * steps_at(m, sampler, t); }
         }
         HIP_TRY(hipMemcpyAsync(g->acc_denom, g->h_denom.data(), (size_t)T * sizeof(int), hipMemcpyHostToDevice, s));
+        // coupled lanes (MalaCouple): this lane's side of the hand-shake
+        MalaCouple* cp = L.couple;
+        const int me = L.idx, other = 1 - L.idx;
+        const size_t N_total = NP_total / (size_t)P;
+        long kstep = 0;                                  // accept steps enqueued so far (both lanes count the same steps)
+        bool owe_wait = false;                           // the other lane's last accept kernel may still read this lane's E(x) / partials
+        auto spin = [&](std::atomic<long>& ctr, long want) -> int {
+            while (ctr.load(std::memory_order_acquire) < want) {
+                if (cp->failed.load(std::memory_order_relaxed)) return fail("chain_run: the other MALA lane failed");
+                std::this_thread::yield();
+            }
+            return 0;
+        };
+        auto before_rewrite = [&]() -> int {             // in front of every evaluation that follows an accept step
+            if (!cp || !owe_wait) return 0;
+            if (spin(cp->recA[other], kstep)) return 1;
+            HIP_TRY(hipStreamWaitEvent(s, cp->evA[other], 0));
+            owe_wait = false;
+            return 0;
+        };
+        if (cp) { cp->E_x[me] = g->Escal; cp->hat_partial[me] = g->partial; }
         for (int t = t_first; t >= t_last; --t) {
             // epsilon = dE/dposes (ComposedEBMDenoiseFn.forward); MALA re-evaluates E at the proposal
             // (energy_function, ddpm.py:285-289) -- the gradient pass already gave E(x)
@@ -209,6 +251,7 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
                 sched(a, t);
                 if (noise_for(L, call0[t], a.noise)) return 1;
                 bool tail_done = false;
+                if (before_rewrite()) return 1;
                 if (launch_eval_energy<H>(m, g, t, g->x, true, E_x, s, nullptr, nullptr, 0, &a, &tail_done)) return 1;
                 if (!tail_done) launch_node<H>(m, g, a, s);
             }
@@ -307,6 +350,7 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
                     a.changed = reuse ? g->mala_changed + (e & 1) : nullptr;
                 }
                 bool tail_done = false;
+                if (before_rewrite()) return 1;
                 if (launch_eval_energy<H>(m, g, t, g->x, true, E_xl, s, skip_flag, nullptr, 0, &a, &tail_done)) return 1;
                 if (!tail_done) launch_node<H>(m, g, a, s);                   // (MALA: x_hat, and its pose embedding)
                 if (sampler != CCSP_SAMPLER_MALA) continue;
@@ -329,21 +373,38 @@ int chain_run_impl(ccsp_model* m, const std::vector<Lane>& lanes, size_t NP_tota
                 b.changed = reuse ? g->mala_changed + (e & 1) : nullptr;
                 b.margin = margin_at(g, ucall0[t] + (uint64_t)(e - 1) - ucall0[t_first]);
                 if (fold_sum) { b.E_hat_partial = g->partial; b.n_hat_partial = g->n_part_last; }
+                if (cp) {                                // the other lane's energies: wait until its forward pass at the proposal is behind us
+                    cp->n_hat[me] = g->n_part_last;
+                    HIP_TRY(hipEventRecord(cp->evF[me], s));
+                    cp->recF[me].store(kstep + 1, std::memory_order_release);
+                    if (spin(cp->recF[other], kstep + 1)) return 1;
+                    HIP_TRY(hipStreamWaitEvent(s, cp->evF[other], 0));
+                    b.E_x2 = cp->E_x[other]; b.E_hat_partial2 = cp->hat_partial[other]; b.n_hat_partial2 = cp->n_hat[other];
+                    b.couple_second = me;
+                }
                 b.reset_mask = (e == S);
                 b.hist = e == S ? hist_at(L, T - t) : nullptr;
                 sched(b, t);
-                b.noise.mode = nz->mode; b.noise.seed = nz->seed; b.noise.row_offset = nz->row_offset;
+                // (uniform draws are indexed by the GLOBAL node row: a lane's rows start at node0)
+                b.noise.mode = nz->mode; b.noise.seed = nz->seed; b.noise.row_offset = nz->row_offset + (unsigned long long)L.node0;
                 const uint64_t uc = ucall0[t] + (uint64_t)(e - 1);
                 b.noise.ucall = (unsigned int)uc;
                 if (nz->mode == CCSP_NOISE_INJECTED) {
                     if (!nz->uniform || uc < nz->ucall_base || uc - nz->ucall_base >= nz->n_uniform)
                         return fail("chain_run: injected uniform stream exhausted at call %llu", (unsigned long long)uc);
-                    b.noise.uniform = nz->uniform + (size_t)(uc - nz->ucall_base) * N;
+                    b.noise.uniform = nz->uniform + (size_t)(uc - nz->ucall_base) * N_total + (size_t)L.node0;
                 }
                 launch_node<H>(m, g, b, s);
+                if (cp) {
+                    HIP_TRY(hipEventRecord(cp->evA[me], s));
+                    cp->recA[me].store(kstep + 1, std::memory_order_release);
+                    owe_wait = true;
+                }
+                ++kstep;
             }
         }
-        if (accept) hipLaunchKernelGGL(k_accept_rates, dim3(nblk(T, 256)), dim3(256), 0, s, T, g->acc_count, g->acc_denom, accept);
+        // (coupled lanes: the caller adds both lanes' counts -- ccsp_chain_run)
+        if (accept && !cp) hipLaunchKernelGGL(k_accept_rates, dim3(nblk(T, 256)), dim3(256), 0, s, T, g->acc_count, g->acc_denom, accept);
 #ifdef CCSP_EXPERIMENTS
     } else if (m->graph_mode && lanes.size() == 1 && lanes[0].g->N < 512 && m->bf16x3 && m->d.model_kind == CCSP_MODEL_DIFFUSION_CCSP &&
                !lanes[0].g->profile && lanes[0].g->plan.E_act > 0 && t_first >= t_last) {

@@ -810,6 +810,12 @@ __global__ __launch_bounds__(256) void k_node_energy_h2_update(EnergyNodeArgs a,
 }
 
 // acceptance counts -> mean acceptance rate per timestep
+// ... of a batch that ran as two coupled lanes: decisions accepted / decisions made over both
+__global__ void k_accept_rates2(int T, const int* __restrict__ c0, const int* __restrict__ d0, const int* __restrict__ c1, const int* __restrict__ d1,
+                                float* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < T) out[t] = d0[t] + d1[t] > 0 ? (float)(c0[t] + c1[t]) / (float)(d0[t] + d1[t]) : 0.0f;
+}
 __global__ void k_accept_rates(int T, const int* __restrict__ count, const int* __restrict__ denom, float* __restrict__ out) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < T) out[t] = denom[t] > 0 ? (float)count[t] / (float)denom[t] : 0.0f;

@@ -19,6 +19,7 @@
 #include <mutex>
 #include <string>
 #include <algorithm>
+#include <atomic>
 #include <thread>
 #include <dlfcn.h>
 #include <type_traits>

@@ -50,6 +50,10 @@ struct ccsp_model {
     float bwd_bound_c = 0.0f;         // 1.21 max|Wd2| max_n sum_j |Wd1[j, n]|: |g_z[k, s H + n]| <= bwd_bound_c sum_p |go[k, s, p]| (k_edge_bwd_h2<true>)
     int bwd_rowsum_fused = 1;         // (CCSP_ENERGY_ROWSUM=kernel turns it off) row sums of g_z inside the decoder backward, transpose GEMM on partial rows
     int bwd_generic_p = 0;            // (CCSP_ENERGY_BWD_P=generic) k_edge_bwd_h2 with the run-time pose_dim even where it is 4 (A/B runs)
+    int mala_lanes = 1;               // (CCSP_MALA_LANES=2 turns it on) MALA on batches of >= lane_min_edges active edges as two coupled lanes (MalaCouple, ccsp_chain.h).
+                                      // Built in round 6, correct (test_mala_two_coupled_lanes), and SLOWER in one call: C4 recomputing 164.5 -> 143.2 samples/s, with reuse
+                                      // 317.7 -> 237.6 (profiles/r06_ab_c4_mala_lanes.txt): two cross-stream event waits per inner step cost more than the kernel tails they overlap
+    hipEvent_t mala_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int edge_fb = 2;                  // (CCSP_EDGE_FB) energy mode's decoder: 2 = forward + backward in one kernel (k_edge_fb_h2, ccsp_edge_fb.h), 1 = the backward alone
                                       // on that kernel's 32-edge tiles (k_edge_bwd2_h2), 0 = round 4's k_edge_bwd_h2 on 64-edge blocks (four workgroups per block)
     int node_energy_fused = 1;        // (CCSP_ENERGY_NODE=split turns it off) k_node_energy_h2_update: the update that consumes the gradient in the same launch

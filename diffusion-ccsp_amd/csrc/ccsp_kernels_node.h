@@ -85,6 +85,12 @@ struct NodeArgs {
     const float* E_hat;
     const float* E_hat_partial;   // MALA accept: if non-null, E(x_hat) is the sum of these per-workgroup partials of the edge
     int n_hat_partial;            // kernel (same order as k_energy_sum) and E_hat is not read: one launch less per inner step
+    // two coupled MALA lanes (round 6, MalaCouple): the batch energies are lane 0's + lane 1's, added in THAT order by both lanes' accept kernels
+    // (the reference's energies are one scalar for the whole batch, ddpm.py:1026-1038).  E_x2 == nullptr: one lane
+    const float* E_x2;            // the OTHER lane's E(x)
+    const float* E_hat_partial2;  // ... and its proposal-energy partials
+    int n_hat_partial2;
+    int couple_second;            // 1: this lane is lane 1 (its own terms are the second summands)
     int* acc_count;         // MALA: accepted-node counter of this timestep
     int* changed;           // MALA reuse: reset by the propose step, += pose elements the accept step changed bitwise (or null)
     float* margin;          // MALA accept, debugging aid (ccsp_chain_margins): [N] log acceptance ratio - log u of this inner step, or null
@@ -170,6 +176,13 @@ __device__ __forceinline__ void node_body(NodeArgs a, const EncW w, const EncOut
             float v = 0.0f;
             for (int i = tid; i < a.n_hat_partial; i += 256) v += a.E_hat_partial[i];
             e_hat = block_sum_256(v, &smax[0][0]);
+            if (a.E_x2) {                                           // (uniform) coupled lanes: lane 0's sum + lane 1's sum
+                float v2 = 0.0f;
+                for (int i = tid; i < a.n_hat_partial2; i += 256) v2 += a.E_hat_partial2[i];
+                __syncthreads();                                    // (block_sum_256's scratch is read by every thread until here)
+                const float e2 = block_sum_256(v2, &smax[0][0]);
+                e_hat = a.couple_second ? e2 + e_hat : e_hat + e2;
+            }
         } else {
             e_hat = a.E_hat[0];
         }
@@ -229,7 +242,7 @@ __device__ __forceinline__ void node_body(NodeArgs a, const EncW w, const EncOut
                     const float dr = xc - mu, df = hc - mu;
                     const float t_rev = -(dr * dr) / (2.0f * var) - log_scale - lc;
                     const float t_fwd = -(df * df) / (2.0f * var) - log_scale - lc;
-                    const float ex0 = a.E_x[0];
+                    const float ex0 = a.E_x2 ? (a.couple_second ? a.E_x2[0] + a.E_x[0] : a.E_x[0] + a.E_x2[0]) : a.E_x[0];
                     float lrev = 0.0f, lfwd = 0.0f;
                     const int lane0 = (tid & 63) & ~7;
 #pragma unroll
