@@ -177,7 +177,7 @@ def _git_blob_hash(path):
 def pmc_traffic_file(config, symbols):
     """fabric-side bytes per launch of each kernel whose name starts with one of `symbols`, from the COMMITTED rocprofv3 --pmc
     summary of this round (profiles/r05_pmc_<config>.txt, else round 4's; made by tools/pmc_run.sh).  -> ({symbol: {kernel name, bytes}}, stamp)"""
-    path = next((q for q in (os.path.join(ROOT, 'profiles', '%s_pmc_%s.txt' % (r, config)) for r in ('r05', 'r04')) if os.path.isfile(q)), None)
+    path = next((q for q in (os.path.join(ROOT, 'profiles', '%s_pmc_%s.txt' % (r, config)) for r in ('r06', 'r05', 'r04')) if os.path.isfile(q)), None)
     if path is None:
         return {}, None
     cur, got = None, {}
