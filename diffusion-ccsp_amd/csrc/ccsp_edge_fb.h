@@ -136,6 +136,7 @@ __device__ __forceinline__ void edge_bwd_phase(unsigned char* __restrict__ smem,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[n][0][j][r] = 0.0f;
     __syncthreads();                                              // the planes are written, W2s has been read: the stage may take its place
+    CCSP_TRK(1, 4);
 #pragma unroll
     for (int it = 0; it < 2 * NCH; ++it) {
         store_b();
@@ -145,7 +146,9 @@ __device__ __forceinline__ void edge_bwd_phase(unsigned char* __restrict__ smem,
         h2_kstep<1>(As, FB_APL, Bst, 0, wm * 32, wn * 64, acc2[it >> 2]);
         h2_kstep<1>(As, FB_APL, Bst, 1, wm * 32, wn * 64, acc2[it >> 2]);
         __syncthreads();                                          // (the stage is rewritten next; after the last chunk: the planes are dead)
+        if (it == NCH - 1) CCSP_TRK(1, 5);
     }
+    CCSP_TRK(1, 6);
     // ---- epilogues: g_z = 2^-(e_row + wd_exp) acc x SiLU'(U[u0] + U[u1]), ordered partial-row sums, operand planes of the transpose GEMM ----
     float* Cs = reinterpret_cast<float*>(smem + FB_CS);
     int* bsb = reinterpret_cast<int*>(smem + FB_BSB);
@@ -188,6 +191,7 @@ __device__ __forceinline__ void edge_bwd_phase(unsigned char* __restrict__ smem,
             }
         if (tid < FB_CLD) Cs[64 * FB_CLD + tid] = 0.0f;            // the all-zero row that pads odd entry counts
         __syncthreads();
+        CCSP_TRK(1, 10 + 4 * n);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = lr + 32 * i;
@@ -203,6 +207,7 @@ __device__ __forceinline__ void edge_bwd_phase(unsigned char* __restrict__ smem,
         }
         if (lq == 0) Cs[lr * FB_CLD + 128] = bnd;
         __syncthreads();
+        CCSP_TRK(1, 11 + 4 * n);
         const int np = bsb[0];
         if (n == 0) {
             // exponents: one thread per partial row adds the bounds of its edges (ascending; the same for both passes)
@@ -220,6 +225,9 @@ __device__ __forceinline__ void edge_bwd_phase(unsigned char* __restrict__ smem,
             }
             __syncthreads();
         }
+        CCSP_TRK(1, 12 + 4 * n);
+        // (round 6, measured and dropped: two partial rows per trip with interleaved loads + four threads per exponent -- C4 recomputing 164.6 -> 161.4
+        //  same call: the phase is 12 k of the kernel's 70 k cycles in the trace, but the longer loop body costs more than the second chain hides)
         // sums: thread = (columns 4 cg .. + 3 and 64 + 4 cg .. + 3 of the pass, half hs, one of 8 row lanes); entries two at a time, ascending
         const int cg = tid & 15, hs = (tid >> 4) & 1, rl = tid >> 5;
         const char* Cb = reinterpret_cast<const char*>(Cs) + cg * 16;
@@ -258,7 +266,7 @@ __device__ __forceinline__ void edge_bwd_phase(unsigned char* __restrict__ smem,
             *reinterpret_cast<uint2*>(fa.bs.GZPH + fa.bs.plane + o + 64) = make_uint2(p2[4] | ((unsigned)p2[5] << 16), p2[6] | ((unsigned)p2[7] << 16));
 #endif
         }
-        if (n == 0) __syncthreads();                              // (the second pass rewrites the tile)
+        if (n == 0) { __syncthreads(); CCSP_TRK(1, 7); }          // (the second pass rewrites the tile)
     }
 }
 
@@ -315,6 +323,8 @@ __global__ __launch_bounds__(256, 3) void k_edge_fb_h2(int E_act, int P_rt, cons
                                                        const float* __restrict__ bd1, const float* __restrict__ Wd2, const float* __restrict__ bd2,
                                                        const int* __restrict__ ent_pos, float* __restrict__ O, EdgeEnergyArgs en, EdgeFbArgs fa) {
     if (en.skip && *en.skip == 0) return;                          // (uniform) MALA reuse
+    CCSP_TRK(1, 0);
+    CCSP_TRK_RT(1, 30);
     constexpr int H = 256, BN = 128, NCH = H / H2_BK;
     constexpr int ME = FB_EDGES, ROWS = 2 * ME, NPASS = ROWS / 32;
     constexpr int APL = ROWS * H2_BK, STAGE = 2 * APL + 2 * H2_BPL;
@@ -423,6 +433,7 @@ __global__ __launch_bounds__(256, 3) void k_edge_fb_h2(int E_act, int P_rt, cons
     gload_b(1);
     gload_a(2, 0);
     __syncthreads();
+    CCSP_TRK(1, 1);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const unsigned short* st = smem + (c & 1) * STAGE;
@@ -435,6 +446,7 @@ __global__ __launch_bounds__(256, 3) void k_edge_fb_h2(int E_act, int P_rt, cons
         if (c + 3 < NCH) gload_a(c + 3, nx);
         __syncthreads();
     }
+    CCSP_TRK(1, 2);
     // forward epilogue (k_edge_h2<true, 1, 0>): q stays in registers, SiLU(q) -> S1, layer 2, d = o - pose, energy partial, -2 d to the CSR slot
     float* S1 = reinterpret_cast<float*>(smem);
     float* W2s = S1 + 64 * S1_LD;
@@ -484,8 +496,8 @@ __global__ __launch_bounds__(256, 3) void k_edge_fb_h2(int E_act, int P_rt, cons
         if (tid == 0) en.partial[blockIdx.x] = tot;
     }
     __syncthreads();
-    int k_lr = e0 + lr;
-    k_lr = k_lr < E_act ? k_lr : E_act - 1;
+    CCSP_TRK(1, 3);
     edge_bwd_phase<PP>(smem_b, qv, W2s, P_rt, wg, r0v[0], r1v[0], U, wd_exp, fa);
-    (void)k_lr;
+    CCSP_TRK(1, 9);
+    CCSP_TRK_RT(1, 31);
 }
