@@ -21,8 +21,10 @@
  *    chain is 33 000 launches per lane: one thread alternating between streams is launch-bound).  The call returns when both
  *    have enqueued everything, i.e. it blocks for the enqueue time but not for the chain.  Host cost measured on an MI355X
  *    box (profiles/r03_findings.md): pinned to two cores (`taskset -c 0-1`) the C2 chain runs at the unpinned rate; with one
- *    lane (CCSP_LANES=1: no threads) pinned to ONE core likewise.  Energy mode, the transformer baseline and profiled runs
- *    use the caller's stream only.  The lane streams are shared by every model of the process (one pool per device): chains of DIFFERENT
+ *    lane (CCSP_LANES=1: no threads) pinned to ONE core likewise.  Round 6 measured what a rank costs its host: 2.67 busy cores with two
+ *    lanes, 1.9 with one (profiles/r06_host_budget.txt; bench.py budgets that for N ranks).  Energy mode and profiled runs use the
+ *    caller's stream only (MALA can run as two coupled lanes, CCSP_MALA_LANES=2: measured slower, off by default); the transformer
+ *    baseline is cut into lanes from 1024 token rows on.  The lane streams are shared by every model of the process (one pool per device): chains of DIFFERENT
  *    models -- or of one model enqueued from different caller streams -- serialise per lane on them, and their fork / join events couple the
  *    caller streams involved (each waits for the other's lane work in front of its own).  ccsp_model_destroy waits for the destroyed model's
  *    own last chains (its join events), not for other models' work on the shared streams;
