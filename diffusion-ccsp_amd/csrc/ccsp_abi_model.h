@@ -90,7 +90,7 @@ int ccsp_model_create(const ccsp_model_desc* d, const float* const* params, void
     m->lane_min_tokens = 1024;
     if (const char* e = getenv("CCSP_LANE_MIN_TOKENS")) m->lane_min_tokens = atoi(e);
     if (const char* e = exp_env("CCSP_SD_PIPE")) m->sd_pipe = atoi(e) != 0;
-    if (const char* e = exp_env("CCSP_SD_TILE")) m->sd_tile = !strcmp(e, "narrow") ? 0 : (!strcmp(e, "wide") ? 1 : -1);
+    if (const char* e = exp_env("CCSP_SD_TILE")) m->sd_tile = !strcmp(e, "narrow") ? 0 : (!strcmp(e, "wide") ? 1 : (!strcmp(e, "wide8") ? 2 : -1));
     if (const char* e = exp_env("CCSP_RELAY")) m->relay = atoi(e);
     if (const char* e = getenv("CCSP_LANES")) { const int v = atoi(e); if (v >= 1 && v <= 8) m->lanes = v; }
     // CCSP_MMA: f16x2 (default at hidden_dim 256: two-term fp16 operands, three MFMA products per fp32 product),

@@ -34,11 +34,12 @@ int sd_gemm_h2(const ccsp_model* m, int M, int K, int N, const float* A, const u
     const int wide_env = m->sd_tile;              // (CCSP_SD_TILE=narrow | wide at model creation; -1: the rule below)
     // (chosen from K, N and a row count that a lane of a split batch always has -- lanes exist from 1024 token rows on, 512 per lane: the same batch
     //  run as one lane or as two takes the same kernels and adds the same K slices in the same order, test_struct_diffusion_lanes_are_bitwise_identical)
-    if (N % 128 == 0 && K % 64 == 0 && M >= 384 && wide_env == 1) {        // (opt-in: measured slower than the 64-row tiles, ccsp_struct.h)
+    if (N % 128 == 0 && K % 64 == 0 && M >= 384 && wide_env >= 1) {        // (opt-in: measured slower than the 64-row tiles, ccsp_struct.h; 2 = the eight-wave form)
         int ksw = 1;
         if (may_split && EPI == SD_EPI_BIAS && cmax == nullptr && K % (64 * SD_KSPLIT) == 0 && K >= 4 * N) ksw = SD_KSPLIT;
         if ((long)(N / 128) * ksw >= 12) {          // (12+ column tiles x K slices: in_proj, c_fc, c_proj; out_proj's four stay narrow)
-            if (m->sd_pipe) hipLaunchKernelGGL((k_sd_gemm_h2w<EPI, true>), dim3(nblk(M, 128) * (N / 128), ksw), dim3(256), 0, s, M, K, N, A, amax, WH, (size_t)N * K, w_exp, b, Cm, cmax);
+            if (m->sd_tile == 2) hipLaunchKernelGGL((k_sd_gemm_h2x<EPI>), dim3(nblk(M, 128) * (N / 128), ksw), dim3(512), 0, s, M, K, N, A, amax, WH, (size_t)N * K, w_exp, b, Cm, cmax);
+            else if (m->sd_pipe) hipLaunchKernelGGL((k_sd_gemm_h2w<EPI, true>), dim3(nblk(M, 128) * (N / 128), ksw), dim3(256), 0, s, M, K, N, A, amax, WH, (size_t)N * K, w_exp, b, Cm, cmax);
             else hipLaunchKernelGGL((k_sd_gemm_h2w<EPI, false>), dim3(nblk(M, 128) * (N / 128), ksw), dim3(256), 0, s, M, K, N, A, amax, WH, (size_t)N * K, w_exp, b, Cm, cmax);
             return ksw;
         }

@@ -666,6 +666,167 @@ __global__ __launch_bounds__(256, 2) void k_sd_gemm_h2w(int M, int K, int N, con
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_sd_gemm_h2x<EPI> (round 6): 128 x 128 tiles on EIGHT waves (512 threads, 4 x 2, 32 x 64 per wave).  k_sd_gemm_h2w showed that a 128-wide tile with
+// one wave per SIMD cannot overlap its own staging with its own MFMAs; here a workgroup brings two waves per SIMD of its own, every thread stages
+// half as much (two A rows, two weight pieces per chunk: 4 requests per wave for a quarter of a 128 x 128 x 32 chunk), and the tile still moves half
+// the operand bytes per product of the 64-wide kernel.  Same split, scaling and product order per accumulator as k_sd_gemm_h2 (bitwise k_sd_gemm_h2w's
+// results).  MEASURED (same call, CCSP_SD_TILE=wide8): 57.0 samples/s against 61.4 with the 64-row tiles -- like k_sd_gemm_h2w with PIPE.  Three
+// organisations of the 128-wide tile end at the same place: what a chunk costs is the chain request -> wait -> split -> store -> barrier -> fragment
+// read -> multiply, and many small co-resident workgroups hide it better than few large ones.  Experiments build.
+// K % 64 == 0, N % 128 == 0; M arbitrary (rows clamped).
+// ------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void k_sd_gemm_h2x(int M, int K, int N, const float* __restrict__ A, const unsigned int* __restrict__ amax,
+                                                        const unsigned short* __restrict__ WH, size_t w_plane, int w_exp,
+                                                        const float* __restrict__ bias, float* __restrict__ Cm, unsigned int* __restrict__ cmax) {
+    constexpr int TM = 128, TN = 128, NJ = 2, PD = 2, NW = 8;
+    constexpr int APL = TM * H2_BK, BPL = TN * H2_BK, STAGE = 2 * APL + 2 * BPL;
+    constexpr int CW_LD = 32 * NJ + 4, CW_SZ = 32 * CW_LD;        // wave-private epilogue tile [32][CW_LD] floats
+    constexpr int SMEM_US = 2 * STAGE * 2 > NW * CW_SZ * 4 ? 2 * STAGE : NW * CW_SZ * 2;
+    __shared__ __attribute__((aligned(16))) unsigned short smem[SMEM_US + 2 * TM];
+    int* sE = reinterpret_cast<int*>(smem + SMEM_US);
+    (void)w_plane;
+    const int nct = N / TN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int row0 = (bid / nct) * TM, col0 = (bid % nct) * TN;
+    const int nrows = M - row0 < TM ? M - row0 : TM;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;                      // rows 32 wm .. + 31, columns 64 wn .. + 63
+    const int Ks = K / (int)gridDim.y, k_first = (int)blockIdx.y * Ks;
+    Cm += (size_t)blockIdx.y * M * N;
+    const int lr = tid >> 3, lq = tid & 7;                        // A producer: rows lr, lr + 64, fp32 columns 4 lq .. + 3 of the chunk
+    const float* a_ptr[2];
+    const unsigned int* a_mx[2];
+    int a_exp[2], a_st[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int r = lr + 64 * i;
+        r = r < nrows ? r : nrows - 1;
+        a_ptr[i] = A + (size_t)(row0 + r) * K + k_first + lq * 4;
+        a_mx[i] = amax + row0 + r;
+        a_st[i] = h2_off(lr + 64 * i, lq >> 1) + (lq & 1) * 4;
+    }
+    const int brow = tid >> 2, bq = tid & 3;                      // B copy: row brow, piece bq, both planes
+    const unsigned short* b_ptr = WH + (size_t)(col0 + brow) * (2 * K) + 2 * k_first + bq * 8;
+    const int b_st = h2_off(brow, bq);
+    h2_f4 ra[PD][2];
+    h2_f4 rb[PD][2];
+    constexpr int NLD = 4;
+    const float* const a_dummy = A + (size_t)row0 * K + k_first;
+    const unsigned short* const b_dummy = WH + (size_t)col0 * (2 * K) + 2 * k_first;
+    auto gload = [&](int c, int set) {                            // (no branch around a load or a wait: see k_sd_gemm_h2)
+        const bool real = c < Ks / H2_BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) h2_ld16(ra[set][i], real ? a_ptr[i] + c * H2_BK : a_dummy);
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            h2_ld16(rb[set][p], reinterpret_cast<const float*>(real ? b_ptr + (size_t)p * H2_BK + c * (2 * H2_BK) : b_dummy));
+    };
+#define CCSP_SDX_GWAIT(set, NN) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ra[set][0]), "+v"(ra[set][1]), "+v"(rb[set][0]), "+v"(rb[set][1]) : "n"(NN) : "memory")
+    auto lstore = [&](int stage, int set) {
+        unsigned short* As = smem + stage * STAGE;
+        unsigned short* Bs = As + 2 * APL;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float h[4] = {ra[set][i][0], ra[set][i][1], ra[set][i][2], ra[set][i][3]};
+            unsigned short p1[4], p2[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split2h(ldexpf(h[e], a_exp[i]), p1[e], p2[e]);
+            unsigned short* d = As + a_st[i];
+            *reinterpret_cast<uint2*>(d) = make_uint2(p1[0] | ((unsigned)p1[1] << 16), p1[2] | ((unsigned)p1[3] << 16));
+            *reinterpret_cast<uint2*>(d + APL) = make_uint2(p2[0] | ((unsigned)p2[1] << 16), p2[2] | ((unsigned)p2[3] << 16));
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) *reinterpret_cast<h2_f4*>(Bs + p * BPL + b_st) = rb[set][p];
+    };
+    floatx16 acc[1][NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.0f;
+    const int nch = Ks / H2_BK;                                   // (even: K % 64 == 0)
+    gload(0, 0);
+    gload(1, 1);
+    {
+        unsigned int mx[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) asm volatile("global_load_dword %0, %1, off" : "=v"(mx[i]) : "v"(a_mx[i]) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(mx[0]), "+v"(mx[1]) :: "memory");
+        CCSP_SDX_GWAIT(0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a_exp[i] = h2_scale_exp(__uint_as_float(mx[i]));
+    }
+    lstore(0, 0);
+    gload(2, 0);
+    if (lq == 0) { sE[lr] = a_exp[0]; sE[lr + 64] = a_exp[1]; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    for (int c0 = 0; c0 < nch; c0 += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const unsigned short* st = smem + (u & 1) * STAGE;
+            h2_kstep<1>(st, APL, st + 2 * APL, 0, wm * 32, wn * 64, acc);
+            h2_kstep<1>(st, APL, st + 2 * APL, 1, wm * 32, wn * 64, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            if (u == 0) CCSP_SDX_GWAIT(1, NLD); else CCSP_SDX_GWAIT(0, NLD);
+            lstore((u + 1) & 1, (u + 1) & 1);
+            gload(c0 + u + 3, (u + 1) & 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (not __syncthreads(): its fence is a vmcnt(0) that drains the prefetch)
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    CCSP_SDX_GWAIT(0, 0);
+    CCSP_SDX_GWAIT(1, 0);
+#undef CCSP_SDX_GWAIT
+    // epilogue: the stages are free (every wave is past the last barrier); one wave-private tile per wave
+    float* Cw = reinterpret_cast<float*>(smem) + wave * CW_SZ;
+    constexpr int LPR = 8 * NJ;
+    const int er = lane / LPR, eq = lane % LPR;
+    const int colw = col0 + wn * 32 * NJ;
+    float4 bv = *reinterpret_cast<const float4*>(bias + colw + 4 * eq);
+    if (blockIdx.y != 0) bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int RPP = 64 / LPR;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            Cw[rr * CW_LD + j * 32 + (lane & 31)] = acc[0][j][r];
+        }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int st = 0; st < 32 / RPP; ++st) {
+        const int trow = wm * 32 + er + RPP * st;
+        const int e = -(sE[trow] + w_exp);
+        const bool live = trow < nrows;
+        float* dst = Cm + (size_t)(row0 + (live ? trow : 0)) * N + colw + 4 * eq;
+        const float4 v = *reinterpret_cast<const float4*>(Cw + (er + RPP * st) * CW_LD + 4 * eq);
+        float o[4] = {ldexpf(v.x, e) + bv.x, ldexpf(v.y, e) + bv.y, ldexpf(v.z, e) + bv.z, ldexpf(v.w, e) + bv.w};
+        if (EPI == SD_EPI_RESID) {
+            const float4 x = *reinterpret_cast<const float4*>(dst);
+            o[0] += x.x; o[1] += x.y; o[2] += x.z; o[3] += x.w;
+        }
+        if (EPI == SD_EPI_QGELU) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = o[q] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.44269504088896341f * o[q]));
+        }
+        if (live) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        if (cmax) {
+            unsigned int b = 0u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const unsigned int ob = __float_as_uint(o[q]) & 0x7fffffffu; b = b > ob ? b : ob; }
+            unsigned int t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)b, 0xB1, 0xF, 0xF, true); b = b > t ? b : t;
+            t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)b, 0x4E, 0xF, 0xF, true); b = b > t ? b : t;
+            t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)b, 0x141, 0xF, 0xF, true); b = b > t ? b : t;
+            t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)b, 0x140, 0xF, 0xF, true); b = b > t ? b : t;
+            if (eq == 0 && live) atomicMax(cmax + row0 + trow, b);
+        }
+    }
+}
+
 #endif  // CCSP_EXPERIMENTS
 
 // token rows: [grasp_emb] geoms_emb (poses_emb + time_emb) + pe[position] -> ln_pre; padding rows are zero

@@ -301,7 +301,7 @@ def test_struct_diffusion_wide_tiles_vs_oracle(device, monkeypatch):
     poses = [(rng.standard_normal((b.x.shape[0], 4)) * 0.7).astype(np.float32) for _ in range(2)]
     want = [og.denoise(p, t) for p, t in zip(poses, (3, 700))]
     outs = {}
-    for tile, pipe in (('wide', '1'), ('wide', '0'), ('narrow', '1')):
+    for tile, pipe in (('wide', '1'), ('wide', '0'), ('narrow', '1'), ('wide8', '1')):       # (wide8: the same tiles on eight waves, k_sd_gemm_h2x)
         monkeypatch.setenv('CCSP_SD_TILE', tile)
         monkeypatch.setenv('CCSP_SD_PIPE', pipe)          # (the staging of the next chunk between the MFMA pairs, or behind them: same products, same order)
         den, _ = hip_model(device, 'qualitative', 256, SD256_W, model='StructDiffusion')
@@ -310,3 +310,4 @@ def test_struct_diffusion_wide_tiles_vs_oracle(device, monkeypatch):
             assert rel_err(got, w) < 2e-5, (tile, pipe)
     assert np.array_equal(np.stack(outs['wide', '1']), np.stack(outs['wide', '0']))
     assert rel_err(np.stack(outs['wide', '1']), np.stack(outs['narrow', '1'])) < 1e-5
+    assert np.array_equal(np.stack(outs['wide8', '1']), np.stack(outs['wide', '1']))          # same products in the same order per accumulator
