@@ -424,8 +424,8 @@ def sd_main(args):
             us = 1e3 * ev[1]
             rec['roofline'] = {'bound': 'mfma', 'achieved': prods * flops_eval / (us * 1e-6) / 1e12, 'peak': PEAKS[pipe], 'unit': 'TFLOP/s',
                                'frac': prods * flops_eval / (us * 1e-6) / 1e12 / PEAKS[pipe], 'traffic': None,
-                               'kernel': 'one whole evaluation (30 launches: embed, 4 x [ln_1, in_proj, attention, out_proj, c_fc, c_proj, ln_2], decode); '
-                                         'per-kernel durations: profiles/r04_kernel_stats_sd.csv',
+                               'kernel': 'one whole evaluation (26 kernel launches: embed + ln_1, 4 x [in_proj, attention, out_proj, c_fc, c_proj, ln_2 + next ln_1], ln_2 + decode, node update); '
+                                         'per-kernel durations: profiles/r06_kernel_stats_sd.csv',
                                'us_per_evaluation': us, 'calls_timed': ev[0], 'executed_flops_fp32_equiv_per_evaluation': flops_eval,
                                'products_per_fp32_product': prods, 'pipe': pipe,
                                'frac_fp32_equiv': flops_eval / (us * 1e-6) / 1e12 / PEAKS['f32'],

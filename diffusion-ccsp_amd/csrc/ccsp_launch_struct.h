@@ -78,7 +78,7 @@ int launch_eval_sd(ccsp_model* m, ccsp_graph* g, int t, hipStream_t s) {
     prof_mark(g, s, CCSP_K_SD_EVAL);
     unsigned int* const nomax = nullptr;
     unsigned int *mY = g->sdMax, *mA = g->sdMax + M, *mX = g->sdMax + 2 * (size_t)M, *mF = g->sdMax + 3 * (size_t)M;
-    // (f16x2 path: ln_1 of the first block runs in the embedding kernel, the last block's ln_2 in the decoder kernel: 28 launches per evaluation, 30 in round 4)
+    // (f16x2 path: ln_1 of the first block runs in the embedding kernel, the last block's ln_2 in the decoder kernel: 26 kernel launches per evaluation, 28 in round 4)
     static const bool sd_fuse_off = getenv("CCSP_SD_FUSE") && atoi(getenv("CCSP_SD_FUSE")) == 0;
     const bool fuse_ends = m->sd_h2 && !sd_fuse_off;
 #define CCSP_SD_EMBED(NVV)                                                                                                                           \
