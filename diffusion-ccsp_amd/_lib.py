@@ -208,6 +208,8 @@ def lib():
     if EXPERIMENTS:
         L.ccsp_plan_fused_host.argtypes = [i32, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp]
     L.ccsp_plan_bwdsum_host.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    if ver % 1000 >= 1:
+        L.ccsp_plan_bwdsum_blocks_host.argtypes = [i32, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
     _lib = L
     return L
 
@@ -266,19 +268,24 @@ def plan_fused_host(n_nodes, n_types, edge_index, edge_attr, rows_per_slot=28, m
     return dict(n_tiles=nt, tiles=tiles[:nt].copy(), rows=rows[:nt].copy(), e_lu=e_lu[:e_act].copy())
 
 
-def plan_bwdsum_host(n_nodes, n_types, edge_index, edge_attr):
-    """host-only partial rows of the energy backward (include/ccsp.h ccsp_plan_bwdsum_host); numpy in, dict out"""
+def plan_bwdsum_host(n_nodes, n_types, edge_index, edge_attr, block_edges=64, max_parts=128):
+    """host-only partial rows of the energy backward (include/ccsp.h ccsp_plan_bwdsum_host / ccsp_plan_bwdsum_blocks_host: (64, 128) = round 4's
+    decoder backward, (32, 64) = round 6's fused decoder kernel); numpy in, dict out"""
     import numpy as np
     L = lib()
     ei = np.ascontiguousarray(edge_index, dtype=np.int64).reshape(2, -1)
     ea = np.ascontiguousarray(edge_attr, dtype=np.float32)
     E = ei.shape[1]
     nb, npart = C.c_int32(), C.c_int32()
-    blocks = np.zeros((E // 64 + 1, 513), dtype=np.int32)
+    blocks = np.zeros((E // block_edges + 1, 1 + 4 * max_parts), dtype=np.int32)
     prow = np.zeros(max(2 * E, 1), dtype=np.int32)
     nptr = np.zeros(n_nodes + 1, dtype=np.int32)
     nidx = np.zeros(max(2 * E, 1), dtype=np.int32)
-    check(L.ccsp_plan_bwdsum_host(n_nodes, E, n_types, ei.ctypes.data, ea.ctypes.data, C.byref(nb), C.byref(npart), blocks.ctypes.data,
-                                  prow.ctypes.data, nptr.ctypes.data, nidx.ctypes.data))
+    if (block_edges, max_parts) == (64, 128):
+        check(L.ccsp_plan_bwdsum_host(n_nodes, E, n_types, ei.ctypes.data, ea.ctypes.data, C.byref(nb), C.byref(npart), blocks.ctypes.data,
+                                      prow.ctypes.data, nptr.ctypes.data, nidx.ctypes.data))
+    else:
+        check(L.ccsp_plan_bwdsum_blocks_host(n_nodes, E, n_types, ei.ctypes.data, ea.ctypes.data, block_edges, max_parts, C.byref(nb), C.byref(npart),
+                                             blocks.ctypes.data, prow.ctypes.data, nptr.ctypes.data, nidx.ctypes.data))
     return dict(n_blocks=nb.value, NP=npart.value, blocks=blocks[:nb.value].copy(), prow_urow=prow[:npart.value].copy(), nrow_ptr=nptr,
                 nrow_idx=nidx[:npart.value].copy())

@@ -251,11 +251,18 @@ int ccsp_plan_fused_host(int32_t N, int32_t E, int32_t C, const int64_t* edge_in
 
 int ccsp_plan_bwdsum_host(int32_t N, int32_t E, int32_t C, const int64_t* edge_index, const float* edge_attr, int32_t* n_blocks, int32_t* n_partial,
                           int32_t* blocks, int32_t* prow_urow, int32_t* nrow_ptr, int32_t* nrow_idx) {
+    return ccsp_plan_bwdsum_blocks_host(N, E, C, edge_index, edge_attr, ccsp::BS_EDGES, 128, n_blocks, n_partial, blocks, prow_urow, nrow_ptr, nrow_idx);
+}
+
+int ccsp_plan_bwdsum_blocks_host(int32_t N, int32_t E, int32_t C, const int64_t* edge_index, const float* edge_attr, int32_t block_edges, int32_t max_parts,
+                                 int32_t* n_blocks, int32_t* n_partial, int32_t* blocks, int32_t* prow_urow, int32_t* nrow_ptr, int32_t* nrow_idx) {
+    if (!n_blocks || !n_partial) return fail("plan_bwdsum_blocks_host: null count");
+    if (block_edges < 1 || block_edges > ccsp::BS_EDGES || max_parts < 2 * block_edges) return fail("plan_bwdsum_blocks_host: block_edges %d (1 .. %d), max_parts %d (>= 2 block_edges)", block_edges, ccsp::BS_EDGES, max_parts);
     ccsp::Plan p;
     const char* perr = "";
     if (ccsp::build_plan(N, E, C, TILE_M, edge_index, edge_attr, p, &perr)) return fail("plan_bwdsum_host: %s", perr);
     ccsp::BwdSumPlan b;
-    ccsp::build_bwdsum_plan(p, TILE_M, b);
+    ccsp::build_bwdsum_plan(p, TILE_M, b, block_edges, max_parts);
     *n_blocks = b.n_blocks;
     *n_partial = b.NP;
     if (blocks && !b.blocks.empty()) memcpy(blocks, b.blocks.data(), b.blocks.size() * sizeof(int32_t));

@@ -46,7 +46,7 @@ extern "C" {
  * built against another MAJOR must refuse the library: diffusion-ccsp_amd/_lib.py does, INTEGRATION.md section 2 shows the check); MINOR
  * counts additions.  1.0 = round 4's 0.7 with ccsp_compose_chain_run's `accept` argument (added in round 4 WITHOUT a bump: the reason for
  * the rule) + ccsp_rccl_comm_count / ccsp_rccl_allreduce_sum_f32 + ccsp_chain_margins; ccsp_plan_fused_host moved behind CCSP_EXPERIMENTS.
- * 1.1 (round 6) adds ccsp_chain_lanes. */
+ * 1.1 (round 6) adds ccsp_chain_lanes, ccsp_plan_bwdsum_blocks_host and the kernel selector CCSP_K_EDGE_FB. */
 #define CCSP_VERSION_MAJOR 1
 #define CCSP_VERSION_MINOR 1
 #define CCSP_MAX_SAMPLES_PER_STEP 100000
@@ -323,6 +323,14 @@ int ccsp_plan_fused_host(int32_t N, int32_t E, int32_t C, const int64_t* edge_in
  * Caller-sized HOST arrays (blocks [513 (E / 64 + 1)], prow_urow and nrow_idx [2 E], nrow_ptr [N + 1]); any of them may be NULL. */
 int ccsp_plan_bwdsum_host(int32_t N, int32_t E, int32_t C, const int64_t* edge_index, const float* edge_attr, int32_t* n_blocks,
                           int32_t* n_partial, int32_t* blocks, int32_t* prow_urow, int32_t* nrow_ptr, int32_t* nrow_idx);
+/* (1.1) The same for blocks of `block_edges` sorted edges with at most `max_parts` partial rows each (max_parts >= 2 block_edges): what the fused
+ * decoder kernel of round 6 runs on is (32, 64) -- its tile is 32 edges x both halves.  blocks [n_blocks][1 + 4 max_parts]: [0] = partial rows,
+ * [1 + p] = global partial row, [1 + max_parts + p] = first << 16 | end of p's pairs, [1 + 2 max_parts + 2 q], [.. + 1] = pair q (528 x block-local
+ * edge; padding entry 528 x 64 in every geometry).  (64, 128) is ccsp_plan_bwdsum_host.  Caller-sized host arrays: blocks
+ * [(1 + 4 max_parts) (E / block_edges + 1)], the rest as above. */
+int ccsp_plan_bwdsum_blocks_host(int32_t N, int32_t E, int32_t C, const int64_t* edge_index, const float* edge_attr, int32_t block_edges,
+                                 int32_t max_parts, int32_t* n_blocks, int32_t* n_partial, int32_t* blocks, int32_t* prow_urow, int32_t* nrow_ptr,
+                                 int32_t* nrow_idx);
 
 #ifdef __cplusplus
 }

@@ -114,9 +114,10 @@ def test_plan_host_matches_numpy(case):
 
 
 @pytest.mark.parametrize('case', ['qualitative', 'triangular', 'robot', 'ragged', 'shuffled'])
-def test_bwdsum_plan_invariants(case):
+@pytest.mark.parametrize('geom', [(64, 128), (32, 64)])
+def test_bwdsum_plan_invariants(case, geom):
     """the partial rows of the energy backward (ccsp_plan_bwdsum_host): every (edge, slot) reference appears in exactly one partial row --
-    that of (its block of 64 sorted edges, its U row) --, a partial row's edges ascend, partial rows are numbered by (U row, block)
+    that of (its block of 64 sorted edges, its U row; round 6's fused decoder kernel: blocks of 32, ccsp_plan_bwdsum_blocks_host) --, a partial row's edges ascend, partial rows are numbered by (U row, block)
     ascending, every node lists exactly the partial rows of its U rows (ascending), and summing the partial rows of a U row is the
     ordered row sum of k_rowsum_h2"""
     if case == 'qualitative':
@@ -135,9 +136,12 @@ def test_bwdsum_plan_invariants(case):
             b.edge_attr = b.edge_attr[perm]
     N = b.x.shape[0]
     pl = _lib.plan_host(N, C, b.edge_index, b.edge_attr)
-    f = _lib.plan_bwdsum_host(N, C, b.edge_index, b.edge_attr)
+    BE, MP = geom
+    f = _lib.plan_bwdsum_host(N, C, b.edge_index, b.edge_attr, BE, MP)
     E, R, NP = pl['E_act'], pl['R'], f['NP']
-    assert f['n_blocks'] == (E + 63) // 64 and R <= NP <= 2 * E
+    assert f['n_blocks'] == (E + BE - 1) // BE and R <= NP <= 2 * E
+    if geom == (32, 64):                                        # smaller blocks: at least as many partial rows
+        assert NP >= _lib.plan_bwdsum_host(N, C, b.edge_index, b.edge_attr)['NP']
     g = np.random.RandomState(1).randn(E, 3)                    # a stand-in for g_z
     want = np.zeros((R, 3))
     for k in range(E):
@@ -148,17 +152,17 @@ def test_bwdsum_plan_invariants(case):
     refs_total = 0
     for t, blk in enumerate(f['blocks']):
         n_p = blk[0]
-        ne = min(64, E - 64 * t)
+        ne = min(BE, E - BE * t)
         assert 1 <= n_p <= 2 * ne
         q0 = 0
         urows = set()
         for j in range(n_p):
-            gid, span = blk[1 + j], blk[129 + j]
+            gid, span = blk[1 + j], blk[1 + MP + j]
             assert span >> 16 == q0 // 2                         # pairs follow each other
             q1 = 2 * (span & 0xffff)
             assert q1 > q0 and not seen[gid]
             seen[gid] = True
-            le = blk[257 + q0:257 + q1]
+            le = blk[1 + 2 * MP + q0:1 + 2 * MP + q1]
             assert (le % 528 == 0).all()                         # byte offsets of rows of the kernel's [65][132] fp32 tile
             le = le // 528
             if le[-1] == 64:                                     # odd count: padded with the all-zero row
@@ -169,9 +173,9 @@ def test_bwdsum_plan_invariants(case):
             assert r not in urows
             urows.add(r)
             for e in le:
-                k = 64 * t + e
+                k = BE * t + e
                 assert r in (pl['e_u0'][k], pl['e_u1'][k])
-            got[r] += g[64 * t + le].sum(0)
+            got[r] += g[BE * t + le].sum(0)
             refs_total += len(le)
             q0 = q1
     assert seen.all() and refs_total == 2 * E
